@@ -1,0 +1,190 @@
+/*
+ * maxsum_gpu.h -- C-ABI of the MI355X-native synchronous Max-Sum engine.
+ *
+ * This is the drop-in boundary for the hot path of
+ * pydcop/algorithms/maxsum.py (reference @ /root/reference).  The reference is
+ * pure Python and has no FFI of its own; the entry points below are what a
+ * ctypes binding for `pydcop.algorithms.maxsum_gpu` binds (INTEGRATION.md shows
+ * the stub).  Each entry point cites the reference code it replaces.
+ *
+ * Conventions
+ *   - every call returns 0 on success, a negative MXS_E_* code otherwise and
+ *     never throws across the ABI; mxs_last_error() gives the message of the
+ *     last failure on the calling thread;
+ *   - host buffers are caller-owned (numpy arrays); device buffers are owned
+ *     by the engine; a handle is NOT thread-safe (one owning thread, like a
+ *     pyDCOP computation: pydcop/infrastructure/computations.py:277-282);
+ *   - there is no CPU fallback: without a usable gfx950 device mxs_create
+ *     fails with MXS_E_NODEVICE.
+ *
+ * Flat factor-graph format (the "compiled" DCOP; indices, never domain values)
+ *   variables  v = 0..n_vars-1      dom_size[v] = |D_v|
+ *   factors    f = 0..n_factors-1   scope = edge_var[factor_rowptr[f] ..
+ *                                   factor_rowptr[f+1]) in `factor.dimensions`
+ *                                   order (pydcop/dcop/relations.py:682-690)
+ *   edges      e = 0..n_edges-1     factor-major: edge e is position
+ *                                   e-factor_rowptr[f] of factor f
+ *   tables     tables[table_off[f] ...] row-major over the scope, C order
+ *                                   (NAryMatrixRelation._m, relations.py:716-733)
+ *   var side   var_edges[var_rowptr[v] .. var_rowptr[v+1]) = edge ids in
+ *                                   VariableComputationNode.links order
+ *                                   (pydcop/computations_graph/factor_graph.py:126-128)
+ *   messages   message of edge e occupies msg_off(e) .. msg_off(e)+D_{var(e)}
+ *              with msg_off = exclusive prefix sum of dom_size[edge_var[e]]
+ */
+#ifndef MAXSUM_GPU_H
+#define MAXSUM_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXS_OK            0
+#define MXS_E_INVALID    -1  /* bad argument / malformed graph               */
+#define MXS_E_NODEVICE   -2  /* no gfx950 device / HIP runtime unusable      */
+#define MXS_E_HIP        -3  /* a HIP call failed (see mxs_last_error)       */
+#define MXS_E_NOMEM      -4
+#define MXS_E_STATE      -5  /* call not valid in the engine's current state */
+
+/* dcop.objective, AlgorithmDef.mode (pydcop/algorithms/__init__.py:141) */
+#define MXS_MODE_MIN 0
+#define MXS_MODE_MAX 1
+/* algo_params "damping_nodes" (pydcop/algorithms/maxsum.py:214-216) */
+#define MXS_DAMP_NONE    0
+#define MXS_DAMP_VARS    1
+#define MXS_DAMP_FACTORS 2
+#define MXS_DAMP_BOTH    3
+/* algo_params "start_messages" (pydcop/algorithms/maxsum.py:219) */
+#define MXS_START_LEAFS      0
+#define MXS_START_LEAFS_VARS 1
+#define MXS_START_ALL        2
+/* arithmetic type of messages/tables on the device */
+#define MXS_DTYPE_F64 0   /* the reference's arithmetic (python float)       */
+#define MXS_DTYPE_F32 1   /* throughput mode                                 */
+
+typedef struct mxs_graph {
+    int32_t        n_vars;
+    int32_t        n_factors;
+    int32_t        n_edges;
+    const int32_t *dom_size;       /* [n_vars]                                */
+    const double  *var_cost;       /* [sum dom_size] Variable.cost_for_val,
+                                      pydcop/dcop/objects.py:231,429,498      */
+    const int32_t *init_idx;       /* [n_vars] index of Variable.initial_value
+                                      or -1; may be NULL (= all -1)           */
+    const int32_t *factor_rowptr;  /* [n_factors+1]                           */
+    const int32_t *edge_var;       /* [n_edges]                               */
+    const int64_t *table_off;      /* [n_factors+1]                           */
+    const double  *tables;         /* [table_off[n_factors]]                  */
+    const int32_t *var_rowptr;     /* [n_vars+1]                              */
+    const int32_t *var_edges;      /* [n_edges]                               */
+    const uint8_t *var_owned;      /* [n_vars] 1 = this engine updates the
+                                      variable, 0 = ghost copy of a variable
+                                      owned by another shard (its V->F
+                                      messages arrive through mxs_halo_*).
+                                      NULL = all owned (single GPU).          */
+} mxs_graph;
+
+typedef struct mxs_params {
+    int32_t mode;            /* MXS_MODE_*                                    */
+    int32_t damping_nodes;   /* MXS_DAMP_*                                    */
+    int32_t start_messages;  /* MXS_START_*                                   */
+    int32_t dtype;           /* MXS_DTYPE_*                                   */
+    double  damping;         /* maxsum.py:213, default 0.5                    */
+    double  stability;       /* maxsum.py:217, default 0.1                    */
+    int32_t graph_chunk;     /* cycles captured per hipGraph replay; 0 = eager
+                                launches; <0 = engine default                 */
+    int32_t layout_flags;    /* tuning knobs (0 = default), see DESIGN.md     */
+} mxs_params;
+
+typedef struct mxs_engine mxs_engine;
+
+/* Number of visible HIP devices (0 and MXS_OK when the runtime loads but
+ * sees no GPU). */
+int mxs_device_count(int32_t *count);
+
+/* Build an engine on HIP device `device`, upload the graph and run cycle 0
+ * (`start()`): replaces building one MaxSum{Factor,Variable}Computation per
+ * node (maxsum.py:118-124, 279-303, 450-487) and their on_start
+ * (maxsum.py:305-328, 495-523; computations.py:741-753). */
+int mxs_create(const mxs_graph *g, const mxs_params *p, int32_t device,
+               mxs_engine **out);
+
+/* Back to the state right after cycle 0. */
+int mxs_reset(mxs_engine *e);
+
+/* Run `n_cycles` synchronous cycles: every factor's and every variable's
+ * on_new_cycle exactly n_cycles times (maxsum.py:339-379, 525-565; the BSP
+ * barrier of computations.py:684-788 becomes the kernel boundary).  Returns
+ * after the device has finished. */
+int mxs_run(mxs_engine *e, int32_t n_cycles);
+
+/* Same, and report the device time of the n_cycles sweeps measured with HIP
+ * events recorded on the engine's own stream (milliseconds). */
+int mxs_run_timed(mxs_engine *e, int32_t n_cycles, float *elapsed_ms);
+
+/* Enqueue `n_cycles` cycles on the engine's stream without waiting. */
+int mxs_run_async(mxs_engine *e, int32_t n_cycles);
+int mxs_sync(mxs_engine *e);
+
+/* Number of on_new_cycle calls done so far (computations.py:790-792). */
+int mxs_cycle_count(const mxs_engine *e, int64_t *cycles);
+
+/* Current selection: idx[v] = index in the domain of the selected value and
+ * belief[v] = its cost, i.e. (current_value, current_cost) set through
+ * value_selection(*select_value(...)) (maxsum.py:532, 584-620;
+ * computations.py:1058-1078).  Either pointer may be NULL. */
+int mxs_get_assignment(mxs_engine *e, int32_t *idx, double *belief);
+
+/* Parity/debug: the messages every receiver currently holds, in the caller's
+ * edge order (msg_off layout above), and the per-directed-edge send counters
+ * (`_prev_messages[...][1]`, maxsum.py:303,474).  Any pointer may be NULL. */
+int mxs_get_messages(mxs_engine *e, double *v2f, double *f2v,
+                     uint8_t *count_v2f, uint8_t *count_f2v);
+
+/* DCOP.solution_cost (pydcop/dcop/dcop.py:308-367): sum of factor costs and
+ * variable costs of an assignment; a term exactly equal to `infinity` counts
+ * as one violation instead.  idx == NULL evaluates the current selection. */
+int mxs_eval_cost(mxs_engine *e, const int32_t *idx, double infinity,
+                  double *cost, int64_t *violations);
+
+/* Algorithmic bytes moved by one cycle (SURVEY.md section 8d formula) and the
+ * number of kernel launches per cycle -- used by bench.py for the roofline. */
+int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
+                    int32_t *launches_per_cycle);
+
+/* ---- sharded (multi-GPU) operation: one engine per rank ----------------
+ * A shard's graph holds its owned variables, every factor touching one of
+ * them, and ghost copies (var_owned = 0) of the remote variables those cut
+ * factors touch.  After each cycle the owner's new V->F messages of cut edges
+ * are copied into the ghost slots of the other shard.  The engine only packs
+ * and unpacks; the exchange itself (RCCL all-to-all) is done by the host on
+ * the device buffers returned here. */
+int mxs_halo_setup(mxs_engine *e, const int32_t *send_edges, int64_t n_send,
+                   const int32_t *recv_edges, int64_t n_recv);
+/* Device pointers + sizes in bytes of the packed send / receive staging
+ * buffers (element type = the engine dtype; a message of edge e takes
+ * dom_size[edge_var[e]] elements, edges in the order given to halo_setup). */
+int mxs_halo_buffers(mxs_engine *e, void **send_dev, int64_t *send_bytes,
+                     void **recv_dev, int64_t *recv_bytes);
+/* One cycle split around the exchange:  step_pack = sweep + pack (async on
+ * the engine stream), then the host runs the collective on the same stream
+ * (mxs_stream), then step_unpack scatters the received messages. */
+int mxs_step_pack(mxs_engine *e);
+int mxs_step_unpack(mxs_engine *e);
+/* The engine's hipStream_t, as an opaque pointer. */
+int mxs_stream(mxs_engine *e, void **stream);
+
+int mxs_destroy(mxs_engine *e);
+
+/* Message of the last error on this thread ("" if none). */
+const char *mxs_last_error(void);
+
+/* Library/ABI version (major*100+minor). */
+int32_t mxs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MAXSUM_GPU_H */

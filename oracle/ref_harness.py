@@ -1,0 +1,197 @@
+"""TEST INFRASTRUCTURE ONLY -- never imported by the product path.
+
+Runs the *reference's own* synchronous Max-Sum computations
+(`/root/reference/pydcop/algorithms/maxsum.py`) deterministically for an exact
+number of cycles, without agents, threads or the orchestrator.  Used to
+
+  * pin `oracle/maxsum_oracle.c` against the real reference (tests run here,
+    in the build container, where `/root/reference` exists), and
+  * generate the committed golden vectors under `tests/golden/`
+    (`oracle/make_golden.py`).
+
+`/root/reference` does not exist on the GPU box: everything that travels is the
+C restatement + the golden fixtures.
+
+Shims (reference untouched, all in-process):
+  1. `collections.Iterable/Mapping/...` aliases (pydcop/dcop/yamldcop.py:32,
+     pydcop/dcop/dcop.py:238 use the pre-3.10 names),
+  2. stub modules for the absent third-party deps `websocket_server`
+     (pydcop/infrastructure/ui.py:36) and `pulp` (pydcop/distribution/ilp_*.py),
+  3. `ndarray.itemset` was removed in numpy 2 (pydcop/dcop/relations.py:857).
+"""
+import collections
+import collections.abc
+import os
+import sys
+import types
+from collections import deque
+
+REFERENCE_ROOT = os.environ.get("PYDCOP_REFERENCE", "/root/reference")
+
+
+def reference_available() -> bool:
+    return os.path.isdir(os.path.join(REFERENCE_ROOT, "pydcop"))
+
+
+class _Permissive(types.ModuleType):
+    """A module whose every attribute is a do-nothing class."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        stub = type(name, (), {"__init__": lambda self, *a, **k: None})
+        setattr(self, name, stub)
+        return stub
+
+
+def install_shims():
+    """Make `import pydcop` work on python 3.10 / numpy 2 without touching it."""
+    for n in ("Iterable", "Mapping", "Sequence", "Callable", "Sized",
+              "MutableMapping", "Hashable", "Set"):
+        if not hasattr(collections, n):
+            setattr(collections, n, getattr(collections.abc, n))
+    for mod in ("websocket_server", "websocket_server.websocket_server",
+                "pulp", "pulp.constants", "pulp.pulp", "pulp.solvers"):
+        if mod not in sys.modules:
+            try:
+                __import__(mod)
+            except Exception:
+                sys.modules[mod] = _Permissive(mod)
+    if reference_available() and REFERENCE_ROOT not in sys.path:
+        sys.path.insert(0, REFERENCE_ROOT)
+    if reference_available():
+        _patch_itemset()
+
+
+def _patch_itemset():
+    # pydcop/dcop/relations.py:857 calls ndarray.itemset (gone in numpy 2).
+    from pydcop.dcop import relations as R
+
+    if getattr(R.NAryMatrixRelation, "_graft_patched", False):
+        return
+    import numpy as np
+
+    if hasattr(np.ndarray, "itemset"):
+        return
+
+    def set_value_for_assignment(self, var_values, rel_value):
+        if isinstance(var_values, list):
+            _, s = self._slice_matrix(var_values)
+            matrix = self._m.copy()
+            matrix[s] = rel_value
+            return R.NAryMatrixRelation(self._variables, matrix, name=self.name)
+        elif isinstance(var_values, dict):
+            values = []
+            for v in self._variables:
+                values.append(var_values[v.name])
+            _, s = self._slice_matrix(values)
+            matrix = self._m.copy()
+            matrix[s] = rel_value
+            return R.NAryMatrixRelation(self._variables, matrix, name=self.name)
+        raise ValueError("Could not set value, must be list or dict")
+
+    R.NAryMatrixRelation.set_value_for_assignment = set_value_for_assignment
+    R.NAryMatrixRelation._graft_patched = True
+
+
+def run_reference_maxsum(dcop, cycles, params=None, cg=None, return_comps=False):
+    """Run the reference's MaxSum{Factor,Variable}Computation objects for exactly
+    `cycles` calls of `on_new_cycle` each.
+
+    Every computation's `message_sender` appends to one FIFO; messages whose
+    `cycle_id >= cycles` are dropped so that no computation can switch to cycle
+    `cycles+1`.  Returns ({var: value}, {var: cost}).
+    """
+    install_shims()
+    from pydcop.algorithms import AlgorithmDef, ComputationDef, load_algorithm_module
+    from pydcop.computations_graph import factor_graph
+
+    p = {"noise": 0}
+    p.update(params or {})
+    algo = AlgorithmDef.build_with_default_param("maxsum", p, mode=dcop.objective)
+    if cg is None:
+        cg = factor_graph.build_computation_graph(dcop)
+    module = load_algorithm_module("maxsum")
+    comps = {}
+    q = deque()
+    import logging
+    logging.disable(logging.CRITICAL)
+    for node in cg.nodes:
+        c = module.build_computation(ComputationDef(node, algo))
+        comps[node.name] = c
+
+    def make_sender():
+        def sender(src, dest, msg, prio=None, on_error=None):
+            q.append((src, dest, msg))
+        return sender
+
+    for c in comps.values():
+        c.message_sender = make_sender()
+    try:
+        for c in comps.values():
+            c.start()
+        while q:
+            s, d, m = q.popleft()
+            if m.cycle_id < cycles:
+                comps[d].on_message(s, m, 0.0)
+    finally:
+        logging.disable(logging.NOTSET)
+    values = {v: comps[v].current_value for v in dcop.variables}
+    costs = {v: comps[v].current_cost for v in dcop.variables}
+    if return_comps:
+        return values, costs, comps
+    return values, costs
+
+
+def flat_to_dcop(graph, mode="min", name="flat"):
+    """Build reference objects (DCOP + ComputationsFactorGraph) from a FlatGraph:
+    VariableWithCostDict variables (pydcop/dcop/objects.py:410) and extensional
+    NAryMatrixRelation constraints (pydcop/dcop/relations.py:672).  The factor
+    graph is assembled in O(E) instead of through the quadratic
+    build_computation_graph (pydcop/computations_graph/factor_graph.py:245),
+    with the same node/link structure."""
+    install_shims()
+    import numpy as np
+    from pydcop.computations_graph.factor_graph import (
+        ComputationsFactorGraph, FactorComputationNode, VariableComputationNode)
+    from pydcop.dcop.dcop import DCOP
+    from pydcop.dcop.objects import Domain, VariableWithCostDict
+    from pydcop.dcop.relations import NAryMatrixRelation
+
+    g = graph
+    names = g.var_names or [f"v{i}" for i in range(g.n_vars)]
+    fnames = g.factor_names or [f"c{i}" for i in range(g.n_factors)]
+    cost_off = g.cost_off
+    doms = {}
+    variables = []
+    dcop = DCOP(name, objective=mode)
+    for i in range(g.n_vars):
+        D = int(g.dom_size[i])
+        values = list(g.domains[i]) if g.domains else list(range(D))
+        key = tuple(values)
+        if key not in doms:
+            doms[key] = Domain(f"d{len(doms)}", "d", values)
+        costs = {values[d]: float(g.var_cost[cost_off[i] + d]) for d in range(D)}
+        init = None
+        if g.init_idx is not None and g.init_idx[i] >= 0:
+            init = values[int(g.init_idx[i])]
+        v = VariableWithCostDict(names[i], doms[key], costs, initial_value=init)
+        variables.append(v)
+        dcop.add_variable(v)
+    factor_nodes = []
+    for f in range(g.n_factors):
+        e0, e1 = int(g.factor_rowptr[f]), int(g.factor_rowptr[f + 1])
+        scope = [variables[int(x)] for x in g.edge_var[e0:e1]]
+        shape = tuple(len(v.domain) for v in scope)
+        m = np.array(g.tables[g.table_off[f]:g.table_off[f + 1]]).reshape(shape)
+        c = NAryMatrixRelation(scope, m, name=fnames[f])
+        dcop.add_constraint(c)
+        factor_nodes.append(FactorComputationNode(c))
+    edge_factor = np.repeat(np.arange(g.n_factors), np.diff(g.factor_rowptr))
+    var_nodes = []
+    for i in range(g.n_vars):
+        k0, k1 = int(g.var_rowptr[i]), int(g.var_rowptr[i + 1])
+        cnames = [fnames[int(edge_factor[e])] for e in g.var_edges[k0:k1]]
+        var_nodes.append(VariableComputationNode(variables[i], cnames))
+    cg = ComputationsFactorGraph(var_nodes, factor_nodes)
+    return dcop, cg

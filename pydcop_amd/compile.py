@@ -1,0 +1,125 @@
+"""Instance compiler: pyDCOP objects -> FlatGraph (indices only).
+
+Works on the reference's own objects by duck typing (nothing is imported from
+pydcop): `Variable` (pydcop/dcop/objects.py:175), `Constraint`
+(pydcop/dcop/relations.py:672 NAryMatrixRelation, :456 NAryFunctionRelation),
+`FactorComputationNode` / `VariableComputationNode`
+(pydcop/computations_graph/factor_graph.py:45,104).
+"""
+import itertools
+from typing import Iterable, List, Optional
+
+import numpy as np
+
+from .graph import FlatGraph
+
+
+def tensorise_constraint(constraint) -> np.ndarray:
+    """Dense cost tensor of a constraint, row-major over `constraint.dimensions`
+    (pydcop/dcop/relations.py:682-690).  Extensional relations expose their
+    ndarray; anything else is enumerated once through `constraint(**assignment)`
+    (NB: the dimension order of an ExpressionFunction constraint is set order,
+    pydcop/utils/expressionfunction.py:74 -- always read `.dimensions`)."""
+    dims = list(constraint.dimensions)
+    shape = tuple(len(v.domain) for v in dims)
+    m = getattr(constraint, "_m", None)
+    if isinstance(m, np.ndarray) and m.shape == shape:
+        return np.ascontiguousarray(m, dtype=np.float64)
+    names = [v.name for v in dims]
+    out = np.empty(shape, dtype=np.float64)
+    flat = out.reshape(-1)
+    for i, values in enumerate(itertools.product(*[list(v.domain) for v in dims])):
+        flat[i] = constraint(**dict(zip(names, values)))
+    return out
+
+
+def _domain_index(variable, value) -> int:
+    for i, d in enumerate(variable.domain):
+        if d == value:
+            return i
+    raise ValueError(f"{value!r} is not in the domain of {variable.name}")
+
+
+def compile_nodes(var_nodes: Iterable, factor_nodes: Iterable,
+                  noise: float = 0.0, rng: Optional[np.random.Generator] = None) -> FlatGraph:
+    """Compile factor-graph computation nodes (what `ComputationDef.node`
+    carries, pydcop/algorithms/__init__.py:336-380) into a FlatGraph.
+
+    Variable order = order of `var_nodes`; factor order = order of
+    `factor_nodes`; a variable's edge order = its node's `links` order, which is
+    the order MaxSumVariableComputation iterates its factors
+    (pydcop/algorithms/maxsum.py:466, 536).
+
+    `noise` > 0 reproduces VariableNoisyCostFunc (pydcop/dcop/objects.py:547-567):
+    one `uniform(0, noise)` draw per domain value added to the variable cost --
+    but from a seedable generator instead of the reference's unseeded `random`.
+    """
+    var_nodes, factor_nodes = list(var_nodes), list(factor_nodes)
+    variables = [n.variable for n in var_nodes]
+    var_id = {n.name: i for i, n in enumerate(var_nodes)}
+    dom_size = np.array([len(v.domain) for v in variables], dtype=np.int32)
+    costs = []
+    init_idx = np.full(len(variables), -1, dtype=np.int32)
+    for i, v in enumerate(variables):
+        costs.extend(float(v.cost_for_val(d)) for d in v.domain)
+        if getattr(v, "initial_value", None) is not None:
+            init_idx[i] = _domain_index(v, v.initial_value)
+    var_cost = np.array(costs, dtype=np.float64)
+    if noise:
+        rng = rng or np.random.default_rng()
+        var_cost = var_cost + rng.uniform(0.0, noise, size=var_cost.shape)
+
+    factor_rowptr = [0]
+    edge_var: List[int] = []
+    table_off = [0]
+    tables = []
+    edge_of = {}  # (factor name, var name) -> edge id
+    for fn in factor_nodes:
+        factor = fn.factor
+        for v in factor.dimensions:
+            if v.name not in var_id:
+                raise ValueError(f"factor {fn.name} depends on unknown variable {v.name}")
+            edge_of[(fn.name, v.name)] = len(edge_var)
+            edge_var.append(var_id[v.name])
+        factor_rowptr.append(len(edge_var))
+        t = tensorise_constraint(factor).reshape(-1)
+        tables.append(t)
+        table_off.append(table_off[-1] + t.shape[0])
+
+    var_rowptr = [0]
+    var_edges: List[int] = []
+    for n in var_nodes:
+        for link in n.links:
+            key = (link.factor_node, n.name)
+            if key not in edge_of:
+                raise ValueError(f"variable {n.name} is linked to unknown factor {link.factor_node}")
+            var_edges.append(edge_of[key])
+        var_rowptr.append(len(var_edges))
+
+    g = FlatGraph(
+        dom_size=dom_size, var_cost=var_cost,
+        factor_rowptr=np.array(factor_rowptr, dtype=np.int32),
+        edge_var=np.array(edge_var, dtype=np.int32),
+        table_off=np.array(table_off, dtype=np.int64),
+        tables=np.concatenate(tables) if tables else np.zeros(0),
+        var_rowptr=np.array(var_rowptr, dtype=np.int32),
+        var_edges=np.array(var_edges, dtype=np.int32),
+        init_idx=init_idx if (init_idx >= 0).any() else None,
+        var_names=[n.name for n in var_nodes],
+        factor_names=[n.name for n in factor_nodes],
+        domains=[list(v.domain) for v in variables],
+    )
+    return g.validate()
+
+
+def compile_computation_graph(cg, noise: float = 0.0, rng=None) -> FlatGraph:
+    """Compile a ComputationsFactorGraph
+    (pydcop/computations_graph/factor_graph.py:210)."""
+    var_nodes = [n for n in cg.nodes if n.type == "VariableComputation"]
+    factor_nodes = [n for n in cg.nodes if n.type == "FactorComputation"]
+    return compile_nodes(var_nodes, factor_nodes, noise=noise, rng=rng)
+
+
+def assignment_to_values(graph: FlatGraph, idx: np.ndarray) -> dict:
+    """{variable name: domain value} for an index assignment."""
+    return {n: graph.domains[i][int(idx[i])] for i, n in enumerate(graph.var_names)}

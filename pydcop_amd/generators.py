@@ -1,0 +1,164 @@
+"""O(E) synthetic instance generators producing FlatGraphs directly.
+
+The reference's generators (pydcop/commands/generators/*.py) build networkx
+graphs and DCOP objects and do not scale (nx.gnp_random_graph is O(N^2),
+build_computation_graph O(V*F)); these follow their *instance conventions* only:
+
+  random_coloring  soft: extensional tables of `randint(0, 9)` costs
+                   (graphcoloring.py:355-375); hard: cost 1000 on equal colours
+                   (graphcoloring.py:378-413)
+  ising_grid       periodic grid, binary [[k,-k],[-k,k]] with k~U(-r, r) and
+                   unary [u,-u] with u~U(-ur, ur) kept as real unary factors
+                   (ising.py:285, 362-383, 412-420)
+  meeting_like     arity-3, D=24 tables, objective max (SURVEY.md section 8d cfg 5)
+
+Symmetry is broken by per-variable unary costs U(0, 0.01) stored as variable
+costs: the deterministic stand-in for the reference's unseeded noise
+(pydcop/dcop/objects.py:566-567).
+"""
+import numpy as np
+
+from .graph import FlatGraph
+
+
+def _finish(dom_size, var_cost, factor_rowptr, edge_var, tables, table_off, names=True):
+    n_vars = len(dom_size)
+    var_rowptr, var_edges = FlatGraph.var_side_from_edges(edge_var, n_vars)
+    g = FlatGraph(dom_size=dom_size, var_cost=var_cost, factor_rowptr=factor_rowptr,
+                  edge_var=edge_var, table_off=table_off, tables=tables,
+                  var_rowptr=var_rowptr, var_edges=var_edges)
+    if names:
+        width = len(str(max(n_vars - 1, 1)))
+        g.var_names = [f"v{i:0{width}d}" for i in range(n_vars)]
+        nf = g.n_factors
+        widthf = len(str(max(nf - 1, 1)))
+        g.factor_names = [f"c{i:0{widthf}d}" for i in range(nf)]
+        g.domains = [list(range(int(d))) for d in g.dom_size]
+    return g
+
+
+def _random_simple_edges(n_vars, n_edges, rng):
+    """G(n, m): m distinct unordered pairs without self loops, O(m)."""
+    pairs = np.zeros((0, 2), dtype=np.int64)
+    seen = np.zeros(0, dtype=np.int64)
+    while pairs.shape[0] < n_edges:
+        need = n_edges - pairs.shape[0]
+        a = rng.integers(0, n_vars, size=int(need * 1.2) + 16)
+        b = rng.integers(0, n_vars, size=a.shape[0])
+        keep = a != b
+        lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+        key = lo * n_vars + hi
+        key, first = np.unique(key, return_index=True)
+        fresh = ~np.isin(key, seen)
+        key = key[fresh]
+        order = rng.permutation(key.shape[0])[:need]
+        key = key[order]
+        seen = np.concatenate([seen, key])
+        pairs = np.concatenate([pairs, np.stack([key // n_vars, key % n_vars], axis=1)])
+    return pairs[:n_edges]
+
+
+def random_coloring(n_vars, avg_degree=4, n_colors=3, seed=0, variant="soft",
+                    unary_noise=0.01, names=True) -> FlatGraph:
+    """Random graph colouring: n_vars*avg_degree/2 binary factors on G(n, m)."""
+    rng = np.random.default_rng(seed)
+    n_factors = int(n_vars * avg_degree // 2)
+    pairs = _random_simple_edges(n_vars, n_factors, rng)
+    # random orientation of each constraint's scope
+    flip = rng.random(n_factors) < 0.5
+    pairs = np.where(flip[:, None], pairs[:, ::-1], pairs)
+    D = n_colors
+    dom_size = np.full(n_vars, D, dtype=np.int32)
+    var_cost = rng.uniform(0.0, unary_noise, size=n_vars * D) if unary_noise else np.zeros(n_vars * D)
+    factor_rowptr = np.arange(0, 2 * n_factors + 1, 2, dtype=np.int32)
+    edge_var = pairs.reshape(-1).astype(np.int32)
+    if variant == "soft":
+        tables = rng.integers(0, 10, size=(n_factors, D, D)).astype(np.float64)
+    elif variant == "hard":
+        tables = np.tile(1000.0 * np.eye(D), (n_factors, 1, 1))
+    else:
+        raise ValueError("variant must be 'soft' or 'hard'")
+    table_off = np.arange(0, (n_factors + 1) * D * D, D * D, dtype=np.int64)
+    return _finish(dom_size, var_cost, factor_rowptr, edge_var, tables.reshape(-1), table_off, names)
+
+
+def ising_grid(rows, cols, seed=0, bin_range=1.6, un_range=0.05, names=True) -> FlatGraph:
+    """Periodic rows x cols Ising grid, D=2; unary terms are real unary factors."""
+    rng = np.random.default_rng(seed)
+    n = rows * cols
+    r, c = np.divmod(np.arange(n, dtype=np.int64), cols)
+    right = r * cols + (c + 1) % cols
+    down = ((r + 1) % rows) * cols + c
+    me = np.arange(n, dtype=np.int64)
+    # per cell: unary factor, horizontal coupling, vertical coupling (keeps locality)
+    k_h = rng.uniform(-bin_range, bin_range, size=n)
+    k_v = rng.uniform(-bin_range, bin_range, size=n)
+    u = rng.uniform(-un_range, un_range, size=n)
+    edge_var = np.stack([me, me, right, me, down], axis=1).reshape(-1).astype(np.int32)
+    per = np.array([0, 1, 3, 5], dtype=np.int64)
+    factor_rowptr = (np.arange(n, dtype=np.int64)[:, None] * 5 + per[None, :3]).reshape(-1)
+    factor_rowptr = np.concatenate([factor_rowptr, [5 * n]]).astype(np.int32)
+    tab = np.empty((n, 10), dtype=np.float64)
+    tab[:, 0], tab[:, 1] = u, -u
+    for off, k in ((2, k_h), (6, k_v)):
+        tab[:, off + 0], tab[:, off + 1], tab[:, off + 2], tab[:, off + 3] = k, -k, -k, k
+    sizes = np.tile(np.array([2, 4, 4], dtype=np.int64), n)
+    table_off = np.zeros(3 * n + 1, dtype=np.int64)
+    np.cumsum(sizes, out=table_off[1:])
+    dom_size = np.full(n, 2, dtype=np.int32)
+    var_cost = np.zeros(2 * n)
+    return _finish(dom_size, var_cost, factor_rowptr, edge_var, tab.reshape(-1), table_off, names)
+
+
+def meeting_like(n_vars, n_factors=None, dom=24, arity=3, seed=0, penalty=100.0,
+                 unary_noise=0.01, names=True) -> FlatGraph:
+    """Meeting-scheduling-like instance: arity-`arity` factors over D=`dom`
+    slot variables; utility `integers(-10, 10)` minus `penalty` when the
+    participants do not all pick the same slot.  To be solved with mode 'max'."""
+    rng = np.random.default_rng(seed)
+    n_factors = n_factors or n_vars
+    scope = np.empty((n_factors, arity), dtype=np.int64)
+    for i in range(n_factors):  # distinct variables per factor
+        scope[i] = rng.choice(n_vars, size=arity, replace=False) if n_vars < 4096 else 0
+    if n_vars >= 4096:
+        scope = rng.integers(0, n_vars, size=(n_factors, arity))
+        for _ in range(8):  # re-draw the rare duplicates
+            s = np.sort(scope, axis=1)
+            bad = (np.diff(s, axis=1) == 0).any(axis=1)
+            if not bad.any():
+                break
+            scope[bad] = rng.integers(0, n_vars, size=(int(bad.sum()), arity))
+    dom_size = np.full(n_vars, dom, dtype=np.int32)
+    var_cost = rng.uniform(0.0, unary_noise, size=n_vars * dom) if unary_noise else np.zeros(n_vars * dom)
+    size = dom ** arity
+    tables = rng.integers(-10, 10, size=(n_factors, size)).astype(np.float64)
+    grid = np.indices((dom,) * arity).reshape(arity, -1)
+    same = (grid == grid[0]).all(axis=0)
+    tables[:, ~same] -= penalty
+    factor_rowptr = np.arange(0, arity * n_factors + 1, arity, dtype=np.int32)
+    table_off = np.arange(0, (n_factors + 1) * size, size, dtype=np.int64)
+    return _finish(dom_size, var_cost, factor_rowptr, scope.reshape(-1).astype(np.int32),
+                   tables.reshape(-1), table_off, names)
+
+
+def random_mixed(n_vars, n_factors, seed=0, max_arity=3, dom_choices=(2, 3, 4, 5),
+                 unary_noise=0.01, float_tables=True, names=True) -> FlatGraph:
+    """Small heterogeneous instances for parity tests: mixed domain sizes,
+    arities 1..max_arity, real-valued tables."""
+    rng = np.random.default_rng(seed)
+    dom_size = rng.choice(np.array(dom_choices), size=n_vars).astype(np.int32)
+    var_cost = rng.uniform(0.0, unary_noise, size=int(dom_size.sum())) if unary_noise \
+        else np.zeros(int(dom_size.sum()))
+    rowptr, edge_var, tables, table_off = [0], [], [], [0]
+    for _ in range(n_factors):
+        a = int(rng.integers(1, min(max_arity, n_vars) + 1))
+        sc = rng.choice(n_vars, size=a, replace=False)
+        edge_var.extend(int(x) for x in sc)
+        rowptr.append(len(edge_var))
+        size = int(np.prod(dom_size[sc]))
+        t = rng.uniform(-5, 5, size=size) if float_tables else rng.integers(0, 10, size=size).astype(float)
+        tables.append(t)
+        table_off.append(table_off[-1] + size)
+    return _finish(dom_size, var_cost, np.array(rowptr, dtype=np.int32),
+                   np.array(edge_var, dtype=np.int32), np.concatenate(tables),
+                   np.array(table_off, dtype=np.int64), names)

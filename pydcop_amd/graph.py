@@ -1,0 +1,191 @@
+"""Flat ("compiled") factor graph: the arrays the C-ABI takes.
+
+Mirrors `struct mxs_graph` / `struct mxs_params` of include/maxsum_gpu.h.  The
+device only ever sees indices; domain *values* stay on the host (the reference
+keys its messages by value, pydcop/algorithms/maxsum.py:223-235).
+"""
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+MODE = {"min": 0, "max": 1}
+DAMPING_NODES = {"none": 0, "vars": 1, "factors": 2, "both": 3}
+START_MESSAGES = {"leafs": 0, "leafs_vars": 1, "all": 2}
+DTYPE = {"f64": 0, "f32": 1}
+
+
+class CGraph(C.Structure):
+    """`struct mxs_graph` (include/maxsum_gpu.h)."""
+    _fields_ = [
+        ("n_vars", C.c_int32), ("n_factors", C.c_int32), ("n_edges", C.c_int32),
+        ("dom_size", C.c_void_p), ("var_cost", C.c_void_p), ("init_idx", C.c_void_p),
+        ("factor_rowptr", C.c_void_p), ("edge_var", C.c_void_p),
+        ("table_off", C.c_void_p), ("tables", C.c_void_p),
+        ("var_rowptr", C.c_void_p), ("var_edges", C.c_void_p),
+        ("var_owned", C.c_void_p),
+    ]
+
+
+class CParams(C.Structure):
+    """`struct mxs_params` (include/maxsum_gpu.h)."""
+    _fields_ = [
+        ("mode", C.c_int32), ("damping_nodes", C.c_int32),
+        ("start_messages", C.c_int32), ("dtype", C.c_int32),
+        ("damping", C.c_double), ("stability", C.c_double),
+        ("graph_chunk", C.c_int32), ("layout_flags", C.c_int32),
+    ]
+
+
+@dataclass
+class Params:
+    """Algorithm parameters: the reference's `algo_params`
+    (pydcop/algorithms/maxsum.py:212-220) minus `noise` (folded into
+    `FlatGraph.var_cost` by the compiler) plus engine knobs."""
+    mode: str = "min"
+    damping: float = 0.5
+    damping_nodes: str = "both"
+    stability: float = 0.1
+    start_messages: str = "leafs"
+    dtype: str = "f64"
+    graph_chunk: int = -1
+    layout_flags: int = 0
+
+    def to_c(self) -> CParams:
+        for name, table in (("mode", MODE), ("damping_nodes", DAMPING_NODES),
+                            ("start_messages", START_MESSAGES), ("dtype", DTYPE)):
+            if getattr(self, name) not in table:
+                raise ValueError(
+                    f"Invalid value {getattr(self, name)!r} for parameter {name}, "
+                    f"must be one of {sorted(table)}")
+        return CParams(MODE[self.mode], DAMPING_NODES[self.damping_nodes],
+                       START_MESSAGES[self.start_messages], DTYPE[self.dtype],
+                       float(self.damping), float(self.stability),
+                       int(self.graph_chunk), int(self.layout_flags))
+
+
+def _arr(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+@dataclass
+class FlatGraph:
+    """Factor graph in the C-ABI array format (see include/maxsum_gpu.h)."""
+    dom_size: np.ndarray        # int32 [n_vars]
+    var_cost: np.ndarray        # float64 [sum dom_size]
+    factor_rowptr: np.ndarray   # int32 [n_factors+1]
+    edge_var: np.ndarray        # int32 [n_edges]
+    table_off: np.ndarray       # int64 [n_factors+1]
+    tables: np.ndarray          # float64 [table_off[-1]]
+    var_rowptr: np.ndarray      # int32 [n_vars+1]
+    var_edges: np.ndarray       # int32 [n_edges]
+    init_idx: Optional[np.ndarray] = None   # int32 [n_vars] or None
+    var_owned: Optional[np.ndarray] = None  # uint8 [n_vars] or None
+    # host-only metadata (names / domain values), optional
+    var_names: Optional[List[str]] = None
+    factor_names: Optional[List[str]] = None
+    domains: Optional[List[Sequence]] = None
+    _keep: list = field(default_factory=list, repr=False)
+
+    def __post_init__(self):
+        self.dom_size = _arr(self.dom_size, np.int32)
+        self.var_cost = _arr(self.var_cost, np.float64)
+        self.factor_rowptr = _arr(self.factor_rowptr, np.int32)
+        self.edge_var = _arr(self.edge_var, np.int32)
+        self.table_off = _arr(self.table_off, np.int64)
+        self.tables = _arr(self.tables, np.float64)
+        self.var_rowptr = _arr(self.var_rowptr, np.int32)
+        self.var_edges = _arr(self.var_edges, np.int32)
+        if self.init_idx is not None:
+            self.init_idx = _arr(self.init_idx, np.int32)
+        if self.var_owned is not None:
+            self.var_owned = _arr(self.var_owned, np.uint8)
+
+    # sizes ---------------------------------------------------------------
+    @property
+    def n_vars(self) -> int:
+        return int(self.dom_size.shape[0])
+
+    @property
+    def n_factors(self) -> int:
+        return int(self.factor_rowptr.shape[0] - 1)
+
+    @property
+    def n_edges(self) -> int:
+        return int(self.edge_var.shape[0])
+
+    @property
+    def cost_off(self) -> np.ndarray:
+        off = np.zeros(self.n_vars + 1, dtype=np.int64)
+        np.cumsum(self.dom_size, out=off[1:])
+        return off
+
+    @property
+    def msg_off(self) -> np.ndarray:
+        """Offset of edge e's message in the message arrays returned by
+        `get_messages` (exclusive prefix sum of the edge domain sizes)."""
+        off = np.zeros(self.n_edges + 1, dtype=np.int64)
+        np.cumsum(self.dom_size[self.edge_var], out=off[1:])
+        return off
+
+    # construction helpers -------------------------------------------------
+    @staticmethod
+    def var_side_from_edges(edge_var: np.ndarray, n_vars: int):
+        """Variable-side CSR with each variable's edges in increasing edge id,
+        i.e. in the order of the factors -- which is the links order the
+        reference's build_computation_graph produces
+        (pydcop/computations_graph/factor_graph.py:276-280)."""
+        edge_var = np.asarray(edge_var, dtype=np.int64)
+        order = np.argsort(edge_var, kind="stable").astype(np.int32)
+        counts = np.bincount(edge_var, minlength=n_vars)
+        rowptr = np.zeros(n_vars + 1, dtype=np.int32)
+        np.cumsum(counts, out=rowptr[1:])
+        return rowptr, order
+
+    def validate(self):
+        nv, nf, ne = self.n_vars, self.n_factors, self.n_edges
+        if (self.dom_size < 1).any():
+            raise ValueError("every variable needs a non-empty domain")
+        if self.var_cost.shape[0] != int(self.dom_size.sum()):
+            raise ValueError("var_cost must hold sum(dom_size) entries")
+        if self.factor_rowptr[0] != 0 or self.factor_rowptr[-1] != ne:
+            raise ValueError("factor_rowptr does not span the edges")
+        if (np.diff(self.factor_rowptr) < 1).any():
+            raise ValueError("every factor needs at least one variable")
+        if ne and (self.edge_var.min() < 0 or self.edge_var.max() >= nv):
+            raise ValueError("edge_var out of range")
+        if self.var_rowptr[0] != 0 or self.var_rowptr[-1] != ne:
+            raise ValueError("var_rowptr does not span the edges")
+        if ne:
+            if not np.array_equal(np.sort(self.var_edges), np.arange(ne, dtype=np.int32)):
+                raise ValueError("var_edges must be a permutation of the edges")
+            owner = np.repeat(np.arange(nv, dtype=np.int32), np.diff(self.var_rowptr))
+            if not np.array_equal(self.edge_var[self.var_edges], owner):
+                raise ValueError("var_edges inconsistent with edge_var")
+        sizes = np.ones(nf, dtype=np.int64)
+        d = self.dom_size[self.edge_var].astype(np.int64)
+        if nf:
+            sizes = np.multiply.reduceat(d, self.factor_rowptr[:-1].astype(np.int64))
+        if not np.array_equal(np.diff(self.table_off), sizes):
+            raise ValueError("table_off inconsistent with the factor scopes")
+        if self.tables.shape[0] != int(self.table_off[-1]):
+            raise ValueError("tables has the wrong size")
+        return self
+
+    def to_c(self) -> CGraph:
+        def p(a):
+            return None if a is None else a.ctypes.data_as(C.c_void_p)
+        return CGraph(self.n_vars, self.n_factors, self.n_edges,
+                      p(self.dom_size), p(self.var_cost), p(self.init_idx),
+                      p(self.factor_rowptr), p(self.edge_var), p(self.table_off),
+                      p(self.tables), p(self.var_rowptr), p(self.var_edges),
+                      p(self.var_owned))
+
+    # algorithmic bytes of one cycle -----------------
+    def cycle_bytes(self, word: int) -> int:
+        d_e = self.dom_size[self.edge_var].astype(np.int64)
+        b = int((6 * d_e * word + 8).sum())
+        b += int(np.diff(self.table_off).sum()) * word
+        b += int((self.dom_size.astype(np.int64) * word + 8 + word).sum())
+        return b

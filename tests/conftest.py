@@ -1,0 +1,45 @@
+import glob
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(path):
+    """-> (FlatGraph, Params kwargs, meta dict, ref_idx, ref_cost)"""
+    from pydcop_amd.graph import FlatGraph
+    z = np.load(path)
+    meta = json.loads(bytes(z["meta"]).decode())
+    g = FlatGraph(dom_size=z["dom_size"], var_cost=z["var_cost"],
+                  factor_rowptr=z["factor_rowptr"], edge_var=z["edge_var"],
+                  table_off=z["table_off"], tables=z["tables"],
+                  var_rowptr=z["var_rowptr"], var_edges=z["var_edges"],
+                  init_idx=z["init_idx"] if "init_idx" in z.files else None)
+    g.var_names = meta["var_names"]
+    g.domains = meta["domains"]
+    params = dict(mode=meta["mode"])
+    params.update(meta["params"])
+    return g.validate(), params, meta, z["ref_idx"], z["ref_cost"]
+
+
+def golden_files():
+    return sorted(glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
+
+
+@pytest.fixture(scope="session")
+def oracle_built():
+    from oracle import maxsum_oracle
+    maxsum_oracle.build()
+    return maxsum_oracle

@@ -1,0 +1,62 @@
+"""Pins the C oracle against the REAL reference, run live through
+oracle/ref_harness.py.  Only possible where /root/reference exists (the build
+container); skipped on the GPU box, where tests/golden/ stands in."""
+import numpy as np
+import pytest
+
+from oracle import ref_harness
+from pydcop_amd import generators as G
+from pydcop_amd.graph import Params
+
+pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
+                                reason="reference tree not present")
+
+CASES = [
+    ("soft", lambda: G.random_coloring(40, seed=11), "min", {}),
+    ("hard", lambda: G.random_coloring(40, seed=12, variant="hard"), "min",
+     {"start_messages": "all", "damping_nodes": "vars"}),
+    ("mixed", lambda: G.random_mixed(20, 30, seed=13), "max",
+     {"start_messages": "leafs_vars", "damping_nodes": "none"}),
+    ("meeting", lambda: G.meeting_like(10, dom=4, seed=14), "max",
+     {"damping_nodes": "factors", "damping": 0.3, "stability": 0.02}),
+]
+
+
+@pytest.mark.parametrize("name,make,mode,params", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("T", [0, 1, 2, 7, 25])
+def test_oracle_equals_reference(name, make, mode, params, T, oracle_built):
+    g = make()
+    dcop, cg = ref_harness.flat_to_dcop(g, mode)
+    vals, costs = ref_harness.run_reference_maxsum(dcop, T, params, cg=cg)
+    o = oracle_built.OracleMaxSum(g, Params(mode=mode, **params))
+    o.run(T)
+    idx, belief = o.assignment()
+    ref_idx = np.array([g.domains[i].index(vals[n]) for i, n in enumerate(g.var_names)])
+    np.testing.assert_array_equal(idx, ref_idx)
+    ref_cost = np.array([costs[n] for n in g.var_names], dtype=float)
+    np.testing.assert_allclose(belief, ref_cost, rtol=1e-12, atol=1e-12)
+    viol, cost = dcop.solution_cost(vals, float("inf"))
+    ocost, oviol = o.eval_cost()
+    assert oviol == viol and ocost == pytest.approx(cost, rel=1e-12, abs=1e-9)
+
+
+def test_reference_unit_pins(oracle_built):
+    """tests/unit/test_algorithms_amaxsum.py:77-150 pins factor_costs_for_var on a
+    binary factor abs((x1-x2)/2) over domains 0..9 with no received costs:
+    costs[5]==0.5? no -- with empty recv the optimum over x2 is 0 for every x1;
+    here we pin the same numbers through one engine cycle instead."""
+    from pydcop_amd.graph import FlatGraph
+    D = 10
+    tab = np.abs((np.arange(D)[:, None] - np.arange(D)[None, :]) / 2.0)
+    dom = np.array([D, D], dtype=np.int32)
+    rowptr, edges = FlatGraph.var_side_from_edges(np.array([0, 1]), 2)
+    g = FlatGraph(dom_size=dom, var_cost=np.zeros(2 * D), factor_rowptr=[0, 2],
+                  edge_var=[0, 1], table_off=[0, D * D], tables=tab.reshape(-1),
+                  var_rowptr=rowptr, var_edges=edges).validate()
+    o = oracle_built.OracleMaxSum(g, Params(start_messages="all"))
+    _, f2v, _, _ = o.messages()
+    np.testing.assert_array_equal(f2v, np.zeros(2 * D))  # min over the other var
+    o2 = oracle_built.OracleMaxSum(g, Params(mode="max", start_messages="all"))
+    _, f2v, _, _ = o2.messages()
+    # max_x2 |x1-x2|/2 : 4.5 at the ends, 2.5 in the middle (x1=5 -> |5-0|/2)
+    assert f2v[0] == 4.5 and f2v[5] == 2.5 and f2v[9] == 4.5
