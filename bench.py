@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- Max-Sum iterations/s on the north-star instance (BASELINE.json):
+random 3-colouring, 100k variables, average degree 4, binary factors, synchronous
+Max-Sum, reference arithmetic (f64).
+
+A "step" is one synchronous Max-Sum cycle over the whole factor graph (every
+F->V and V->F message recomputed once + value selection) = one k_sweep launch.
+Inputs are resident in HBM before the timed region (the graph is uploaded at
+engine creation).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
+                    [--dtype f64|f32] [--no-cpu-baseline]
+
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU);
+the factor graph is partitioned across the ranks and boundary V->F messages are
+exchanged once per cycle with an RCCL all-to-all (pydcop_amd/sharded.py).
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+
+
+def make_workload(name, n_gpus=1):
+    from pydcop_amd import generators as G
+    if name == "coloring_100k":     # the metric's configuration (north-star)
+        return G.random_coloring(100_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+    if name == "coloring_10k":      # BASELINE.json configs[1]
+        return G.random_coloring(10_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+    if name == "coloring_100k_hard":
+        return G.random_coloring(100_000, seed=0, variant="hard", names=False), "min"
+    if name == "ising_1024":        # configs[2]
+        return G.ising_grid(1024, 1024, seed=0, names=False), "min"
+    if name == "coloring_1m_deg6":  # configs[3]
+        return G.random_coloring(1_000_000, avg_degree=6, n_colors=3, seed=0, names=False), "min"
+    if name == "meeting_50k":       # configs[4]
+        return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max"
+    raise SystemExit(f"unknown workload {name}")
+
+
+def cpu_baseline(graph, mode, dtype, budget_s=12.0):
+    """The oracle (plain-C port of the reference algorithm) timed on the host
+    cores on a bounded number of cycles of the same workload."""
+    from oracle.maxsum_oracle import OracleMaxSum, build
+    from pydcop_amd.graph import Params
+    build()
+    cores = os.cpu_count() or 1
+    ora = OracleMaxSum(graph, Params(mode=mode, dtype=dtype), threads=cores)
+    ora.run(1)  # warm
+    t0 = time.perf_counter()
+    ora.run(2)
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(3, min(400, budget_s / max(per, 1e-6))))
+    t0 = time.perf_counter()
+    ora.run(n)
+    dt = time.perf_counter() - t0
+    ora.close()
+    return {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c with OpenMP on {cores} threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=200)
+    ap.add_argument("--workload", default="coloring_100k")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--layout-flags", type=int, default=0)
+    ap.add_argument("--graph-chunk", type=int, default=-1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import torch
+    from pydcop_amd.engine import MaxSumEngine
+    from pydcop_amd.graph import Params
+
+    graph, mode = make_workload(args.workload, args.gpus)
+    params = Params(mode=mode, dtype=args.dtype, layout_flags=args.layout_flags,
+                    graph_chunk=args.graph_chunk)
+    word = 8 if args.dtype == "f64" else 4
+    n_edges_total = graph.n_edges
+
+    if world > 1:
+        from pydcop_amd.sharded import ShardedMaxSum
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl")
+        runner = ShardedMaxSum(graph, params, rank, world, device=local_rank)
+        barrier = dist.barrier
+    else:
+        runner = MaxSumEngine(graph, params, device=local_rank)
+        barrier = lambda: None  # noqa: E731
+
+    def sync():
+        runner.sync()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    runner.run(args.warmup)
+    sync()
+    barrier()
+    t0 = time.perf_counter()
+    if world > 1:
+        runner.run(args.steps)
+        event_ms = None
+    else:
+        event_ms = runner.run_timed(args.steps)  # HIP events on the engine's stream
+    sync()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        its = args.steps / elapsed
+        bytes_cycle = graph.cycle_bytes(word)
+        out = {
+            "metric": "MaxSum iterations/sec on 100k-var random graph-coloring DCOP",
+            "value": its, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": args.workload, "n_vars": graph.n_vars,
+                       "n_factors": graph.n_factors, "n_edges": graph.n_edges,
+                       "domain": int(graph.dom_size.max()),
+                       "edge_messages_per_s": its * 2 * n_edges_total,
+                       "params": "damping 0.5/both, stability 0.1, start leafs",
+                       "parallelism": f"graph-partition x{args.gpus}"},
+        }
+        if event_ms is not None:
+            kernel_s = event_ms * 1e-3 / args.steps
+            achieved = bytes_cycle / kernel_s / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                               "kernel": "k_sweep", "algorithmic_bytes_per_launch": bytes_cycle,
+                               "avg_launch_us": kernel_s * 1e6}
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,609 @@
+// engine.hip -- the C-ABI of include/maxsum_gpu.h on top of the gfx950 kernels.
+//
+// Host side of one engine = one GPU, one HIP stream:
+//   create   build_layout (layout.cpp) -> upload -> cycle 0 (start) on the device
+//   run      one k_sweep launch per synchronous cycle (+ one k_factor_nary launch
+//            when the graph has LDS-tiled factor classes), ping-ponging the two
+//            record buffers; launch-bound cycle loops are replayed from a hipGraph
+//   get_*    copy back, undo the internal permutation (and the max-mode negation)
+// There is no host fallback: every cycle runs on the device.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/maxsum_gpu.h"
+#include "kernels.h"
+#include "layout.h"
+
+namespace mxs {
+
+static thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind,
+                            hipStream_t st) {
+    if (!bytes) return hipSuccess;
+    hipError_t e = hipMemcpyAsync(dst, src, bytes, kind, st);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(st);
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess)                                                               \
+            return fail(MXS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+template <typename U>
+struct DevBuf {
+    U* p = nullptr;
+    size_t n = 0;
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(U));
+    }
+    // Copies go through the engine's own (non-blocking) stream so that they are
+    // ordered with its kernels; the host vector may die right after the call.
+    hipError_t upload(const std::vector<U>& h, hipStream_t st) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        e = hipMemcpyAsync(p, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    }
+    ~DevBuf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+struct EngineBase {
+    virtual ~EngineBase() {}
+    virtual int init(const mxs_graph& g, const mxs_params& p, int device) = 0;
+    virtual int reset() = 0;
+    virtual int run_async(int n) = 0;
+    virtual int sync() = 0;
+    virtual int run_timed(int n, float* ms) = 0;
+    virtual int get_assignment(int32_t* idx, double* belief) = 0;
+    virtual int get_messages(double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) = 0;
+    virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
+    virtual int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) = 0;
+    virtual int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) = 0;
+    virtual int step_pack() = 0;
+    virtual int step_unpack() = 0;
+    Layout L;
+    mxs_params params{};
+    int64_t cycles = 0;
+    hipStream_t stream = nullptr;
+    int launches_per_cycle = 1;
+};
+
+template <typename T>
+struct Engine : EngineBase {
+    int device = 0;
+    int cur = 0;  // record buffer holding the messages of the last finished cycle
+    DevBuf<T> rec[2], tables, var_cost, belief, halo_send, halo_recv;
+    DevBuf<uint8_t> cF, cV, owned;
+    DevBuf<int32_t> vrowptr, vdom, vhalf, init_idx, edge_gen_factor, edge_dom, edge_half, sel;
+    DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
+    DevBuf<int64_t> vslot_rec, vcost_off, rec_off, eval_tab_off, halo_send_off, halo_recv_off;
+    DevBuf<FactorGen> fgen;
+    DevBuf<ClassInfo> classes;
+    DevBuf<BlockDesc> blocks_sweep, blocks_nary;
+    DevBuf<double> eval_tables, eval_var_cost, part_cost;
+    DevBuf<unsigned long long> part_viol;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipGraphExec_t graph_exec = nullptr;
+    int graph_cycles = 0;  // cycles per replay (even), 0 = no graph
+    bool graph_tried = false;
+    int64_t n_halo_send = 0, n_halo_recv = 0;
+    static constexpr int EVAL_BLOCKS = 1024;
+
+    ~Engine() override {
+        if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    SweepArgs<T> make_args(int from, bool start) const {
+        SweepArgs<T> a{};
+        a.old_rec = rec[from].p;
+        a.new_rec = rec[from ^ 1].p;
+        a.tables = tables.p;
+        a.var_cost = var_cost.p;
+        a.cF = cF.p;
+        a.cV = cV.p;
+        a.vrowptr = vrowptr.p;
+        a.vslot_rec = vslot_rec.p;
+        a.vdom = vdom.p;
+        a.vhalf = vhalf.p;
+        a.vcost_off = vcost_off.p;
+        a.init_idx = init_idx.p;
+        a.fgen = fgen.p;
+        a.edge_gen_factor = edge_gen_factor.p;
+        a.rec_off = rec_off.p;
+        a.edge_dom = edge_dom.p;
+        a.edge_half = edge_half.p;
+        a.sel = sel.p;
+        a.belief = belief.p;
+        a.classes = classes.p;
+        a.blocks = blocks_sweep.p;
+        a.damping = (T)params.damping;
+        a.stability = (T)params.stability;
+        a.damp_f = (params.damping_nodes & MXS_DAMP_FACTORS) ? 1 : 0;
+        a.damp_v = (params.damping_nodes & MXS_DAMP_VARS) ? 1 : 0;
+        a.start = start ? 1 : 0;
+        a.start_mode = params.start_messages;
+        return a;
+    }
+
+    // Enqueue one cycle reading buffer `from`.
+    int launch_cycle(int from, bool start) {
+        const SweepArgs<T> a = make_args(from, start);
+        const int nb = (int)L.blocks_sweep.size();
+        if (nb > 0) {
+            if (L.opt.aligned_halves)
+                hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(BLOCK), 0, stream, a);
+            else
+                hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(BLOCK), 0, stream, a);
+            HIP_TRY(hipGetLastError());
+        }
+        return MXS_OK;
+    }
+
+    int init(const mxs_graph& g, const mxs_params& p, int dev) override {
+        params = p;
+        device = dev;
+        std::string e = build_layout(g, p, L);
+        if (!e.empty()) return fail(MXS_E_INVALID, e);
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(MXS_E_NODEVICE, "no HIP device visible: the Max-Sum engine has no CPU fallback");
+        if (dev < 0 || dev >= count) return fail(MXS_E_INVALID, "device index out of range");
+        hipDeviceProp_t prop;
+        HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        if (std::string(prop.gcnArchName).find("gfx950") == std::string::npos)
+            return fail(MXS_E_NODEVICE, std::string("device is ") + prop.gcnArchName +
+                                            ", this library is built for gfx950 (MI355X) only");
+        HIP_TRY(hipSetDevice(dev));
+        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&ev0));
+        HIP_TRY(hipEventCreate(&ev1));
+
+        auto conv = [](const std::vector<double>& src) {
+            std::vector<T> out(src.size());
+            for (size_t i = 0; i < src.size(); ++i) out[i] = (T)src[i];
+            return out;
+        };
+        HIP_TRY(rec[0].alloc((size_t)L.rec_elems));
+        HIP_TRY(rec[1].alloc((size_t)L.rec_elems));
+        HIP_TRY(tables.upload(conv(L.tables), stream));
+        HIP_TRY(var_cost.upload(conv(L.var_cost), stream));
+        HIP_TRY(cF.alloc((size_t)L.n_edges));
+        HIP_TRY(cV.alloc((size_t)L.n_edges));
+        HIP_TRY(owned.upload(L.owned, stream));
+        HIP_TRY(vrowptr.upload(L.vrowptr, stream));
+        HIP_TRY(vdom.upload(L.vdom, stream));
+        HIP_TRY(vhalf.upload(L.vhalf, stream));
+        HIP_TRY(init_idx.upload(L.init_idx, stream));
+        HIP_TRY(edge_gen_factor.upload(L.edge_gen_factor, stream));
+        HIP_TRY(edge_dom.upload(L.edge_dom, stream));
+        HIP_TRY(edge_half.upload(L.edge_half, stream));
+        HIP_TRY(sel.alloc((size_t)L.n_vars));
+        HIP_TRY(belief.alloc((size_t)L.n_vars));
+        HIP_TRY(vslot_rec.upload(L.vslot_rec, stream));
+        HIP_TRY(vcost_off.upload(L.vcost_off, stream));
+        HIP_TRY(rec_off.upload(L.rec_off, stream));
+        HIP_TRY(fgen.upload(L.fgen, stream));
+        HIP_TRY(classes.upload(L.classes, stream));
+        HIP_TRY(blocks_sweep.upload(L.blocks_sweep, stream));
+        HIP_TRY(blocks_nary.upload(L.blocks_nary, stream));
+        // solution_cost data
+        HIP_TRY(frowptr.upload(L.frowptr, stream));
+        HIP_TRY(edge_var_int.upload(L.edge_var_int, stream));
+        HIP_TRY(eval_tab_off.upload(L.eval_tab_off, stream));
+        HIP_TRY(eval_tables.upload(L.eval_tables, stream));
+        HIP_TRY(eval_var_cost.upload(L.eval_var_cost, stream));
+        HIP_TRY(eval_idx.alloc((size_t)L.n_vars));
+        HIP_TRY(part_cost.alloc(EVAL_BLOCKS));
+        HIP_TRY(part_viol.alloc(EVAL_BLOCKS));
+        launches_per_cycle = 1 + (L.blocks_nary.empty() ? 0 : 1);
+        return reset();
+    }
+
+    int reset() override {
+        HIP_TRY(hipSetDevice(device));
+        for (int b = 0; b < 2; ++b)
+            HIP_TRY(hipMemsetAsync(rec[b].p, 0, std::max<size_t>(rec[b].n, 1) * sizeof(T), stream));
+        HIP_TRY(hipMemsetAsync(cF.p, 0, std::max<size_t>(cF.n, 1), stream));
+        HIP_TRY(hipMemsetAsync(cV.p, 0, std::max<size_t>(cV.n, 1), stream));
+        HIP_TRY(hipMemsetAsync(sel.p, 0, std::max<size_t>(sel.n, 1) * sizeof(int32_t), stream));
+        HIP_TRY(hipMemsetAsync(belief.p, 0, std::max<size_t>(belief.n, 1) * sizeof(T), stream));
+        cur = 0;
+        cycles = 0;
+        // cycle 0 == start() of every computation (computations.py:741-753)
+        int rc = launch_cycle(cur, true);
+        if (rc) return rc;
+        cur ^= 1;
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MXS_OK;
+    }
+
+    // Capture `chunk` (even) cycles into a hipGraph: launch-bound loops replay it.
+    void try_build_graph() {
+        graph_tried = true;
+        int chunk = params.graph_chunk;
+        if (chunk < 0) chunk = 32;
+        if (chunk < 2) return;
+        chunk &= ~1;
+        if (cur != 0) return;  // captured with parity 0; run() aligns first
+        hipGraph_t graph = nullptr;
+        if (hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return;
+        }
+        int from = 0;
+        bool ok = true;
+        for (int i = 0; i < chunk && ok; ++i) {
+            ok = launch_cycle(from, false) == MXS_OK;
+            from ^= 1;
+        }
+        if (hipStreamEndCapture(stream, &graph) != hipSuccess || !ok || !graph) {
+            (void)hipGetLastError();
+            if (graph) (void)hipGraphDestroy(graph);
+            return;
+        }
+        if (hipGraphInstantiate(&graph_exec, graph, nullptr, nullptr, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            graph_exec = nullptr;
+        } else {
+            graph_cycles = chunk;
+        }
+        (void)hipGraphDestroy(graph);
+    }
+
+    int run_async(int n) override {
+        if (n < 0) return fail(MXS_E_INVALID, "n_cycles must be >= 0");
+        HIP_TRY(hipSetDevice(device));
+        if (n_halo_recv > 0 || n_halo_send > 0)
+            return fail(MXS_E_STATE, "a sharded engine must be stepped with mxs_step_pack/unpack");
+        int left = n;
+        if (left > 0 && cur != 0) {  // align to the parity the graph was captured with
+            int rc = launch_cycle(cur, false);
+            if (rc) return rc;
+            cur ^= 1;
+            --left;
+        }
+        if (!graph_tried && left >= 2 * std::max(2, params.graph_chunk < 0 ? 32 : params.graph_chunk))
+            try_build_graph();
+        while (graph_exec && left >= graph_cycles) {
+            HIP_TRY(hipGraphLaunch(graph_exec, stream));
+            left -= graph_cycles;
+        }
+        for (; left > 0; --left) {
+            int rc = launch_cycle(cur, false);
+            if (rc) return rc;
+            cur ^= 1;
+        }
+        cycles += n;
+        return MXS_OK;
+    }
+
+    int sync() override {
+        HIP_TRY(hipStreamSynchronize(stream));
+        return MXS_OK;
+    }
+
+    int run_timed(int n, float* ms) override {
+        HIP_TRY(hipSetDevice(device));
+        // build the graph outside the timed region
+        if (!graph_tried && cur == 0 && n >= 2 * std::max(2, params.graph_chunk < 0 ? 32 : params.graph_chunk))
+            try_build_graph();
+        HIP_TRY(hipEventRecord(ev0, stream));
+        int rc = run_async(n);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev1, stream));
+        HIP_TRY(hipEventSynchronize(ev1));
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, ev0, ev1));
+        if (ms) *ms = t;
+        return MXS_OK;
+    }
+
+    int get_assignment(int32_t* idx, double* bel) override {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int nV = L.n_vars;
+        std::vector<int32_t> hs(nV);
+        std::vector<T> hb(nV);
+        if (nV) {
+            HIP_TRY(copy_sync(hs.data(), sel.p, sizeof(int32_t) * nV, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hb.data(), belief.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+        }
+        const double sign = L.is_max ? -1.0 : 1.0;
+        for (int vi = 0; vi < nV; ++vi) {
+            const int v = L.var_i2e[vi];
+            if (idx) idx[v] = hs[vi];
+            if (bel) bel[v] = sign * (double)hb[vi];
+        }
+        return MXS_OK;
+    }
+
+    int get_messages(double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) override {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int nE = L.n_edges;
+        std::vector<T> hr((size_t)L.rec_elems);
+        std::vector<uint8_t> hcF(nE), hcV(nE);
+        if (L.rec_elems)
+            HIP_TRY(copy_sync(hr.data(), rec[cur].p, sizeof(T) * hr.size(), hipMemcpyDeviceToHost, stream));
+        if (nE) {
+            HIP_TRY(copy_sync(hcF.data(), cF.p, nE, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hcV.data(), cV.p, nE, hipMemcpyDeviceToHost, stream));
+        }
+        // caller's message offsets: prefix of the edge domain sizes in caller order
+        std::vector<int64_t> ext_off(nE + 1, 0);
+        for (int e = 0; e < nE; ++e) ext_off[e + 1] = ext_off[e] + L.edge_dom[L.edge_e2i[e]];
+        const double sign = L.is_max ? -1.0 : 1.0;
+        for (int ei = 0; ei < nE; ++ei) {
+            const int e = L.edge_i2e[ei];
+            const int D = L.edge_dom[ei], H = L.edge_half[ei];
+            for (int d = 0; d < D; ++d) {
+                if (v2f) v2f[ext_off[e] + d] = sign * (double)hr[L.rec_off[ei] + d];
+                if (f2v) f2v[ext_off[e] + d] = sign * (double)hr[L.rec_off[ei] + H + d];
+            }
+            if (cf) cf[e] = hcF[ei];
+        }
+        if (cv)
+            for (int k = 0; k < nE; ++k) cv[L.edge_i2e[L.vslot_edge[k]]] = hcV[k];
+        return MXS_OK;
+    }
+
+    int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) override {
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(hipStreamSynchronize(stream));
+        const int nV = L.n_vars;
+        const int32_t* didx = sel.p;
+        if (idx) {
+            std::vector<int32_t> h(nV);
+            for (int vi = 0; vi < nV; ++vi) {
+                const int32_t x = idx[L.var_i2e[vi]];
+                if (x < 0 || x >= L.vdom[vi]) return fail(MXS_E_INVALID, "assignment index out of the domain");
+                h[vi] = x;
+            }
+            HIP_TRY(copy_sync(eval_idx.p, h.data(), sizeof(int32_t) * nV, hipMemcpyHostToDevice, stream));
+            didx = eval_idx.p;
+        }
+        EvalArgs a{};
+        a.frowptr = frowptr.p;
+        a.edge_var_int = edge_var_int.p;
+        a.edge_dom = edge_dom.p;
+        a.tab_off = eval_tab_off.p;
+        a.tables = eval_tables.p;
+        a.vdom = vdom.p;
+        a.vcost_off = vcost_off.p;
+        a.var_cost = eval_var_cost.p;
+        a.owned = owned.p;
+        a.idx = didx;
+        a.part_cost = part_cost.p;
+        a.part_viol = part_viol.p;
+        a.n_factors = L.n_factors;
+        a.n_vars = nV;
+        a.infinity = infinity;
+        const int total = L.n_factors + nV;
+        const int nb = std::max(1, std::min(EVAL_BLOCKS, (total + BLOCK - 1) / BLOCK));
+        hipLaunchKernelGGL(k_eval, dim3(nb), dim3(BLOCK), 0, stream, a);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> pc(nb);
+        std::vector<unsigned long long> pv(nb);
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(copy_sync(pc.data(), part_cost.p, sizeof(double) * nb, hipMemcpyDeviceToHost, stream));
+        HIP_TRY(copy_sync(pv.data(), part_viol.p, sizeof(unsigned long long) * nb, hipMemcpyDeviceToHost, stream));
+        double c = 0;
+        int64_t v = 0;
+        for (int i = 0; i < nb; ++i) {
+            c += pc[i];
+            v += (int64_t)pv[i];
+        }
+        if (cost) *cost = c;
+        if (viol) *viol = v;
+        return MXS_OK;
+    }
+
+    // ---- halo -------------------------------------------------------------
+    int build_elem_offsets(const int32_t* edges, int64_t n, std::vector<int64_t>& out) {
+        out.clear();
+        for (int64_t i = 0; i < n; ++i) {
+            const int32_t e = edges[i];
+            if (e < 0 || e >= L.n_edges) return fail(MXS_E_INVALID, "halo edge out of range");
+            const int ei = L.edge_e2i[e];
+            for (int d = 0; d < L.edge_dom[ei]; ++d) out.push_back(L.rec_off[ei] + d);  // V->F half
+        }
+        return MXS_OK;
+    }
+
+    int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) override {
+        HIP_TRY(hipSetDevice(device));
+        std::vector<int64_t> so, ro;
+        int rc = build_elem_offsets(se, ns, so);
+        if (rc) return rc;
+        rc = build_elem_offsets(re, nr, ro);
+        if (rc) return rc;
+        n_halo_send = (int64_t)so.size();
+        n_halo_recv = (int64_t)ro.size();
+        HIP_TRY(halo_send_off.upload(so, stream));
+        HIP_TRY(halo_recv_off.upload(ro, stream));
+        HIP_TRY(halo_send.alloc((size_t)n_halo_send));
+        HIP_TRY(halo_recv.alloc((size_t)n_halo_recv));
+        // the start messages of cycle 0 have to cross too: pack them now
+        return pack();
+    }
+
+    int pack() {
+        if (n_halo_send > 0) {
+            const int nb = (int)((n_halo_send + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, stream,
+                               (const T*)rec[cur].p, (const int64_t*)halo_send_off.p, halo_send.p,
+                               n_halo_send);
+            HIP_TRY(hipGetLastError());
+        }
+        return MXS_OK;
+    }
+
+    int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) override {
+        if (s) *s = halo_send.p;
+        if (sb) *sb = n_halo_send * (int64_t)sizeof(T);
+        if (r) *r = halo_recv.p;
+        if (rb) *rb = n_halo_recv * (int64_t)sizeof(T);
+        return MXS_OK;
+    }
+
+    int step_pack() override {
+        HIP_TRY(hipSetDevice(device));
+        int rc = launch_cycle(cur, false);
+        if (rc) return rc;
+        cur ^= 1;
+        cycles += 1;
+        return pack();
+    }
+
+    int step_unpack() override {
+        HIP_TRY(hipSetDevice(device));
+        if (n_halo_recv > 0) {
+            const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, stream, rec[cur].p,
+                               (const int64_t*)halo_recv_off.p, (const T*)halo_recv.p, n_halo_recv);
+            HIP_TRY(hipGetLastError());
+        }
+        return MXS_OK;
+    }
+};
+
+}  // namespace mxs
+
+struct mxs_engine {
+    std::unique_ptr<mxs::EngineBase> impl;
+};
+
+using mxs::fail;
+using mxs::g_err;
+
+#define CHECK_HANDLE(e)                                           \
+    do {                                                          \
+        if (!(e) || !(e)->impl) return fail(MXS_E_INVALID, "null engine handle"); \
+    } while (0)
+
+extern "C" {
+
+int mxs_device_count(int32_t* count) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    if (count) *count = n;
+    return MXS_OK;
+}
+
+int mxs_create(const mxs_graph* g, const mxs_params* p, int32_t device, mxs_engine** out) {
+    if (!g || !p || !out) return fail(MXS_E_INVALID, "null argument");
+    *out = nullptr;
+    try {
+        std::unique_ptr<mxs::EngineBase> impl;
+        if (p->dtype == MXS_DTYPE_F32) impl.reset(new mxs::Engine<float>());
+        else if (p->dtype == MXS_DTYPE_F64) impl.reset(new mxs::Engine<double>());
+        else return fail(MXS_E_INVALID, "invalid dtype");
+        int rc = impl->init(*g, *p, device);
+        if (rc) return rc;
+        *out = new mxs_engine{std::move(impl)};
+        return MXS_OK;
+    } catch (const std::bad_alloc&) {
+        return fail(MXS_E_NOMEM, "out of host memory");
+    } catch (const std::exception& ex) {
+        return fail(MXS_E_INVALID, ex.what());
+    }
+}
+
+int mxs_reset(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->reset(); }
+
+int mxs_run(mxs_engine* e, int32_t n) {
+    CHECK_HANDLE(e);
+    int rc = e->impl->run_async(n);
+    if (rc) return rc;
+    return e->impl->sync();
+}
+
+int mxs_run_timed(mxs_engine* e, int32_t n, float* ms) { CHECK_HANDLE(e); return e->impl->run_timed(n, ms); }
+int mxs_run_async(mxs_engine* e, int32_t n) { CHECK_HANDLE(e); return e->impl->run_async(n); }
+int mxs_sync(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->sync(); }
+
+int mxs_cycle_count(const mxs_engine* e, int64_t* cycles) {
+    CHECK_HANDLE(e);
+    if (cycles) *cycles = e->impl->cycles;
+    return MXS_OK;
+}
+
+int mxs_get_assignment(mxs_engine* e, int32_t* idx, double* belief) {
+    CHECK_HANDLE(e);
+    return e->impl->get_assignment(idx, belief);
+}
+
+int mxs_get_messages(mxs_engine* e, double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) {
+    CHECK_HANDLE(e);
+    return e->impl->get_messages(v2f, f2v, cv, cf);
+}
+
+int mxs_eval_cost(mxs_engine* e, const int32_t* idx, double infinity, double* cost, int64_t* viol) {
+    CHECK_HANDLE(e);
+    return e->impl->eval_cost(idx, infinity, cost, viol);
+}
+
+int mxs_cycle_bytes(const mxs_engine* e, int64_t* bytes, int32_t* launches) {
+    CHECK_HANDLE(e);
+    if (bytes) *bytes = e->impl->L.algorithmic_bytes;
+    if (launches) *launches = e->impl->launches_per_cycle;
+    return MXS_OK;
+}
+
+int mxs_halo_setup(mxs_engine* e, const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) {
+    CHECK_HANDLE(e);
+    if ((ns && !se) || (nr && !re) || ns < 0 || nr < 0) return fail(MXS_E_INVALID, "bad halo lists");
+    return e->impl->halo_setup(se, ns, re, nr);
+}
+
+int mxs_halo_buffers(mxs_engine* e, void** s, int64_t* sb, void** r, int64_t* rb) {
+    CHECK_HANDLE(e);
+    return e->impl->halo_buffers(s, sb, r, rb);
+}
+
+int mxs_step_pack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_pack(); }
+int mxs_step_unpack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_unpack(); }
+
+int mxs_stream(mxs_engine* e, void** stream) {
+    CHECK_HANDLE(e);
+    if (stream) *stream = (void*)e->impl->stream;
+    return MXS_OK;
+}
+
+int mxs_destroy(mxs_engine* e) {
+    if (!e) return MXS_OK;
+    delete e;
+    return MXS_OK;
+}
+
+const char* mxs_last_error(void) { return g_err.c_str(); }
+
+int32_t mxs_version(void) { return 100; }
+
+}  // extern "C"

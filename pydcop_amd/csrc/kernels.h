@@ -1,0 +1,546 @@
+// kernels.h -- gfx950 (CDNA4) device code of the synchronous Max-Sum sweep.
+//
+// One launch of `k_sweep` is one synchronous cycle: every factor's and every
+// variable's on_new_cycle (pydcop/algorithms/maxsum.py:339-379, 525-565).  Both
+// sides read only the record buffer of cycle t-1 and write the buffer of cycle t
+// (the reference's BSP barrier, pydcop/infrastructure/computations.py:684-788,
+// becomes the kernel boundary), so factor blocks and variable blocks run side by
+// side in the same grid.
+//
+// This is a min-plus semiring bounded by memory traffic -- no MFMA.  What matters
+// (cdna_hip_programming.md section 6): every byte of a record is used by the
+// thread that fetches it, tables are stored entry-major so a wave reads them as
+// one coalesced segment per entry, counters are never gathered, and all per-item
+// state lives in registers (compile-time D / degree bounds, no scratch).
+//
+// Max mode runs as min mode on negated costs (exact in IEEE arithmetic; the host
+// negates on upload/download), so only `<` appears below.
+//
+// Arithmetic follows the reference's evaluation order expression by expression
+// (see oracle/maxsum_oracle.c, which restates it on the CPU); build with
+// -ffp-contract=off so no FMA contraction changes a rounding.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+
+#include "layout.h"
+
+namespace mxs {
+
+constexpr int SAME_COUNT = 4;  // maxsum.py:106
+
+template <typename T>
+struct SweepArgs {
+    const T* old_rec;   // records of cycle t-1
+    T* new_rec;         // records of cycle t
+    const T* tables;
+    const T* var_cost;
+    uint8_t* cF;        // [n_edges] factor-major send counters
+    uint8_t* cV;        // [n_edges] variable-major send counters
+    const int32_t* vrowptr;
+    const int64_t* vslot_rec;
+    const int32_t* vdom;
+    const int32_t* vhalf;
+    const int64_t* vcost_off;
+    const int32_t* init_idx;
+    const FactorGen* fgen;
+    const int32_t* edge_gen_factor;
+    const int64_t* rec_off;
+    const int32_t* edge_dom;
+    const int32_t* edge_half;
+    int32_t* sel;
+    T* belief;
+    const ClassInfo* classes;
+    const BlockDesc* blocks;
+    T damping;
+    T stability;
+    int32_t damp_f;      // damping_nodes in {factors, both}
+    int32_t damp_v;      // damping_nodes in {vars, both}
+    int32_t start;       // 1: cycle 0 (on_start), 0: regular cycle
+    int32_t start_mode;  // MXS_START_*
+};
+
+template <typename T>
+__device__ __forceinline__ T pos_inf() {
+    return (T)INFINITY;
+}
+__device__ __forceinline__ double absT(double x) { return fabs(x); }
+__device__ __forceinline__ float absT(float x) { return fabsf(x); }
+
+// approx_match, maxsum.py:688-710, one component (prev is not None).
+template <typename T>
+__device__ __forceinline__ bool comp_match(T c, T prev_c, T stability) {
+    if (prev_c != c) {
+        const T delta = absT(prev_c - c);
+        if (prev_c + c != (T)0) {
+            if (!(((T)2 * delta / absT(prev_c + c)) < stability)) return false;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+// apply_damping (maxsum.py:679-685) + the send rule of on_new_cycle
+// (maxsum.py:349-377 / 540-564) on a register-resident message.  On return `m`
+// is what the receiver holds after this cycle; returns the new send counter.
+template <typename T, int D>
+__device__ __forceinline__ uint8_t damp_and_filter(T (&m)[D], const T (&prev)[D], uint8_t cnt,
+                                                   bool damp_on, T damping, T stability) {
+    if (cnt > 0 && damp_on) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = damping * prev[d] + ((T)1 - damping) * m[d];
+    }
+    bool match = cnt > 0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) match = match && comp_match(m[d], prev[d], stability);
+    if (!match) return 1;                                   // sent (first time)
+    if (cnt < SAME_COUNT) return (uint8_t)(cnt + 1);        // sent again
+#pragma unroll
+    for (int d = 0; d < D; ++d) m[d] = prev[d];             // not sent: receiver keeps
+    return cnt;
+}
+
+template <bool ALIGNED, typename T>
+__device__ __forceinline__ const T* rec_ptr(const T* p) {
+    if (ALIGNED) return (const T*)__builtin_assume_aligned(p, 16);
+    return p;
+}
+template <bool ALIGNED, typename T>
+__device__ __forceinline__ T* rec_ptr(T* p) {
+    if (ALIGNED) return (T*)__builtin_assume_aligned(p, 16);
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// Factor side, register classes (thread per factor).
+// factor_costs_for_var, maxsum.py:382-447:  out_i[d] = min over the other
+// variables' values of  table[..] + sum of their messages.
+// ---------------------------------------------------------------------------
+template <typename T, int D, bool ALIGNED>
+__device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    const int H = ci.H;
+    const int64_t ro = ci.rec_base + (int64_t)j * 2 * H;
+    const T* r = rec_ptr<ALIGNED>(a.old_rec + ro);
+    T* w = rec_ptr<ALIGNED>(a.new_rec + ro) + H;
+    const int e = ci.edge_base + j;
+    T out[D], prev[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        prev[d] = r[H + d];
+        // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
+        out[d] = a.tables[ci.tab_base + (int64_t)d * ci.count + j] + (T)0;
+    }
+    if (a.start) {  // on_start, maxsum.py:311-319: unary factors send in every mode
+#pragma unroll
+        for (int d = 0; d < D; ++d) w[d] = out[d];
+        a.cF[e] = 0;
+        return;
+    }
+    const uint8_t c = damp_and_filter<T, D>(out, prev, a.cF[e], a.damp_f != 0, a.damping, a.stability);
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = out[d];
+    a.cF[e] = c;
+}
+
+template <typename T, int D, bool ALIGNED>
+__device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    const int H = ci.H;
+    const int64_t ro = ci.rec_base + (int64_t)j * 4 * H;  // two records of 2H
+    const T* r = rec_ptr<ALIGNED>(a.old_rec + ro);
+    T* w = rec_ptr<ALIGNED>(a.new_rec + ro);
+    const int e = ci.edge_base + 2 * j;
+    T m0[D], p0[D], m1[D], p1[D], tab[D * D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        m0[d] = r[d];              // V->F message of scope variable 0
+        p0[d] = r[H + d];          // F->V message last sent to variable 0
+        m1[d] = r[2 * H + d];
+        p1[d] = r[3 * H + d];
+    }
+#pragma unroll
+    for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
+    T o0[D], o1[D];
+#pragma unroll
+    for (int x = 0; x < D; ++x) {
+        T best0 = pos_inf<T>(), best1 = pos_inf<T>();
+#pragma unroll
+        for (int y = 0; y < D; ++y) {
+            const T c0 = tab[x * D + y] + ((T)0 + m1[y]);  // to var 0, value x; other = var 1
+            if (best0 > c0) best0 = c0;
+            const T c1 = tab[y * D + x] + ((T)0 + m0[y]);  // to var 1, value x; other = var 0
+            if (best1 > c1) best1 = c1;
+        }
+        o0[x] = best0;
+        o1[x] = best1;
+    }
+    if (a.start) {  // only start_messages == all makes a binary factor send (maxsum.py:320-328)
+        const bool sends = a.start_mode == MXS_START_ALL;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            w[H + d] = sends ? o0[d] : (T)0;
+            w[3 * H + d] = sends ? o1[d] : (T)0;
+        }
+        a.cF[e] = 0;
+        a.cF[e + 1] = 0;
+        return;
+    }
+    const uint8_t c0 = damp_and_filter<T, D>(o0, p0, a.cF[e], a.damp_f != 0, a.damping, a.stability);
+    const uint8_t c1 = damp_and_filter<T, D>(o1, p1, a.cF[e + 1], a.damp_f != 0, a.damping, a.stability);
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        w[H + d] = o0[d];
+        w[3 * H + d] = o1[d];
+    }
+    a.cF[e] = c0;
+    a.cF[e + 1] = c1;
+}
+
+// ---------------------------------------------------------------------------
+// Factor side, generic class: thread per edge, any arity / domain sizes, scalar
+// loops only (no local arrays -> no scratch).
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ T factor_gen_value(const SweepArgs<T>& a, const FactorGen& fg, int pos,
+                                              int d, int64_t others) {
+    T best = pos_inf<T>();
+    for (int64_t lin = 0; lin < others; ++lin) {
+        int64_t rem = others, l = lin, t = 0;
+        T sum_cost = (T)0;
+        for (int i = 0; i < fg.arity; ++i) {  // scope in dimensions order
+            const int e = fg.edge_base + i;
+            const int Di = a.edge_dom[e];
+            int digit;
+            if (i == pos) {
+                digit = d;
+            } else {
+                rem /= Di;
+                digit = (int)(l / rem);
+                l -= (int64_t)digit * rem;
+                sum_cost += a.old_rec[a.rec_off[e] + digit];  // V->F half
+            }
+            t = t * Di + digit;
+        }
+        const T cur = a.tables[fg.tab_off + t] + sum_cost;
+        if (best > cur) best = cur;
+    }
+    return best;
+}
+
+template <typename T>
+__device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    const int e = ci.edge_base + j;
+    const FactorGen fg = a.fgen[a.edge_gen_factor[e]];
+    const int pos = e - fg.edge_base;
+    const int D = a.edge_dom[e], H = a.edge_half[e];
+    const T* prev = a.old_rec + a.rec_off[e] + H;
+    T* w = a.new_rec + a.rec_off[e] + H;
+    int64_t others = 1;
+    for (int i = 0; i < fg.arity; ++i)
+        if (i != pos) others *= a.edge_dom[fg.edge_base + i];
+    if (a.start) {
+        const bool sends = (fg.arity == 1 && a.start_mode != MXS_START_ALL) ||
+                           a.start_mode == MXS_START_ALL;
+        for (int d = 0; d < D; ++d) w[d] = sends ? factor_gen_value(a, fg, pos, d, others) : (T)0;
+        a.cF[e] = 0;
+        return;
+    }
+    const uint8_t cnt = a.cF[e];
+    const bool damp = cnt > 0 && a.damp_f;
+    bool match = cnt > 0;
+    for (int d = 0; d < D; ++d) {
+        T m = factor_gen_value(a, fg, pos, d, others);
+        const T p = prev[d];
+        if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+        if (match) match = comp_match(m, p, a.stability);
+        w[d] = m;
+    }
+    uint8_t out = 1;
+    if (match) {
+        if (cnt < SAME_COUNT) {
+            out = (uint8_t)(cnt + 1);
+        } else {
+            out = cnt;
+            for (int d = 0; d < D; ++d) w[d] = prev[d];
+        }
+    }
+    a.cF[e] = out;
+}
+
+// ---------------------------------------------------------------------------
+// Variable side, register class: thread per variable, D and a degree bound are
+// compile-time so the deg incoming messages stay in VGPRs.
+//   select_value      maxsum.py:584-620
+//   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
+// ---------------------------------------------------------------------------
+template <typename T, int D, int MAXDEG, bool ALIGNED>
+__device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    const int v = ci.first + j;
+    const int H = ci.H;
+    const int k0 = a.vrowptr[v];
+    const int deg = a.vrowptr[v + 1] - k0;
+    T c[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)j * D + d];
+    int64_t off[MAXDEG];
+    T in[MAXDEG][D], pv[MAXDEG][D];
+    uint8_t cnt[MAXDEG];
+#pragma unroll
+    for (int k = 0; k < MAXDEG; ++k) {
+        off[k] = 0;
+        cnt[k] = 0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) in[k][d] = pv[k][d] = (T)0;
+        if (k < deg) {
+            off[k] = a.vslot_rec[k0 + k];
+            cnt[k] = a.cV[k0 + k];
+            const T* r = rec_ptr<ALIGNED>(a.old_rec + off[k]);
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                pv[k][d] = r[d];      // V->F message last sent on this edge
+                in[k][d] = r[H + d];  // F->V message held from this factor
+            }
+        }
+    }
+    // select_value: belief[d] = cost(d) + sum of the factor messages, first optimum
+    int best = 0;
+    T best_c = (T)0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        T b = c[d];
+#pragma unroll
+        for (int k = 0; k < MAXDEG; ++k)
+            if (k < deg) b += in[k][d];
+        if (d == 0 || b < best_c) {
+            best = d;
+            best_c = b;
+        }
+    }
+    if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+        best = a.init_idx[v];
+        best_c = (T)0;
+    }
+    a.sel[v] = best;
+    a.belief[v] = best_c;
+    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                             a.start_mode != MXS_START_LEAFS;
+#pragma unroll
+    for (int ko = 0; ko < MAXDEG; ++ko) {
+        if (ko < deg) {
+            T m[D];
+            T sum_cost = (T)0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                T x = c[d];
+#pragma unroll
+                for (int k = 0; k < MAXDEG; ++k)
+                    if (k < deg && k != ko) {
+                        sum_cost += in[k][d];
+                        x += in[k][d];
+                    }
+                m[d] = x;
+            }
+            const T avg = sum_cost / (T)D;
+#pragma unroll
+            for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
+            T* w = rec_ptr<ALIGNED>(a.new_rec + off[ko]);
+            if (a.start) {
+#pragma unroll
+                for (int d = 0; d < D; ++d) w[d] = start_sends ? m[d] : (T)0;
+                a.cV[k0 + ko] = 0;
+            } else {
+                const uint8_t co = damp_and_filter<T, D>(m, pv[ko], cnt[ko], a.damp_v != 0,
+                                                         a.damping, a.stability);
+#pragma unroll
+                for (int d = 0; d < D; ++d) w[d] = m[d];
+                a.cV[k0 + ko] = co;
+            }
+        }
+    }
+}
+
+// Variable side, generic class: thread per variable, any domain size / degree,
+// scalar loops only.  Sums run in the reference's order (d outer, factors inner).
+template <typename T>
+__device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    if (ci.start_only && !a.start) return;  // a variable without factor never cycles
+    const int v = ci.first + j;
+    const int D = a.vdom[v];
+    const int H = a.vhalf[v];  // all records of a variable share the half stride
+    const int k0 = a.vrowptr[v], k1 = a.vrowptr[v + 1];
+    const int deg = k1 - k0;
+    const T* c = a.var_cost + a.vcost_off[v];
+    int best = 0;
+    T best_c = (T)0;
+    for (int d = 0; d < D; ++d) {
+        T b = c[d];
+        for (int k = k0; k < k1; ++k) b += a.old_rec[a.vslot_rec[k] + H + d];
+        if (d == 0 || b < best_c) {
+            best = d;
+            best_c = b;
+        }
+    }
+    if (a.start && a.init_idx[v] >= 0) {
+        best = a.init_idx[v];
+        best_c = (T)0;
+    }
+    a.sel[v] = best;
+    a.belief[v] = best_c;
+    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                             a.start_mode != MXS_START_LEAFS;
+    for (int ko = k0; ko < k1; ++ko) {
+        const int64_t oo = a.vslot_rec[ko];
+        const T* prev = a.old_rec + oo;
+        T* w = a.new_rec + oo;
+        T sum_cost = (T)0;
+        for (int d = 0; d < D; ++d)
+            for (int k = k0; k < k1; ++k)
+                if (k != ko) sum_cost += a.old_rec[a.vslot_rec[k] + H + d];
+        const T avg = sum_cost / (T)D;
+        const uint8_t cnt = a.start ? 0 : a.cV[ko];
+        const bool damp = cnt > 0 && a.damp_v;
+        bool match = cnt > 0;
+        for (int d = 0; d < D; ++d) {
+            T m = c[d];
+            for (int k = k0; k < k1; ++k)
+                if (k != ko) m += a.old_rec[a.vslot_rec[k] + H + d];
+            m = m - avg;
+            if (a.start) {
+                w[d] = start_sends ? m : (T)0;
+                continue;
+            }
+            const T p = prev[d];
+            if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+            if (match) match = comp_match(m, p, a.stability);
+            w[d] = m;
+        }
+        uint8_t out = 1;
+        if (a.start) {
+            out = 0;
+        } else if (match) {
+            if (cnt < SAME_COUNT) {
+                out = (uint8_t)(cnt + 1);
+            } else {
+                out = cnt;
+                for (int d = 0; d < D; ++d) w[d] = prev[d];
+            }
+        }
+        a.cV[ko] = out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// The sweep: one block = up to blockDim.x items of one class.
+// ---------------------------------------------------------------------------
+template <typename T, bool ALIGNED, int D>
+__device__ __forceinline__ void dispatch_d(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    switch (ci.kind) {
+        case K_F_UNARY: factor_unary<T, D, ALIGNED>(a, ci, j); break;
+        case K_F_BIN: factor_binary<T, D, ALIGNED>(a, ci, j); break;
+        case K_V_REG:
+            if (ci.maxdeg <= 4) variable_reg<T, D, 4, ALIGNED>(a, ci, j);
+            else variable_reg<T, D, 8, ALIGNED>(a, ci, j);
+            break;
+        default: break;
+    }
+}
+
+template <typename T, bool ALIGNED>
+__global__ void __launch_bounds__(BLOCK) k_sweep(SweepArgs<T> a) {
+    const BlockDesc bd = a.blocks[blockIdx.x];
+    const ClassInfo ci = a.classes[bd.cls];
+    const int j = bd.item + (int)threadIdx.x;
+    if (j >= ci.count) return;
+    switch (ci.kind) {
+        case K_F_GEN: factor_generic<T>(a, ci, j); break;
+        case K_V_GEN: variable_generic<T>(a, ci, j); break;
+        default:
+            switch (ci.D) {
+                case 2: dispatch_d<T, ALIGNED, 2>(a, ci, j); break;
+                case 3: dispatch_d<T, ALIGNED, 3>(a, ci, j); break;
+                case 4: dispatch_d<T, ALIGNED, 4>(a, ci, j); break;
+                default: break;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// solution_cost (pydcop/dcop/dcop.py:319-367): per-block partial sums of the
+// factor and variable costs of an assignment; a term equal to `infinity` is a
+// violation.  Always f64 on row-major un-negated tables.
+// ---------------------------------------------------------------------------
+struct EvalArgs {
+    const int32_t* frowptr;       // [n_factors+1] internal
+    const int32_t* edge_var_int;  // [n_edges]
+    const int32_t* edge_dom;
+    const int64_t* tab_off;
+    const double* tables;
+    const int32_t* vdom;
+    const int64_t* vcost_off;
+    const double* var_cost;
+    const uint8_t* owned;
+    const int32_t* idx;           // [n_vars] internal order
+    double* part_cost;            // [gridDim.x]
+    unsigned long long* part_viol;
+    int32_t n_factors, n_vars;
+    double infinity;
+};
+
+__global__ void __launch_bounds__(BLOCK) k_eval(EvalArgs a) {
+    __shared__ double s_cost[BLOCK];
+    __shared__ unsigned long long s_viol[BLOCK];
+    double cost = 0.0;
+    unsigned long long viol = 0;
+    const int stride = (int)(gridDim.x * blockDim.x);
+    for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < a.n_factors + a.n_vars; i += stride) {
+        double r;
+        if (i < a.n_factors) {
+            int64_t lin = 0;
+            for (int e = a.frowptr[i]; e < a.frowptr[i + 1]; ++e)
+                lin = lin * a.edge_dom[e] + a.idx[a.edge_var_int[e]];
+            r = a.tables[a.tab_off[i] + lin];
+        } else {
+            const int v = i - a.n_factors;
+            if (!a.owned[v]) continue;
+            r = a.var_cost[a.vcost_off[v] + a.idx[v]];
+        }
+        if (r != a.infinity) cost += r;
+        else viol += 1;
+    }
+    s_cost[threadIdx.x] = cost;
+    s_viol[threadIdx.x] = viol;
+    __syncthreads();
+    for (int s = BLOCK / 2; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) {
+            s_cost[threadIdx.x] += s_cost[threadIdx.x + s];
+            s_viol[threadIdx.x] += s_viol[threadIdx.x + s];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        a.part_cost[blockIdx.x] = s_cost[0];
+        a.part_viol[blockIdx.x] = s_viol[0];
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Halo (multi-GPU): pack the V->F halves of the cut edges this shard owns into a
+// dense send buffer / scatter the received ones into the ghost records.
+// One thread per (edge, d) element; `elem_edge`/`elem_d` are precomputed.
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_halo_pack(const T* rec, const int64_t* elem_off, T* out,
+                                                     int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = rec[elem_off[i]];
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_halo_unpack(T* rec, const int64_t* elem_off, const T* in,
+                                                       int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) rec[elem_off[i]] = in[i];
+}
+
+}  // namespace mxs

@@ -1,0 +1,353 @@
+// layout.cpp -- see layout.h.  Pure host C++ (no HIP): O(E) compilation of the
+// caller's flat factor graph into classes, records and block descriptors.
+#include "layout.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <sstream>
+
+namespace mxs {
+
+LayoutOptions options_from_params(const mxs_params& p) {
+    LayoutOptions o;
+    o.word = (p.dtype == MXS_DTYPE_F32) ? 4 : 8;
+    const int f = p.layout_flags;
+    o.aligned_halves = !(f & 1);  // bit0: tight records (halves not 16-B aligned)
+    o.pad64 = (f & 2) != 0;       // bit1: pad records to 64 bytes
+    o.no_specialise = (f & 4) != 0;   // bit2: generic kernels only
+    o.sort_by_degree = !(f & 8);      // bit3: keep the caller's variable order
+    if (f & 16) o.nary_min_entries = (int64_t)1 << 60;  // bit4: no LDS n-ary kernel
+    return o;
+}
+
+int Layout::half_stride(int D) const {
+    int H = D;
+    if (opt.aligned_halves) {
+        const int a = 16 / opt.word;
+        H = (D + a - 1) / a * a;
+    }
+    if (opt.pad64) {
+        const int per64 = 64 / opt.word;  // elements in 64 bytes
+        if (2 * H <= per64) {             // round the record up to 64/32/16 bytes
+            int rec = per64;
+            while (rec / 2 >= 2 * H && rec / 2 >= 16 / opt.word) rec /= 2;
+            H = rec / 2;
+        }
+    }
+    return H;
+}
+
+namespace {
+
+struct FKey {
+    int kind, D;
+    bool operator<(const FKey& o) const { return kind != o.kind ? kind < o.kind : D < o.D; }
+    bool operator==(const FKey& o) const { return kind == o.kind && D == o.D; }
+};
+
+std::string validate(const mxs_graph& g) {
+    std::ostringstream err;
+    if (g.n_vars < 0 || g.n_factors < 0 || g.n_edges < 0) return "negative size";
+    if (g.n_vars && (!g.dom_size || !g.var_cost || !g.var_rowptr)) return "null variable arrays";
+    if (g.n_factors && (!g.factor_rowptr || !g.table_off || !g.tables)) return "null factor arrays";
+    if (g.n_edges && (!g.edge_var || !g.var_edges)) return "null edge arrays";
+    for (int32_t v = 0; v < g.n_vars; ++v)
+        if (g.dom_size[v] < 1 || g.dom_size[v] > 4096) {
+            err << "variable " << v << ": domain size " << g.dom_size[v] << " not in 1..4096";
+            return err.str();
+        }
+    if (g.n_factors) {
+        if (g.factor_rowptr[0] != 0 || g.factor_rowptr[g.n_factors] != g.n_edges)
+            return "factor_rowptr does not span the edges";
+        if (g.table_off[0] != 0) return "table_off[0] must be 0";
+    } else if (g.n_edges) {
+        return "edges without factors";
+    }
+    for (int32_t f = 0; f < g.n_factors; ++f) {
+        const int32_t e0 = g.factor_rowptr[f], e1 = g.factor_rowptr[f + 1];
+        if (e1 <= e0) { err << "factor " << f << " has no variable"; return err.str(); }
+        if (e1 - e0 > 16) { err << "factor " << f << ": arity > 16 not supported"; return err.str(); }
+        int64_t size = 1;
+        for (int32_t e = e0; e < e1; ++e) {
+            const int32_t v = g.edge_var[e];
+            if (v < 0 || v >= g.n_vars) { err << "edge " << e << ": variable out of range"; return err.str(); }
+            for (int32_t e2 = e0; e2 < e; ++e2)
+                if (g.edge_var[e2] == v) { err << "factor " << f << " lists variable " << v << " twice"; return err.str(); }
+            size *= g.dom_size[v];
+            if (size > ((int64_t)1 << 40)) { err << "factor " << f << ": table too large"; return err.str(); }
+        }
+        if (g.table_off[f + 1] - g.table_off[f] != size) {
+            err << "factor " << f << ": table_off inconsistent with scope (" << size << " entries expected)";
+            return err.str();
+        }
+    }
+    if (g.n_vars) {
+        if (g.var_rowptr[0] != 0 || g.var_rowptr[g.n_vars] != g.n_edges)
+            return "var_rowptr does not span the edges";
+        std::vector<uint8_t> seen(g.n_edges, 0);
+        for (int32_t v = 0; v < g.n_vars; ++v) {
+            if (g.var_rowptr[v + 1] < g.var_rowptr[v]) return "var_rowptr not monotone";
+            for (int32_t k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k) {
+                const int32_t e = g.var_edges[k];
+                if (e < 0 || e >= g.n_edges || seen[e] || g.edge_var[e] != v) {
+                    err << "var_edges[" << k << "] inconsistent";
+                    return err.str();
+                }
+                seen[e] = 1;
+            }
+            if (g.init_idx && g.init_idx[v] >= g.dom_size[v]) return "init_idx out of the domain";
+        }
+    }
+    return "";
+}
+
+}  // namespace
+
+std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
+    {
+        std::string e = validate(g);
+        if (!e.empty()) return e;
+    }
+    if (p.mode != MXS_MODE_MIN && p.mode != MXS_MODE_MAX) return "invalid mode";
+    if (p.damping_nodes < 0 || p.damping_nodes > 3) return "invalid damping_nodes";
+    if (p.start_messages < 0 || p.start_messages > 2) return "invalid start_messages";
+    if (p.dtype != MXS_DTYPE_F64 && p.dtype != MXS_DTYPE_F32) return "invalid dtype";
+
+    L = Layout();
+    L.opt = options_from_params(p);
+    L.n_vars = g.n_vars;
+    L.n_factors = g.n_factors;
+    L.n_edges = g.n_edges;
+    L.is_max = (p.mode == MXS_MODE_MAX);
+    const double sign = L.is_max ? -1.0 : 1.0;  // max-sum == min-sum on negated costs
+    const int nV = g.n_vars, nF = g.n_factors, nE = g.n_edges;
+
+    // ---- classify factors ------------------------------------------------
+    std::vector<FKey> fkey(nF);
+    for (int f = 0; f < nF; ++f) {
+        const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
+        const int D0 = g.dom_size[g.edge_var[e0]];
+        const int64_t entries = g.table_off[f + 1] - g.table_off[f];
+        FKey k{K_F_GEN, 0};
+        if (!L.opt.no_specialise) {
+            if (ar == 1 && D0 >= 2 && D0 <= MAX_REG_D) k = FKey{K_F_UNARY, D0};
+            else if (ar == 2 && D0 >= 2 && D0 <= MAX_REG_D && g.dom_size[g.edge_var[e0 + 1]] == D0)
+                k = FKey{K_F_BIN, D0};
+            else if (ar >= 2 && ar <= 4 && entries >= L.opt.nary_min_entries &&
+                     entries * L.opt.word <= L.opt.nary_max_bytes)
+                k = FKey{K_F_NARY, 0};
+        }
+        fkey[f] = k;
+    }
+    L.factor_i2e.resize(nF);
+    std::iota(L.factor_i2e.begin(), L.factor_i2e.end(), 0);
+    std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(),
+                     [&](int a, int b) { return fkey[a] < fkey[b]; });
+
+    // ---- internal edges, records ------------------------------------------
+    L.edge_i2e.resize(nE);
+    L.edge_e2i.resize(nE);
+    L.frowptr.assign(nF + 1, 0);
+    L.rec_off.resize(nE);
+    L.edge_dom.resize(nE);
+    L.edge_half.resize(nE);
+    L.edge_gen_factor.assign(nE, -1);
+    {
+        int ei = 0;
+        int64_t off = 0;
+        for (int fi = 0; fi < nF; ++fi) {
+            const int f = L.factor_i2e[fi];
+            L.frowptr[fi] = ei;
+            for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e, ++ei) {
+                L.edge_i2e[ei] = e;
+                L.edge_e2i[e] = ei;
+                const int D = g.dom_size[g.edge_var[e]];
+                const int H = L.half_stride(D);
+                L.edge_dom[ei] = D;
+                L.edge_half[ei] = H;
+                L.rec_off[ei] = off;
+                off += 2 * (int64_t)H;
+            }
+        }
+        L.frowptr[nF] = ei;
+        L.rec_elems = off;
+        if (off > ((int64_t)1 << 31) - 64) return "message buffer exceeds 2^31 elements";
+    }
+
+    // ---- classify and order variables ---------------------------------------
+    std::vector<int> vkind(nV), vsort(nV);
+    for (int v = 0; v < nV; ++v) {
+        const int deg = g.var_rowptr[v + 1] - g.var_rowptr[v];
+        const int D = g.dom_size[v];
+        const bool own = !g.var_owned || g.var_owned[v];
+        int kind, sub;
+        if (!own) { kind = 90; sub = 0; }                       // ghost: never swept
+        else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
+        else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_REG_DEG) {
+            kind = K_V_REG; sub = D * 16 + (deg <= 4 ? 4 : 8);
+        } else { kind = K_V_GEN; sub = 0; }
+        vkind[v] = kind;
+        // sort key: class, then degree (uniform waves), stable in caller order
+        vsort[v] = (kind * 1024 + sub) * 4096 + (L.opt.sort_by_degree ? std::min(deg, 4095) : 0);
+    }
+    L.var_i2e.resize(nV);
+    std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);
+    std::stable_sort(L.var_i2e.begin(), L.var_i2e.end(),
+                     [&](int a, int b) { return vsort[a] < vsort[b]; });
+    L.var_e2i.resize(nV);
+    for (int vi = 0; vi < nV; ++vi) L.var_e2i[L.var_i2e[vi]] = vi;
+
+    L.vrowptr.assign(nV + 1, 0);
+    L.vslot_rec.resize(nE);
+    L.vslot_edge.resize(nE);
+    L.vdom.resize(nV);
+    L.vhalf.resize(nV);
+    L.vcost_off.resize(nV);
+    L.init_idx.assign(nV, -1);
+    L.owned.assign(nV, 1);
+    L.edge_var_int.resize(nE);
+    {
+        std::vector<int64_t> ext_cost_off(nV + 1, 0);
+        for (int v = 0; v < nV; ++v) ext_cost_off[v + 1] = ext_cost_off[v] + g.dom_size[v];
+        L.var_cost.resize(ext_cost_off[nV]);
+        L.eval_var_cost.resize(ext_cost_off[nV]);
+        int k = 0;
+        int64_t coff = 0;
+        for (int vi = 0; vi < nV; ++vi) {
+            const int v = L.var_i2e[vi];
+            L.vrowptr[vi] = k;
+            for (int kk = g.var_rowptr[v]; kk < g.var_rowptr[v + 1]; ++kk, ++k) {
+                const int ei = L.edge_e2i[g.var_edges[kk]];
+                L.vslot_edge[k] = ei;
+                L.vslot_rec[k] = L.rec_off[ei];
+                L.edge_var_int[ei] = vi;
+            }
+            L.vdom[vi] = g.dom_size[v];
+            L.vhalf[vi] = L.half_stride(g.dom_size[v]);
+            L.vcost_off[vi] = coff;
+            for (int d = 0; d < g.dom_size[v]; ++d) {
+                L.var_cost[coff + d] = sign * g.var_cost[ext_cost_off[v] + d];
+                L.eval_var_cost[coff + d] = g.var_cost[ext_cost_off[v] + d];
+            }
+            coff += g.dom_size[v];
+            if (g.init_idx) L.init_idx[vi] = g.init_idx[v];
+            if (g.var_owned) L.owned[vi] = g.var_owned[v] ? 1 : 0;
+        }
+        L.vrowptr[nV] = k;
+    }
+
+    // ---- factor classes, tables, blocks ---------------------------------------
+    L.eval_tab_off.assign(nF + 1, 0);
+    for (int fi = 0; fi < nF; ++fi) {
+        const int f = L.factor_i2e[fi];
+        L.eval_tab_off[fi + 1] = L.eval_tab_off[fi] + (g.table_off[f + 1] - g.table_off[f]);
+    }
+    L.eval_tables.resize(L.eval_tab_off[nF]);
+    L.tables.resize(L.eval_tab_off[nF]);
+    for (int fi = 0; fi < nF; ++fi) {
+        const int f = L.factor_i2e[fi];
+        std::copy(g.tables + g.table_off[f], g.tables + g.table_off[f + 1],
+                  L.eval_tables.begin() + L.eval_tab_off[fi]);
+    }
+    auto add_blocks = [&](std::vector<BlockDesc>& blocks, int cls, int count, int per_block) {
+        L.classes[cls].block_base = (int)blocks.size();
+        for (int i = 0; i < count; i += per_block) blocks.push_back(BlockDesc{cls, i});
+    };
+    for (int fi = 0; fi < nF;) {
+        const FKey key = fkey[L.factor_i2e[fi]];
+        int fj = fi;
+        while (fj < nF && fkey[L.factor_i2e[fj]] == key) ++fj;
+        const int n = fj - fi;
+        ClassInfo ci{};
+        ci.kind = key.kind;
+        ci.D = key.D;
+        ci.H = key.D ? L.half_stride(key.D) : 0;
+        ci.first = fi;
+        ci.count = n;
+        ci.edge_base = L.frowptr[fi];
+        ci.rec_base = L.rec_off.empty() ? 0 : L.rec_off[L.frowptr[fi]];
+        ci.tab_base = L.eval_tab_off[fi];
+        const int cls = (int)L.classes.size();
+        if (key.kind == K_F_UNARY || key.kind == K_F_BIN) {
+            // entry-major (SoA) tables: entry k of the class's j-th factor at k*n+j
+            const int entries = (key.kind == K_F_UNARY) ? key.D : key.D * key.D;
+            for (int j = 0; j < n; ++j) {
+                const double* src = L.eval_tables.data() + L.eval_tab_off[fi + j];
+                for (int k = 0; k < entries; ++k)
+                    L.tables[ci.tab_base + (int64_t)k * n + j] = sign * src[k];
+            }
+            L.classes.push_back(ci);
+            add_blocks(L.blocks_sweep, cls, n, BLOCK);
+        } else {
+            const int gen_base = (int)L.fgen.size();
+            for (int j = 0; j < n; ++j) {
+                const int f2 = fi + j;
+                FactorGen fg{L.frowptr[f2], L.frowptr[f2 + 1] - L.frowptr[f2], L.eval_tab_off[f2]};
+                for (int e = L.frowptr[f2]; e < L.frowptr[f2 + 1]; ++e)
+                    L.edge_gen_factor[e] = gen_base + j;
+                L.fgen.push_back(fg);
+                for (int64_t k = L.eval_tab_off[f2]; k < L.eval_tab_off[f2 + 1]; ++k)
+                    L.tables[k] = sign * L.eval_tables[k];
+                if (key.kind == K_F_NARY)
+                    L.max_nary_lds_bytes = std::max<int>(
+                        L.max_nary_lds_bytes,
+                        (int)((L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2]) * L.opt.word));
+            }
+            if (key.kind == K_F_GEN) {
+                ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
+                L.classes.push_back(ci);
+                add_blocks(L.blocks_sweep, cls, ci.count, BLOCK);
+            } else {  // K_F_NARY: one workgroup per factor, own launch
+                ci.first = gen_base;  // index into fgen
+                L.classes.push_back(ci);
+                add_blocks(L.blocks_nary, cls, n, 1);
+            }
+        }
+        fi = fj;
+    }
+
+    // ---- variable classes -------------------------------------------------------
+    for (int vi = 0; vi < nV;) {
+        const int v0 = L.var_i2e[vi];
+        const int key = vsort[v0] / 4096;
+        int vj = vi;
+        while (vj < nV && vsort[L.var_i2e[vj]] / 4096 == key) ++vj;
+        const int kind = key / 1024, sub = key % 1024;
+        ClassInfo ci{};
+        ci.first = vi;
+        ci.count = vj - vi;
+        ci.cost_base = L.vcost_off[vi];
+        if (kind == K_V_REG) {
+            ci.kind = K_V_REG;
+            ci.D = sub / 16;
+            ci.maxdeg = sub % 16;
+            ci.H = L.half_stride(ci.D);
+        } else if (kind == K_V_GEN) {
+            ci.kind = K_V_GEN;
+        } else if (kind == 80) {
+            ci.kind = K_V_GEN;
+            ci.start_only = 1;
+        } else {  // ghosts: no work
+            vi = vj;
+            continue;
+        }
+        const int cls = (int)L.classes.size();
+        L.classes.push_back(ci);
+        add_blocks(L.blocks_sweep, cls, ci.count, BLOCK);
+        vi = vj;
+    }
+
+    // ---- algorithmic bytes per cycle --------------------
+    {
+        const int64_t w = L.opt.word;
+        int64_t b = 0;
+        for (int e = 0; e < nE; ++e) b += 6 * (int64_t)L.edge_dom[e] * w + 8;
+        b += L.eval_tab_off[nF] * w;
+        for (int v = 0; v < nV; ++v) b += (int64_t)g.dom_size[v] * w + 8 + w;
+        L.algorithmic_bytes = b;
+    }
+    return "";
+}
+
+}  // namespace mxs

@@ -1,0 +1,206 @@
+"""ctypes binding of the C-ABI in include/maxsum_gpu.h (libmaxsum_hip.so).
+
+`MaxSumEngine` is the array-level entry point of the batched GPU sweep that
+replaces the reference's per-agent message loop
+(pydcop/algorithms/maxsum.py:279-565 driven by
+pydcop/infrastructure/computations.py:633-829).  There is no CPU fallback: if the
+HIP library is missing or no MI355X is visible, construction raises.
+"""
+import ctypes as C
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .graph import CGraph, CParams, FlatGraph, Params
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmaxsum_hip.so")
+
+# every symbol include/maxsum_gpu.h declares
+ABI_SYMBOLS = (
+    "mxs_device_count", "mxs_create", "mxs_reset", "mxs_run", "mxs_run_timed",
+    "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
+    "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
+    "mxs_halo_buffers", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
+    "mxs_destroy", "mxs_last_error", "mxs_version",
+)
+
+
+class MaxSumGpuError(RuntimeError):
+    """A C-ABI call failed (the message comes from mxs_last_error)."""
+
+
+_libs = {}
+
+
+def load_library(path: Optional[str] = None) -> C.CDLL:
+    """Load the engine library and declare the prototypes of its C-ABI."""
+    path = os.path.abspath(path or DEFAULT_LIB)
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise MaxSumGpuError(
+            f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). maxsum_gpu has no CPU fallback.")
+    lib = C.CDLL(path)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    protos = {
+        "mxs_device_count": ([C.POINTER(i32)], C.c_int),
+        "mxs_create": ([C.POINTER(CGraph), C.POINTER(CParams), i32, C.POINTER(vp)], C.c_int),
+        "mxs_reset": ([vp], C.c_int),
+        "mxs_run": ([vp, i32], C.c_int),
+        "mxs_run_timed": ([vp, i32, C.POINTER(C.c_float)], C.c_int),
+        "mxs_run_async": ([vp, i32], C.c_int),
+        "mxs_sync": ([vp], C.c_int),
+        "mxs_cycle_count": ([vp, C.POINTER(i64)], C.c_int),
+        "mxs_get_assignment": ([vp, vp, vp], C.c_int),
+        "mxs_get_messages": ([vp, vp, vp, vp, vp], C.c_int),
+        "mxs_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
+        "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
+        "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
+        "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
+        "mxs_step_pack": ([vp], C.c_int),
+        "mxs_step_unpack": ([vp], C.c_int),
+        "mxs_stream": ([vp, C.POINTER(vp)], C.c_int),
+        "mxs_destroy": ([vp], C.c_int),
+        "mxs_last_error": ([], C.c_char_p),
+        "mxs_version": ([], i32),
+    }
+    for name, (argtypes, restype) in protos.items():
+        fn = getattr(lib, name)  # AttributeError if the library misses a symbol
+        fn.argtypes = argtypes
+        fn.restype = restype
+    _libs[path] = lib
+    return lib
+
+
+def device_count(lib_path: Optional[str] = None) -> int:
+    n = C.c_int32(0)
+    load_library(lib_path).mxs_device_count(C.byref(n))
+    return int(n.value)
+
+
+class MaxSumEngine:
+    """One engine = one GPU sweeping one (shard of a) factor graph.
+
+    >>> eng = MaxSumEngine(graph, Params(mode="min"))     # cycle 0 (start) done
+    >>> eng.run(30)                                       # 30 synchronous cycles
+    >>> idx, belief = eng.assignment()
+    """
+
+    def __init__(self, graph: FlatGraph, params: Optional[Params] = None, device: int = 0,
+                 lib_path: Optional[str] = None):
+        self._h = None
+        self._lib = load_library(lib_path)
+        self.graph = graph
+        self.params = params or Params()
+        cg, cp = graph.to_c(), self.params.to_c()
+        h = C.c_void_p()
+        self._check(self._lib.mxs_create(C.byref(cg), C.byref(cp), int(device), C.byref(h)))
+        self._h = h
+
+    def _check(self, rc: int):
+        if rc != 0:
+            raise MaxSumGpuError(f"maxsum_gpu error {rc}: {self._lib.mxs_last_error().decode()}")
+
+    # -- cycles --------------------------------------------------------------
+    def reset(self):
+        self._check(self._lib.mxs_reset(self._h))
+
+    def run(self, n_cycles: int):
+        self._check(self._lib.mxs_run(self._h, int(n_cycles)))
+
+    def run_timed(self, n_cycles: int) -> float:
+        """Run and return the device time in milliseconds (HIP events on the
+        engine's stream)."""
+        ms = C.c_float(0)
+        self._check(self._lib.mxs_run_timed(self._h, int(n_cycles), C.byref(ms)))
+        return float(ms.value)
+
+    def run_async(self, n_cycles: int):
+        self._check(self._lib.mxs_run_async(self._h, int(n_cycles)))
+
+    def sync(self):
+        self._check(self._lib.mxs_sync(self._h))
+
+    @property
+    def cycle_count(self) -> int:
+        n = C.c_int64(0)
+        self._check(self._lib.mxs_cycle_count(self._h, C.byref(n)))
+        return int(n.value)
+
+    # -- results ---------------------------------------------------------------
+    def assignment(self) -> Tuple[np.ndarray, np.ndarray]:
+        idx = np.empty(self.graph.n_vars, dtype=np.int32)
+        belief = np.empty(self.graph.n_vars, dtype=np.float64)
+        self._check(self._lib.mxs_get_assignment(self._h, idx.ctypes.data, belief.ctypes.data))
+        return idx, belief
+
+    def messages(self):
+        nm, ne = int(self.graph.msg_off[-1]), self.graph.n_edges
+        v2f, f2v = np.empty(nm), np.empty(nm)
+        cv, cf = np.empty(ne, dtype=np.uint8), np.empty(ne, dtype=np.uint8)
+        self._check(self._lib.mxs_get_messages(self._h, v2f.ctypes.data, f2v.ctypes.data,
+                                               cv.ctypes.data, cf.ctypes.data))
+        return v2f, f2v, cv, cf
+
+    def eval_cost(self, idx=None, infinity: float = float("inf")) -> Tuple[float, int]:
+        """(cost, violations) as DCOP.solution_cost (pydcop/dcop/dcop.py:319-367)."""
+        cost, viol = C.c_double(0), C.c_int64(0)
+        p = None
+        if idx is not None:
+            idx = np.ascontiguousarray(idx, dtype=np.int32)
+            if idx.shape[0] != self.graph.n_vars:
+                raise ValueError("assignment must have one index per variable")
+            p = idx.ctypes.data
+        self._check(self._lib.mxs_eval_cost(self._h, p, float(infinity), C.byref(cost), C.byref(viol)))
+        return float(cost.value), int(viol.value)
+
+    def cycle_bytes(self) -> Tuple[int, int]:
+        """(algorithmic bytes per cycle, kernel launches per cycle)."""
+        b, n = C.c_int64(0), C.c_int32(0)
+        self._check(self._lib.mxs_cycle_bytes(self._h, C.byref(b), C.byref(n)))
+        return int(b.value), int(n.value)
+
+    # -- sharded operation ---------------------------------------------------------
+    def halo_setup(self, send_edges, recv_edges):
+        s = np.ascontiguousarray(send_edges, dtype=np.int32)
+        r = np.ascontiguousarray(recv_edges, dtype=np.int32)
+        self._check(self._lib.mxs_halo_setup(self._h, s.ctypes.data, s.shape[0],
+                                             r.ctypes.data, r.shape[0]))
+
+    def halo_buffers(self):
+        """((send device pointer, bytes), (recv device pointer, bytes))"""
+        s, r = C.c_void_p(), C.c_void_p()
+        sb, rb = C.c_int64(0), C.c_int64(0)
+        self._check(self._lib.mxs_halo_buffers(self._h, C.byref(s), C.byref(sb), C.byref(r), C.byref(rb)))
+        return (s.value, int(sb.value)), (r.value, int(rb.value))
+
+    def step_pack(self):
+        self._check(self._lib.mxs_step_pack(self._h))
+
+    def step_unpack(self):
+        self._check(self._lib.mxs_step_unpack(self._h))
+
+    def stream(self) -> int:
+        s = C.c_void_p()
+        self._check(self._lib.mxs_stream(self._h, C.byref(s)))
+        return s.value or 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mxs_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,161 @@
+// TEST INFRASTRUCTURE ONLY -- a tiny serial stand-in for <hip/hip_runtime.h>.
+//
+// Compiling pydcop_amd/csrc/{engine.hip,layout.cpp} with g++ and this directory
+// first on the include path gives `tests/emu/_build/libmaxsum_emu.so`: the very
+// same engine source (no #ifdef in the product code) whose "device" is host
+// memory and whose kernel launches run block after block, each thread of a block
+// as a ucontext fiber so that __syncthreads() works.  It lets the host logic
+// (layout, permutations, launch sequencing, C-ABI) and the kernels' index
+// arithmetic be checked against the oracle in the GPU-less build container.
+// It is never loaded by pydcop_amd (which only opens csrc/libmaxsum_hip.so and
+// fails without a GPU) and is not a fallback: see tests/test_emu_engine.py.
+#pragma once
+#include <ucontext.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <tuple>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__ static
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+inline thread_local dim3 threadIdx, blockIdx, blockDim, gridDim;
+
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorNotSupported = 801, hipErrorInvalidValue = 1 };
+typedef void* hipStream_t;
+typedef void* hipEvent_t;
+typedef void* hipGraph_t;
+typedef void* hipGraphExec_t;
+typedef void* hipGraphNode_t;
+enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice };
+enum { hipStreamNonBlocking = 1, hipStreamCaptureModeThreadLocal = 1 };
+struct hipDeviceProp_t {
+    char gcnArchName[64];
+};
+
+inline const char* hipGetErrorString(hipError_t) { return "emulated HIP error"; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipSetDevice(int) { return hipSuccess; }
+inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
+    std::strcpy(p->gcnArchName, "gfx950:emulated-on-host");
+    return hipSuccess;
+}
+inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 2; }
+inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
+    std::memcpy(d, s, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
+inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t) { return hipSuccess; }
+// no graph capture in the emulation: the engine falls back to plain launches
+inline hipError_t hipStreamBeginCapture(hipStream_t, int) { return hipErrorNotSupported; }
+inline hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*) { return hipErrorNotSupported; }
+inline hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, hipGraphNode_t*, char*, size_t) {
+    return hipErrorNotSupported;
+}
+inline hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t) { return hipErrorNotSupported; }
+inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
+inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
+
+// ---- block execution with fibers ------------------------------------------
+namespace hipemu {
+struct Fiber {
+    ucontext_t ctx;
+    std::vector<char> stack;
+    bool done = false;
+};
+struct BlockRun {
+    ucontext_t sched;
+    std::vector<Fiber> fibers;
+    int current = 0;
+    void (*body)(void*) = nullptr;
+    void* arg = nullptr;
+};
+inline thread_local BlockRun* g_run = nullptr;
+
+inline void trampoline() {
+    BlockRun* r = g_run;
+    Fiber& f = r->fibers[r->current];
+    r->body(r->arg);
+    f.done = true;
+    swapcontext(&f.ctx, &r->sched);
+}
+inline void yield_barrier() {  // __syncthreads(): back to the scheduler
+    BlockRun* r = g_run;
+    swapcontext(&r->fibers[r->current].ctx, &r->sched);
+}
+inline void run_block(unsigned nthreads, void (*body)(void*), void* arg) {
+    static thread_local BlockRun run;
+    run.body = body;
+    run.arg = arg;
+    if (run.fibers.size() < nthreads) run.fibers.resize(nthreads);
+    g_run = &run;
+    for (unsigned t = 0; t < nthreads; ++t) {
+        Fiber& f = run.fibers[t];
+        if (f.stack.empty()) f.stack.resize(256 * 1024);
+        f.done = false;
+        getcontext(&f.ctx);
+        f.ctx.uc_stack.ss_sp = f.stack.data();
+        f.ctx.uc_stack.ss_size = f.stack.size();
+        f.ctx.uc_link = nullptr;
+        makecontext(&f.ctx, trampoline, 0);
+    }
+    bool alive = true;
+    while (alive) {  // one pass == everything up to the next barrier
+        alive = false;
+        for (unsigned t = 0; t < nthreads; ++t) {
+            Fiber& f = run.fibers[t];
+            if (f.done) continue;
+            run.current = (int)t;
+            threadIdx = dim3(t);
+            swapcontext(&run.sched, &f.ctx);
+            if (!f.done) alive = true;
+        }
+    }
+}
+template <typename K, typename... A>
+struct Call {
+    K k;
+    std::tuple<A...> args;
+    static void invoke(void* self) {
+        Call* c = (Call*)self;
+        std::apply(c->k, c->args);
+    }
+};
+}  // namespace hipemu
+
+inline void __syncthreads() { hipemu::yield_barrier(); }
+
+template <typename K, typename... A>
+inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
+    hipemu::Call<K, A...> call{kernel, std::tuple<A...>(args...)};
+    gridDim = grid;
+    blockDim = block;
+    for (unsigned b = 0; b < grid.x; ++b) {
+        blockIdx = dim3(b);
+        hipemu::run_block(block.x, &hipemu::Call<K, A...>::invoke, &call);
+    }
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    hipemu_launch(kernel, grid, block, __VA_ARGS__)

@@ -1,0 +1,104 @@
+"""Shared checks: an engine (HIP on the GPU, or the emulated build on the CPU)
+against the oracle and the golden vectors."""
+import numpy as np
+
+from pydcop_amd import generators as G
+from pydcop_amd.engine import MaxSumEngine
+from pydcop_amd.graph import Params
+
+
+def compare_with_oracle(oracle_mod, graph, params: Params, T, lib_path=None, exact=True,
+                        steps=None):
+    """Run engine and oracle side by side; compare messages, counters, selection,
+    beliefs and solution cost after every chunk of `steps` cycles."""
+    eng = MaxSumEngine(graph, params, lib_path=lib_path)
+    ora = oracle_mod.OracleMaxSum(graph, params)
+    done = 0
+    for n in (steps or [T]):
+        eng.run(n)
+        ora.run(n)
+        done += n
+        assert eng.cycle_count == ora.cycle_count == done
+        ie, be = eng.assignment()
+        io, bo = ora.assignment()
+        me, mo = eng.messages(), ora.messages()
+        if exact:
+            np.testing.assert_array_equal(me[2], mo[2], err_msg=f"V->F counters, cycle {done}")
+            np.testing.assert_array_equal(me[3], mo[3], err_msg=f"F->V counters, cycle {done}")
+            np.testing.assert_array_equal(me[0], mo[0], err_msg=f"V->F messages, cycle {done}")
+            np.testing.assert_array_equal(me[1], mo[1], err_msg=f"F->V messages, cycle {done}")
+            np.testing.assert_array_equal(ie, io, err_msg=f"selection, cycle {done}")
+            np.testing.assert_array_equal(be, bo, err_msg=f"beliefs, cycle {done}")
+        else:
+            np.testing.assert_allclose(me[0], mo[0], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(me[1], mo[1], rtol=1e-9, atol=1e-9)
+            np.testing.assert_array_equal(ie, io)
+            np.testing.assert_allclose(be, bo, rtol=1e-9, atol=1e-9)
+        ce, ve = eng.eval_cost()
+        co, vo = ora.eval_cost()
+        assert ve == vo
+        assert abs(ce - co) <= 1e-9 * max(1.0, abs(co))
+    eng.close()
+    ora.close()
+
+
+def check_golden(graph, params_kw, meta, ref_idx, ref_cost, lib_path=None, **extra):
+    """Engine against the reference's own result stored in a golden fixture:
+    final assignment identical, costs within 1e-5 (the north-star tolerance)."""
+    p = Params(**{**params_kw, **extra})
+    eng = MaxSumEngine(graph, p, lib_path=lib_path)
+    eng.run(meta["T"])
+    idx, belief = eng.assignment()
+    np.testing.assert_array_equal(idx, ref_idx)
+    ok = ~np.isnan(ref_cost)
+    np.testing.assert_allclose(belief[ok], ref_cost[ok], rtol=1e-5, atol=1e-5)
+    cost, viol = eng.eval_cost()
+    assert viol == meta["violation"]
+    assert abs(cost - meta["cost"]) <= 1e-5 * max(1.0, abs(meta["cost"]))
+    eng.close()
+
+
+# (name, graph factory, Params kwargs) -- small seeded instances covering every
+# kernel class: register binary/unary D in {2,3,4}, generic factors (mixed
+# domains, arity 1..3, D=5..8), register variables deg<=4 / <=8, generic
+# variables (deg>8, D>4), isolated variables, initial values.
+def parity_cases():
+    def with_init(g, seed):
+        rng = np.random.default_rng(seed)
+        init = np.where(rng.random(g.n_vars) < 0.3, rng.integers(0, 2, g.n_vars), -1)
+        g.init_idx = init.astype(np.int32)
+        return g
+
+    def hub(seed):
+        # one variable in 40 factors (generic variable class), some isolated variables
+        g = G.random_coloring(60, avg_degree=3, seed=seed)
+        rng = np.random.default_rng(seed)
+        nf = 40
+        others = rng.choice(np.arange(1, 50), size=nf, replace=False)
+        edge_var = np.concatenate([g.edge_var, np.stack([np.zeros(nf, int), others], 1).reshape(-1)])
+        rowptr = np.concatenate([g.factor_rowptr, g.factor_rowptr[-1] + 2 * np.arange(1, nf + 1)])
+        tables = np.concatenate([g.tables, rng.integers(0, 10, nf * 9).astype(float)])
+        toff = np.concatenate([g.table_off, g.table_off[-1] + 9 * np.arange(1, nf + 1)])
+        from pydcop_amd.graph import FlatGraph
+        dom = np.concatenate([g.dom_size, [3, 3, 2]])  # 3 isolated variables
+        cost = np.concatenate([g.var_cost, rng.uniform(0, 1, 8)])
+        vr, ve = FlatGraph.var_side_from_edges(edge_var, dom.shape[0])
+        return FlatGraph(dom_size=dom, var_cost=cost, factor_rowptr=rowptr, edge_var=edge_var,
+                         table_off=toff, tables=tables, var_rowptr=vr, var_edges=ve).validate()
+
+    return [
+        ("coloring3_soft", lambda: G.random_coloring(300, seed=1), {}),
+        ("coloring3_hard_all", lambda: G.random_coloring(300, seed=2, variant="hard"),
+         {"start_messages": "all", "damping_nodes": "vars"}),
+        ("coloring2_deg6_max", lambda: G.random_coloring(200, avg_degree=6, n_colors=2, seed=3),
+         {"mode": "max", "start_messages": "leafs_vars", "damping_nodes": "factors"}),
+        ("coloring4_none", lambda: G.random_coloring(200, n_colors=4, seed=4),
+         {"damping_nodes": "none", "stability": 0.01}),
+        ("coloring5_generic", lambda: G.random_coloring(120, n_colors=5, seed=5), {"damping": 0.8}),
+        ("ising", lambda: G.ising_grid(9, 7, seed=6), {}),
+        ("mixed", lambda: G.random_mixed(60, 90, seed=7), {}),
+        ("mixed_max_all", lambda: G.random_mixed(60, 90, seed=8), {"mode": "max", "start_messages": "all"}),
+        ("meeting", lambda: G.meeting_like(20, dom=6, seed=9), {"mode": "max"}),
+        ("hub_isolated", lambda: hub(10), {}),
+        ("init_values", lambda: with_init(G.random_coloring(100, n_colors=2, seed=11), 11), {}),
+    ]

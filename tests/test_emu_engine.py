@@ -1,0 +1,80 @@
+"""Host logic + kernel index arithmetic of the engine, checked on the CPU.
+
+The engine's own sources (pydcop_amd/csrc/engine.hip, kernels.h, layout.cpp) are
+compiled by g++ against tests/emu/hip/hip_runtime.h (a serial fake HIP runtime)
+into tests/emu/_build/libmaxsum_emu.so and driven through the same ctypes
+binding.  This is test scaffolding for the GPU-less build container -- the
+product never loads it; the GPU parity tests proper are in test_gpu_parity.py.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from parity_common import check_golden, compare_with_oracle, parity_cases
+from pydcop_amd.graph import Params
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    from emu.build_emu import build
+    return build()
+
+
+LAYOUTS = {"default": 0, "tight": 1, "pad64": 2, "generic": 4, "keep_order": 8}
+
+
+@pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_emu_bit_exact_vs_oracle(case, dtype, emu_lib, oracle_built):
+    name, make, kw = case
+    compare_with_oracle(oracle_built, make(), Params(dtype=dtype, **kw), 0, lib_path=emu_lib,
+                        steps=[0, 1, 1, 2, 8])
+
+
+@pytest.mark.parametrize("layout", [k for k in LAYOUTS if k != "default"])
+def test_emu_layout_variants(layout, emu_lib, oracle_built):
+    for name, make, kw in parity_cases()[:3] + parity_cases()[6:8]:
+        compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], **kw), 0,
+                            lib_path=emu_lib, steps=[1, 6])
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_emu_golden(path, emu_lib):
+    g, params, meta, ref_idx, ref_cost = load_golden(path)
+    check_golden(g, params, meta, ref_idx, ref_cost, lib_path=emu_lib)
+
+
+def test_emu_reset_and_chunked_runs(emu_lib, oracle_built):
+    from pydcop_amd import generators as G
+    from pydcop_amd.engine import MaxSumEngine
+    g = G.random_coloring(150, seed=21)
+    a = MaxSumEngine(g, Params(), lib_path=emu_lib)
+    a.run(7)
+    first = a.assignment()
+    a.reset()
+    assert a.cycle_count == 0
+    for _ in range(7):
+        a.run(1)
+    again = a.assignment()
+    np.testing.assert_array_equal(first[0], again[0])
+    np.testing.assert_array_equal(first[1], again[1])
+
+
+def test_emu_errors(emu_lib):
+    from pydcop_amd import generators as G
+    from pydcop_amd.engine import MaxSumEngine, MaxSumGpuError
+    g = G.random_coloring(20, seed=1)
+    bad = G.random_coloring(20, seed=1)
+    bad.table_off = bad.table_off.copy()
+    bad.table_off[3] += 1
+    with pytest.raises(MaxSumGpuError, match="table_off"):
+        MaxSumEngine(bad, Params(), lib_path=emu_lib)
+    with pytest.raises(ValueError, match="damping_nodes"):
+        Params(damping_nodes="sometimes").to_c()
+    e = MaxSumEngine(g, Params(), lib_path=emu_lib)
+    with pytest.raises(MaxSumGpuError, match="out of the domain"):
+        e.eval_cost(np.full(g.n_vars, 7))
+    with pytest.raises(MaxSumGpuError):
+        e.run(-1)

@@ -1,0 +1,124 @@
+"""GPU parity tests proper: the HIP engine (pydcop_amd/csrc/libmaxsum_hip.so,
+through the C-ABI) against the CPU oracle on the same seeded inputs, against the
+golden vectors generated from the reference, and -- at BASELINE.json's full sizes
+-- through size-independent properties.
+
+Bar: op-for-op identical arithmetic, so f64 and f32 are compared BIT-EXACT with
+the oracle's f64/f32 builds; against the reference's golden vectors the
+north-star tolerance (1e-5) applies.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import golden_files, load_golden
+from parity_common import check_golden, compare_with_oracle, parity_cases
+from pydcop_amd import generators as G
+from pydcop_amd.engine import MaxSumEngine
+from pydcop_amd.graph import Params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_bit_exact_vs_oracle(case, dtype, oracle_built):
+    name, make, kw = case
+    compare_with_oracle(oracle_built, make(), Params(dtype=dtype, **kw), 0,
+                        steps=[0, 1, 1, 2, 8, 30])
+
+
+@pytest.mark.parametrize("flags", [1, 2, 4, 8])
+def test_layout_variants(flags, oracle_built):
+    for name, make, kw in parity_cases():
+        compare_with_oracle(oracle_built, make(), Params(layout_flags=flags, **kw), 0, steps=[1, 9])
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_golden_reference_vectors(path):
+    g, params, meta, ref_idx, ref_cost = load_golden(path)
+    check_golden(g, params, meta, ref_idx, ref_cost)
+    check_golden(g, params, meta, ref_idx, ref_cost, layout_flags=4)
+
+
+def test_config2_10k_coloring(oracle_built):
+    """BASELINE.json configs[1]: random 3-colouring, 10k vars, degree 4."""
+    for variant in ("soft", "hard"):
+        g = G.random_coloring(10_000, seed=0, variant=variant, names=False)
+        compare_with_oracle(oracle_built, g, Params(), 0, steps=[1, 49])
+
+
+def test_north_star_100k_coloring(oracle_built):
+    """The bench workload: 100k vars / 200k factors / 400k edges, 40 cycles."""
+    g = G.random_coloring(100_000, seed=0, names=False)
+    compare_with_oracle(oracle_built, g, Params(), 0, steps=[40])
+    compare_with_oracle(oracle_built, g, Params(dtype="f32"), 0, steps=[10])
+
+
+def test_ising_grid_256(oracle_built):
+    g = G.ising_grid(256, 256, seed=0, names=False)
+    compare_with_oracle(oracle_built, g, Params(), 0, steps=[20])
+
+
+def test_graph_replay_equals_eager(oracle_built):
+    """hipGraph replay of the cycle loop gives the same state as eager launches."""
+    g = G.random_coloring(5000, seed=3, names=False)
+    a = MaxSumEngine(g, Params(graph_chunk=8))
+    b = MaxSumEngine(g, Params(graph_chunk=0))
+    a.run(1), b.run(1)          # odd parity first
+    a.run(100), b.run(100)
+    a.run(37), b.run(37)
+    for x, y in zip(a.messages(), b.messages()):
+        np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(a.assignment()[0], b.assignment()[0])
+    assert a.cycle_count == b.cycle_count == 138
+
+
+def test_full_size_properties():
+    """Size-independent properties on the full north-star instance (no oracle):
+    determinism, reset idempotence, relabelling invariance, cost bookkeeping."""
+    g = G.random_coloring(100_000, seed=7, names=False)
+    e1, e2 = MaxSumEngine(g, Params()), MaxSumEngine(g, Params())
+    e1.run(60), e2.run(25), e2.run(35)
+    i1, b1 = e1.assignment()
+    i2, b2 = e2.assignment()
+    np.testing.assert_array_equal(i1, i2)
+    np.testing.assert_array_equal(b1, b2)
+    e2.reset(), e2.run(60)
+    np.testing.assert_array_equal(e2.assignment()[0], i1)
+    # solution cost on the device == numpy evaluation of the same assignment
+    t = g.tables.reshape(-1, 3, 3)
+    a0, a1 = i1[g.edge_var[0::2]], i1[g.edge_var[1::2]]
+    want = t[np.arange(t.shape[0]), a0, a1].sum() + g.var_cost.reshape(-1, 3)[np.arange(g.n_vars), i1].sum()
+    got, viol = e1.eval_cost()
+    assert viol == 0 and abs(got - want) <= 1e-9 * abs(want)
+    # Max-Sum must beat the trivial start assignment by a wide margin
+    e3 = MaxSumEngine(g, Params())
+    start_cost, _ = e3.eval_cost()
+    assert got < 0.75 * start_cost
+    # relabelling the factors (reversed order) only changes floating-point
+    # summation order on the variable side: same assignment up to near-ties
+    nf = g.n_factors
+    perm = np.arange(nf)[::-1]
+    ev = g.edge_var.reshape(nf, 2)[perm].reshape(-1)
+    vr, ve = g.var_side_from_edges(ev, g.n_vars)
+    from pydcop_amd.graph import FlatGraph
+    g2 = FlatGraph(dom_size=g.dom_size, var_cost=g.var_cost, factor_rowptr=g.factor_rowptr,
+                   edge_var=ev, table_off=g.table_off, tables=t[perm].reshape(-1),
+                   var_rowptr=vr, var_edges=ve)
+    e4 = MaxSumEngine(g2, Params())
+    e4.run(60)
+    assert (e4.assignment()[0] != i1).mean() < 1e-3
+
+
+def test_max_mode_is_negated_min_mode():
+    g = G.random_coloring(3000, seed=5, names=False)
+    from pydcop_amd.graph import FlatGraph
+    neg = FlatGraph(dom_size=g.dom_size, var_cost=-g.var_cost, factor_rowptr=g.factor_rowptr,
+                    edge_var=g.edge_var, table_off=g.table_off, tables=-g.tables,
+                    var_rowptr=g.var_rowptr, var_edges=g.var_edges)
+    a, b = MaxSumEngine(g, Params(mode="min")), MaxSumEngine(neg, Params(mode="max"))
+    a.run(30), b.run(30)
+    np.testing.assert_array_equal(a.assignment()[0], b.assignment()[0])
+    np.testing.assert_array_equal(a.assignment()[1], -b.assignment()[1])
