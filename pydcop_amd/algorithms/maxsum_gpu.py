@@ -1,0 +1,290 @@
+"""maxsum_gpu -- synchronous Max-Sum as one batched GPU sweep, behind pyDCOP's
+algorithm-module contract (docs/implementation/algorithms.rst; enforced by
+pydcop/algorithms/__init__.py:527-566).
+
+Drop-in for `pydcop.algorithms.maxsum`: same GRAPH_TYPE, the same five
+parameters with the same defaults (pydcop/algorithms/maxsum.py:212-220), the
+same computation_memory / communication_load formulas, and a
+`build_computation(comp_def)` factory.  The reference hands the plugin ONE node
+at a time; the computations returned here are thin proxies that register their
+ComputationDef with a process-global session.  When the first proxy is started
+the session checks that the registered set is closed (every neighbour is
+registered), compiles the factor graph to flat arrays (pydcop_amd.compile),
+creates one `MaxSumEngine` (HIP, MI355X) and sweeps the whole graph; every
+variable proxy then reports its value through `value_selection` on its own
+agent's thread, which is all the unmodified orchestrator needs to produce the
+usual result JSON (pydcop/infrastructure/orchestrator.py:1215-1274).
+
+Extra parameters
+  stop_cycle  int, default 0   >0: run exactly that many cycles then call
+                               finished() (status FINISHED); 0: keep sweeping in
+                               chunks until the orchestrator's timeout, like the
+                               reference (which never terminates, maxsum.py:62)
+  precision   f64 (reference arithmetic, default) | f32
+  seed        seed of the noise draw (the reference's noise is unseeded,
+              pydcop/dcop/objects.py:566-567)
+  chunk       cycles per device run between two reports when stop_cycle == 0
+
+Only thread mode with all computations in one process can be served (the whole
+graph must be visible to one engine); anything else raises ComputationException.
+"""
+import threading
+from typing import Dict, Optional, Union
+
+import numpy as np
+
+from pydcop.algorithms import AlgoParameterDef, ComputationDef
+from pydcop.computations_graph.factor_graph import (FactorComputationNode,
+                                                     VariableComputationNode)
+from pydcop.infrastructure.computations import (ComputationException, DcopComputation,
+                                                VariableComputation)
+
+from pydcop_amd.compile import compile_nodes
+from pydcop_amd.graph import Params
+
+GRAPH_TYPE = "factor_graph"
+
+HEADER_SIZE = 0
+UNIT_SIZE = 1
+FACTOR_UNIT_SIZE = 1
+VARIABLE_UNIT_SIZE = 1
+
+algo_params = [
+    AlgoParameterDef("damping", "float", None, 0.5),
+    AlgoParameterDef("damping_nodes", "str", ["vars", "factors", "both", "none"], "both"),
+    AlgoParameterDef("stability", "float", None, 0.1),
+    AlgoParameterDef("noise", "float", None, 0.01),
+    AlgoParameterDef("start_messages", "str", ["leafs", "leafs_vars", "all"], "leafs"),
+    AlgoParameterDef("stop_cycle", "int", None, 0),
+    AlgoParameterDef("precision", "str", ["f64", "f32"], "f64"),
+    AlgoParameterDef("seed", "int", None, 0),
+    AlgoParameterDef("chunk", "int", None, 10),
+]
+
+# Test hook ONLY: tests/test_plugin.py points this at the emulated-engine build to
+# check the plumbing in the GPU-less container.  None = the HIP library.
+_ENGINE_LIB_PATH: Optional[str] = None
+
+
+def computation_memory(computation: Union[FactorComputationNode, VariableComputationNode]) -> float:
+    """Same footprint model as pydcop/algorithms/maxsum.py:127-171."""
+    if isinstance(computation, FactorComputationNode):
+        return sum(len(v.domain) * FACTOR_UNIT_SIZE for v in computation.variables)
+    if isinstance(computation, VariableComputationNode):
+        return len(list(computation.links)) * len(computation.variable.domain) * VARIABLE_UNIT_SIZE
+    raise ValueError(
+        "Invalid computation node type {}, maxsum_gpu only defines VariableComputationNode "
+        "and FactorComputationNode".format(computation))
+
+
+def communication_load(src: Union[FactorComputationNode, VariableComputationNode],
+                       target: str) -> float:
+    """Same message-size model as pydcop/algorithms/maxsum.py:174-209."""
+    if isinstance(src, VariableComputationNode):
+        return UNIT_SIZE * len(src.variable.domain) + HEADER_SIZE
+    if isinstance(src, FactorComputationNode):
+        for v in src.variables:
+            if v.name == target:
+                return UNIT_SIZE * len(v.domain) + HEADER_SIZE
+        raise ValueError("Could not find variable {} in constraint of factor {}".format(target, src))
+    raise ValueError("maxsum_gpu communication_load only supports VariableComputationNode and "
+                     "FactorComputationNode, invalid computation: " + str(src))
+
+
+class _Session:
+    """All the computations of one solve: collects ComputationDefs, owns the engine."""
+
+    def __init__(self):
+        self.lock = threading.RLock()
+        self.comp_defs: Dict[str, ComputationDef] = {}
+        self.engine = None
+        self.graph = None
+        self.var_index: Dict[str, int] = {}
+        self.idx = None
+        self.belief = None
+        self.cycles = 0
+        self.generation = 0
+        self.done = False
+        self.stopped = False
+        self.error: Optional[Exception] = None
+
+    def register(self, comp_def: ComputationDef):
+        with self.lock:
+            self.comp_defs[comp_def.node.name] = comp_def
+
+    # -- solve ------------------------------------------------------------------
+    def _open(self):
+        """Compile the registered graph and create the engine (cycle 0 runs there)."""
+        from pydcop_amd.engine import MaxSumEngine
+        missing = sorted({n for cd in self.comp_defs.values() for n in cd.node.neighbors}
+                         - set(self.comp_defs))
+        if missing:
+            raise ComputationException(
+                "maxsum_gpu needs every computation of the factor graph in one process "
+                "(thread mode); not deployed here: " + ", ".join(missing[:8]))
+        any_def = next(iter(self.comp_defs.values()))
+        algo = any_def.algo
+        p = algo.params
+        var_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "VariableComputation"]
+        fac_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "FactorComputation"]
+        var_nodes.sort(key=lambda n: n.name)
+        fac_nodes.sort(key=lambda n: n.name)
+        self.graph = compile_nodes(var_nodes, fac_nodes, noise=float(p["noise"]),
+                                   rng=np.random.default_rng(int(p["seed"])))
+        self.var_index = {n: i for i, n in enumerate(self.graph.var_names)}
+        params = Params(mode=algo.mode, damping=float(p["damping"]),
+                        damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
+                        start_messages=p["start_messages"], dtype=p["precision"])
+        self.engine = MaxSumEngine(self.graph, params, lib_path=_ENGINE_LIB_PATH)
+        self.stop_cycle = int(p["stop_cycle"])
+        self.chunk = max(1, int(p["chunk"]))
+        self._fetch()
+
+    def _fetch(self):
+        self.idx, self.belief = self.engine.assignment()
+        self.cycles = self.engine.cycle_count
+        self.generation += 1
+
+    def advance(self):
+        """Called from any proxy's agent thread: make progress if nobody else is."""
+        if not self.lock.acquire(blocking=False):
+            return
+        try:
+            if self.error or self.done or self.stopped:
+                return
+            if self.engine is None:
+                self._open()
+                if self.stop_cycle > 0:
+                    self.engine.run(self.stop_cycle)
+                    self._fetch()
+                    self.done = True
+                return
+            if self.stop_cycle == 0:
+                self.engine.run(self.chunk)
+                self._fetch()
+        except Exception as e:  # surfaced by every proxy
+            self.error = e
+            raise
+        finally:
+            self.lock.release()
+
+    def wait_open(self):
+        with self.lock:
+            if self.error:
+                raise self.error
+            if self.engine is None and not self.stopped:
+                self.advance()
+            if self.error:
+                raise self.error
+
+    def value_of(self, name):
+        i = self.var_index[name]
+        return self.graph.domains[i][int(self.idx[i])], float(self.belief[i])
+
+    def stop(self):
+        with self.lock:
+            self.stopped = True
+            if self.engine is not None:
+                self.engine.close()
+                self.engine = None
+
+
+_registry_lock = threading.Lock()
+_current: Optional[_Session] = None
+
+
+def _session_for(comp_def: ComputationDef) -> _Session:
+    """The open session, or a new one when the previous solve is over / already
+    holds a computation of that name (a new run in the same process)."""
+    global _current
+    with _registry_lock:
+        s = _current
+        if (s is None or s.stopped or s.engine is not None or s.error is not None
+                or comp_def.node.name in s.comp_defs):
+            s = _current = _Session()
+        s.register(comp_def)
+        return s
+
+
+class _ProxyMixin:
+    """Behaviour shared by the factor and variable proxies."""
+
+    POLL_PERIOD = 0.02
+
+    def _init_proxy(self, comp_def):
+        assert comp_def.algo.algo == "maxsum_gpu"
+        self._session = _session_for(comp_def)
+        self._seen_generation = 0
+        self._poll_handle = None
+        self._reported_done = False
+
+    @property
+    def cycle_count(self):
+        return self._session.cycles
+
+    def footprint(self) -> float:
+        return computation_memory(self.computation_def.node)
+
+    def on_start(self):
+        s = self._session
+        s.wait_open()            # first proxy started compiles + creates the engine
+        self._report()
+        if not self._reported_done:
+            self._poll_handle = self.add_periodic_action(self.POLL_PERIOD, self._tick)
+
+    def _tick(self):
+        s = self._session
+        if not s.done:
+            s.advance()
+        if s.error:
+            raise s.error
+        self._report()
+
+    def _report(self):
+        s = self._session
+        if s.generation != self._seen_generation:
+            self._seen_generation = s.generation
+            self._publish()
+        if s.done and not self._reported_done:
+            self._reported_done = True
+            if self._poll_handle is not None:
+                self.remove_periodic_action(self._poll_handle)
+                self._poll_handle = None
+            self.finished()
+            self.stop()
+
+    def _publish(self):
+        pass
+
+    def on_stop(self):
+        self._session.stop()
+
+
+class MaxSumGpuFactorComputation(_ProxyMixin, DcopComputation):
+    """Stands for a MaxSumFactorComputation (pydcop/algorithms/maxsum.py:279): holds
+    no state, its messages are computed by the factor side of the GPU sweep."""
+
+    def __init__(self, comp_def: ComputationDef):
+        super().__init__(comp_def.node.factor.name, comp_def)
+        self._init_proxy(comp_def)
+
+
+class MaxSumGpuVariableComputation(_ProxyMixin, VariableComputation):
+    """Stands for a MaxSumVariableComputation (pydcop/algorithms/maxsum.py:450):
+    publishes the value the GPU sweep selected for its variable."""
+
+    def __init__(self, comp_def: ComputationDef):
+        super().__init__(comp_def.node.variable, comp_def)
+        self._init_proxy(comp_def)
+
+    def _publish(self):
+        val, cost = self._session.value_of(self.name)
+        self.value_selection(val, cost)
+
+
+def build_computation(comp_def: ComputationDef):
+    if comp_def.node.type == "VariableComputation":
+        return MaxSumGpuVariableComputation(comp_def)
+    if comp_def.node.type == "FactorComputation":
+        return MaxSumGpuFactorComputation(comp_def)
+    raise ValueError("maxsum_gpu: unsupported computation node type " + str(comp_def.node.type))

@@ -361,6 +361,88 @@ __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassI
     }
 }
 
+// ---------------------------------------------------------------------------
+// Variable side, wave class (8 < deg <= 64): G lanes per variable, lane k holds the
+// record of the variable's k-th edge; the sums walk the lanes in edge order with
+// cross-lane reads, so the arithmetic order is still the reference's.
+// ---------------------------------------------------------------------------
+template <typename T, int D, int G, bool ALIGNED>
+__device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const ClassInfo& ci,
+                                              int first_var) {
+    const int vloc = first_var + (int)threadIdx.x / G;
+    if (vloc >= ci.count) return;  // whole group leaves together
+    const int k = (int)threadIdx.x % G;
+    const int v = ci.first + vloc;
+    const int H = ci.H;
+    const int k0 = a.vrowptr[v];
+    const int deg = a.vrowptr[v + 1] - k0;
+    const bool has = k < deg;
+    T c[D], in[D], pv[D], b[D], m[D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        c[d] = a.var_cost[ci.cost_base + (int64_t)vloc * D + d];
+        in[d] = pv[d] = (T)0;
+    }
+    int64_t off = 0;
+    uint8_t cnt = 0;
+    if (has) {
+        off = a.vslot_rec[k0 + k];
+        cnt = a.cV[k0 + k];
+        const T* r = rec_ptr<ALIGNED>(a.old_rec + off);
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            pv[d] = r[d];
+            in[d] = r[H + d];
+        }
+    }
+    T sum_cost = (T)0;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        b[d] = c[d];
+        m[d] = c[d];
+        for (int kk = 0; kk < deg; ++kk) {
+            const T x = __shfl(in[d], kk, G);
+            b[d] += x;                 // select_value: every factor
+            if (kk != k) {             // costs_for_factor: every factor but the target
+                sum_cost += x;
+                m[d] += x;
+            }
+        }
+    }
+    int best = 0;
+    T best_c = b[0];
+#pragma unroll
+    for (int d = 1; d < D; ++d)
+        if (b[d] < best_c) {
+            best = d;
+            best_c = b[d];
+        }
+    if (a.start && a.init_idx[v] >= 0) {
+        best = a.init_idx[v];
+        best_c = (T)0;
+    }
+    if (k == 0) {
+        a.sel[v] = best;
+        a.belief[v] = best_c;
+    }
+    if (!has) return;
+    const T avg = sum_cost / (T)D;
+#pragma unroll
+    for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
+    T* w = rec_ptr<ALIGNED>(a.new_rec + off);
+    if (a.start) {  // deg > 1 here: only leafs_vars / all make the variable send
+        const bool sends = a.start_mode != MXS_START_LEAFS;
+#pragma unroll
+        for (int d = 0; d < D; ++d) w[d] = sends ? m[d] : (T)0;
+        a.cV[k0 + k] = 0;
+        return;
+    }
+    const uint8_t co = damp_and_filter<T, D>(m, pv, cnt, a.damp_v != 0, a.damping, a.stability);
+#pragma unroll
+    for (int d = 0; d < D; ++d) w[d] = m[d];
+    a.cV[k0 + k] = co;
+}
+
 // Variable side, generic class: thread per variable, any domain size / degree,
 // scalar loops only.  Sums run in the reference's order (d outer, factors inner).
 template <typename T>
@@ -451,6 +533,18 @@ template <typename T, bool ALIGNED>
 __global__ void __launch_bounds__(BLOCK) k_sweep(SweepArgs<T> a) {
     const BlockDesc bd = a.blocks[blockIdx.x];
     const ClassInfo ci = a.classes[bd.cls];
+    if (ci.kind == K_V_WAVE) {  // several lanes per item
+        switch (ci.D * 100 + ci.maxdeg) {
+            case 216: variable_wave<T, 2, 16, ALIGNED>(a, ci, bd.item); break;
+            case 264: variable_wave<T, 2, 64, ALIGNED>(a, ci, bd.item); break;
+            case 316: variable_wave<T, 3, 16, ALIGNED>(a, ci, bd.item); break;
+            case 364: variable_wave<T, 3, 64, ALIGNED>(a, ci, bd.item); break;
+            case 416: variable_wave<T, 4, 16, ALIGNED>(a, ci, bd.item); break;
+            case 464: variable_wave<T, 4, 64, ALIGNED>(a, ci, bd.item); break;
+            default: break;
+        }
+        return;
+    }
     const int j = bd.item + (int)threadIdx.x;
     if (j >= ci.count) return;
     switch (ci.kind) {

@@ -186,6 +186,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_REG_DEG) {
             kind = K_V_REG; sub = D * 16 + (deg <= 4 ? 4 : 8);
+        } else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_WAVE_DEG) {
+            kind = K_V_WAVE; sub = D * 128 + (deg <= 16 ? 16 : 64);
         } else { kind = K_V_GEN; sub = 0; }
         vkind[v] = kind;
         // sort key: class, then degree (uniform waves), stable in caller order
@@ -323,6 +325,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.D = sub / 16;
             ci.maxdeg = sub % 16;
             ci.H = L.half_stride(ci.D);
+        } else if (kind == K_V_WAVE) {
+            ci.kind = K_V_WAVE;
+            ci.D = sub / 128;
+            ci.maxdeg = sub % 128;
+            ci.H = L.half_stride(ci.D);
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
         } else if (kind == 80) {
@@ -334,8 +341,31 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         }
         const int cls = (int)L.classes.size();
         L.classes.push_back(ci);
-        add_blocks(L.blocks_sweep, cls, ci.count, BLOCK);
+        add_blocks(L.blocks_sweep, cls, ci.count, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
         vi = vj;
+    }
+
+    // Blocks with the longest per-thread chains first (generic classes, then the
+    // gathering variable classes, then the streaming factor classes), so that
+    // the tail of the launch is made of short blocks.
+    {
+        auto prio = [&](const BlockDesc& b) {
+            switch (L.classes[b.cls].kind) {
+                case K_V_GEN: return 0;
+                case K_F_GEN: return 1;
+                case K_V_WAVE: return 2;
+                case K_V_REG: return 3;
+                default: return 4;
+            }
+        };
+        std::stable_sort(L.blocks_sweep.begin(), L.blocks_sweep.end(),
+                         [&](const BlockDesc& x, const BlockDesc& y) { return prio(x) < prio(y); });
+        std::vector<int> seen(L.classes.size(), 0);
+        for (size_t i = 0; i < L.blocks_sweep.size(); ++i)
+            if (!seen[L.blocks_sweep[i].cls]) {
+                seen[L.blocks_sweep[i].cls] = 1;
+                L.classes[L.blocks_sweep[i].cls].block_base = (int)i;
+            }
     }
 
     // ---- algorithmic bytes per cycle --------------------

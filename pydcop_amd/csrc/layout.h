@@ -41,17 +41,20 @@ enum Kind : int32_t {
     K_F_NARY = 4,   // large tables: workgroup per factor, LDS tile (own launch)
     K_V_REG = 5,    // D in {2,3,4}, 1 <= deg <= 8: thread per variable, registers
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
+    K_V_WAVE = 7,   // D in {2,3,4}, 8 < deg <= 64: G = 16 or 64 lanes per variable,
+                    // one lane per incoming edge, cross-lane sums
 };
 
 constexpr int BLOCK = 256;
 constexpr int MAX_REG_D = 4;
 constexpr int MAX_REG_DEG = 8;
+constexpr int MAX_WAVE_DEG = 64;
 
 struct ClassInfo {       // one per class, read with scalar loads
     int32_t kind;
     int32_t D;           // uniform domain size (0 for generic classes)
     int32_t H;           // half stride of the class's records (uniform classes)
-    int32_t maxdeg;      // K_V_REG: 4 or 8
+    int32_t maxdeg;      // K_V_REG: 4 or 8; K_V_WAVE: lanes per variable (16 or 64)
     int32_t first;       // first internal factor / variable id of the class
     int32_t count;       // number of factors / variables (K_F_GEN: edges)
     int32_t edge_base;   // first internal edge id (factor classes)

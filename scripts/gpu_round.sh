@@ -16,21 +16,25 @@ echo "== bench default"
 timeout 600 python bench.py 2>&1 | tail -3 | tee $OUT/bench_default.json
 echo "== bench variants (no cpu baseline)"
 for v in "--dtype f32" "--layout-flags 1" "--layout-flags 2" "--layout-flags 8" "--graph-chunk 0" \
-         "--dtype f32 --layout-flags 2" "--workload coloring_10k" "--workload coloring_100k_hard" \
-         "--workload ising_1024 --steps 300 --warmup 30" "--workload coloring_1m_deg6 --steps 200 --warmup 20"; do
+         "--dtype f32 --layout-flags 2" "--workload coloring_10k" \
+         "--workload ising_1024 --steps 300 --warmup 30" "--workload ising_1024 --steps 300 --warmup 30 --dtype f32" \
+         "--workload coloring_1m_deg6 --steps 200 --warmup 20"; do
   echo "-- $v"
   timeout 600 python bench.py --no-cpu-baseline $v 2>&1 | tail -1 | tee -a $OUT/bench_variants.jsonl
 done
 echo "== rocprofv3 kernel trace"
 cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/prof_default -o trace -- python $R/bench.py --no-cpu-baseline --steps 500 --warmup 50 > $OUT/prof_default.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_default -o trace -- python $R/bench.py --no-cpu-baseline --steps 500 --warmup 50 > $OUT/prof_default.log 2>&1
 tail -2 $OUT/prof_default.log
-find $OUT/prof_default -name "*kernel_stats*" | head -3 | while read f; do echo "## $f"; head -8 "$f"; done
+find $OUT/prof_default -name "*stats*.csv" | head -4 | while read f; do echo "## $f"; head -8 "$f"; done
 echo "== rocprofv3 pmc (separate passes)"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 600 rocprofv3 --pmc $c -d $OUT/pmc_$c -o pmc -- python $R/bench.py --no-cpu-baseline --steps 100 --warmup 10 --graph-chunk 0 > $OUT/pmc_$c.log 2>&1
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -o pmc -- python $R/bench.py --no-cpu-baseline --steps 100 --warmup 10 --graph-chunk 0 > $OUT/pmc_$c.log 2>&1
   f=$(find $OUT/pmc_$c -name "*counter_collection*.csv" | head -1)
   echo "## $c -> $f"; [ -n "$f" ] && (head -1 "$f"; grep k_sweep "$f" | tail -3)
+  # keep only a few dispatches of the (large) per-dispatch table
+  [ -n "$f" ] && (head -1 "$f"; grep k_sweep "$f" | tail -20) > $OUT/pmc_$c.csv
+  rm -rf $OUT/pmc_$c
 done
 # keep the merged-back output small: drop bulky traces, keep csv summaries
 find $OUT -name "*.rocpd" -size +8M -delete 2>/dev/null

@@ -147,6 +147,29 @@ struct Call {
 
 inline void __syncthreads() { hipemu::yield_barrier(); }
 
+// Cross-lane read (wave = 64 lanes): publish, barrier, read, barrier.  Valid as long
+// as all lanes of a (sub-)wave group reach the same __shfl together, which the
+// kernels guarantee (group-uniform control flow around cross-lane reads).
+namespace hipemu {
+inline thread_local unsigned long long g_xchg[1024];
+}
+template <typename V>
+inline V __shfl(V var, int src_lane, int width = 64) {
+    static_assert(sizeof(V) <= 8, "emulated __shfl moves at most 8 bytes");
+    const unsigned t = threadIdx.x;
+    unsigned long long bits = 0;
+    std::memcpy(&bits, &var, sizeof(V));
+    hipemu::g_xchg[t] = bits;
+    hipemu::yield_barrier();
+    const unsigned lane = t % 64, wave_base = t - lane;
+    const unsigned src = wave_base + (lane / width) * width + ((unsigned)src_lane % (unsigned)width);
+    V out;
+    bits = hipemu::g_xchg[src];
+    std::memcpy(&out, &bits, sizeof(V));
+    hipemu::yield_barrier();
+    return out;
+}
+
 template <typename K, typename... A>
 inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
     hipemu::Call<K, A...> call{kernel, std::tuple<A...>(args...)};

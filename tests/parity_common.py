@@ -100,5 +100,10 @@ def parity_cases():
         ("mixed_max_all", lambda: G.random_mixed(60, 90, seed=8), {"mode": "max", "start_messages": "all"}),
         ("meeting", lambda: G.meeting_like(20, dom=6, seed=9), {"mode": "max"}),
         ("hub_isolated", lambda: hub(10), {}),
+        ("coloring3_deg14", lambda: G.random_coloring(120, avg_degree=14, seed=12), {}),
+        ("coloring2_deg30_max", lambda: G.random_coloring(90, avg_degree=30, n_colors=2, seed=13),
+         {"mode": "max", "start_messages": "leafs_vars"}),
+        ("coloring4_deg20_all", lambda: G.random_coloring(80, avg_degree=20, n_colors=4, seed=14),
+         {"start_messages": "all", "damping_nodes": "vars"}),
         ("init_values", lambda: with_init(G.random_coloring(100, n_colors=2, seed=11), 11), {}),
     ]
