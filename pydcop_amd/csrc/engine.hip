@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <climits>
 #include <cstdio>
 #include <cstring>
 #include <memory>
@@ -92,13 +93,13 @@ struct Engine : EngineBase {
     int device = 0;
     int cur = 0;  // record buffer holding the messages of the last finished cycle
     DevBuf<T> rec[2], tables, var_cost, belief, halo_send, halo_recv;
-    DevBuf<uint8_t> cF, cV, owned;
-    DevBuf<int32_t> vrowptr, vdom, vhalf, init_idx, edge_gen_factor, edge_dom, edge_half, sel;
+    DevBuf<uint8_t> cF, cV, owned, vdeg8;
+    DevBuf<int32_t> vrowptr, vdom, vhalf, init_idx, edge_gen_factor, edge_dom, edge_half, sel, vell;
     DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
     DevBuf<int64_t> vslot_rec, vcost_off, rec_off, eval_tab_off, halo_send_off, halo_recv_off;
     DevBuf<FactorGen> fgen;
-    DevBuf<ClassInfo> classes;
-    DevBuf<BlockDesc> blocks_sweep, blocks_nary;
+    DevBuf<ClassInfo> classes;  // sweep classes in launch order
+    DevBuf<BlockDesc> blocks_nary;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -125,6 +126,8 @@ struct Engine : EngineBase {
         a.cV = cV.p;
         a.vrowptr = vrowptr.p;
         a.vslot_rec = vslot_rec.p;
+        a.vell = vell.p;
+        a.vdeg8 = vdeg8.p;
         a.vdom = vdom.p;
         a.vhalf = vhalf.p;
         a.vcost_off = vcost_off.p;
@@ -136,26 +139,36 @@ struct Engine : EngineBase {
         a.edge_half = edge_half.p;
         a.sel = sel.p;
         a.belief = belief.p;
-        a.classes = classes.p;
-        a.blocks = blocks_sweep.p;
         a.damping = (T)params.damping;
         a.stability = (T)params.stability;
         a.damp_f = (params.damping_nodes & MXS_DAMP_FACTORS) ? 1 : 0;
         a.damp_v = (params.damping_nodes & MXS_DAMP_VARS) ? 1 : 0;
         a.start = start ? 1 : 0;
         a.start_mode = params.start_messages;
+        a.null_rec = (int32_t)L.null_rec;
+        a.n_classes = (int32_t)L.sweep_order.size();
+        for (int i = 0; i < MAX_CLASSES; ++i)
+            a.block_base[i] = i < a.n_classes ? L.classes[L.sweep_order[i]].block_base : INT32_MAX;
+        a.classes = classes.p;
         return a;
     }
 
     // Enqueue one cycle reading buffer `from`.
     int launch_cycle(int from, bool start) {
         const SweepArgs<T> a = make_args(from, start);
-        const int nb = (int)L.blocks_sweep.size();
+        const int nb = L.n_blocks_sweep;
         if (nb > 0) {
-            if (L.opt.aligned_halves)
-                hipLaunchKernelGGL((k_sweep<T, true>), dim3(nb), dim3(BLOCK), 0, stream, a);
-            else
-                hipLaunchKernelGGL((k_sweep<T, false>), dim3(nb), dim3(BLOCK), 0, stream, a);
+            const dim3 grid(nb), block(BLOCK);
+            if (!L.opt.aligned_halves) {
+                hipLaunchKernelGGL((k_sweep<T, false, 0>), grid, block, 0, stream, a);
+            } else {
+                switch (L.dsel) {
+                    case 2: hipLaunchKernelGGL((k_sweep<T, true, 2>), grid, block, 0, stream, a); break;
+                    case 3: hipLaunchKernelGGL((k_sweep<T, true, 3>), grid, block, 0, stream, a); break;
+                    case 4: hipLaunchKernelGGL((k_sweep<T, true, 4>), grid, block, 0, stream, a); break;
+                    default: hipLaunchKernelGGL((k_sweep<T, true, 0>), grid, block, 0, stream, a); break;
+                }
+            }
             HIP_TRY(hipGetLastError());
         }
         return MXS_OK;
@@ -190,7 +203,9 @@ struct Engine : EngineBase {
         HIP_TRY(tables.upload(conv(L.tables), stream));
         HIP_TRY(var_cost.upload(conv(L.var_cost), stream));
         HIP_TRY(cF.alloc((size_t)L.n_edges));
-        HIP_TRY(cV.alloc((size_t)L.n_edges));
+        HIP_TRY(cV.alloc((size_t)L.n_cv));
+        HIP_TRY(vell.upload(L.vell, stream));
+        HIP_TRY(vdeg8.upload(L.vdeg8, stream));
         HIP_TRY(owned.upload(L.owned, stream));
         HIP_TRY(vrowptr.upload(L.vrowptr, stream));
         HIP_TRY(vdom.upload(L.vdom, stream));
@@ -205,8 +220,11 @@ struct Engine : EngineBase {
         HIP_TRY(vcost_off.upload(L.vcost_off, stream));
         HIP_TRY(rec_off.upload(L.rec_off, stream));
         HIP_TRY(fgen.upload(L.fgen, stream));
-        HIP_TRY(classes.upload(L.classes, stream));
-        HIP_TRY(blocks_sweep.upload(L.blocks_sweep, stream));
+        {
+            std::vector<ClassInfo> order;
+            for (int c : L.sweep_order) order.push_back(L.classes[c]);
+            HIP_TRY(classes.upload(order, stream));
+        }
         HIP_TRY(blocks_nary.upload(L.blocks_nary, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
@@ -344,12 +362,12 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(stream));
         const int nE = L.n_edges;
         std::vector<T> hr((size_t)L.rec_elems);
-        std::vector<uint8_t> hcF(nE), hcV(nE);
+        std::vector<uint8_t> hcF(nE), hcV((size_t)L.n_cv);
         if (L.rec_elems)
             HIP_TRY(copy_sync(hr.data(), rec[cur].p, sizeof(T) * hr.size(), hipMemcpyDeviceToHost, stream));
         if (nE) {
             HIP_TRY(copy_sync(hcF.data(), cF.p, nE, hipMemcpyDeviceToHost, stream));
-            HIP_TRY(copy_sync(hcV.data(), cV.p, nE, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hcV.data(), cV.p, (size_t)L.n_cv, hipMemcpyDeviceToHost, stream));
         }
         // caller's message offsets: prefix of the edge domain sizes in caller order
         std::vector<int64_t> ext_off(nE + 1, 0);
@@ -365,7 +383,7 @@ struct Engine : EngineBase {
             if (cf) cf[e] = hcF[ei];
         }
         if (cv)
-            for (int k = 0; k < nE; ++k) cv[L.edge_i2e[L.vslot_edge[k]]] = hcV[k];
+            for (int k = 0; k < nE; ++k) cv[L.edge_i2e[L.vslot_edge[k]]] = hcV[L.vslot_cv[k]];
         return MXS_OK;
     }
 

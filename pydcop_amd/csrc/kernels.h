@@ -30,6 +30,9 @@
 namespace mxs {
 
 constexpr int SAME_COUNT = 4;  // maxsum.py:106
+#ifndef SWEEP_MIN_WAVES
+#define SWEEP_MIN_WAVES 4
+#endif
 
 template <typename T>
 struct SweepArgs {
@@ -38,9 +41,11 @@ struct SweepArgs {
     const T* tables;
     const T* var_cost;
     uint8_t* cF;        // [n_edges] factor-major send counters
-    uint8_t* cV;        // [n_edges] variable-major send counters
+    uint8_t* cV;        // [n_cv] variable-side send counters (CSR slots + class tables)
     const int32_t* vrowptr;
     const int64_t* vslot_rec;
+    const int32_t* vell;   // slot tables of the register / wave variable classes
+    const uint8_t* vdeg8;  // [n_vars] degree (saturated), internal order
     const int32_t* vdom;
     const int32_t* vhalf;
     const int64_t* vcost_off;
@@ -52,14 +57,20 @@ struct SweepArgs {
     const int32_t* edge_half;
     int32_t* sel;
     T* belief;
-    const ClassInfo* classes;
-    const BlockDesc* blocks;
     T damping;
     T stability;
     int32_t damp_f;      // damping_nodes in {factors, both}
     int32_t damp_v;      // damping_nodes in {vars, both}
     int32_t start;       // 1: cycle 0 (on_start), 0: regular cycle
     int32_t start_mode;  // MXS_START_*
+    int32_t null_rec;    // offset of the all-zero record (padding slots)
+    int32_t n_classes;
+    // First block of every class of the launch (in launch order; unused entries
+    // hold INT32_MAX): a block finds its class with compares on kernel arguments,
+    // then one scalar load of its ClassInfo -- no chain of dependent global loads
+    // before the block can start.
+    int32_t block_base[MAX_CLASSES];
+    const ClassInfo* classes;  // [n_classes] in launch order
 };
 
 template <typename T>
@@ -270,38 +281,44 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
 }
 
 // ---------------------------------------------------------------------------
-// Variable side, register class: thread per variable, D and a degree bound are
-// compile-time so the deg incoming messages stay in VGPRs.
+// Variable side, register class (1 <= deg <= 4): thread per variable, D is a
+// compile-time constant so the incoming messages stay in VGPRs.
 //   select_value      maxsum.py:584-620
 //   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
+// Loads are issued in two batches -- everything addressed by the variable index
+// (slot table, counters, costs: coalesced), then all records at once -- so a
+// thread has 4 x 64 B in flight instead of a slot->record chain per edge.
+// Padding slots read the all-zero record: adding 0.0 is exact, so the sums can
+// run over all four slots unconditionally.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int MAXDEG, bool ALIGNED>
+template <typename T, int D, bool ALIGNED>
 __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    constexpr int K = MAX_REG_DEG;
     const int v = ci.first + j;
     const int H = ci.H;
-    const int k0 = a.vrowptr[v];
-    const int deg = a.vrowptr[v + 1] - k0;
+    const int n = ci.count;
+    int32_t slot[K];
+    uint8_t cnt[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        slot[k] = a.vell[ci.ell_base + (int64_t)k * n + j];
+        cnt[k] = a.cV[ci.cv_base + (int64_t)k * n + j];
+    }
+    const int deg = a.vdeg8[v];
     T c[D];
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)j * D + d];
-    int64_t off[MAXDEG];
-    T in[MAXDEG][D], pv[MAXDEG][D];
-    uint8_t cnt[MAXDEG];
+    int init = -1;
+    if (a.start) init = a.init_idx[v];
+    T in[K][D], pv[K][D];
 #pragma unroll
-    for (int k = 0; k < MAXDEG; ++k) {
-        off[k] = 0;
-        cnt[k] = 0;
+    for (int k = 0; k < K; ++k) {
+        const int off = slot[k] < 0 ? a.null_rec : slot[k];
+        const T* r = rec_ptr<ALIGNED>(a.old_rec + off);
 #pragma unroll
-        for (int d = 0; d < D; ++d) in[k][d] = pv[k][d] = (T)0;
-        if (k < deg) {
-            off[k] = a.vslot_rec[k0 + k];
-            cnt[k] = a.cV[k0 + k];
-            const T* r = rec_ptr<ALIGNED>(a.old_rec + off[k]);
-#pragma unroll
-            for (int d = 0; d < D; ++d) {
-                pv[k][d] = r[d];      // V->F message last sent on this edge
-                in[k][d] = r[H + d];  // F->V message held from this factor
-            }
+        for (int d = 0; d < D; ++d) {
+            pv[k][d] = r[d];      // V->F message last sent on this edge
+            in[k][d] = r[H + d];  // F->V message held from this factor
         }
     }
     // select_value: belief[d] = cost(d) + sum of the factor messages, first optimum
@@ -311,15 +328,14 @@ __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassI
     for (int d = 0; d < D; ++d) {
         T b = c[d];
 #pragma unroll
-        for (int k = 0; k < MAXDEG; ++k)
-            if (k < deg) b += in[k][d];
+        for (int k = 0; k < K; ++k) b += in[k][d];
         if (d == 0 || b < best_c) {
             best = d;
             best_c = b;
         }
     }
-    if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
-        best = a.init_idx[v];
+    if (init >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+        best = init;
         best_c = (T)0;
     }
     a.sel[v] = best;
@@ -327,44 +343,45 @@ __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassI
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
                              a.start_mode != MXS_START_LEAFS;
 #pragma unroll
-    for (int ko = 0; ko < MAXDEG; ++ko) {
-        if (ko < deg) {
-            T m[D];
-            T sum_cost = (T)0;
+    for (int ko = 0; ko < K; ++ko) {
+        T m[D];
+        T sum_cost = (T)0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) {
-                T x = c[d];
+        for (int d = 0; d < D; ++d) {
+            T x = c[d];
 #pragma unroll
-                for (int k = 0; k < MAXDEG; ++k)
-                    if (k < deg && k != ko) {
-                        sum_cost += in[k][d];
-                        x += in[k][d];
-                    }
-                m[d] = x;
-            }
-            const T avg = sum_cost / (T)D;
+            for (int k = 0; k < K; ++k)
+                if (k != ko) {
+                    sum_cost += in[k][d];
+                    x += in[k][d];
+                }
+            m[d] = x;
+        }
+        const T avg = sum_cost / (T)D;
 #pragma unroll
-            for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-            T* w = rec_ptr<ALIGNED>(a.new_rec + off[ko]);
-            if (a.start) {
+        for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
+        uint8_t co = 0;
+        if (a.start) {
 #pragma unroll
-                for (int d = 0; d < D; ++d) w[d] = start_sends ? m[d] : (T)0;
-                a.cV[k0 + ko] = 0;
-            } else {
-                const uint8_t co = damp_and_filter<T, D>(m, pv[ko], cnt[ko], a.damp_v != 0,
-                                                         a.damping, a.stability);
+            for (int d = 0; d < D; ++d) m[d] = start_sends ? m[d] : (T)0;
+        } else {
+            co = damp_and_filter<T, D>(m, pv[ko], cnt[ko], a.damp_v != 0, a.damping, a.stability);
+        }
+        if (slot[ko] >= 0) {
+            T* w = rec_ptr<ALIGNED>(a.new_rec + slot[ko]);
 #pragma unroll
-                for (int d = 0; d < D; ++d) w[d] = m[d];
-                a.cV[k0 + ko] = co;
-            }
+            for (int d = 0; d < D; ++d) w[d] = m[d];
+            a.cV[ci.cv_base + (int64_t)ko * n + j] = co;
         }
     }
 }
 
 // ---------------------------------------------------------------------------
-// Variable side, wave class (8 < deg <= 64): G lanes per variable, lane k holds the
-// record of the variable's k-th edge; the sums walk the lanes in edge order with
-// cross-lane reads, so the arithmetic order is still the reference's.
+// Variable side, wave class (4 < deg <= 64): G = 8, 16 or 64 lanes per variable,
+// lane k holds the record of the variable's k-th edge (one slot + one 64-B record
+// per lane: every load of the wave is in flight at once); the sums walk the lanes
+// in edge order with cross-lane reads, so the arithmetic order is still the
+// reference's.  Padding lanes hold zeros (the all-zero record).
 // ---------------------------------------------------------------------------
 template <typename T, int D, int G, bool ALIGNED>
 __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const ClassInfo& ci,
@@ -374,21 +391,18 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
     const int k = (int)threadIdx.x % G;
     const int v = ci.first + vloc;
     const int H = ci.H;
-    const int k0 = a.vrowptr[v];
-    const int deg = a.vrowptr[v + 1] - k0;
-    const bool has = k < deg;
+    const int64_t pos = (int64_t)vloc * G + k;
+    const int32_t slot = a.vell[ci.ell_base + pos];
+    const uint8_t cnt = a.cV[ci.cv_base + pos];
+    const int deg = a.vdeg8[v];
+    const bool has = slot >= 0;
+    int init = -1;
+    if (a.start) init = a.init_idx[v];
     T c[D], in[D], pv[D], b[D], m[D];
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        c[d] = a.var_cost[ci.cost_base + (int64_t)vloc * D + d];
-        in[d] = pv[d] = (T)0;
-    }
-    int64_t off = 0;
-    uint8_t cnt = 0;
-    if (has) {
-        off = a.vslot_rec[k0 + k];
-        cnt = a.cV[k0 + k];
-        const T* r = rec_ptr<ALIGNED>(a.old_rec + off);
+    for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)vloc * D + d];
+    {
+        const T* r = rec_ptr<ALIGNED>(a.old_rec + (has ? slot : a.null_rec));
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             pv[d] = r[d];
@@ -400,12 +414,24 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
     for (int d = 0; d < D; ++d) {
         b[d] = c[d];
         m[d] = c[d];
-        for (int kk = 0; kk < deg; ++kk) {
-            const T x = __shfl(in[d], kk, G);
-            b[d] += x;                 // select_value: every factor
-            if (kk != k) {             // costs_for_factor: every factor but the target
-                sum_cost += x;
-                m[d] += x;
+        if (G <= 16) {
+#pragma unroll
+            for (int kk = 0; kk < G; ++kk) {  // lanes past deg hold zeros
+                const T x = __shfl(in[d], kk, G);
+                b[d] += x;                 // select_value: every factor
+                if (kk != k) {             // costs_for_factor: every factor but the target
+                    sum_cost += x;
+                    m[d] += x;
+                }
+            }
+        } else {
+            for (int kk = 0; kk < deg; ++kk) {  // one variable per wave: uniform bound
+                const T x = __shfl(in[d], kk, G);
+                b[d] += x;
+                if (kk != k) {
+                    sum_cost += x;
+                    m[d] += x;
+                }
             }
         }
     }
@@ -417,8 +443,8 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
             best = d;
             best_c = b[d];
         }
-    if (a.start && a.init_idx[v] >= 0) {
-        best = a.init_idx[v];
+    if (init >= 0) {
+        best = init;
         best_c = (T)0;
     }
     if (k == 0) {
@@ -429,18 +455,18 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
     const T avg = sum_cost / (T)D;
 #pragma unroll
     for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-    T* w = rec_ptr<ALIGNED>(a.new_rec + off);
+    T* w = rec_ptr<ALIGNED>(a.new_rec + slot);
     if (a.start) {  // deg > 1 here: only leafs_vars / all make the variable send
         const bool sends = a.start_mode != MXS_START_LEAFS;
 #pragma unroll
         for (int d = 0; d < D; ++d) w[d] = sends ? m[d] : (T)0;
-        a.cV[k0 + k] = 0;
+        a.cV[ci.cv_base + pos] = 0;
         return;
     }
     const uint8_t co = damp_and_filter<T, D>(m, pv, cnt, a.damp_v != 0, a.damping, a.stability);
 #pragma unroll
     for (int d = 0; d < D; ++d) w[d] = m[d];
-    a.cV[k0 + k] = co;
+    a.cV[ci.cv_base + pos] = co;
 }
 
 // Variable side, generic class: thread per variable, any domain size / degree,
@@ -514,49 +540,55 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 }
 
 // ---------------------------------------------------------------------------
-// The sweep: one block = up to blockDim.x items of one class.
+// The sweep: one block = up to blockDim.x items of one class.  The class and the
+// first item of a block follow from blockIdx and the class table in the kernel
+// arguments.  DSEL != 0 instantiates the register / wave paths for that domain
+// size only (the engine picks it when the graph has a single D), which keeps the
+// kernel's register allocation -- the maximum over all paths -- small.
 // ---------------------------------------------------------------------------
 template <typename T, bool ALIGNED, int D>
-__device__ __forceinline__ void dispatch_d(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+__device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
+    if (ci.kind == K_V_WAVE) {  // several lanes per variable
+        switch (ci.maxdeg) {
+            case 8: variable_wave<T, D, 8, ALIGNED>(a, ci, item); break;
+            case 16: variable_wave<T, D, 16, ALIGNED>(a, ci, item); break;
+            default: variable_wave<T, D, 64, ALIGNED>(a, ci, item); break;
+        }
+        return;
+    }
+    const int j = item + (int)threadIdx.x;
+    if (j >= ci.count) return;
     switch (ci.kind) {
         case K_F_UNARY: factor_unary<T, D, ALIGNED>(a, ci, j); break;
         case K_F_BIN: factor_binary<T, D, ALIGNED>(a, ci, j); break;
-        case K_V_REG:
-            if (ci.maxdeg <= 4) variable_reg<T, D, 4, ALIGNED>(a, ci, j);
-            else variable_reg<T, D, 8, ALIGNED>(a, ci, j);
-            break;
+        case K_V_REG: variable_reg<T, D, ALIGNED>(a, ci, j); break;
         default: break;
     }
 }
 
-template <typename T, bool ALIGNED>
-__global__ void __launch_bounds__(BLOCK) k_sweep(SweepArgs<T> a) {
-    const BlockDesc bd = a.blocks[blockIdx.x];
-    const ClassInfo ci = a.classes[bd.cls];
-    if (ci.kind == K_V_WAVE) {  // several lanes per item
-        switch (ci.D * 100 + ci.maxdeg) {
-            case 216: variable_wave<T, 2, 16, ALIGNED>(a, ci, bd.item); break;
-            case 264: variable_wave<T, 2, 64, ALIGNED>(a, ci, bd.item); break;
-            case 316: variable_wave<T, 3, 16, ALIGNED>(a, ci, bd.item); break;
-            case 364: variable_wave<T, 3, 64, ALIGNED>(a, ci, bd.item); break;
-            case 416: variable_wave<T, 4, 16, ALIGNED>(a, ci, bd.item); break;
-            case 464: variable_wave<T, 4, 64, ALIGNED>(a, ci, bd.item); break;
-            default: break;
-        }
+template <typename T, bool ALIGNED, int DSEL>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a) {
+    int c = 0;
+#pragma unroll
+    for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
+    const ClassInfo ci = a.classes[c];
+    const int item = ((int)blockIdx.x - ci.block_base) * ci.per_block;
+    if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
+        const int j = item + (int)threadIdx.x;
+        if (j >= ci.count) return;
+        if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
+        else variable_generic<T>(a, ci, j);
         return;
     }
-    const int j = bd.item + (int)threadIdx.x;
-    if (j >= ci.count) return;
-    switch (ci.kind) {
-        case K_F_GEN: factor_generic<T>(a, ci, j); break;
-        case K_V_GEN: variable_generic<T>(a, ci, j); break;
-        default:
-            switch (ci.D) {
-                case 2: dispatch_d<T, ALIGNED, 2>(a, ci, j); break;
-                case 3: dispatch_d<T, ALIGNED, 3>(a, ci, j); break;
-                case 4: dispatch_d<T, ALIGNED, 4>(a, ci, j); break;
-                default: break;
-            }
+    if (DSEL != 0) {
+        sweep_d<T, ALIGNED, (DSEL != 0 ? DSEL : 2)>(a, ci, item);
+    } else {
+        switch (ci.D) {
+            case 2: sweep_d<T, ALIGNED, 2>(a, ci, item); break;
+            case 3: sweep_d<T, ALIGNED, 3>(a, ci, item); break;
+            case 4: sweep_d<T, ALIGNED, 4>(a, ci, item); break;
+            default: break;
+        }
     }
 }
 

@@ -171,6 +171,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             }
         }
         L.frowptr[nF] = ei;
+        // one all-zero record nobody writes, read through the padding slots of
+        // the variable classes (16-byte aligned, large enough for D <= MAX_REG_D)
+        off = (off + 1) / 2 * 2;
+        L.null_rec = off;
+        off += 2 * (int64_t)std::max(L.half_stride(MAX_REG_D), 4);
         L.rec_elems = off;
         if (off > ((int64_t)1 << 31) - 64) return "message buffer exceeds 2^31 elements";
     }
@@ -185,9 +190,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (!own) { kind = 90; sub = 0; }                       // ghost: never swept
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_REG_DEG) {
-            kind = K_V_REG; sub = D * 16 + (deg <= 4 ? 4 : 8);
+            kind = K_V_REG; sub = D * 16 + MAX_REG_DEG;
         } else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_WAVE_DEG) {
-            kind = K_V_WAVE; sub = D * 128 + (deg <= 16 ? 16 : 64);
+            kind = K_V_WAVE; sub = D * 128 + (deg <= 8 ? 8 : deg <= 16 ? 16 : 64);
         } else { kind = K_V_GEN; sub = 0; }
         vkind[v] = kind;
         // sort key: class, then degree (uniform waves), stable in caller order
@@ -203,6 +208,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     L.vrowptr.assign(nV + 1, 0);
     L.vslot_rec.resize(nE);
     L.vslot_edge.resize(nE);
+    L.vslot_cv.resize(nE);
+    L.vdeg8.resize(nV);
     L.vdom.resize(nV);
     L.vhalf.resize(nV);
     L.vcost_off.resize(nV);
@@ -225,6 +232,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.vslot_rec[k] = L.rec_off[ei];
                 L.edge_var_int[ei] = vi;
             }
+            L.vdeg8[vi] = (uint8_t)std::min(g.var_rowptr[v + 1] - g.var_rowptr[v], 255);
             L.vdom[vi] = g.dom_size[v];
             L.vhalf[vi] = L.half_stride(g.dom_size[v]);
             L.vcost_off[vi] = coff;
@@ -254,7 +262,12 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     }
     auto add_blocks = [&](std::vector<BlockDesc>& blocks, int cls, int count, int per_block) {
         L.classes[cls].block_base = (int)blocks.size();
+        L.classes[cls].per_block = per_block;
         for (int i = 0; i < count; i += per_block) blocks.push_back(BlockDesc{cls, i});
+    };
+    auto sweep_class = [&](int cls, int per_block) {  // blocks are derived from blockIdx
+        L.classes[cls].per_block = per_block;
+        L.sweep_order.push_back(cls);
     };
     for (int fi = 0; fi < nF;) {
         const FKey key = fkey[L.factor_i2e[fi]];
@@ -280,7 +293,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     L.tables[ci.tab_base + (int64_t)k * n + j] = sign * src[k];
             }
             L.classes.push_back(ci);
-            add_blocks(L.blocks_sweep, cls, n, BLOCK);
+            sweep_class(cls, BLOCK);
         } else {
             const int gen_base = (int)L.fgen.size();
             for (int j = 0; j < n; ++j) {
@@ -299,7 +312,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (key.kind == K_F_GEN) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
                 L.classes.push_back(ci);
-                add_blocks(L.blocks_sweep, cls, ci.count, BLOCK);
+                sweep_class(cls, BLOCK);
             } else {  // K_F_NARY: one workgroup per factor, own launch
                 ci.first = gen_base;  // index into fgen
                 L.classes.push_back(ci);
@@ -310,6 +323,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     }
 
     // ---- variable classes -------------------------------------------------------
+    // Send counters: positions [0, nE) follow the CSR slot order (generic class);
+    // the register / wave classes keep theirs in padded, coalesced tables behind.
+    L.n_cv = nE;
+    for (int k = 0; k < nE; ++k) L.vslot_cv[k] = k;
     for (int vi = 0; vi < nV;) {
         const int v0 = L.var_i2e[vi];
         const int key = vsort[v0] / 4096;
@@ -339,18 +356,36 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             vi = vj;
             continue;
         }
+        if (ci.kind == K_V_REG || ci.kind == K_V_WAVE) {
+            // slot table: record offset of the variable's k-th edge, -1 = padding.
+            //   K_V_REG  [maxdeg][count]  (a wave reads one k of 64 variables)
+            //   K_V_WAVE [count][G]       (lane k of a variable's group reads slot k)
+            const int64_t n = ci.count, G = ci.maxdeg;
+            ci.ell_base = (int64_t)L.vell.size();
+            ci.cv_base = L.n_cv;
+            L.vell.resize(L.vell.size() + (size_t)(n * G), -1);
+            L.n_cv += n * G;
+            for (int64_t j = 0; j < n; ++j) {
+                const int k0 = L.vrowptr[vi + j], deg = L.vrowptr[vi + j + 1] - k0;
+                for (int k = 0; k < deg; ++k) {
+                    const int64_t pos = ci.kind == K_V_REG ? (int64_t)k * n + j : j * G + k;
+                    L.vell[ci.ell_base + pos] = (int32_t)L.vslot_rec[k0 + k];
+                    L.vslot_cv[k0 + k] = ci.cv_base + pos;
+                }
+            }
+        }
         const int cls = (int)L.classes.size();
         L.classes.push_back(ci);
-        add_blocks(L.blocks_sweep, cls, ci.count, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
+        sweep_class(cls, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
         vi = vj;
     }
 
-    // Blocks with the longest per-thread chains first (generic classes, then the
-    // gathering variable classes, then the streaming factor classes), so that
-    // the tail of the launch is made of short blocks.
+    // Launch order of the sweep classes: the longest per-thread chains first
+    // (generic classes, then the gathering variable classes, then the streaming
+    // factor classes), so that the tail of the launch is made of short blocks.
     {
-        auto prio = [&](const BlockDesc& b) {
-            switch (L.classes[b.cls].kind) {
+        auto prio = [&](int c) {
+            switch (L.classes[c].kind) {
                 case K_V_GEN: return 0;
                 case K_F_GEN: return 1;
                 case K_V_WAVE: return 2;
@@ -358,14 +393,33 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 default: return 4;
             }
         };
-        std::stable_sort(L.blocks_sweep.begin(), L.blocks_sweep.end(),
-                         [&](const BlockDesc& x, const BlockDesc& y) { return prio(x) < prio(y); });
-        std::vector<int> seen(L.classes.size(), 0);
-        for (size_t i = 0; i < L.blocks_sweep.size(); ++i)
-            if (!seen[L.blocks_sweep[i].cls]) {
-                seen[L.blocks_sweep[i].cls] = 1;
-                L.classes[L.blocks_sweep[i].cls].block_base = (int)i;
+        std::stable_sort(L.sweep_order.begin(), L.sweep_order.end(),
+                         [&](int x, int y) { return prio(x) < prio(y); });
+        if (p.layout_flags & (32 | 64)) {  // timing experiments only (results are wrong):
+            std::vector<int32_t> keep;     // bit5 = factor side only, bit6 = variable side only
+            for (int c : L.sweep_order) {
+                const bool is_var = prio(c) == 0 || prio(c) == 2 || prio(c) == 3;
+                if (((p.layout_flags & 32) && !is_var) || ((p.layout_flags & 64) && is_var)) keep.push_back(c);
             }
+            L.sweep_order = keep;
+        }
+        if ((int)L.sweep_order.size() > MAX_CLASSES) return "too many kernel classes";
+        int nb = 0;
+        for (int c : L.sweep_order) {
+            ClassInfo& ci = L.classes[c];
+            ci.block_base = nb;
+            nb += (ci.count + ci.per_block - 1) / ci.per_block;
+        }
+        L.n_blocks_sweep = nb;
+        // one compile-time D for every register / wave class -> leaner kernel
+        int dsel = -1;
+        for (int c : L.sweep_order) {
+            const ClassInfo& ci = L.classes[c];
+            if (ci.D == 0) continue;
+            if (dsel == -1) dsel = ci.D;
+            else if (dsel != ci.D) dsel = 0;
+        }
+        L.dsel = dsel < 0 ? 0 : dsel;
     }
 
     // ---- algorithmic bytes per cycle --------------------

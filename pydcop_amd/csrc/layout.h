@@ -39,22 +39,23 @@ enum Kind : int32_t {
     K_F_BIN = 2,    // arity 2, D x D, D in {2,3,4}: thread per factor, registers
     K_F_GEN = 3,    // anything: thread per edge, scalar loops
     K_F_NARY = 4,   // large tables: workgroup per factor, LDS tile (own launch)
-    K_V_REG = 5,    // D in {2,3,4}, 1 <= deg <= 8: thread per variable, registers
+    K_V_REG = 5,    // D in {2,3,4}, 1 <= deg <= 4: thread per variable, registers
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
-    K_V_WAVE = 7,   // D in {2,3,4}, 8 < deg <= 64: G = 16 or 64 lanes per variable,
+    K_V_WAVE = 7,   // D in {2,3,4}, 4 < deg <= 64: G = 8, 16 or 64 lanes per variable,
                     // one lane per incoming edge, cross-lane sums
 };
 
 constexpr int BLOCK = 256;
 constexpr int MAX_REG_D = 4;
-constexpr int MAX_REG_DEG = 8;
+constexpr int MAX_REG_DEG = 4;
+constexpr int MAX_CLASSES = 24;  // ClassInfo table travels in the kernel arguments
 constexpr int MAX_WAVE_DEG = 64;
 
 struct ClassInfo {       // one per class, read with scalar loads
     int32_t kind;
     int32_t D;           // uniform domain size (0 for generic classes)
     int32_t H;           // half stride of the class's records (uniform classes)
-    int32_t maxdeg;      // K_V_REG: 4 or 8; K_V_WAVE: lanes per variable (16 or 64)
+    int32_t maxdeg;      // K_V_REG: 4; K_V_WAVE: lanes per variable G (8, 16 or 64)
     int32_t first;       // first internal factor / variable id of the class
     int32_t count;       // number of factors / variables (K_F_GEN: edges)
     int32_t edge_base;   // first internal edge id (factor classes)
@@ -63,10 +64,12 @@ struct ClassInfo {       // one per class, read with scalar loads
     int64_t tab_base;    // element offset of the class's tables
     int64_t cost_base;   // element offset of the class's variable costs
     int32_t block_base;  // index of the class's first block in its launch
-    int32_t pad_;
+    int32_t per_block;   // items a block covers (BLOCK, or BLOCK/G for K_V_WAVE)
+    int64_t ell_base;    // K_V_REG / K_V_WAVE: first entry of the class's slot table
+    int64_t cv_base;     // variable classes: first send counter of the class in cV
 };
 
-struct BlockDesc {
+struct BlockDesc {  // n-ary launch only; the sweep derives (class, item) from blockIdx
     int32_t cls;   // index into classes
     int32_t item;  // first item (factor / edge / variable index within class)
 };
@@ -98,7 +101,9 @@ struct Layout {
 
     // classes and blocks; launch 0 = sweep kernel, launch 1 = n-ary kernel
     std::vector<ClassInfo> classes;
-    std::vector<BlockDesc> blocks_sweep, blocks_nary;
+    std::vector<int32_t> sweep_order;  // classes of launch 0 in launch order
+    int32_t n_blocks_sweep = 0;        // grid size of launch 0
+    std::vector<BlockDesc> blocks_nary;
 
     // per internal edge
     std::vector<int64_t> rec_off;    // element offset of the record
@@ -115,6 +120,14 @@ struct Layout {
     std::vector<int32_t> vrowptr;    // [n_vars+1] var-major slot ranges
     std::vector<int64_t> vslot_rec;  // [n_edges] record offset of the slot's edge
     std::vector<int32_t> vslot_edge; // [n_edges] internal edge id of the slot
+    std::vector<int64_t> vslot_cv;   // [n_edges] position of the slot's send counter in cV
+    std::vector<int32_t> vell;       // slot tables of the K_V_REG ([4][count], edge-slot-major)
+                                     // and K_V_WAVE ([count][G]) classes: record offset or -1
+    std::vector<uint8_t> vdeg8;      // [n_vars] min(degree, 255), internal order
+    int64_t n_cv = 0;                // size of the cV array (CSR slots + padded class slots)
+    int64_t null_rec = 0;            // offset of an all-zero record nobody writes (padding
+                                     // slots read it: adding 0.0 is exact)
+    int dsel = 0;                    // the one D all register/wave classes share, else 0
     std::vector<int32_t> vdom;       // [n_vars]
     std::vector<int32_t> vhalf;      // [n_vars] half stride of the variable's records
     std::vector<int64_t> vcost_off;  // [n_vars]
