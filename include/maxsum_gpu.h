@@ -84,6 +84,11 @@ typedef struct mxs_graph {
                                       owned by another shard (its V->F
                                       messages arrive through mxs_halo_*).
                                       NULL = all owned (single GPU).          */
+    const uint8_t *factor_owned;   /* [n_factors] 1 = mxs_eval_cost counts the
+                                      factor on this shard (a cut factor is
+                                      replicated on every shard that owns one
+                                      of its variables but must be counted
+                                      once).  NULL = all.                     */
 } mxs_graph;
 
 typedef struct mxs_params {
@@ -168,6 +173,11 @@ int mxs_halo_setup(mxs_engine *e, const int32_t *send_edges, int64_t n_send,
  * dom_size[edge_var[e]] elements, edges in the order given to halo_setup). */
 int mxs_halo_buffers(mxs_engine *e, void **send_dev, int64_t *send_bytes,
                      void **recv_dev, int64_t *recv_bytes);
+/* Use caller-owned device memory (e.g. tensors of the framework that runs the
+ * collective) as the packed send / receive buffers instead of the engine's own;
+ * sizes as reported by mxs_halo_buffers.  Call after mxs_halo_setup; the
+ * current messages are packed into the new send buffer. */
+int mxs_halo_bind(mxs_engine *e, void *send_dev, void *recv_dev);
 /* One cycle split around the exchange:  step_pack = sweep + pack (async on
  * the engine stream), then the host runs the collective on the same stream
  * (mxs_stream), then step_unpack scatters the received messages. */

@@ -79,6 +79,7 @@ struct EngineBase {
     virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
     virtual int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) = 0;
     virtual int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) = 0;
+    virtual int halo_bind(void* s, void* r) = 0;
     virtual int step_pack() = 0;
     virtual int step_unpack() = 0;
     Layout L;
@@ -93,7 +94,7 @@ struct Engine : EngineBase {
     int device = 0;
     int cur = 0;  // record buffer holding the messages of the last finished cycle
     DevBuf<T> rec[2], tables, var_cost, belief, halo_send, halo_recv;
-    DevBuf<uint8_t> cF, cV, owned, vdeg8;
+    DevBuf<uint8_t> cF, cV, owned, fowned, vdeg8;
     DevBuf<int32_t> vrowptr, vdom, vhalf, init_idx, edge_gen_factor, edge_dom, edge_half, sel, vell;
     DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
     DevBuf<int64_t> vslot_rec, vcost_off, rec_off, eval_tab_off, halo_send_off, halo_recv_off;
@@ -107,6 +108,9 @@ struct Engine : EngineBase {
     int graph_cycles = 0;  // cycles per replay (even), 0 = no graph
     bool graph_tried = false;
     int64_t n_halo_send = 0, n_halo_recv = 0;
+    T* send_buf = nullptr;  // packed staging buffers: the engine's own (halo_send /
+    T* recv_buf = nullptr;  // halo_recv) or caller-owned memory (mxs_halo_bind)
+    bool halo_ready = false;
     static constexpr int EVAL_BLOCKS = 1024;
 
     ~Engine() override {
@@ -207,6 +211,7 @@ struct Engine : EngineBase {
         HIP_TRY(vell.upload(L.vell, stream));
         HIP_TRY(vdeg8.upload(L.vdeg8, stream));
         HIP_TRY(owned.upload(L.owned, stream));
+        HIP_TRY(fowned.upload(L.fowned, stream));
         HIP_TRY(vrowptr.upload(L.vrowptr, stream));
         HIP_TRY(vdom.upload(L.vdom, stream));
         HIP_TRY(vhalf.upload(L.vhalf, stream));
@@ -253,6 +258,10 @@ struct Engine : EngineBase {
         int rc = launch_cycle(cur, true);
         if (rc) return rc;
         cur ^= 1;
+        if (halo_ready) {  // the start messages have to cross too
+            rc = pack();
+            if (rc) return rc;
+        }
         HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
     }
@@ -293,7 +302,7 @@ struct Engine : EngineBase {
     int run_async(int n) override {
         if (n < 0) return fail(MXS_E_INVALID, "n_cycles must be >= 0");
         HIP_TRY(hipSetDevice(device));
-        if (n_halo_recv > 0 || n_halo_send > 0)
+        if (halo_ready)
             return fail(MXS_E_STATE, "a sharded engine must be stepped with mxs_step_pack/unpack");
         int left = n;
         if (left > 0 && cur != 0) {  // align to the parity the graph was captured with
@@ -412,6 +421,7 @@ struct Engine : EngineBase {
         a.vcost_off = vcost_off.p;
         a.var_cost = eval_var_cost.p;
         a.owned = owned.p;
+        a.fowned = fowned.p;
         a.idx = didx;
         a.part_cost = part_cost.p;
         a.part_viol = part_viol.p;
@@ -463,6 +473,9 @@ struct Engine : EngineBase {
         HIP_TRY(halo_recv_off.upload(ro, stream));
         HIP_TRY(halo_send.alloc((size_t)n_halo_send));
         HIP_TRY(halo_recv.alloc((size_t)n_halo_recv));
+        send_buf = halo_send.p;
+        recv_buf = halo_recv.p;
+        halo_ready = true;
         // the start messages of cycle 0 have to cross too: pack them now
         return pack();
     }
@@ -471,7 +484,7 @@ struct Engine : EngineBase {
         if (n_halo_send > 0) {
             const int nb = (int)((n_halo_send + BLOCK - 1) / BLOCK);
             hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, stream,
-                               (const T*)rec[cur].p, (const int64_t*)halo_send_off.p, halo_send.p,
+                               (const T*)rec[cur].p, (const int64_t*)halo_send_off.p, send_buf,
                                n_halo_send);
             HIP_TRY(hipGetLastError());
         }
@@ -479,11 +492,20 @@ struct Engine : EngineBase {
     }
 
     int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) override {
-        if (s) *s = halo_send.p;
+        if (s) *s = send_buf;
         if (sb) *sb = n_halo_send * (int64_t)sizeof(T);
-        if (r) *r = halo_recv.p;
+        if (r) *r = recv_buf;
         if (rb) *rb = n_halo_recv * (int64_t)sizeof(T);
         return MXS_OK;
+    }
+
+    int halo_bind(void* s, void* r) override {
+        if (!halo_ready) return fail(MXS_E_STATE, "mxs_halo_bind needs mxs_halo_setup first");
+        if ((n_halo_send && !s) || (n_halo_recv && !r)) return fail(MXS_E_INVALID, "null halo buffer");
+        HIP_TRY(hipSetDevice(device));
+        send_buf = (T*)s;
+        recv_buf = (T*)r;
+        return pack();
     }
 
     int step_pack() override {
@@ -500,7 +522,7 @@ struct Engine : EngineBase {
         if (n_halo_recv > 0) {
             const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
             hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, stream, rec[cur].p,
-                               (const int64_t*)halo_recv_off.p, (const T*)halo_recv.p, n_halo_recv);
+                               (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv);
             HIP_TRY(hipGetLastError());
         }
         return MXS_OK;
@@ -604,6 +626,8 @@ int mxs_halo_buffers(mxs_engine* e, void** s, int64_t* sb, void** r, int64_t* rb
     CHECK_HANDLE(e);
     return e->impl->halo_buffers(s, sb, r, rb);
 }
+
+int mxs_halo_bind(mxs_engine* e, void* s, void* r) { CHECK_HANDLE(e); return e->impl->halo_bind(s, r); }
 
 int mxs_step_pack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_pack(); }
 int mxs_step_unpack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_unpack(); }

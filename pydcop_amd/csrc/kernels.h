@@ -607,6 +607,7 @@ struct EvalArgs {
     const int64_t* vcost_off;
     const double* var_cost;
     const uint8_t* owned;
+    const uint8_t* fowned;        // [n_factors] 1 = counted on this shard
     const int32_t* idx;           // [n_vars] internal order
     double* part_cost;            // [gridDim.x]
     unsigned long long* part_viol;
@@ -623,6 +624,7 @@ __global__ void __launch_bounds__(BLOCK) k_eval(EvalArgs a) {
     for (int i = (int)(blockIdx.x * blockDim.x + threadIdx.x); i < a.n_factors + a.n_vars; i += stride) {
         double r;
         if (i < a.n_factors) {
+            if (!a.fowned[i]) continue;
             int64_t lin = 0;
             for (int e = a.frowptr[i]; e < a.frowptr[i + 1]; ++e)
                 lin = lin * a.edge_dom[e] + a.idx[a.edge_var_int[e]];

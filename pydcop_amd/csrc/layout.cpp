@@ -253,6 +253,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         const int f = L.factor_i2e[fi];
         L.eval_tab_off[fi + 1] = L.eval_tab_off[fi] + (g.table_off[f + 1] - g.table_off[f]);
     }
+    L.fowned.assign(nF, 1);
+    if (g.factor_owned)
+        for (int fi = 0; fi < nF; ++fi) L.fowned[fi] = g.factor_owned[L.factor_i2e[fi]] ? 1 : 0;
     L.eval_tables.resize(L.eval_tab_off[nF]);
     L.tables.resize(L.eval_tab_off[nF]);
     for (int fi = 0; fi < nF; ++fi) {

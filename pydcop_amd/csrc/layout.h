@@ -134,6 +134,7 @@ struct Layout {
     std::vector<double> var_cost;    // device image (negated for max)
     std::vector<int32_t> init_idx;   // [n_vars] internal order, -1 = none
     std::vector<uint8_t> owned;      // [n_vars] internal order
+    std::vector<uint8_t> fowned;     // [n_factors] internal order (eval_cost)
 
     // bookkeeping for eval_cost (row-major tables in internal factor order)
     std::vector<int64_t> eval_tab_off;  // [n_factors+1]

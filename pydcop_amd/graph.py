@@ -24,7 +24,7 @@ class CGraph(C.Structure):
         ("factor_rowptr", C.c_void_p), ("edge_var", C.c_void_p),
         ("table_off", C.c_void_p), ("tables", C.c_void_p),
         ("var_rowptr", C.c_void_p), ("var_edges", C.c_void_p),
-        ("var_owned", C.c_void_p),
+        ("var_owned", C.c_void_p), ("factor_owned", C.c_void_p),
     ]
 
 
@@ -82,6 +82,7 @@ class FlatGraph:
     var_edges: np.ndarray       # int32 [n_edges]
     init_idx: Optional[np.ndarray] = None   # int32 [n_vars] or None
     var_owned: Optional[np.ndarray] = None  # uint8 [n_vars] or None
+    factor_owned: Optional[np.ndarray] = None  # uint8 [n_factors] or None
     # host-only metadata (names / domain values), optional
     var_names: Optional[List[str]] = None
     factor_names: Optional[List[str]] = None
@@ -101,6 +102,8 @@ class FlatGraph:
             self.init_idx = _arr(self.init_idx, np.int32)
         if self.var_owned is not None:
             self.var_owned = _arr(self.var_owned, np.uint8)
+        if self.factor_owned is not None:
+            self.factor_owned = _arr(self.factor_owned, np.uint8)
 
     # sizes ---------------------------------------------------------------
     @property
@@ -180,7 +183,7 @@ class FlatGraph:
                       p(self.dom_size), p(self.var_cost), p(self.init_idx),
                       p(self.factor_rowptr), p(self.edge_var), p(self.table_off),
                       p(self.tables), p(self.var_rowptr), p(self.var_edges),
-                      p(self.var_owned))
+                      p(self.var_owned), p(self.factor_owned))
 
     # algorithmic bytes of one cycle -----------------
     def cycle_bytes(self, word: int) -> int:

@@ -1,0 +1,226 @@
+"""k-way partition of a factor graph's variables and construction of the shards.
+
+The reference's analogue is the distribution of computations on agents
+(pydcop/distribution/*.py); for one batched sweep per GPU what matters is a
+balanced split of the *edges* with few cut factors, because every cut factor is
+replicated on the shards that own one of its variables and its remote variables'
+V->F messages have to cross once per cycle.
+
+METIS is not available in this environment, so `partition_variables` is a small
+O(E) heuristic of its own: breadth-first order over the bipartite graph (locality)
+cut into k chunks of equal edge weight, then a few rounds of balanced label
+propagation that move a variable to the part holding most of its neighbours.
+"""
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+
+from .graph import FlatGraph
+
+
+def _edge_factor(g: FlatGraph) -> np.ndarray:
+    return np.repeat(np.arange(g.n_factors, dtype=np.int64), np.diff(g.factor_rowptr))
+
+
+def partition_variables(g: FlatGraph, k: int, rounds: int = 6, seed: int = 0,
+                        imbalance: float = 1.03) -> np.ndarray:
+    """part[v] in 0..k-1 for every variable."""
+    nv, nf = g.n_vars, g.n_factors
+    if k <= 1 or nv == 0:
+        return np.zeros(nv, dtype=np.int32)
+    import scipy.sparse as sp
+    from scipy.sparse.csgraph import breadth_first_order
+
+    ev = g.edge_var.astype(np.int64)
+    ef = _edge_factor(g)
+    ne = ev.shape[0]
+    # bipartite incidence B (factors x variables)
+    B = sp.csr_matrix((np.ones(ne, dtype=np.float32), (ef, ev)), shape=(nf, nv))
+    # ---- initial partition: BFS order, chunks of equal weight (1 + degree) --------
+    A = sp.bmat([[None, B.T], [B, None]], format="csr")
+    seen = np.zeros(nv + nf, dtype=bool)
+    order: List[np.ndarray] = []
+    start = 0
+    while start < nv:  # every connected component
+        o = breadth_first_order(A, start, directed=False, return_predecessors=False)
+        seen[o] = True
+        order.append(o[o < nv])
+        rest = np.flatnonzero(~seen[:nv])
+        if rest.size == 0:
+            break
+        if rest.size < 64 or len(order) > 256:  # many tiny components: just append them
+            order.append(rest)
+            break
+        start = int(rest[0])
+    order = np.concatenate(order)
+    weight = 1.0 + np.diff(g.var_rowptr).astype(np.float64)
+    cum = np.cumsum(weight[order])
+    total = cum[-1]
+    part = np.empty(nv, dtype=np.int32)
+    part[order] = np.minimum((cum - 1e-9) * k / total, k - 1).astype(np.int32)
+    # ---- refinement: balanced label propagation --------------------------------------
+    rng = np.random.default_rng(seed)
+    cap = imbalance * total / k
+    for _ in range(rounds):
+        P = sp.csr_matrix((np.ones(nv, dtype=np.float32), (np.arange(nv), part)), shape=(nv, k))
+        cnt = (B.T @ (B @ P)).toarray()  # [nv, k] neighbours (with multiplicity) per part, incl. self
+        own = cnt[np.arange(nv), part] - np.asarray(B.multiply(B).sum(axis=0)).ravel()
+        cnt[np.arange(nv), part] = -1
+        best = cnt.argmax(axis=1).astype(np.int32)
+        gain = cnt[np.arange(nv), best] - own
+        cand = np.flatnonzero((gain > 0) & (rng.random(nv) < 0.5))  # half at a time: no ping-pong
+        if cand.size == 0:
+            break
+        cand = cand[np.argsort(-gain[cand], kind="stable")]
+        load = np.bincount(part, weights=weight, minlength=k)
+        moved = 0
+        for p in range(k):  # accept the best moves into p while it has room
+            into = cand[best[cand] == p]
+            if into.size == 0:
+                continue
+            room = cap - load[p]
+            ok = np.cumsum(weight[into]) <= room
+            into = into[ok]
+            part[into] = p
+            moved += into.size
+        if moved == 0:
+            break
+    return part
+
+
+def cut_statistics(g: FlatGraph, part: np.ndarray) -> dict:
+    ef = _edge_factor(g)
+    pe = part[g.edge_var]
+    lo = np.full(g.n_factors, np.iinfo(np.int32).max, dtype=np.int64)
+    hi = np.full(g.n_factors, -1, dtype=np.int64)
+    np.minimum.at(lo, ef, pe)
+    np.maximum.at(hi, ef, pe)
+    cut = lo != hi
+    k = int(part.max()) + 1 if part.size else 1
+    load = np.bincount(part, weights=np.diff(g.var_rowptr).astype(np.float64), minlength=k)
+    return {"parts": k, "cut_factors": int(cut.sum()), "cut_fraction": float(cut.mean()) if cut.size else 0.0,
+            "edge_imbalance": float(load.max() / max(load.mean(), 1e-9))}
+
+
+@dataclass
+class Shard:
+    """What one rank sweeps, plus the halo lists in local edge ids."""
+    rank: int
+    graph: FlatGraph             # local graph (owned + ghost variables, var_owned/factor_owned set)
+    local_vars: np.ndarray       # [n_local_vars] global variable id (owned first)
+    n_owned: int
+    local_factors: np.ndarray    # [n_local_factors] global factor id
+    send_edges: np.ndarray       # local edge ids, grouped by destination rank (ascending)
+    send_counts: np.ndarray      # [world] elements (not edges) sent to each rank
+    recv_edges: np.ndarray       # local edge ids, grouped by source rank
+    recv_counts: np.ndarray      # [world] elements received from each rank
+
+
+def build_shard(g: FlatGraph, part: np.ndarray, rank: int, world: int) -> Shard:
+    """Local graph of `rank`: its variables, every factor touching one of them and
+    ghost copies of the remote variables of those (cut) factors.
+
+    Orders are inherited from the global graph -- factors ascending, an owned
+    variable's edges in its global links order -- so a shard's arithmetic is the
+    global graph's, operation for operation.
+    """
+    part = np.asarray(part, dtype=np.int32)
+    nf = g.n_factors
+    ev = g.edge_var.astype(np.int64)
+    ef = _edge_factor(g)
+    edge_part = part[ev]
+    mine_e = edge_part == rank
+    f_local = np.zeros(nf, dtype=bool)
+    f_local[ef[mine_e]] = True
+    local_factors = np.flatnonzero(f_local)
+    # local edges = all edges of local factors, in global order (factor-major)
+    e_local = np.flatnonzero(f_local[ef])
+    owned = np.flatnonzero(part == rank)
+    touched = np.unique(ev[e_local])
+    ghosts = touched[part[touched] != rank]
+    local_vars = np.concatenate([owned, ghosts]).astype(np.int64)
+    g2l = np.full(g.n_vars, -1, dtype=np.int64)
+    g2l[local_vars] = np.arange(local_vars.shape[0])
+    e_g2l = np.full(g.n_edges, -1, dtype=np.int64)
+    e_g2l[e_local] = np.arange(e_local.shape[0])
+
+    arity = np.diff(g.factor_rowptr)[local_factors]
+    factor_rowptr = np.zeros(local_factors.shape[0] + 1, dtype=np.int32)
+    np.cumsum(arity, out=factor_rowptr[1:])
+    sizes = np.diff(g.table_off)[local_factors]
+    table_off = np.zeros(local_factors.shape[0] + 1, dtype=np.int64)
+    np.cumsum(sizes, out=table_off[1:])
+    # gather the tables (vectorised ragged copy)
+    src0 = g.table_off[:-1][local_factors]
+    idx = np.repeat(src0 - table_off[:-1], sizes) + np.arange(int(table_off[-1]))
+    tables = g.tables[idx] if idx.size else np.zeros(0)
+    edge_var = g2l[ev[e_local]].astype(np.int32)
+
+    # variable side: owned variables keep their global edge order; ghosts list
+    # their local edges in any order (never swept)
+    dom_size = g.dom_size[local_vars]
+    cost_off = g.cost_off
+    cidx = np.repeat(cost_off[:-1][local_vars] - np.concatenate([[0], np.cumsum(dom_size)[:-1]]),
+                     dom_size) + np.arange(int(dom_size.sum()))
+    var_cost = g.var_cost[cidx] if cidx.size else np.zeros(0)
+    deg_owned = np.diff(g.var_rowptr)[owned]
+    k_src = np.repeat(g.var_rowptr[:-1][owned].astype(np.int64) - np.concatenate([[0], np.cumsum(deg_owned)[:-1]]),
+                      deg_owned) + np.arange(int(deg_owned.sum()))
+    owned_edges = e_g2l[g.var_edges[k_src]] if k_src.size else np.zeros(0, dtype=np.int64)
+    assert (owned_edges >= 0).all()
+    ghost_edge_mask = edge_part[e_local] != rank
+    ghost_edges = np.flatnonzero(ghost_edge_mask)
+    gorder = np.argsort(edge_var[ghost_edges], kind="stable")
+    ghost_edges = ghost_edges[gorder]
+    deg_ghost = np.bincount(edge_var[ghost_edges] - owned.shape[0], minlength=ghosts.shape[0])
+    var_rowptr = np.zeros(local_vars.shape[0] + 1, dtype=np.int32)
+    np.cumsum(np.concatenate([deg_owned, deg_ghost]), out=var_rowptr[1:])
+    var_edges = np.concatenate([owned_edges, ghost_edges]).astype(np.int32)
+    var_owned = np.zeros(local_vars.shape[0], dtype=np.uint8)
+    var_owned[:owned.shape[0]] = 1
+    # a factor is counted (solution cost) by the owner of its first variable
+    first_owner = part[ev[g.factor_rowptr[:-1][local_factors]]] if local_factors.size else np.zeros(0)
+    factor_owned = (first_owner == rank).astype(np.uint8)
+    init_idx = g.init_idx[local_vars] if g.init_idx is not None else None
+    lg = FlatGraph(dom_size=dom_size, var_cost=var_cost, factor_rowptr=factor_rowptr,
+                   edge_var=edge_var, table_off=table_off, tables=tables,
+                   var_rowptr=var_rowptr, var_edges=var_edges, init_idx=init_idx,
+                   var_owned=var_owned, factor_owned=factor_owned)
+
+    # ---- halo lists -----------------------------------------------------------------
+    # The V->F message of global edge e=(f, u) goes from owner(u) to every other
+    # rank on which f is local.  Both ends enumerate (src, dst) pairs' edges in
+    # ascending global edge id, which fixes the packing order without any handshake.
+    D_e = g.dom_size[ev]
+    send_edges, recv_edges = [], []
+    send_counts = np.zeros(world, dtype=np.int64)
+    recv_counts = np.zeros(world, dtype=np.int64)
+    # factors local here that are also local elsewhere = cut factors
+    cut_local = local_factors[(arity > 1)] if local_factors.size else local_factors
+    if cut_local.size:
+        # ranks present in each local factor
+        fe = np.flatnonzero(np.isin(ef, cut_local))  # global edges of candidate factors
+        for q in range(world):
+            if q == rank:
+                send_edges.append(np.zeros(0, dtype=np.int64))
+                recv_edges.append(np.zeros(0, dtype=np.int64))
+                continue
+            f_has_q = np.zeros(nf, dtype=bool)
+            f_has_q[ef[fe][edge_part[fe] == q]] = True     # local factors touching rank q
+            shared = fe[f_has_q[ef[fe]]]                    # their edges (ascending)
+            out = shared[edge_part[shared] == rank]         # my variables' messages -> q
+            inc = shared[edge_part[shared] == q]            # q's variables' messages -> me
+            send_edges.append(e_g2l[out])
+            recv_edges.append(e_g2l[inc])
+            send_counts[q] = int(D_e[out].sum())
+            recv_counts[q] = int(D_e[inc].sum())
+    else:
+        send_edges = [np.zeros(0, dtype=np.int64)] * world
+        recv_edges = [np.zeros(0, dtype=np.int64)] * world
+    return Shard(rank=rank, graph=lg, local_vars=local_vars, n_owned=int(owned.shape[0]),
+                 local_factors=local_factors,
+                 send_edges=np.concatenate(send_edges).astype(np.int32),
+                 send_counts=send_counts,
+                 recv_edges=np.concatenate(recv_edges).astype(np.int32),
+                 recv_counts=recv_counts)

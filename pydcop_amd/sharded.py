@@ -1,0 +1,143 @@
+"""Max-Sum on a factor graph partitioned across the GPUs of one node: one process
+per GPU, one `MaxSumEngine` per process, one exchange of boundary V->F messages
+per synchronous cycle.
+
+The reference's counterpart is message passing between agents
+(pydcop/infrastructure/communication.py:588-698); here the only messages that
+leave a GPU are those of cut factors' remote variables:
+
+    cycle t:   sweep + pack   (engine stream; kernels of pydcop_amd/csrc)
+               all-to-all     (torch.distributed; backend "nccl" = RCCL over xGMI,
+                               enqueued behind the pack on the same stream)
+               unpack         (engine stream; scatters into the ghost records)
+
+Both message directions of cycle t read only cycle t-1 (Jacobi schedule), so one
+exchange per cycle is enough and a suppressed (unsent) message needs no special
+case: the sender's record simply still holds the old value.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .engine import MaxSumEngine
+from .graph import FlatGraph, Params
+from .partition import Shard, build_shard, partition_variables
+
+
+class ShardedMaxSum:
+    """Same surface as `MaxSumEngine`, over `world` ranks.
+
+    Every rank passes the same (whole) graph and partition; a rank only uploads
+    its shard.  `torch.distributed` must be initialised (nccl on GPUs; gloo works
+    for host-memory engines, which is what the CPU tests use)."""
+
+    def __init__(self, graph: FlatGraph, params: Optional[Params], rank: int, world: int,
+                 device: int = 0, part: Optional[np.ndarray] = None,
+                 lib_path: Optional[str] = None, group=None):
+        import torch
+        import torch.distributed as dist
+        self._torch, self._dist = torch, dist
+        self.rank, self.world, self.group = rank, world, group
+        self.graph = graph
+        self.params = params or Params()
+        self.part = partition_variables(graph, world) if part is None else np.asarray(part, dtype=np.int32)
+        self.shard: Shard = build_shard(graph, self.part, rank, world)
+        self.engine = MaxSumEngine(self.shard.graph, self.params, device=device, lib_path=lib_path)
+        self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
+        backend = dist.get_backend(group) if world > 1 else "none"
+        self._on_gpu = backend == "nccl"
+        tdtype = torch.float64 if self.params.dtype == "f64" else torch.float32
+        tdev = torch.device("cuda", device) if self._on_gpu else torch.device("cpu")
+        n_send, n_recv = int(self.shard.send_counts.sum()), int(self.shard.recv_counts.sum())
+        # the collective runs on tensors torch owns; the engine packs into / unpacks
+        # from them directly (mxs_halo_bind)
+        self._send = torch.zeros(max(n_send, 1), dtype=tdtype, device=tdev)
+        self._recv = torch.zeros(max(n_recv, 1), dtype=tdtype, device=tdev)
+        self._n_send, self._n_recv = n_send, n_recv
+        self._send_splits = [int(x) for x in self.shard.send_counts]
+        self._recv_splits = [int(x) for x in self.shard.recv_counts]
+        self._stream_ctx = None
+        if self._on_gpu:
+            # torch's collectives order themselves against the *current* stream:
+            # make that the engine's own stream
+            self._ext_stream = torch.cuda.ExternalStream(self.engine.stream(), device=tdev)
+        if self._on_gpu:
+            torch.cuda.synchronize(tdev)
+        self.engine.halo_bind(self._send.data_ptr(), self._recv.data_ptr())
+        self._exchange()          # the start messages of cycle 0
+        self.engine.step_unpack()
+        self.engine.sync()
+
+    # -- the per-cycle exchange ------------------------------------------------------
+    def _exchange(self):
+        if self.world == 1:
+            return
+        torch, dist = self._torch, self._dist
+        send = self._send[:self._n_send]
+        recv = self._recv[:self._n_recv]
+        if self._on_gpu:
+            with torch.cuda.stream(self._ext_stream):
+                dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
+        else:
+            self.engine.sync()
+            dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
+
+    def run_async(self, n_cycles: int):
+        for _ in range(int(n_cycles)):
+            self.engine.step_pack()
+            self._exchange()
+            self.engine.step_unpack()
+
+    def sync(self):
+        self.engine.sync()
+
+    def run(self, n_cycles: int):
+        self.run_async(n_cycles)
+        self.sync()
+
+    def reset(self):
+        self.engine.reset()
+        self._exchange()
+        self.engine.step_unpack()
+        self.engine.sync()
+
+    @property
+    def cycle_count(self) -> int:
+        return self.engine.cycle_count
+
+    # -- results -----------------------------------------------------------------------
+    def _all_gather_owned(self, values: np.ndarray) -> np.ndarray:
+        """Owned entries of every rank -> one global array (same on all ranks)."""
+        out = np.empty(self.graph.n_vars, dtype=values.dtype)
+        sh = self.shard
+        if self.world == 1:
+            out[sh.local_vars[:sh.n_owned]] = values[:sh.n_owned]
+            return out
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, (sh.local_vars[:sh.n_owned], values[:sh.n_owned]),
+                                     group=self.group)
+        for ids, vals in parts:
+            out[ids] = vals
+        return out
+
+    def assignment(self) -> Tuple[np.ndarray, np.ndarray]:
+        """(idx, belief) of the WHOLE graph, gathered from the owners."""
+        idx, belief = self.engine.assignment()
+        return self._all_gather_owned(idx), self._all_gather_owned(belief)
+
+    def eval_cost(self, idx=None, infinity: float = float("inf")) -> Tuple[float, int]:
+        """DCOP.solution_cost (pydcop/dcop/dcop.py:319-367) of a whole-graph
+        assignment (default: the current selection): every shard evaluates the
+        factors and variables it owns, then one all-reduce."""
+        if idx is None:
+            idx = self.assignment()[0]
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        cost, viol = self.engine.eval_cost(idx[self.shard.local_vars], infinity)
+        if self.world == 1:
+            return cost, viol
+        parts = [None] * self.world
+        self._dist.all_gather_object(parts, (cost, viol), group=self.group)
+        return float(sum(p[0] for p in parts)), int(sum(p[1] for p in parts))
+
+    def close(self):
+        self.engine.close()
