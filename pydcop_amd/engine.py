@@ -8,6 +8,7 @@ HIP library is missing or no MI355X is visible, construction raises.
 """
 import ctypes as C
 import os
+import sys
 from typing import Optional, Tuple
 
 import numpy as np
@@ -32,6 +33,43 @@ class MaxSumGpuError(RuntimeError):
 
 
 _libs = {}
+_hip_runtime = None
+
+
+def hip_runtime_path() -> str:
+    """The HIP runtime (libamdhip64) this process uses.
+
+    libmaxsum_hip.so is linked without it so that there is exactly ONE runtime per
+    process: torch bundles its own copy, and the multi-GPU path hands the engine's
+    stream and halo buffers to torch.distributed (RCCL), which only works inside
+    one runtime.  Order: $MAXSUM_HIP_RUNTIME, the copy bundled with an already
+    imported torch, then the system ROCm."""
+    env = os.environ.get("MAXSUM_HIP_RUNTIME")
+    if env:
+        return env
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            return cand
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    for name in ("libamdhip64.so", "libamdhip64.so.7", "libamdhip64.so.6"):
+        cand = os.path.join(rocm, "lib", name)
+        if os.path.exists(cand):
+            return cand
+    return "libamdhip64.so"
+
+
+def _load_hip_runtime():
+    global _hip_runtime
+    if _hip_runtime is None:
+        path = hip_runtime_path()
+        try:
+            _hip_runtime = (path, C.CDLL(path, mode=C.RTLD_GLOBAL))
+        except OSError as e:
+            raise MaxSumGpuError(f"cannot load the HIP runtime {path}: {e}. "
+                                 "maxsum_gpu has no CPU fallback.") from e
+    return _hip_runtime[0]
 
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
@@ -43,6 +81,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise MaxSumGpuError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). maxsum_gpu has no CPU fallback.")
+    if os.path.basename(path) == os.path.basename(DEFAULT_LIB):
+        _load_hip_runtime()  # the emulated test build carries its own fake runtime
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     protos = {

@@ -6,6 +6,14 @@ import sys
 import numpy as np
 import pytest
 
+try:
+    # One HIP runtime per process: importing torch first makes the engine bind to
+    # the runtime torch bundles (pydcop_amd/engine.py:hip_runtime_path), which the
+    # GPU tests of the sharded path need (they hand device buffers to torch).
+    import torch  # noqa: F401
+except ImportError:  # pragma: no cover
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
