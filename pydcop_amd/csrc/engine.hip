@@ -3,8 +3,9 @@
 // Host side of one engine = one GPU, one HIP stream:
 //   create   build_layout (layout.cpp) -> upload -> cycle 0 (start) on the device
 //   run      one k_sweep launch per synchronous cycle (+ one k_factor_nary launch
-//            when the graph has LDS-tiled factor classes), ping-ponging the two
-//            record buffers; launch-bound cycle loops are replayed from a hipGraph
+//            when the graph has workgroup-per-factor classes), ping-ponging the
+//            two buffers of each message array; launch-bound cycle loops are
+//            replayed from a hipGraph
 //   get_*    copy back, undo the internal permutation (and the max-mode negation)
 // There is no host fallback: every cycle runs on the device.
 #include <hip/hip_runtime.h>
@@ -92,12 +93,13 @@ struct EngineBase {
 template <typename T>
 struct Engine : EngineBase {
     int device = 0;
-    int cur = 0;  // record buffer holding the messages of the last finished cycle
-    DevBuf<T> rec[2], tables, var_cost, belief, halo_send, halo_recv;
+    int cur = 0;  // buffers holding the messages of the last finished cycle
+    DevBuf<T> v2f[2], f2v[2], tables, var_cost, belief, halo_send, halo_recv;
     DevBuf<uint8_t> cF, cV, owned, fowned, vdeg8;
-    DevBuf<int32_t> vrowptr, vdom, vhalf, init_idx, edge_gen_factor, edge_dom, edge_half, sel, vell;
+    DevBuf<int32_t> vrowptr, vdom, init_idx, edge_gen_factor, edge_dom, sel, vell;
+    DevBuf<int32_t> edge_v2f, f2v_off, vslot_f2v, vslot_v2f;
     DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
-    DevBuf<int64_t> vslot_rec, vcost_off, rec_off, eval_tab_off, halo_send_off, halo_recv_off;
+    DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off;
     DevBuf<FactorGen> fgen;
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<BlockDesc> blocks_nary;
@@ -122,25 +124,27 @@ struct Engine : EngineBase {
 
     SweepArgs<T> make_args(int from, bool start) const {
         SweepArgs<T> a{};
-        a.old_rec = rec[from].p;
-        a.new_rec = rec[from ^ 1].p;
+        a.v2f_old = v2f[from].p;
+        a.v2f_new = v2f[from ^ 1].p;
+        a.f2v_old = f2v[from].p;
+        a.f2v_new = f2v[from ^ 1].p;
         a.tables = tables.p;
         a.var_cost = var_cost.p;
         a.cF = cF.p;
         a.cV = cV.p;
+        a.edge_v2f = edge_v2f.p;
+        a.f2v_off = f2v_off.p;
         a.vrowptr = vrowptr.p;
-        a.vslot_rec = vslot_rec.p;
+        a.vslot_f2v = vslot_f2v.p;
+        a.vslot_v2f = vslot_v2f.p;
         a.vell = vell.p;
         a.vdeg8 = vdeg8.p;
         a.vdom = vdom.p;
-        a.vhalf = vhalf.p;
         a.vcost_off = vcost_off.p;
         a.init_idx = init_idx.p;
         a.fgen = fgen.p;
         a.edge_gen_factor = edge_gen_factor.p;
-        a.rec_off = rec_off.p;
         a.edge_dom = edge_dom.p;
-        a.edge_half = edge_half.p;
         a.sel = sel.p;
         a.belief = belief.p;
         a.damping = (T)params.damping;
@@ -149,7 +153,7 @@ struct Engine : EngineBase {
         a.damp_v = (params.damping_nodes & MXS_DAMP_VARS) ? 1 : 0;
         a.start = start ? 1 : 0;
         a.start_mode = params.start_messages;
-        a.null_rec = (int32_t)L.null_rec;
+        a.null_f2v = (int32_t)L.null_f2v;
         a.n_classes = (int32_t)L.sweep_order.size();
         for (int i = 0; i < MAX_CLASSES; ++i)
             a.block_base[i] = i < a.n_classes ? L.classes[L.sweep_order[i]].block_base : INT32_MAX;
@@ -163,15 +167,11 @@ struct Engine : EngineBase {
         const int nb = L.n_blocks_sweep;
         if (nb > 0) {
             const dim3 grid(nb), block(BLOCK);
-            if (!L.opt.aligned_halves) {
-                hipLaunchKernelGGL((k_sweep<T, false, 0>), grid, block, 0, stream, a);
-            } else {
-                switch (L.dsel) {
-                    case 2: hipLaunchKernelGGL((k_sweep<T, true, 2>), grid, block, 0, stream, a); break;
-                    case 3: hipLaunchKernelGGL((k_sweep<T, true, 3>), grid, block, 0, stream, a); break;
-                    case 4: hipLaunchKernelGGL((k_sweep<T, true, 4>), grid, block, 0, stream, a); break;
-                    default: hipLaunchKernelGGL((k_sweep<T, true, 0>), grid, block, 0, stream, a); break;
-                }
+            switch (L.dsel) {
+                case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
+                default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
             }
             HIP_TRY(hipGetLastError());
         }
@@ -202,8 +202,14 @@ struct Engine : EngineBase {
             for (size_t i = 0; i < src.size(); ++i) out[i] = (T)src[i];
             return out;
         };
-        HIP_TRY(rec[0].alloc((size_t)L.rec_elems));
-        HIP_TRY(rec[1].alloc((size_t)L.rec_elems));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(v2f[b].alloc((size_t)L.v2f_elems));
+            HIP_TRY(f2v[b].alloc((size_t)L.f2v_elems));
+        }
+        HIP_TRY(edge_v2f.upload(L.v2f_off, stream));
+        HIP_TRY(f2v_off.upload(L.f2v_off, stream));
+        HIP_TRY(vslot_f2v.upload(L.vslot_f2v, stream));
+        HIP_TRY(vslot_v2f.upload(L.vslot_v2f, stream));
         HIP_TRY(tables.upload(conv(L.tables), stream));
         HIP_TRY(var_cost.upload(conv(L.var_cost), stream));
         HIP_TRY(cF.alloc((size_t)L.n_edges));
@@ -214,16 +220,12 @@ struct Engine : EngineBase {
         HIP_TRY(fowned.upload(L.fowned, stream));
         HIP_TRY(vrowptr.upload(L.vrowptr, stream));
         HIP_TRY(vdom.upload(L.vdom, stream));
-        HIP_TRY(vhalf.upload(L.vhalf, stream));
         HIP_TRY(init_idx.upload(L.init_idx, stream));
         HIP_TRY(edge_gen_factor.upload(L.edge_gen_factor, stream));
         HIP_TRY(edge_dom.upload(L.edge_dom, stream));
-        HIP_TRY(edge_half.upload(L.edge_half, stream));
         HIP_TRY(sel.alloc((size_t)L.n_vars));
         HIP_TRY(belief.alloc((size_t)L.n_vars));
-        HIP_TRY(vslot_rec.upload(L.vslot_rec, stream));
         HIP_TRY(vcost_off.upload(L.vcost_off, stream));
-        HIP_TRY(rec_off.upload(L.rec_off, stream));
         HIP_TRY(fgen.upload(L.fgen, stream));
         {
             std::vector<ClassInfo> order;
@@ -246,8 +248,10 @@ struct Engine : EngineBase {
 
     int reset() override {
         HIP_TRY(hipSetDevice(device));
-        for (int b = 0; b < 2; ++b)
-            HIP_TRY(hipMemsetAsync(rec[b].p, 0, std::max<size_t>(rec[b].n, 1) * sizeof(T), stream));
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(hipMemsetAsync(v2f[b].p, 0, std::max<size_t>(v2f[b].n, 1) * sizeof(T), stream));
+            HIP_TRY(hipMemsetAsync(f2v[b].p, 0, std::max<size_t>(f2v[b].n, 1) * sizeof(T), stream));
+        }
         HIP_TRY(hipMemsetAsync(cF.p, 0, std::max<size_t>(cF.n, 1), stream));
         HIP_TRY(hipMemsetAsync(cV.p, 0, std::max<size_t>(cV.n, 1), stream));
         HIP_TRY(hipMemsetAsync(sel.p, 0, std::max<size_t>(sel.n, 1) * sizeof(int32_t), stream));
@@ -366,14 +370,16 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
-    int get_messages(double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) override {
+    int get_messages(double* v2f_out, double* f2v_out, uint8_t* cv, uint8_t* cf) override {
         HIP_TRY(hipSetDevice(device));
         HIP_TRY(hipStreamSynchronize(stream));
         const int nE = L.n_edges;
-        std::vector<T> hr((size_t)L.rec_elems);
+        std::vector<T> hv((size_t)L.v2f_elems), hf((size_t)L.f2v_elems);
         std::vector<uint8_t> hcF(nE), hcV((size_t)L.n_cv);
-        if (L.rec_elems)
-            HIP_TRY(copy_sync(hr.data(), rec[cur].p, sizeof(T) * hr.size(), hipMemcpyDeviceToHost, stream));
+        if (L.v2f_elems)
+            HIP_TRY(copy_sync(hv.data(), v2f[cur].p, sizeof(T) * hv.size(), hipMemcpyDeviceToHost, stream));
+        if (L.f2v_elems)
+            HIP_TRY(copy_sync(hf.data(), f2v[cur].p, sizeof(T) * hf.size(), hipMemcpyDeviceToHost, stream));
         if (nE) {
             HIP_TRY(copy_sync(hcF.data(), cF.p, nE, hipMemcpyDeviceToHost, stream));
             HIP_TRY(copy_sync(hcV.data(), cV.p, (size_t)L.n_cv, hipMemcpyDeviceToHost, stream));
@@ -384,10 +390,10 @@ struct Engine : EngineBase {
         const double sign = L.is_max ? -1.0 : 1.0;
         for (int ei = 0; ei < nE; ++ei) {
             const int e = L.edge_i2e[ei];
-            const int D = L.edge_dom[ei], H = L.edge_half[ei];
+            const int D = L.edge_dom[ei];
             for (int d = 0; d < D; ++d) {
-                if (v2f) v2f[ext_off[e] + d] = sign * (double)hr[L.rec_off[ei] + d];
-                if (f2v) f2v[ext_off[e] + d] = sign * (double)hr[L.rec_off[ei] + H + d];
+                if (v2f_out) v2f_out[ext_off[e] + d] = sign * (double)hv[L.v2f_off[ei] + d];
+                if (f2v_out) f2v_out[ext_off[e] + d] = sign * (double)hf[L.f2v_off[ei] + d];
             }
             if (cf) cf[e] = hcF[ei];
         }
@@ -455,7 +461,7 @@ struct Engine : EngineBase {
             const int32_t e = edges[i];
             if (e < 0 || e >= L.n_edges) return fail(MXS_E_INVALID, "halo edge out of range");
             const int ei = L.edge_e2i[e];
-            for (int d = 0; d < L.edge_dom[ei]; ++d) out.push_back(L.rec_off[ei] + d);  // V->F half
+            for (int d = 0; d < L.edge_dom[ei]; ++d) out.push_back((int64_t)L.v2f_off[ei] + d);
         }
         return MXS_OK;
     }
@@ -484,7 +490,7 @@ struct Engine : EngineBase {
         if (n_halo_send > 0) {
             const int nb = (int)((n_halo_send + BLOCK - 1) / BLOCK);
             hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, stream,
-                               (const T*)rec[cur].p, (const int64_t*)halo_send_off.p, send_buf,
+                               (const T*)v2f[cur].p, (const int64_t*)halo_send_off.p, send_buf,
                                n_halo_send);
             HIP_TRY(hipGetLastError());
         }
@@ -521,7 +527,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipSetDevice(device));
         if (n_halo_recv > 0) {
             const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
-            hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, stream, rec[cur].p,
+            hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, stream, v2f[cur].p,
                                (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv);
             HIP_TRY(hipGetLastError());
         }

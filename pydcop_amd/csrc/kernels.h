@@ -2,16 +2,21 @@
 //
 // One launch of `k_sweep` is one synchronous cycle: every factor's and every
 // variable's on_new_cycle (pydcop/algorithms/maxsum.py:339-379, 525-565).  Both
-// sides read only the record buffer of cycle t-1 and write the buffer of cycle t
+// sides read only the message buffers of cycle t-1 and write those of cycle t
 // (the reference's BSP barrier, pydcop/infrastructure/computations.py:684-788,
 // becomes the kernel boundary), so factor blocks and variable blocks run side by
 // side in the same grid.
 //
 // This is a min-plus semiring bounded by memory traffic -- no MFMA.  What matters
-// (cdna_hip_programming.md section 6): every byte of a record is used by the
-// thread that fetches it, tables are stored entry-major so a wave reads them as
-// one coalesced segment per entry, counters are never gathered, and all per-item
-// state lives in registers (compile-time D / degree bounds, no scratch).
+// (cdna_hip_programming.md section 6, and the measurements of
+// tools/pattern_bench.hip): every store is a coalesced full-line stream (F2V is
+// factor-major and written by the factor side, V2F variable-major and written by
+// the variable side), each side finds its own previous output in the old buffer
+// of its own array, the only irregular accesses are two message-sized gathers
+// per edge whose addresses come from coalesced index tables, tables are stored
+// entry-major so a wave reads them as one coalesced segment per entry, counters
+// are never gathered, and all per-item state lives in registers (compile-time
+// D / degree bounds, no scratch).
 //
 // Max mode runs as min mode on negated costs (exact in IEEE arithmetic; the host
 // negates on upload/download), so only `<` appears below.
@@ -36,25 +41,27 @@ constexpr int SAME_COUNT = 4;  // maxsum.py:106
 
 template <typename T>
 struct SweepArgs {
-    const T* old_rec;   // records of cycle t-1
-    T* new_rec;         // records of cycle t
+    const T* v2f_old;   // V->F messages of cycle t-1 (variable-major)
+    T* v2f_new;         // ... of cycle t
+    const T* f2v_old;   // F->V messages of cycle t-1 (factor-major)
+    T* f2v_new;
     const T* tables;
     const T* var_cost;
     uint8_t* cF;        // [n_edges] factor-major send counters
     uint8_t* cV;        // [n_cv] variable-side send counters (CSR slots + class tables)
+    const int32_t* edge_v2f;  // [n_edges] V2F offset of the edge's message (factor-major)
+    const int32_t* f2v_off;   // [n_edges] F2V offset of the edge's message
     const int32_t* vrowptr;
-    const int64_t* vslot_rec;
+    const int32_t* vslot_f2v;  // [n_edges] CSR slot -> F2V offset (generic variables)
+    const int32_t* vslot_v2f;  // [n_edges] CSR slot -> V2F offset
     const int32_t* vell;   // slot tables of the register / wave variable classes
     const uint8_t* vdeg8;  // [n_vars] degree (saturated), internal order
     const int32_t* vdom;
-    const int32_t* vhalf;
     const int64_t* vcost_off;
     const int32_t* init_idx;
     const FactorGen* fgen;
     const int32_t* edge_gen_factor;
-    const int64_t* rec_off;
     const int32_t* edge_dom;
-    const int32_t* edge_half;
     int32_t* sel;
     T* belief;
     T damping;
@@ -63,7 +70,7 @@ struct SweepArgs {
     int32_t damp_v;      // damping_nodes in {vars, both}
     int32_t start;       // 1: cycle 0 (on_start), 0: regular cycle
     int32_t start_mode;  // MXS_START_*
-    int32_t null_rec;    // offset of the all-zero record (padding slots)
+    int32_t null_f2v;    // offset of the all-zero F2V block (padding slots)
     int32_t n_classes;
     // First block of every class of the launch (in launch order; unused entries
     // hold INT32_MAX): a block finds its class with compares on kernel arguments,
@@ -114,65 +121,63 @@ __device__ __forceinline__ uint8_t damp_and_filter(T (&m)[D], const T (&prev)[D]
     return cnt;
 }
 
-template <bool ALIGNED, typename T>
-__device__ __forceinline__ const T* rec_ptr(const T* p) {
-    if (ALIGNED) return (const T*)__builtin_assume_aligned(p, 16);
-    return p;
-}
-template <bool ALIGNED, typename T>
-__device__ __forceinline__ T* rec_ptr(T* p) {
-    if (ALIGNED) return (T*)__builtin_assume_aligned(p, 16);
-    return p;
-}
+// A message of a uniform class: D values padded to H = half_stride(D) elements,
+// aligned to its own (power-of-two, <= 32 bytes) size.
+template <typename T, int D>
+struct Msg {
+    static constexpr int H = half_stride(D, (int)sizeof(T));
+    static constexpr int ALIGN = H * (int)sizeof(T) >= 16 ? 16 : 8;
+    static __device__ __forceinline__ void load(const T* p, T (&m)[D]) {
+        const T* q = (const T*)__builtin_assume_aligned(p, ALIGN);
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = q[d];
+    }
+    // stores the padding too: full-sector, fully coalesced writes
+    static __device__ __forceinline__ void store(T* p, const T (&m)[D]) {
+        T* q = (T*)__builtin_assume_aligned(p, ALIGN);
+#pragma unroll
+        for (int d = 0; d < H; ++d) q[d] = d < D ? m[d < D ? d : 0] : (T)0;
+    }
+};
 
 // ---------------------------------------------------------------------------
 // Factor side, register classes (thread per factor).
 // factor_costs_for_var, maxsum.py:382-447:  out_i[d] = min over the other
 // variables' values of  table[..] + sum of their messages.
 // ---------------------------------------------------------------------------
-template <typename T, int D, bool ALIGNED>
+template <typename T, int D>
 __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
-    const int H = ci.H;
-    const int64_t ro = ci.rec_base + (int64_t)j * 2 * H;
-    const T* r = rec_ptr<ALIGNED>(a.old_rec + ro);
-    T* w = rec_ptr<ALIGNED>(a.new_rec + ro) + H;
+    constexpr int H = Msg<T, D>::H;
+    const int64_t fo = ci.f2v_base + (int64_t)j * H;
     const int e = ci.edge_base + j;
     T out[D], prev[D];
+    Msg<T, D>::load(a.f2v_old + fo, prev);
 #pragma unroll
-    for (int d = 0; d < D; ++d) {
-        prev[d] = r[H + d];
-        // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
+    for (int d = 0; d < D; ++d)  // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
         out[d] = a.tables[ci.tab_base + (int64_t)d * ci.count + j] + (T)0;
-    }
-    if (a.start) {  // on_start, maxsum.py:311-319: unary factors send in every mode
-#pragma unroll
-        for (int d = 0; d < D; ++d) w[d] = out[d];
-        a.cF[e] = 0;
-        return;
-    }
-    const uint8_t c = damp_and_filter<T, D>(out, prev, a.cF[e], a.damp_f != 0, a.damping, a.stability);
-#pragma unroll
-    for (int d = 0; d < D; ++d) w[d] = out[d];
+    uint8_t c = 0;
+    if (!a.start)  // on_start (maxsum.py:311-319): unary factors send in every mode, counter stays 0
+        c = damp_and_filter<T, D>(out, prev, a.cF[e], a.damp_f != 0, a.damping, a.stability);
+    Msg<T, D>::store(a.f2v_new + fo, out);
     a.cF[e] = c;
 }
 
-template <typename T, int D, bool ALIGNED>
+template <typename T, int D>
 __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
-    const int H = ci.H;
-    const int64_t ro = ci.rec_base + (int64_t)j * 4 * H;  // two records of 2H
-    const T* r = rec_ptr<ALIGNED>(a.old_rec + ro);
-    T* w = rec_ptr<ALIGNED>(a.new_rec + ro);
+    constexpr int H = Msg<T, D>::H;
     const int e = ci.edge_base + 2 * j;
+    const int64_t fo = ci.f2v_base + (int64_t)j * 2 * H;  // both messages of the factor
+    // everything addressed by j: coalesced
+    const int v0 = a.edge_v2f[e], v1 = a.edge_v2f[e + 1];
+    const uint8_t cn0 = a.cF[e], cn1 = a.cF[e + 1];
     T m0[D], p0[D], m1[D], p1[D], tab[D * D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        m0[d] = r[d];              // V->F message of scope variable 0
-        p0[d] = r[H + d];          // F->V message last sent to variable 0
-        m1[d] = r[2 * H + d];
-        p1[d] = r[3 * H + d];
-    }
+    Msg<T, D>::load(a.f2v_old + fo, p0);      // F->V message last sent to variable 0
+    Msg<T, D>::load(a.f2v_old + fo + H, p1);
 #pragma unroll
     for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
+    // the two gathers
+    Msg<T, D>::load(a.v2f_old + v0, m0);      // V->F message of scope variable 0
+    Msg<T, D>::load(a.v2f_old + v1, m1);
     T o0[D], o1[D];
 #pragma unroll
     for (int x = 0; x < D; ++x) {
@@ -187,24 +192,20 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         o0[x] = best0;
         o1[x] = best1;
     }
+    uint8_t c0 = 0, c1 = 0;
     if (a.start) {  // only start_messages == all makes a binary factor send (maxsum.py:320-328)
         const bool sends = a.start_mode == MXS_START_ALL;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
-            w[H + d] = sends ? o0[d] : (T)0;
-            w[3 * H + d] = sends ? o1[d] : (T)0;
+            o0[d] = sends ? o0[d] : (T)0;
+            o1[d] = sends ? o1[d] : (T)0;
         }
-        a.cF[e] = 0;
-        a.cF[e + 1] = 0;
-        return;
+    } else {
+        c0 = damp_and_filter<T, D>(o0, p0, cn0, a.damp_f != 0, a.damping, a.stability);
+        c1 = damp_and_filter<T, D>(o1, p1, cn1, a.damp_f != 0, a.damping, a.stability);
     }
-    const uint8_t c0 = damp_and_filter<T, D>(o0, p0, a.cF[e], a.damp_f != 0, a.damping, a.stability);
-    const uint8_t c1 = damp_and_filter<T, D>(o1, p1, a.cF[e + 1], a.damp_f != 0, a.damping, a.stability);
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        w[H + d] = o0[d];
-        w[3 * H + d] = o1[d];
-    }
+    Msg<T, D>::store(a.f2v_new + fo, o0);
+    Msg<T, D>::store(a.f2v_new + fo + H, o1);
     a.cF[e] = c0;
     a.cF[e + 1] = c1;
 }
@@ -230,7 +231,7 @@ __device__ __forceinline__ T factor_gen_value(const SweepArgs<T>& a, const Facto
                 rem /= Di;
                 digit = (int)(l / rem);
                 l -= (int64_t)digit * rem;
-                sum_cost += a.old_rec[a.rec_off[e] + digit];  // V->F half
+                sum_cost += a.v2f_old[a.edge_v2f[e] + digit];
             }
             t = t * Di + digit;
         }
@@ -245,9 +246,9 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
     const int e = ci.edge_base + j;
     const FactorGen fg = a.fgen[a.edge_gen_factor[e]];
     const int pos = e - fg.edge_base;
-    const int D = a.edge_dom[e], H = a.edge_half[e];
-    const T* prev = a.old_rec + a.rec_off[e] + H;
-    T* w = a.new_rec + a.rec_off[e] + H;
+    const int D = a.edge_dom[e];
+    const T* prev = a.f2v_old + a.f2v_off[e];
+    T* w = a.f2v_new + a.f2v_off[e];
     int64_t others = 1;
     for (int i = 0; i < fg.arity; ++i)
         if (i != pos) others *= a.edge_dom[fg.edge_base + i];
@@ -285,24 +286,26 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
 // compile-time constant so the incoming messages stay in VGPRs.
 //   select_value      maxsum.py:584-620
 //   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
-// Loads are issued in two batches -- everything addressed by the variable index
-// (slot table, counters, costs: coalesced), then all records at once -- so a
-// thread has 4 x 64 B in flight instead of a slot->record chain per edge.
-// Padding slots read the all-zero record: adding 0.0 is exact, so the sums can
-// run over all four slots unconditionally.
+// Everything but the incoming F->V messages is addressed by the variable index
+// (slot table, counters, costs, the V->F messages sent last cycle: coalesced);
+// the four gathers are then issued together.  Padding slots gather the all-zero
+// block: adding 0.0 is exact, so the sums run over all four slots.
 // ---------------------------------------------------------------------------
-template <typename T, int D, bool ALIGNED>
+template <typename T, int D>
 __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
     constexpr int K = MAX_REG_DEG;
+    constexpr int H = Msg<T, D>::H;
     const int v = ci.first + j;
-    const int H = ci.H;
     const int n = ci.count;
     int32_t slot[K];
     uint8_t cnt[K];
+    T pv[K][D];
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-        slot[k] = a.vell[ci.ell_base + (int64_t)k * n + j];
-        cnt[k] = a.cV[ci.cv_base + (int64_t)k * n + j];
+        const int64_t pos = (int64_t)k * n + j;
+        slot[k] = a.vell[ci.ell_base + pos];
+        cnt[k] = a.cV[ci.cv_base + pos];
+        Msg<T, D>::load(a.v2f_old + ci.v2f_base + pos * H, pv[k]);  // V->F sent last on this edge
     }
     const int deg = a.vdeg8[v];
     T c[D];
@@ -310,17 +313,10 @@ __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassI
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)j * D + d];
     int init = -1;
     if (a.start) init = a.init_idx[v];
-    T in[K][D], pv[K][D];
+    T in[K][D];
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int off = slot[k] < 0 ? a.null_rec : slot[k];
-        const T* r = rec_ptr<ALIGNED>(a.old_rec + off);
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            pv[k][d] = r[d];      // V->F message last sent on this edge
-            in[k][d] = r[H + d];  // F->V message held from this factor
-        }
-    }
+    for (int k = 0; k < K; ++k)  // F->V message held from this factor
+        Msg<T, D>::load(a.f2v_old + (slot[k] < 0 ? a.null_f2v : slot[k]), in[k]);
     // select_value: belief[d] = cost(d) + sum of the factor messages, first optimum
     int best = 0;
     T best_c = (T)0;
@@ -367,30 +363,32 @@ __device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassI
         } else {
             co = damp_and_filter<T, D>(m, pv[ko], cnt[ko], a.damp_v != 0, a.damping, a.stability);
         }
-        if (slot[ko] >= 0) {
-            T* w = rec_ptr<ALIGNED>(a.new_rec + slot[ko]);
+        if (slot[ko] < 0) {  // padding slot: keep it zero
+            co = 0;
 #pragma unroll
-            for (int d = 0; d < D; ++d) w[d] = m[d];
-            a.cV[ci.cv_base + (int64_t)ko * n + j] = co;
+            for (int d = 0; d < D; ++d) m[d] = (T)0;
         }
+        const int64_t pos = (int64_t)ko * n + j;
+        Msg<T, D>::store(a.v2f_new + ci.v2f_base + pos * H, m);
+        a.cV[ci.cv_base + pos] = co;
     }
 }
 
 // ---------------------------------------------------------------------------
 // Variable side, wave class (4 < deg <= 64): G = 8, 16 or 64 lanes per variable,
-// lane k holds the record of the variable's k-th edge (one slot + one 64-B record
-// per lane: every load of the wave is in flight at once); the sums walk the lanes
-// in edge order with cross-lane reads, so the arithmetic order is still the
-// reference's.  Padding lanes hold zeros (the all-zero record).
+// lane k owns the variable's k-th edge (its slot, counter and previous V->F
+// message are contiguous across lanes; one gathered F->V message per lane); the
+// sums walk the lanes in edge order with cross-lane reads, so the arithmetic
+// order is still the reference's.  Padding lanes hold zeros.
 // ---------------------------------------------------------------------------
-template <typename T, int D, int G, bool ALIGNED>
+template <typename T, int D, int G>
 __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const ClassInfo& ci,
                                               int first_var) {
+    constexpr int H = Msg<T, D>::H;
     const int vloc = first_var + (int)threadIdx.x / G;
     if (vloc >= ci.count) return;  // whole group leaves together
     const int k = (int)threadIdx.x % G;
     const int v = ci.first + vloc;
-    const int H = ci.H;
     const int64_t pos = (int64_t)vloc * G + k;
     const int32_t slot = a.vell[ci.ell_base + pos];
     const uint8_t cnt = a.cV[ci.cv_base + pos];
@@ -399,16 +397,10 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
     int init = -1;
     if (a.start) init = a.init_idx[v];
     T c[D], in[D], pv[D], b[D], m[D];
+    Msg<T, D>::load(a.v2f_old + ci.v2f_base + pos * H, pv);
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)vloc * D + d];
-    {
-        const T* r = rec_ptr<ALIGNED>(a.old_rec + (has ? slot : a.null_rec));
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            pv[d] = r[d];
-            in[d] = r[H + d];
-        }
-    }
+    Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);
     T sum_cost = (T)0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
@@ -451,21 +443,23 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
         a.sel[v] = best;
         a.belief[v] = best_c;
     }
-    if (!has) return;
     const T avg = sum_cost / (T)D;
 #pragma unroll
     for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-    T* w = rec_ptr<ALIGNED>(a.new_rec + slot);
+    uint8_t co = 0;
     if (a.start) {  // deg > 1 here: only leafs_vars / all make the variable send
         const bool sends = a.start_mode != MXS_START_LEAFS;
 #pragma unroll
-        for (int d = 0; d < D; ++d) w[d] = sends ? m[d] : (T)0;
-        a.cV[ci.cv_base + pos] = 0;
-        return;
+        for (int d = 0; d < D; ++d) m[d] = sends ? m[d] : (T)0;
+    } else {
+        co = damp_and_filter<T, D>(m, pv, cnt, a.damp_v != 0, a.damping, a.stability);
     }
-    const uint8_t co = damp_and_filter<T, D>(m, pv, cnt, a.damp_v != 0, a.damping, a.stability);
+    if (!has) {  // padding lane: keep its slot zero
+        co = 0;
 #pragma unroll
-    for (int d = 0; d < D; ++d) w[d] = m[d];
+        for (int d = 0; d < D; ++d) m[d] = (T)0;
+    }
+    Msg<T, D>::store(a.v2f_new + ci.v2f_base + pos * H, m);
     a.cV[ci.cv_base + pos] = co;
 }
 
@@ -476,7 +470,6 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
     if (ci.start_only && !a.start) return;  // a variable without factor never cycles
     const int v = ci.first + j;
     const int D = a.vdom[v];
-    const int H = a.vhalf[v];  // all records of a variable share the half stride
     const int k0 = a.vrowptr[v], k1 = a.vrowptr[v + 1];
     const int deg = k1 - k0;
     const T* c = a.var_cost + a.vcost_off[v];
@@ -484,7 +477,7 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
     T best_c = (T)0;
     for (int d = 0; d < D; ++d) {
         T b = c[d];
-        for (int k = k0; k < k1; ++k) b += a.old_rec[a.vslot_rec[k] + H + d];
+        for (int k = k0; k < k1; ++k) b += a.f2v_old[a.vslot_f2v[k] + d];
         if (d == 0 || b < best_c) {
             best = d;
             best_c = b;
@@ -499,13 +492,12 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
                              a.start_mode != MXS_START_LEAFS;
     for (int ko = k0; ko < k1; ++ko) {
-        const int64_t oo = a.vslot_rec[ko];
-        const T* prev = a.old_rec + oo;
-        T* w = a.new_rec + oo;
+        const T* prev = a.v2f_old + a.vslot_v2f[ko];
+        T* w = a.v2f_new + a.vslot_v2f[ko];
         T sum_cost = (T)0;
         for (int d = 0; d < D; ++d)
             for (int k = k0; k < k1; ++k)
-                if (k != ko) sum_cost += a.old_rec[a.vslot_rec[k] + H + d];
+                if (k != ko) sum_cost += a.f2v_old[a.vslot_f2v[k] + d];
         const T avg = sum_cost / (T)D;
         const uint8_t cnt = a.start ? 0 : a.cV[ko];
         const bool damp = cnt > 0 && a.damp_v;
@@ -513,7 +505,7 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
         for (int d = 0; d < D; ++d) {
             T m = c[d];
             for (int k = k0; k < k1; ++k)
-                if (k != ko) m += a.old_rec[a.vslot_rec[k] + H + d];
+                if (k != ko) m += a.f2v_old[a.vslot_f2v[k] + d];
             m = m - avg;
             if (a.start) {
                 w[d] = start_sends ? m : (T)0;
@@ -546,27 +538,27 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // size only (the engine picks it when the graph has a single D), which keeps the
 // kernel's register allocation -- the maximum over all paths -- small.
 // ---------------------------------------------------------------------------
-template <typename T, bool ALIGNED, int D>
+template <typename T, int D>
 __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     if (ci.kind == K_V_WAVE) {  // several lanes per variable
         switch (ci.maxdeg) {
-            case 8: variable_wave<T, D, 8, ALIGNED>(a, ci, item); break;
-            case 16: variable_wave<T, D, 16, ALIGNED>(a, ci, item); break;
-            default: variable_wave<T, D, 64, ALIGNED>(a, ci, item); break;
+            case 8: variable_wave<T, D, 8>(a, ci, item); break;
+            case 16: variable_wave<T, D, 16>(a, ci, item); break;
+            default: variable_wave<T, D, 64>(a, ci, item); break;
         }
         return;
     }
     const int j = item + (int)threadIdx.x;
     if (j >= ci.count) return;
     switch (ci.kind) {
-        case K_F_UNARY: factor_unary<T, D, ALIGNED>(a, ci, j); break;
-        case K_F_BIN: factor_binary<T, D, ALIGNED>(a, ci, j); break;
-        case K_V_REG: variable_reg<T, D, ALIGNED>(a, ci, j); break;
+        case K_F_UNARY: factor_unary<T, D>(a, ci, j); break;
+        case K_F_BIN: factor_binary<T, D>(a, ci, j); break;
+        case K_V_REG: variable_reg<T, D>(a, ci, j); break;
         default: break;
     }
 }
 
-template <typename T, bool ALIGNED, int DSEL>
+template <typename T, int DSEL>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a) {
     int c = 0;
 #pragma unroll
@@ -581,12 +573,12 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a
         return;
     }
     if (DSEL != 0) {
-        sweep_d<T, ALIGNED, (DSEL != 0 ? DSEL : 2)>(a, ci, item);
+        sweep_d<T, (DSEL != 0 ? DSEL : 2)>(a, ci, item);
     } else {
         switch (ci.D) {
-            case 2: sweep_d<T, ALIGNED, 2>(a, ci, item); break;
-            case 3: sweep_d<T, ALIGNED, 3>(a, ci, item); break;
-            case 4: sweep_d<T, ALIGNED, 4>(a, ci, item); break;
+            case 2: sweep_d<T, 2>(a, ci, item); break;
+            case 3: sweep_d<T, 3>(a, ci, item); break;
+            case 4: sweep_d<T, 4>(a, ci, item); break;
             default: break;
         }
     }

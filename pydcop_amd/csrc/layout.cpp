@@ -13,29 +13,12 @@ LayoutOptions options_from_params(const mxs_params& p) {
     LayoutOptions o;
     o.word = (p.dtype == MXS_DTYPE_F32) ? 4 : 8;
     const int f = p.layout_flags;
-    o.aligned_halves = !(f & 1);  // bit0: tight records (halves not 16-B aligned)
-    o.pad64 = (f & 2) != 0;       // bit1: pad records to 64 bytes
+    // bits 0/1 selected record paddings of the v1 layout; ignored since the
+    // gather-only layout (messages are always padded to a sector-friendly size)
     o.no_specialise = (f & 4) != 0;   // bit2: generic kernels only
     o.sort_by_degree = !(f & 8);      // bit3: keep the caller's variable order
-    if (f & 16) o.nary_min_entries = (int64_t)1 << 60;  // bit4: no LDS n-ary kernel
+    if (f & 16) o.nary_min_entries = (int64_t)1 << 60;  // bit4: no workgroup-per-factor kernel
     return o;
-}
-
-int Layout::half_stride(int D) const {
-    int H = D;
-    if (opt.aligned_halves) {
-        const int a = 16 / opt.word;
-        H = (D + a - 1) / a * a;
-    }
-    if (opt.pad64) {
-        const int per64 = 64 / opt.word;  // elements in 64 bytes
-        if (2 * H <= per64) {             // round the record up to 64/32/16 bytes
-            int rec = per64;
-            while (rec / 2 >= 2 * H && rec / 2 >= 16 / opt.word) rec /= 2;
-            H = rec / 2;
-        }
-    }
-    return H;
 }
 
 namespace {
@@ -134,8 +117,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (ar == 1 && D0 >= 2 && D0 <= MAX_REG_D) k = FKey{K_F_UNARY, D0};
             else if (ar == 2 && D0 >= 2 && D0 <= MAX_REG_D && g.dom_size[g.edge_var[e0 + 1]] == D0)
                 k = FKey{K_F_BIN, D0};
-            else if (ar >= 2 && ar <= 4 && entries >= L.opt.nary_min_entries &&
-                     entries * L.opt.word <= L.opt.nary_max_bytes)
+            else if (ar <= 8 && entries >= L.opt.nary_min_entries && entries <= L.opt.nary_max_entries)
                 k = FKey{K_F_NARY, 0};
         }
         fkey[f] = k;
@@ -145,43 +127,46 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(),
                      [&](int a, int b) { return fkey[a] < fkey[b]; });
 
-    // ---- internal edges, records ------------------------------------------
+    // ---- internal edges, F2V array (factor-major) ------------------------------
     L.edge_i2e.resize(nE);
     L.edge_e2i.resize(nE);
     L.frowptr.assign(nF + 1, 0);
-    L.rec_off.resize(nE);
+    L.f2v_off.resize(nE);
+    L.v2f_off.assign(nE, 0);
     L.edge_dom.resize(nE);
     L.edge_half.resize(nE);
     L.edge_gen_factor.assign(nE, -1);
     {
         int ei = 0;
         int64_t off = 0;
+        const int align = 32 / L.opt.word;  // every class starts on a 32-byte boundary
         for (int fi = 0; fi < nF; ++fi) {
             const int f = L.factor_i2e[fi];
             L.frowptr[fi] = ei;
+            if (fi == 0 || !(fkey[f] == fkey[L.factor_i2e[fi - 1]])) off = (off + align - 1) / align * align;
             for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e, ++ei) {
                 L.edge_i2e[ei] = e;
                 L.edge_e2i[e] = ei;
                 const int D = g.dom_size[g.edge_var[e]];
-                const int H = L.half_stride(D);
+                const int H = L.half(D);
                 L.edge_dom[ei] = D;
                 L.edge_half[ei] = H;
-                L.rec_off[ei] = off;
-                off += 2 * (int64_t)H;
+                if (off > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
+                L.f2v_off[ei] = (int32_t)off;
+                off += H;
             }
         }
         L.frowptr[nF] = ei;
-        // one all-zero record nobody writes, read through the padding slots of
-        // the variable classes (16-byte aligned, large enough for D <= MAX_REG_D)
-        off = (off + 1) / 2 * 2;
-        L.null_rec = off;
-        off += 2 * (int64_t)std::max(L.half_stride(MAX_REG_D), 4);
-        L.rec_elems = off;
-        if (off > ((int64_t)1 << 31) - 64) return "message buffer exceeds 2^31 elements";
+        // an all-zero block nobody writes, gathered through the padding slots of the
+        // register / wave variable classes (32-byte aligned)
+        off = (off + align - 1) / align * align;
+        L.null_f2v = off;
+        off += L.half(MAX_REG_D);
+        L.f2v_elems = off;
     }
 
     // ---- classify and order variables ---------------------------------------
-    std::vector<int> vkind(nV), vsort(nV);
+    std::vector<int> vsort(nV);
     for (int v = 0; v < nV; ++v) {
         const int deg = g.var_rowptr[v + 1] - g.var_rowptr[v];
         const int D = g.dom_size[v];
@@ -194,7 +179,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         } else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_WAVE_DEG) {
             kind = K_V_WAVE; sub = D * 128 + (deg <= 8 ? 8 : deg <= 16 ? 16 : 64);
         } else { kind = K_V_GEN; sub = 0; }
-        vkind[v] = kind;
         // sort key: class, then degree (uniform waves), stable in caller order
         vsort[v] = (kind * 1024 + sub) * 4096 + (L.opt.sort_by_degree ? std::min(deg, 4095) : 0);
     }
@@ -206,8 +190,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     for (int vi = 0; vi < nV; ++vi) L.var_e2i[L.var_i2e[vi]] = vi;
 
     L.vrowptr.assign(nV + 1, 0);
-    L.vslot_rec.resize(nE);
     L.vslot_edge.resize(nE);
+    L.vslot_f2v.resize(nE);
+    L.vslot_v2f.assign(nE, 0);
     L.vslot_cv.resize(nE);
     L.vdeg8.resize(nV);
     L.vdom.resize(nV);
@@ -229,12 +214,12 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             for (int kk = g.var_rowptr[v]; kk < g.var_rowptr[v + 1]; ++kk, ++k) {
                 const int ei = L.edge_e2i[g.var_edges[kk]];
                 L.vslot_edge[k] = ei;
-                L.vslot_rec[k] = L.rec_off[ei];
+                L.vslot_f2v[k] = L.f2v_off[ei];
                 L.edge_var_int[ei] = vi;
             }
             L.vdeg8[vi] = (uint8_t)std::min(g.var_rowptr[v + 1] - g.var_rowptr[v], 255);
             L.vdom[vi] = g.dom_size[v];
-            L.vhalf[vi] = L.half_stride(g.dom_size[v]);
+            L.vhalf[vi] = L.half(g.dom_size[v]);
             L.vcost_off[vi] = coff;
             for (int d = 0; d < g.dom_size[v]; ++d) {
                 L.var_cost[coff + d] = sign * g.var_cost[ext_cost_off[v] + d];
@@ -247,7 +232,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         L.vrowptr[nV] = k;
     }
 
-    // ---- factor classes, tables, blocks ---------------------------------------
+    // ---- factor classes, tables ---------------------------------------------------
     L.eval_tab_off.assign(nF + 1, 0);
     for (int fi = 0; fi < nF; ++fi) {
         const int f = L.factor_i2e[fi];
@@ -263,11 +248,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         std::copy(g.tables + g.table_off[f], g.tables + g.table_off[f + 1],
                   L.eval_tables.begin() + L.eval_tab_off[fi]);
     }
-    auto add_blocks = [&](std::vector<BlockDesc>& blocks, int cls, int count, int per_block) {
-        L.classes[cls].block_base = (int)blocks.size();
-        L.classes[cls].per_block = per_block;
-        for (int i = 0; i < count; i += per_block) blocks.push_back(BlockDesc{cls, i});
-    };
     auto sweep_class = [&](int cls, int per_block) {  // blocks are derived from blockIdx
         L.classes[cls].per_block = per_block;
         L.sweep_order.push_back(cls);
@@ -280,11 +260,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         ClassInfo ci{};
         ci.kind = key.kind;
         ci.D = key.D;
-        ci.H = key.D ? L.half_stride(key.D) : 0;
+        ci.H = key.D ? L.half(key.D) : 0;
         ci.first = fi;
         ci.count = n;
         ci.edge_base = L.frowptr[fi];
-        ci.rec_base = L.rec_off.empty() ? 0 : L.rec_off[L.frowptr[fi]];
+        ci.f2v_base = nE ? L.f2v_off[L.frowptr[fi]] : 0;
         ci.tab_base = L.eval_tab_off[fi];
         const int cls = (int)L.classes.size();
         if (key.kind == K_F_UNARY || key.kind == K_F_BIN) {
@@ -307,10 +287,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.fgen.push_back(fg);
                 for (int64_t k = L.eval_tab_off[f2]; k < L.eval_tab_off[f2 + 1]; ++k)
                     L.tables[k] = sign * L.eval_tables[k];
-                if (key.kind == K_F_NARY)
-                    L.max_nary_lds_bytes = std::max<int>(
-                        L.max_nary_lds_bytes,
-                        (int)((L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2]) * L.opt.word));
             }
             if (key.kind == K_F_GEN) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
@@ -318,18 +294,21 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 sweep_class(cls, BLOCK);
             } else {  // K_F_NARY: one workgroup per factor, own launch
                 ci.first = gen_base;  // index into fgen
+                ci.block_base = (int)L.blocks_nary.size();
+                ci.per_block = 1;
                 L.classes.push_back(ci);
-                add_blocks(L.blocks_nary, cls, n, 1);
+                for (int i = 0; i < n; ++i) L.blocks_nary.push_back(BlockDesc{cls, i});
             }
         }
         fi = fj;
     }
 
-    // ---- variable classes -------------------------------------------------------
+    // ---- variable classes, V2F array (variable-major) -----------------------------
     // Send counters: positions [0, nE) follow the CSR slot order (generic class);
     // the register / wave classes keep theirs in padded, coalesced tables behind.
     L.n_cv = nE;
     for (int k = 0; k < nE; ++k) L.vslot_cv[k] = k;
+    int64_t voff = 0;
     for (int vi = 0; vi < nV;) {
         const int v0 = L.var_i2e[vi];
         const int key = vsort[v0] / 4096;
@@ -340,48 +319,67 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         ci.first = vi;
         ci.count = vj - vi;
         ci.cost_base = L.vcost_off[vi];
+        bool swept = true;
+        {
+            const int64_t align = 32 / L.opt.word;  // every class starts on a 32-byte boundary
+            voff = (voff + align - 1) / align * align;
+        }
         if (kind == K_V_REG) {
             ci.kind = K_V_REG;
             ci.D = sub / 16;
             ci.maxdeg = sub % 16;
-            ci.H = L.half_stride(ci.D);
+            ci.H = L.half(ci.D);
         } else if (kind == K_V_WAVE) {
             ci.kind = K_V_WAVE;
             ci.D = sub / 128;
             ci.maxdeg = sub % 128;
-            ci.H = L.half_stride(ci.D);
+            ci.H = L.half(ci.D);
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
         } else if (kind == 80) {
             ci.kind = K_V_GEN;
             ci.start_only = 1;
-        } else {  // ghosts: no work
-            vi = vj;
-            continue;
+        } else {  // ghosts: storage only
+            swept = false;
         }
         if (ci.kind == K_V_REG || ci.kind == K_V_WAVE) {
-            // slot table: record offset of the variable's k-th edge, -1 = padding.
+            // slot table: F2V offset of the variable's k-th edge, -1 = padding; the
+            // slot's own V->F message sits at v2f_base + position * H.
             //   K_V_REG  [maxdeg][count]  (a wave reads one k of 64 variables)
             //   K_V_WAVE [count][G]       (lane k of a variable's group reads slot k)
             const int64_t n = ci.count, G = ci.maxdeg;
             ci.ell_base = (int64_t)L.vell.size();
             ci.cv_base = L.n_cv;
+            ci.v2f_base = voff;
             L.vell.resize(L.vell.size() + (size_t)(n * G), -1);
             L.n_cv += n * G;
+            voff += n * G * ci.H;
             for (int64_t j = 0; j < n; ++j) {
                 const int k0 = L.vrowptr[vi + j], deg = L.vrowptr[vi + j + 1] - k0;
                 for (int k = 0; k < deg; ++k) {
                     const int64_t pos = ci.kind == K_V_REG ? (int64_t)k * n + j : j * G + k;
-                    L.vell[ci.ell_base + pos] = (int32_t)L.vslot_rec[k0 + k];
+                    L.vell[ci.ell_base + pos] = L.vslot_f2v[k0 + k];
                     L.vslot_cv[k0 + k] = ci.cv_base + pos;
+                    L.vslot_v2f[k0 + k] = (int32_t)(ci.v2f_base + pos * ci.H);
                 }
             }
+        } else {  // generic, isolated and ghost variables: CSR slots
+            for (int w = vi; w < vj; ++w)
+                for (int k = L.vrowptr[w]; k < L.vrowptr[w + 1]; ++k) {
+                    L.vslot_v2f[k] = (int32_t)voff;
+                    voff += L.vhalf[w];
+                }
         }
-        const int cls = (int)L.classes.size();
-        L.classes.push_back(ci);
-        sweep_class(cls, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
+        if (voff > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
+        if (swept) {
+            const int cls = (int)L.classes.size();
+            L.classes.push_back(ci);
+            sweep_class(cls, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
+        }
         vi = vj;
     }
+    L.v2f_elems = voff;
+    for (int k = 0; k < nE; ++k) L.v2f_off[L.vslot_edge[k]] = L.vslot_v2f[k];
 
     // Launch order of the sweep classes: the longest per-thread chains first
     // (generic classes, then the gathering variable classes, then the streaming

@@ -10,6 +10,8 @@
 //      with coalesced 16-B-per-lane loads
 //   C  split arrays V2F[e], F2V[e] (factor-major) + a variable-private prevV in
 //      slot order: factor streams, variable gathers 32 B + scatters 32 B
+//   G  gather-only: V2F variable-major, F2V factor-major, every write coalesced,
+//      each side gathers the other's array; no private copies
 //   S  scatter layout: V2F factor-major, F2V variable-major (slot order), private
 //      prevF / prevV: both sides stream their inputs and scatter 32-B outputs
 // Every variable has 4 slots (degree 4); slot -> edge is a random permutation.
@@ -210,6 +212,63 @@ __device__ __forceinline__ void factor_S(const Args& a, int j) {
     a.cF[2 * j + 1] = c1 + 1;
 }
 
+// gather-only layout: V2F slot-major (written coalesced by the variable side),
+// F2V factor-major (written coalesced by the factor side); each side gathers the
+// other's array (32-B random reads) and finds its previous output in its own one.
+__device__ __forceinline__ void factor_G(const Args& a, int j) {
+    if (j >= a.nF) return;
+    const int s0 = a.edge_slot[2 * j], s1 = a.edge_slot[2 * j + 1];
+    const uint8_t c0 = a.cF[2 * j], c1 = a.cF[2 * j + 1];
+    const d2* p = a.f2v_old + (size_t)j * 4;
+    d2 m[8];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) m[4 + i] = p[i];
+    double t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = a.tables[(size_t)k * a.nF + j];
+    const d2* r0 = a.v2f_old + (size_t)s0 * 2;
+    const d2* r1 = a.v2f_old + (size_t)s1 * 2;
+    m[0] = r0[0]; m[1] = r0[1]; m[2] = r1[0]; m[3] = r1[1];
+    d2 o[4];
+    f_compute(m, t, o);
+    d2* w = a.f2v_new + (size_t)j * 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = o[i];
+    a.cF[2 * j] = c0 + 1;
+    a.cF[2 * j + 1] = c1 + 1;
+}
+
+__device__ __forceinline__ void var_G(const Args& a, int j) {
+    if (j >= a.nV) return;
+    int e[4];
+    uint8_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        e[k] = a.slot_edge[(size_t)k * a.nV + j];
+        c[k] = a.cV[(size_t)k * a.nV + j];
+    }
+    d2 in[4][2], pv[4][2];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const d2* p = a.v2f_old + ((size_t)k * a.nV + j) * 2;
+        pv[k][0] = p[0];
+        pv[k][1] = p[1];
+        const d2* r = a.f2v_old + (size_t)e[k] * 2;
+        in[k][0] = r[0];
+        in[k][1] = r[1];
+    }
+    d2 s0 = add2(add2(in[0][0], in[1][0]), add2(in[2][0], in[3][0]));
+    d2 s1 = add2(add2(in[0][1], in[1][1]), add2(in[2][1], in[3][1]));
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        d2* w = a.v2f_new + ((size_t)k * a.nV + j) * 2;
+        w[0] = add2(s0, pv[k][0]);
+        w[1] = add2(s1, pv[k][1]);
+        a.cV[(size_t)k * a.nV + j] = c[k] + 1;
+    }
+    a.belief[j] = s0.x + s1.y;
+}
+
 // ---- variable side -----------------------------------------------------------
 __device__ __forceinline__ void var_A(const Args& a, int j) {  // thread per variable, 4 record gathers
     if (j >= a.nV) return;
@@ -333,6 +392,7 @@ __global__ void __launch_bounds__(BLOCK) k_cycle(Args a, int mode) {
         else if (L == 'B') factor_B(a, first);
         else if (L == 'C') factor_C(a, j);
         else if (L == 'D') factor_D(a, first);
+        else if (L == 'G') factor_G(a, j);
         else factor_S(a, j);
     } else {
         const int vb = (mode == 3) ? b - a.fblocks : b;
@@ -340,6 +400,7 @@ __global__ void __launch_bounds__(BLOCK) k_cycle(Args a, int mode) {
         if (L == 'A' || L == 'B') var_A(a, j);
         else if (L == 'E') var_E(a, (size_t)vb * BLOCK + threadIdx.x);
         else if (L == 'C' || L == 'D') var_C(a, j);
+        else if (L == 'G') var_G(a, j);
         else var_S(a, j);
     }
 }
@@ -430,6 +491,7 @@ int main() {
         run<'C'>("C split arrays, direct", a, st, e0, e1, reps);
         run<'D'>("D split arrays, factor via LDS", a, st, e0, e1, reps);
         run<'S'>("S scatter layout", a, st, e0, e1, reps);
+        run<'G'>("G gather-only layout", a, st, e0, e1, reps);
         for (int b = 0; b < 2; ++b) {
             CHECK(hipFree(rec[b])); CHECK(hipFree(v2f[b])); CHECK(hipFree(f2v[b]));
         }
