@@ -95,8 +95,8 @@ struct Engine : EngineBase {
     int device = 0;
     int cur = 0;  // buffers holding the messages of the last finished cycle
     DevBuf<T> v2f[2], f2v[2], tables, var_cost, belief, halo_send, halo_recv;
-    DevBuf<uint8_t> cF, cV, owned, fowned, vdeg8;
-    DevBuf<int32_t> vrowptr, vdom, init_idx, edge_gen_factor, edge_dom, sel, vell;
+    DevBuf<uint8_t> cF, cV, owned, fowned, vdeg8, vlane_k;
+    DevBuf<int32_t> vrowptr, vdom, init_idx, edge_gen_factor, edge_dom, sel, vell, vlane_var;
     DevBuf<int32_t> edge_v2f, f2v_off, vslot_f2v, vslot_v2f;
     DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
     DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off;
@@ -138,6 +138,8 @@ struct Engine : EngineBase {
         a.vslot_f2v = vslot_f2v.p;
         a.vslot_v2f = vslot_v2f.p;
         a.vell = vell.p;
+        a.vlane_var = vlane_var.p;
+        a.vlane_k = vlane_k.p;
         a.vdeg8 = vdeg8.p;
         a.vdom = vdom.p;
         a.vcost_off = vcost_off.p;
@@ -215,6 +217,8 @@ struct Engine : EngineBase {
         HIP_TRY(cF.alloc((size_t)L.n_edges));
         HIP_TRY(cV.alloc((size_t)L.n_cv));
         HIP_TRY(vell.upload(L.vell, stream));
+        HIP_TRY(vlane_var.upload(L.vlane_var, stream));
+        HIP_TRY(vlane_k.upload(L.vlane_k, stream));
         HIP_TRY(vdeg8.upload(L.vdeg8, stream));
         HIP_TRY(owned.upload(L.owned, stream));
         HIP_TRY(fowned.upload(L.fowned, stream));

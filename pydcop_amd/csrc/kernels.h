@@ -54,7 +54,9 @@ struct SweepArgs {
     const int32_t* vrowptr;
     const int32_t* vslot_f2v;  // [n_edges] CSR slot -> F2V offset (generic variables)
     const int32_t* vslot_v2f;  // [n_edges] CSR slot -> V2F offset
-    const int32_t* vell;   // slot tables of the register / wave variable classes
+    const int32_t* vell;       // per lane of the packed variable classes: F2V offset / -1,
+    const int32_t* vlane_var;  // variable id,
+    const uint8_t* vlane_k;    // edge position in the variable
     const uint8_t* vdeg8;  // [n_vars] degree (saturated), internal order
     const int32_t* vdom;
     const int64_t* vcost_off;
@@ -282,150 +284,54 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
 }
 
 // ---------------------------------------------------------------------------
-// Variable side, register class (1 <= deg <= 4): thread per variable, D is a
-// compile-time constant so the incoming messages stay in VGPRs.
+// Variable side, packed class (1 <= deg <= 64): ONE LANE PER EDGE.  The variables
+// of a wave have the same degree and sit side by side (lane = var*deg + k); a
+// lane's slot, counter, variable id and previous V->F message are contiguous
+// across lanes (coalesced), then every lane gathers exactly one F->V message --
+// all gathers of the wave are in flight together.  The sums walk the variable's
+// lanes in edge order with cross-lane reads, so the arithmetic order is still the
+// reference's:
 //   select_value      maxsum.py:584-620
 //   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
-// Everything but the incoming F->V messages is addressed by the variable index
-// (slot table, counters, costs, the V->F messages sent last cycle: coalesced);
-// the four gathers are then issued together.  Padding slots gather the all-zero
-// block: adding 0.0 is exact, so the sums run over all four slots.
 // ---------------------------------------------------------------------------
 template <typename T, int D>
-__device__ __forceinline__ void variable_reg(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
-    constexpr int K = MAX_REG_DEG;
+__device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     constexpr int H = Msg<T, D>::H;
-    const int v = ci.first + j;
-    const int n = ci.count;
-    int32_t slot[K];
-    uint8_t cnt[K];
-    T pv[K][D];
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const int64_t pos = (int64_t)k * n + j;
-        slot[k] = a.vell[ci.ell_base + pos];
-        cnt[k] = a.cV[ci.cv_base + pos];
-        Msg<T, D>::load(a.v2f_old + ci.v2f_base + pos * H, pv[k]);  // V->F sent last on this edge
-    }
-    const int deg = a.vdeg8[v];
-    T c[D];
-#pragma unroll
-    for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)j * D + d];
-    int init = -1;
-    if (a.start) init = a.init_idx[v];
-    T in[K][D];
-#pragma unroll
-    for (int k = 0; k < K; ++k)  // F->V message held from this factor
-        Msg<T, D>::load(a.f2v_old + (slot[k] < 0 ? a.null_f2v : slot[k]), in[k]);
-    // select_value: belief[d] = cost(d) + sum of the factor messages, first optimum
-    int best = 0;
-    T best_c = (T)0;
-#pragma unroll
-    for (int d = 0; d < D; ++d) {
-        T b = c[d];
-#pragma unroll
-        for (int k = 0; k < K; ++k) b += in[k][d];
-        if (d == 0 || b < best_c) {
-            best = d;
-            best_c = b;
-        }
-    }
-    if (init >= 0) {  // value_selection(initial_value), maxsum.py:497-498
-        best = init;
-        best_c = (T)0;
-    }
-    a.sel[v] = best;
-    a.belief[v] = best_c;
-    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
-                             a.start_mode != MXS_START_LEAFS;
-#pragma unroll
-    for (int ko = 0; ko < K; ++ko) {
-        T m[D];
-        T sum_cost = (T)0;
-#pragma unroll
-        for (int d = 0; d < D; ++d) {
-            T x = c[d];
-#pragma unroll
-            for (int k = 0; k < K; ++k)
-                if (k != ko) {
-                    sum_cost += in[k][d];
-                    x += in[k][d];
-                }
-            m[d] = x;
-        }
-        const T avg = sum_cost / (T)D;
-#pragma unroll
-        for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-        uint8_t co = 0;
-        if (a.start) {
-#pragma unroll
-            for (int d = 0; d < D; ++d) m[d] = start_sends ? m[d] : (T)0;
-        } else {
-            co = damp_and_filter<T, D>(m, pv[ko], cnt[ko], a.damp_v != 0, a.damping, a.stability);
-        }
-        if (slot[ko] < 0) {  // padding slot: keep it zero
-            co = 0;
-#pragma unroll
-            for (int d = 0; d < D; ++d) m[d] = (T)0;
-        }
-        const int64_t pos = (int64_t)ko * n + j;
-        Msg<T, D>::store(a.v2f_new + ci.v2f_base + pos * H, m);
-        a.cV[ci.cv_base + pos] = co;
-    }
-}
-
-// ---------------------------------------------------------------------------
-// Variable side, wave class (4 < deg <= 64): G = 8, 16 or 64 lanes per variable,
-// lane k owns the variable's k-th edge (its slot, counter and previous V->F
-// message are contiguous across lanes; one gathered F->V message per lane); the
-// sums walk the lanes in edge order with cross-lane reads, so the arithmetic
-// order is still the reference's.  Padding lanes hold zeros.
-// ---------------------------------------------------------------------------
-template <typename T, int D, int G>
-__device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const ClassInfo& ci,
-                                              int first_var) {
-    constexpr int H = Msg<T, D>::H;
-    const int vloc = first_var + (int)threadIdx.x / G;
-    if (vloc >= ci.count) return;  // whole group leaves together
-    const int k = (int)threadIdx.x % G;
-    const int v = ci.first + vloc;
-    const int64_t pos = (int64_t)vloc * G + k;
-    const int32_t slot = a.vell[ci.ell_base + pos];
-    const uint8_t cnt = a.cV[ci.cv_base + pos];
-    const int deg = a.vdeg8[v];
+    const int lane_id = item + (int)threadIdx.x;
+    if (lane_id >= ci.count) return;  // whole waves (count is a multiple of 64)
+    const int64_t pos = ci.ell_base + lane_id;
+    const int32_t slot = a.vell[pos];
+    const int v = a.vlane_var[pos];
+    const int k = a.vlane_k[pos];
+    const uint8_t cnt = a.cV[ci.cv_base + lane_id];
+    T pv[D], in[D], c[D], b[D], m[D];
+    const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
+    Msg<T, D>::load(a.v2f_old + vo, pv);  // V->F message last sent on this edge
     const bool has = slot >= 0;
+    Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);  // F->V held from this factor
+    const int deg = a.vdeg8[v];  // the same for every lane of the wave
+#pragma unroll
+    for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)(v - ci.first) * D + d];
     int init = -1;
     if (a.start) init = a.init_idx[v];
-    T c[D], in[D], pv[D], b[D], m[D];
-    Msg<T, D>::load(a.v2f_old + ci.v2f_base + pos * H, pv);
-#pragma unroll
-    for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)vloc * D + d];
-    Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);
+    const int seg = ((int)threadIdx.x & 63) - (has ? k : 0);  // first lane of the variable
+    // d outer / factors inner, as the reference sums (maxsum.py:607-610, 651-665):
+    // sum_cost is ONE accumulator running through all of it
     T sum_cost = (T)0;
 #pragma unroll
     for (int d = 0; d < D; ++d) {
-        b[d] = c[d];
-        m[d] = c[d];
-        if (G <= 16) {
-#pragma unroll
-            for (int kk = 0; kk < G; ++kk) {  // lanes past deg hold zeros
-                const T x = __shfl(in[d], kk, G);
-                b[d] += x;                 // select_value: every factor
-                if (kk != k) {             // costs_for_factor: every factor but the target
-                    sum_cost += x;
-                    m[d] += x;
-                }
-            }
-        } else {
-            for (int kk = 0; kk < deg; ++kk) {  // one variable per wave: uniform bound
-                const T x = __shfl(in[d], kk, G);
-                b[d] += x;
-                if (kk != k) {
-                    sum_cost += x;
-                    m[d] += x;
-                }
+        T bd = c[d], md = c[d];
+#pragma unroll 4
+        for (int kk = 0; kk < deg; ++kk) {
+            const T x = __shfl(in[d], seg + kk, 64);
+            bd += x;                   // select_value: every factor
+            if (kk != k) {             // costs_for_factor: every factor but the target
+                sum_cost += x;
+                md += x;
             }
         }
+        b[d] = bd;
+        m[d] = md;
     }
     int best = 0;
     T best_c = b[0];
@@ -435,11 +341,11 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
             best = d;
             best_c = b[d];
         }
-    if (init >= 0) {
+    if (init >= 0) {  // value_selection(initial_value), maxsum.py:497-498
         best = init;
         best_c = (T)0;
     }
-    if (k == 0) {
+    if (has && k == 0) {
         a.sel[v] = best;
         a.belief[v] = best_c;
     }
@@ -447,8 +353,9 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
 #pragma unroll
     for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
     uint8_t co = 0;
-    if (a.start) {  // deg > 1 here: only leafs_vars / all make the variable send
-        const bool sends = a.start_mode != MXS_START_LEAFS;
+    if (a.start) {
+        const bool sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                           a.start_mode != MXS_START_LEAFS;
 #pragma unroll
         for (int d = 0; d < D; ++d) m[d] = sends ? m[d] : (T)0;
     } else {
@@ -459,8 +366,8 @@ __device__ __forceinline__ void variable_wave(const SweepArgs<T>& a, const Class
 #pragma unroll
         for (int d = 0; d < D; ++d) m[d] = (T)0;
     }
-    Msg<T, D>::store(a.v2f_new + ci.v2f_base + pos * H, m);
-    a.cV[ci.cv_base + pos] = co;
+    Msg<T, D>::store(a.v2f_new + vo, m);
+    a.cV[ci.cv_base + lane_id] = co;
 }
 
 // Variable side, generic class: thread per variable, any domain size / degree,
@@ -540,22 +447,14 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // ---------------------------------------------------------------------------
 template <typename T, int D>
 __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
-    if (ci.kind == K_V_WAVE) {  // several lanes per variable
-        switch (ci.maxdeg) {
-            case 8: variable_wave<T, D, 8>(a, ci, item); break;
-            case 16: variable_wave<T, D, 16>(a, ci, item); break;
-            default: variable_wave<T, D, 64>(a, ci, item); break;
-        }
+    if (ci.kind == K_V_PACK) {  // one lane per edge
+        variable_pack<T, D>(a, ci, item);
         return;
     }
     const int j = item + (int)threadIdx.x;
     if (j >= ci.count) return;
-    switch (ci.kind) {
-        case K_F_UNARY: factor_unary<T, D>(a, ci, j); break;
-        case K_F_BIN: factor_binary<T, D>(a, ci, j); break;
-        case K_V_REG: variable_reg<T, D>(a, ci, j); break;
-        default: break;
-    }
+    if (ci.kind == K_F_BIN) factor_binary<T, D>(a, ci, j);
+    else if (ci.kind == K_F_UNARY) factor_unary<T, D>(a, ci, j);
 }
 
 template <typename T, int DSEL>

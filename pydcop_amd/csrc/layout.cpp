@@ -158,7 +158,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         }
         L.frowptr[nF] = ei;
         // an all-zero block nobody writes, gathered through the padding slots of the
-        // register / wave variable classes (32-byte aligned)
+        // packed variable classes (32-byte aligned)
         off = (off + align - 1) / align * align;
         L.null_f2v = off;
         off += L.half(MAX_REG_D);
@@ -174,13 +174,13 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         int kind, sub;
         if (!own) { kind = 90; sub = 0; }                       // ghost: never swept
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
-        else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_REG_DEG) {
-            kind = K_V_REG; sub = D * 16 + MAX_REG_DEG;
-        } else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_WAVE_DEG) {
-            kind = K_V_WAVE; sub = D * 128 + (deg <= 8 ? 8 : deg <= 16 ? 16 : 64);
+        else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
+            kind = K_V_PACK; sub = D;
         } else { kind = K_V_GEN; sub = 0; }
-        // sort key: class, then degree (uniform waves), stable in caller order
-        vsort[v] = (kind * 1024 + sub) * 4096 + (L.opt.sort_by_degree ? std::min(deg, 4095) : 0);
+        // sort key: class, then degree (the packed class needs equal degrees side
+        // by side; bit3 of layout_flags keeps the caller's order elsewhere)
+        const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
+        vsort[v] = (kind * 1024 + sub) * 4096 + (by_deg ? std::min(deg, 4095) : 0);
     }
     L.var_i2e.resize(nV);
     std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);
@@ -305,7 +305,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
 
     // ---- variable classes, V2F array (variable-major) -----------------------------
     // Send counters: positions [0, nE) follow the CSR slot order (generic class);
-    // the register / wave classes keep theirs in padded, coalesced tables behind.
+    // the packed classes keep theirs in lane order behind.
     L.n_cv = nE;
     for (int k = 0; k < nE; ++k) L.vslot_cv[k] = k;
     int64_t voff = 0;
@@ -324,15 +324,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             const int64_t align = 32 / L.opt.word;  // every class starts on a 32-byte boundary
             voff = (voff + align - 1) / align * align;
         }
-        if (kind == K_V_REG) {
-            ci.kind = K_V_REG;
-            ci.D = sub / 16;
-            ci.maxdeg = sub % 16;
-            ci.H = L.half(ci.D);
-        } else if (kind == K_V_WAVE) {
-            ci.kind = K_V_WAVE;
-            ci.D = sub / 128;
-            ci.maxdeg = sub % 128;
+        if (kind == K_V_PACK) {
+            ci.kind = K_V_PACK;
+            ci.D = sub;
             ci.H = L.half(ci.D);
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
@@ -342,27 +336,44 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         } else {  // ghosts: storage only
             swept = false;
         }
-        if (ci.kind == K_V_REG || ci.kind == K_V_WAVE) {
-            // slot table: F2V offset of the variable's k-th edge, -1 = padding; the
-            // slot's own V->F message sits at v2f_base + position * H.
-            //   K_V_REG  [maxdeg][count]  (a wave reads one k of 64 variables)
-            //   K_V_WAVE [count][G]       (lane k of a variable's group reads slot k)
-            const int64_t n = ci.count, G = ci.maxdeg;
+        if (ci.kind == K_V_PACK) {
+            // One lane per edge.  The variables are sorted by degree; a wave holds
+            // floor(64/deg) variables of one degree side by side (lane = var*deg + k)
+            // and its tail lanes are padding.  Per lane: F2V offset of its edge (-1 =
+            // padding), its variable, k; its own V->F message sits at v2f_base + lane*H.
             ci.ell_base = (int64_t)L.vell.size();
             ci.cv_base = L.n_cv;
             ci.v2f_base = voff;
-            L.vell.resize(L.vell.size() + (size_t)(n * G), -1);
-            L.n_cv += n * G;
-            voff += n * G * ci.H;
-            for (int64_t j = 0; j < n; ++j) {
-                const int k0 = L.vrowptr[vi + j], deg = L.vrowptr[vi + j + 1] - k0;
-                for (int k = 0; k < deg; ++k) {
-                    const int64_t pos = ci.kind == K_V_REG ? (int64_t)k * n + j : j * G + k;
-                    L.vell[ci.ell_base + pos] = L.vslot_f2v[k0 + k];
-                    L.vslot_cv[k0 + k] = ci.cv_base + pos;
-                    L.vslot_v2f[k0 + k] = (int32_t)(ci.v2f_base + pos * ci.H);
+            int64_t lanes = 0;
+            for (int w = vi; w < vj;) {
+                const int deg = L.vrowptr[w + 1] - L.vrowptr[w];
+                int w2 = w;
+                while (w2 < vj && L.vrowptr[w2 + 1] - L.vrowptr[w2] == deg) ++w2;
+                const int per_wave = 64 / deg;
+                for (int x = w; x < w2; x += per_wave) {  // one wave
+                    const int nv = std::min(per_wave, w2 - x);
+                    for (int lane = 0; lane < 64; ++lane) {
+                        const int var = lane / deg, k = lane % deg;
+                        if (var < nv) {
+                            const int ks = L.vrowptr[x + var] + k;
+                            L.vell.push_back(L.vslot_f2v[ks]);
+                            L.vlane_var.push_back(x + var);
+                            L.vlane_k.push_back((uint8_t)k);
+                            L.vslot_cv[ks] = ci.cv_base + lanes;
+                            L.vslot_v2f[ks] = (int32_t)(ci.v2f_base + lanes * ci.H);
+                        } else {
+                            L.vell.push_back(-1);
+                            L.vlane_var.push_back(x);
+                            L.vlane_k.push_back(255);
+                        }
+                        ++lanes;
+                    }
                 }
+                w = w2;
             }
+            ci.count = (int32_t)lanes;
+            L.n_cv += lanes;
+            voff += lanes * ci.H;
         } else {  // generic, isolated and ghost variables: CSR slots
             for (int w = vi; w < vj; ++w)
                 for (int k = L.vrowptr[w]; k < L.vrowptr[w + 1]; ++k) {
@@ -374,7 +385,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (swept) {
             const int cls = (int)L.classes.size();
             L.classes.push_back(ci);
-            sweep_class(cls, ci.kind == K_V_WAVE ? BLOCK / ci.maxdeg : BLOCK);
+            sweep_class(cls, BLOCK);
         }
         vi = vj;
     }
@@ -389,8 +400,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             switch (L.classes[c].kind) {
                 case K_V_GEN: return 0;
                 case K_F_GEN: return 1;
-                case K_V_WAVE: return 2;
-                case K_V_REG: return 3;
+                case K_V_PACK: return 2;
                 default: return 4;
             }
         };
@@ -399,7 +409,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (p.layout_flags & (32 | 64)) {  // timing experiments only (results are wrong):
             std::vector<int32_t> keep;     // bit5 = factor side only, bit6 = variable side only
             for (int c : L.sweep_order) {
-                const bool is_var = prio(c) == 0 || prio(c) == 2 || prio(c) == 3;
+                const bool is_var = prio(c) == 0 || prio(c) == 2;
                 if (((p.layout_flags & 32) && !is_var) || ((p.layout_flags & 64) && is_var)) keep.push_back(c);
             }
             L.sweep_order = keep;

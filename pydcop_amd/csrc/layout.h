@@ -44,16 +44,15 @@ enum Kind : int32_t {
     K_F_BIN = 2,    // arity 2, D x D, D in {2,3,4}: thread per factor, registers
     K_F_GEN = 3,    // anything: thread per edge, scalar loops
     K_F_NARY = 4,   // larger tables: workgroup per factor (own launch)
-    K_V_REG = 5,    // D in {2,3,4}, 1 <= deg <= 4: thread per variable, registers
+    K_V_PACK = 5,   // D in {2,3,4}, 1 <= deg <= 64: one lane per incoming edge, the
+                    // variables of a wave have the same degree and are packed side
+                    // by side (64/deg per wave), cross-lane sums
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
-    K_V_WAVE = 7,   // D in {2,3,4}, 4 < deg <= 64: G = 8, 16 or 64 lanes per variable,
-                    // one lane per incoming edge, cross-lane sums
 };
 
 constexpr int BLOCK = 256;
 constexpr int MAX_REG_D = 4;
-constexpr int MAX_REG_DEG = 4;
-constexpr int MAX_WAVE_DEG = 64;
+constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
 
 // Padded message length (elements) for a domain of D values of `word` bytes.
@@ -67,19 +66,19 @@ struct ClassInfo {       // one per class, read with one scalar load
     int32_t kind;
     int32_t D;           // uniform domain size (0 for generic classes)
     int32_t H;           // padded message length of the class (uniform classes)
-    int32_t maxdeg;      // K_V_REG: 4; K_V_WAVE: lanes per variable G (8, 16 or 64)
+    int32_t maxdeg;      // unused
     int32_t first;       // first internal factor / variable id of the class
-    int32_t count;       // number of factors / variables (K_F_GEN: edges)
+    int32_t count;       // number of factors / variables (K_F_GEN: edges; K_V_PACK: lanes)
     int32_t edge_base;   // first internal edge id (factor classes)
     int32_t start_only;  // K_V_GEN class of degree-0 variables: only cycle 0
     int64_t f2v_base;    // factor classes: element offset of the class in F2V
     int64_t tab_base;    // element offset of the class's tables
     int64_t cost_base;   // element offset of the class's variable costs
     int32_t block_base;  // index of the class's first block in its launch
-    int32_t per_block;   // items a block covers (BLOCK, or BLOCK/G for K_V_WAVE)
-    int64_t ell_base;    // K_V_REG / K_V_WAVE: first entry of the class's slot table
-    int64_t cv_base;     // K_V_REG / K_V_WAVE: first send counter of the class in cV
-    int64_t v2f_base;    // K_V_REG / K_V_WAVE: element offset of the class in V2F
+    int32_t per_block;   // items a block covers
+    int64_t ell_base;    // K_V_PACK: first lane of the class in the per-lane tables
+    int64_t cv_base;     // K_V_PACK: first send counter of the class in cV
+    int64_t v2f_base;    // K_V_PACK: element offset of the class in V2F
 };
 
 struct BlockDesc {  // n-ary launch only; the sweep derives (class, item) from blockIdx
@@ -136,8 +135,11 @@ struct Layout {
     std::vector<int32_t> vslot_f2v;  // [n_edges] F2V offset of the slot's edge
     std::vector<int32_t> vslot_v2f;  // [n_edges] V2F offset of the slot
     std::vector<int64_t> vslot_cv;   // [n_edges] position of the slot's send counter in cV
-    std::vector<int32_t> vell;       // slot tables of the K_V_REG ([4][count], slot-major)
-                                     // and K_V_WAVE ([count][G]) classes: F2V offset or -1
+    // per lane of the K_V_PACK classes (lane = one edge of one variable, or padding)
+    std::vector<int32_t> vell;       // F2V offset of the lane's edge, -1 = padding lane
+    std::vector<int32_t> vlane_var;  // internal id of the lane's variable (padding: the
+                                     // wave's first variable)
+    std::vector<uint8_t> vlane_k;    // position of the edge in the variable's links order
     std::vector<uint8_t> vdeg8;      // [n_vars] min(degree, 255), internal order
     int64_t n_cv = 0;                // size of the cV array (CSR slots + padded class slots)
     int dsel = 0;                    // the one D all register/wave classes share, else 0
