@@ -102,6 +102,7 @@ struct Engine : EngineBase {
     DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off;
     DevBuf<FactorGen> fgen;
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
+    DevBuf<ClassInfo> classes_all;  // every class (indexed by BlockDesc.cls)
     DevBuf<BlockDesc> blocks_nary;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
@@ -177,6 +178,11 @@ struct Engine : EngineBase {
             }
             HIP_TRY(hipGetLastError());
         }
+        if (!L.blocks_nary.empty()) {
+            hipLaunchKernelGGL((k_factor_nary<T>), dim3((unsigned)L.blocks_nary.size()), dim3(BLOCK), 0,
+                               stream, a, (const ClassInfo*)classes_all.p, (const BlockDesc*)blocks_nary.p);
+            HIP_TRY(hipGetLastError());
+        }
         return MXS_OK;
     }
 
@@ -236,6 +242,7 @@ struct Engine : EngineBase {
             for (int c : L.sweep_order) order.push_back(L.classes[c]);
             HIP_TRY(classes.upload(order, stream));
         }
+        HIP_TRY(classes_all.upload(L.classes, stream));
         HIP_TRY(blocks_nary.upload(L.blocks_nary, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));

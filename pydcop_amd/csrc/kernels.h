@@ -29,6 +29,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstring>
 
 #include "layout.h"
 
@@ -321,7 +322,6 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
 #pragma unroll
     for (int d = 0; d < D; ++d) {
         T bd = c[d], md = c[d];
-#pragma unroll 4
         for (int kk = 0; kk < deg; ++kk) {
             const T x = __shfl(in[d], seg + kk, 64);
             bd += x;                   // select_value: every factor
@@ -479,6 +479,195 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a
             case 3: sweep_d<T, 3>(a, ci, item); break;
             case 4: sweep_d<T, 4>(a, ci, item); break;
             default: break;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Factor side, workgroup-per-factor class (arity 2..4, 64 <= R <= 1024 where R is
+// the product of the dimensions after the first): factor_costs_for_var
+// (maxsum.py:382-447) for tables too large for one thread.
+//
+// The table [D0][R] is read from HBM exactly once, coalesced (lane <-> q in [0,R),
+// loop over d0); every entry feeds all `arity` outputs at once:
+//   * outputs to variables 1.. : the digits of q are fixed while d0 runs, so the
+//     running minima live in registers and reach LDS with ONE atomic per (q, p);
+//   * output to variable 0     : for each d0 the minimum over all q is a wavefront
+//     reduction (cross-lane min) followed by one LDS atomic per wave.
+// Minima are exact and order-independent, so reducing in any order reproduces the
+// reference's sequential `optimal > current` scan (maxsum.py:439-443) bit for bit;
+// each candidate is evaluated with the reference's own expression
+//   table[...] + (((0 + m_a) + m_b) + ...)   others in dimensions order (:425-438).
+// The incoming V->F messages are staged in LDS; minima are combined in LDS as
+// order-preserving integer keys (ds_min_u64 / ds_min_u32).
+// ---------------------------------------------------------------------------
+constexpr int NARY_MAX_SUMD = 1024;  // sum of the scope's domain sizes
+constexpr int NARY_MAX_R = 1024;     // BLOCK * NARY_NJ
+constexpr int NARY_NJ = NARY_MAX_R / BLOCK;
+constexpr int NARY_MAX_ARITY = 4;
+
+template <typename T>
+struct OrdKey;
+template <>
+struct OrdKey<double> {
+    typedef unsigned long long U;
+    static __device__ __forceinline__ U enc(double x) {
+        U b;
+        memcpy(&b, &x, 8);
+        return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+    }
+    static __device__ __forceinline__ double dec(U k) {
+        const U b = (k >> 63) ? (k & 0x7fffffffffffffffull) : ~k;
+        double x;
+        memcpy(&x, &b, 8);
+        return x;
+    }
+};
+template <>
+struct OrdKey<float> {
+    typedef unsigned int U;
+    static __device__ __forceinline__ U enc(float x) {
+        U b;
+        memcpy(&b, &x, 4);
+        return (b >> 31) ? ~b : (b | 0x80000000u);
+    }
+    static __device__ __forceinline__ float dec(U k) {
+        const U b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+        float x;
+        memcpy(&x, &b, 4);
+        return x;
+    }
+};
+
+template <typename T>
+__device__ __forceinline__ T wave_min(T x) {  // all 64 lanes get the minimum
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) {
+        const T y = __shfl(x, (int)((threadIdx.x & 63) ^ s), 64);
+        x = y < x ? y : x;
+    }
+    return x;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const ClassInfo* classes,
+                                                       const BlockDesc* blocks) {
+    typedef typename OrdKey<T>::U U;
+    __shared__ T s_msg[NARY_MAX_SUMD];
+    __shared__ U s_key[NARY_MAX_SUMD];
+    const BlockDesc bd = blocks[blockIdx.x];
+    const ClassInfo ci = classes[bd.cls];
+    const FactorGen fg = a.fgen[ci.first + bd.item];
+    const int A = fg.arity;
+    const int tid = (int)threadIdx.x;
+    int Dm[NARY_MAX_ARITY], off[NARY_MAX_ARITY];
+    int sumd = 0;
+#pragma unroll
+    for (int i = 0; i < NARY_MAX_ARITY; ++i) {
+        Dm[i] = i < A ? a.edge_dom[fg.edge_base + i] : 1;
+        off[i] = sumd;
+        sumd += i < A ? Dm[i] : 0;
+    }
+    // stage the incoming messages, arm the minima
+#pragma unroll
+    for (int i = 0; i < NARY_MAX_ARITY; ++i)
+        if (i < A) {
+            const int vo = a.edge_v2f[fg.edge_base + i];
+            for (int d = tid; d < Dm[i]; d += BLOCK) {
+                s_msg[off[i] + d] = a.v2f_old[vo + d];
+                s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
+            }
+        }
+    __syncthreads();
+    const int R = Dm[1] * Dm[2] * Dm[3];
+    // per owned q: its digits' messages and the running minima for p >= 1
+    T ms[NARY_NJ][NARY_MAX_ARITY], acc[NARY_NJ][NARY_MAX_ARITY];
+    int dig[NARY_NJ][NARY_MAX_ARITY];
+    bool live[NARY_NJ];
+#pragma unroll
+    for (int j = 0; j < NARY_NJ; ++j) {
+        const int q = tid + j * BLOCK;
+        live[j] = q < R;
+        int rem = live[j] ? q : 0;
+#pragma unroll
+        for (int i = NARY_MAX_ARITY - 1; i >= 1; --i) {
+            dig[j][i] = rem % Dm[i];
+            rem /= Dm[i];
+            ms[j][i] = i < A ? s_msg[off[i] + dig[j][i]] : (T)0;
+            acc[j][i] = pos_inf<T>();
+        }
+    }
+    const T* tab = a.tables + fg.tab_off;
+    const int D0 = Dm[0];
+    for (int d0 = 0; d0 < D0; ++d0) {
+        const T m0 = s_msg[off[0] + d0];
+        T best0 = pos_inf<T>();
+#pragma unroll
+        for (int j = 0; j < NARY_NJ; ++j) {
+            if (j * BLOCK >= R) break;  // uniform
+            const T t = live[j] ? tab[(int64_t)d0 * R + tid + j * BLOCK] : pos_inf<T>();
+            // to variable 0: the others are 1..A-1 in dimensions order
+            T s0 = (T)0;
+#pragma unroll
+            for (int i = 1; i < NARY_MAX_ARITY; ++i)
+                if (i < A) s0 += ms[j][i];
+            const T c0 = t + s0;
+            if (best0 > c0) best0 = c0;
+            // to variable p >= 1: the others are 0 and the remaining ones, in order
+#pragma unroll
+            for (int p = 1; p < NARY_MAX_ARITY; ++p)
+                if (p < A) {
+                    T sp = (T)0 + m0;
+#pragma unroll
+                    for (int i = 1; i < NARY_MAX_ARITY; ++i)
+                        if (i < A && i != p) sp += ms[j][i];
+                    const T cp = t + sp;
+                    if (acc[j][p] > cp) acc[j][p] = cp;
+                }
+        }
+        best0 = wave_min(best0);
+        if ((tid & 63) == 0) atomicMin(&s_key[off[0] + d0], OrdKey<T>::enc(best0));
+    }
+#pragma unroll
+    for (int j = 0; j < NARY_NJ; ++j)
+        if (live[j]) {
+#pragma unroll
+            for (int p = 1; p < NARY_MAX_ARITY; ++p)
+                if (p < A) atomicMin(&s_key[off[p] + dig[j][p]], OrdKey<T>::enc(acc[j][p]));
+        }
+    __syncthreads();
+    // apply_damping + the send rule, one thread per outgoing message
+    if (tid < A) {
+        const int e = fg.edge_base + tid;
+        const int D = Dm[tid];
+        const T* prev = a.f2v_old + a.f2v_off[e];
+        T* w = a.f2v_new + a.f2v_off[e];
+        const U* key = s_key + off[tid];
+        if (a.start) {  // only start_messages == all makes a non-unary factor send
+            const bool sends = a.start_mode == MXS_START_ALL;
+            for (int d = 0; d < D; ++d) w[d] = sends ? OrdKey<T>::dec(key[d]) : (T)0;
+            a.cF[e] = 0;
+        } else {
+            const uint8_t cnt = a.cF[e];
+            const bool damp = cnt > 0 && a.damp_f;
+            bool match = cnt > 0;
+            for (int d = 0; d < D; ++d) {
+                T m = OrdKey<T>::dec(key[d]);
+                const T p = prev[d];
+                if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+                if (match) match = comp_match(m, p, a.stability);
+                w[d] = m;
+            }
+            uint8_t out = 1;
+            if (match) {
+                if (cnt < SAME_COUNT) {
+                    out = (uint8_t)(cnt + 1);
+                } else {
+                    out = cnt;
+                    for (int d = 0; d < D; ++d) w[d] = prev[d];
+                }
+            }
+            a.cF[e] = out;
         }
     }
 }

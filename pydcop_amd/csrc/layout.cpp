@@ -17,7 +17,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     // gather-only layout (messages are always padded to a sector-friendly size)
     o.no_specialise = (f & 4) != 0;   // bit2: generic kernels only
     o.sort_by_degree = !(f & 8);      // bit3: keep the caller's variable order
-    if (f & 16) o.nary_min_entries = (int64_t)1 << 60;  // bit4: no workgroup-per-factor kernel
+    o.nary = !(f & 16);               // bit4: no workgroup-per-factor kernel
     return o;
 }
 
@@ -111,14 +111,22 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     for (int f = 0; f < nF; ++f) {
         const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
         const int D0 = g.dom_size[g.edge_var[e0]];
-        const int64_t entries = g.table_off[f + 1] - g.table_off[f];
         FKey k{K_F_GEN, 0};
         if (!L.opt.no_specialise) {
             if (ar == 1 && D0 >= 2 && D0 <= MAX_REG_D) k = FKey{K_F_UNARY, D0};
             else if (ar == 2 && D0 >= 2 && D0 <= MAX_REG_D && g.dom_size[g.edge_var[e0 + 1]] == D0)
                 k = FKey{K_F_BIN, D0};
-            else if (ar <= 8 && entries >= L.opt.nary_min_entries && entries <= L.opt.nary_max_entries)
-                k = FKey{K_F_NARY, 0};
+            else if (L.opt.nary && ar >= 2 && ar <= 4) {
+                // workgroup-per-factor kernel: 64 <= R <= 1024 (R = product of the
+                // dimensions after the first), staged messages fit its LDS arrays
+                int64_t R = 1, sumd = 0;
+                for (int i = 0; i < ar; ++i) {
+                    const int Di = g.dom_size[g.edge_var[e0 + i]];
+                    sumd += Di;
+                    if (i) R *= Di;
+                }
+                if (R >= 64 && R <= 1024 && sumd <= 1024) k = FKey{K_F_NARY, 0};
+            }
         }
         fkey[f] = k;
     }

@@ -43,7 +43,8 @@ enum Kind : int32_t {
     K_F_UNARY = 1,  // arity 1, D in {2,3,4}: thread per factor, registers
     K_F_BIN = 2,    // arity 2, D x D, D in {2,3,4}: thread per factor, registers
     K_F_GEN = 3,    // anything: thread per edge, scalar loops
-    K_F_NARY = 4,   // larger tables: workgroup per factor (own launch)
+    K_F_NARY = 4,   // arity 2..4 with 64..1024 entries per value of the first variable:
+                    // workgroup per factor, wavefront min-reductions (own launch)
     K_V_PACK = 5,   // D in {2,3,4}, 1 <= deg <= 64: one lane per incoming edge, the
                     // variables of a wave have the same degree and are packed side
                     // by side (64/deg per wave), cross-lane sums
@@ -96,8 +97,7 @@ struct LayoutOptions {
     int word = 8;                // sizeof(T)
     bool no_specialise = false;  // force the generic kernels (testing)
     bool sort_by_degree = true;
-    int64_t nary_min_entries = (int64_t)1 << 60;  // tables at least this big go to K_F_NARY (off until that kernel lands)
-    int64_t nary_max_entries = (int64_t)1 << 22;
+    bool nary = true;            // use the workgroup-per-factor kernel (K_F_NARY)
 };
 
 struct Layout {

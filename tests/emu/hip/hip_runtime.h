@@ -170,6 +170,13 @@ inline V __shfl(V var, int src_lane, int width = 64) {
     return out;
 }
 
+template <typename U>
+inline U atomicMin(U* addr, U val) {  // fibers run one at a time: plain read-modify-write
+    const U old = *addr;
+    if (val < old) *addr = val;
+    return old;
+}
+
 template <typename K, typename... A>
 inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
     hipemu::Call<K, A...> call{kernel, std::tuple<A...>(args...)};

@@ -106,4 +106,12 @@ def parity_cases():
         ("coloring4_deg20_all", lambda: G.random_coloring(80, avg_degree=20, n_colors=4, seed=14),
          {"start_messages": "all", "damping_nodes": "vars"}),
         ("init_values", lambda: with_init(G.random_coloring(100, n_colors=2, seed=11), 11), {}),
+        # workgroup-per-factor kernel (arity 2..4, 64 <= R <= 1024)
+        ("nary_meeting_d8", lambda: G.meeting_like(30, n_factors=25, dom=8, arity=3, seed=15), {"mode": "max"}),
+        ("nary_meeting_d24", lambda: G.meeting_like(12, n_factors=6, dom=24, arity=3, seed=16),
+         {"mode": "max", "start_messages": "all"}),
+        ("nary_binary_d70", lambda: G.meeting_like(16, n_factors=12, dom=70, arity=2, seed=17), {}),
+        ("nary_arity4_d5", lambda: G.meeting_like(25, n_factors=15, dom=5, arity=4, seed=18),
+         {"damping_nodes": "factors"}),
+        ("nary_mixed_dims", lambda: G.random_mixed(40, 50, seed=19, max_arity=4, dom_choices=(3, 7, 10, 12)), {}),
     ]

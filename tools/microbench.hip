@@ -38,6 +38,26 @@ __global__ void __launch_bounds__(256) k_copy(const float4* __restrict__ in, flo
     for (; i < n; i += stride) out[i] = in[i];
 }
 
+__global__ void __launch_bounds__(256) k_read(const float4* __restrict__ in, float* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    float4 acc = {0, 0, 0, 0};
+    for (; i + 3 * stride < n; i += 4 * stride) {  // 4 independent 16-B loads in flight per lane
+        const float4 a = in[i], b = in[i + stride], c = in[i + 2 * stride], d = in[i + 3 * stride];
+        acc.x += a.x + b.x + c.x + d.x; acc.y += a.y + b.y + c.y + d.y;
+        acc.z += a.z + b.z + c.z + d.z; acc.w += a.w + b.w + c.w + d.w;
+    }
+    for (; i < n; i += stride) { const float4 a = in[i]; acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w; }
+    if (acc.x + acc.y + acc.z + acc.w == 12345.678f) out[0] = acc.x;  // keep the loads alive
+}
+
+__global__ void __launch_bounds__(256) k_fill(float4* __restrict__ out, size_t n, float v) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const float4 x = {v, v, v, v};
+    for (; i < n; i += stride) out[i] = x;
+}
+
 // one 64-B record gathered, 32 B scattered per lane (records of 4 x float4)
 __global__ void __launch_bounds__(256) k_gather(const float4* __restrict__ rec, float4* __restrict__ out,
                                                 const uint32_t* __restrict__ idx, size_t n_lanes) {
@@ -117,6 +137,22 @@ int main() {
         const float ms = time_ms(st, e0, e1);
         printf("{\"bench\": \"copy\", \"mb_each_way\": %zu, \"us_per_launch\": %.2f, \"read_plus_write_GBps\": %.1f}\n",
                mb, 1e3 * ms / reps, 2.0 * bytes * reps / (ms * 1e-3) / 1e9);
+        float* sink;
+        CHECK(hipMalloc((void**)&sink, 64));
+        for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, st, a, sink, n);
+        CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_read, dim3(blocks), dim3(256), 0, st, a, sink, n);
+        CHECK(hipEventRecord(e1, st));
+        const float msr = time_ms(st, e0, e1);
+        CHECK(hipEventRecord(e0, st));
+        for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, st, b, n, 1.0f);
+        CHECK(hipEventRecord(e1, st));
+        const float msw = time_ms(st, e0, e1);
+        printf("{\"bench\": \"read_only\", \"mb\": %zu, \"us_per_launch\": %.2f, \"GBps\": %.1f}\n", mb,
+               1e3 * msr / reps, (double)bytes * reps / (msr * 1e-3) / 1e9);
+        printf("{\"bench\": \"write_only\", \"mb\": %zu, \"us_per_launch\": %.2f, \"GBps\": %.1f}\n", mb,
+               1e3 * msw / reps, (double)bytes * reps / (msw * 1e-3) / 1e9);
+        CHECK(hipFree(sink));
         CHECK(hipFree(a));
         CHECK(hipFree(b));
     }

@@ -212,9 +212,30 @@ __device__ __forceinline__ void factor_S(const Args& a, int j) {
     a.cF[2 * j + 1] = c1 + 1;
 }
 
+template <bool NT>
+__device__ __forceinline__ d2 ld(const d2* p) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        const v2d v = __builtin_nontemporal_load((const v2d*)p);
+        return d2{v.x, v.y};
+    }
+    return *p;
+}
+template <bool NT>
+__device__ __forceinline__ void st(d2* p, d2 v) {
+    if (NT) {
+        typedef double v2d __attribute__((ext_vector_type(2)));
+        v2d x = {v.x, v.y};
+        __builtin_nontemporal_store(x, (v2d*)p);
+    } else {
+        *p = v;
+    }
+}
+
 // gather-only layout: V2F slot-major (written coalesced by the variable side),
 // F2V factor-major (written coalesced by the factor side); each side gathers the
 // other's array (32-B random reads) and finds its previous output in its own one.
+template <bool NT>
 __device__ __forceinline__ void factor_G(const Args& a, int j) {
     if (j >= a.nF) return;
     const int s0 = a.edge_slot[2 * j], s1 = a.edge_slot[2 * j + 1];
@@ -222,22 +243,45 @@ __device__ __forceinline__ void factor_G(const Args& a, int j) {
     const d2* p = a.f2v_old + (size_t)j * 4;
     d2 m[8];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) m[4 + i] = p[i];
+    for (int i = 0; i < 4; ++i) m[4 + i] = ld<NT>(p + i);
     double t[9];
 #pragma unroll
     for (int k = 0; k < 9; ++k) t[k] = a.tables[(size_t)k * a.nF + j];
     const d2* r0 = a.v2f_old + (size_t)s0 * 2;
     const d2* r1 = a.v2f_old + (size_t)s1 * 2;
-    m[0] = r0[0]; m[1] = r0[1]; m[2] = r1[0]; m[3] = r1[1];
+    m[0] = ld<NT>(r0); m[1] = ld<NT>(r0 + 1); m[2] = ld<NT>(r1); m[3] = ld<NT>(r1 + 1);
     d2 o[4];
     f_compute(m, t, o);
     d2* w = a.f2v_new + (size_t)j * 4;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) w[i] = o[i];
+    for (int i = 0; i < 4; ++i) st<NT>(w + i, o[i]);
     a.cF[2 * j] = c0 + 1;
     a.cF[2 * j + 1] = c1 + 1;
 }
 
+// gather-only layout, factor side with ONE LANE PER EDGE: lane i of factor j reads its
+// own previous output (coalesced), the partner edge's V2F message (gather) and the
+// table, writes its own F2V message (coalesced)
+__device__ __forceinline__ void factor_H(const Args& a, size_t e) {
+    if (e >= (size_t)2 * a.nF) return;
+    const size_t j = e >> 1;
+    const int s = a.edge_slot[e ^ 1];
+    const uint8_t c = a.cF[e];
+    const d2* p = a.f2v_old + e * 2;
+    const d2 p0 = p[0], p1 = p[1];
+    double t[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) t[k] = a.tables[(size_t)((e & 1) ? (k % 3) * 3 + k / 3 : k) * a.nF + j];
+    const d2* r = a.v2f_old + (size_t)s * 2;
+    const d2 m0 = r[0], m1 = r[1];
+    double tt = t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7] + t[8];
+    d2* w = a.f2v_new + e * 2;
+    w[0] = min2(add2(m0, p0), d2{tt, tt});
+    w[1] = min2(add2(m1, p1), m0);
+    a.cF[e] = c + 1;
+}
+
+template <bool NT>
 __device__ __forceinline__ void var_G(const Args& a, int j) {
     if (j >= a.nV) return;
     int e[4];
@@ -251,19 +295,19 @@ __device__ __forceinline__ void var_G(const Args& a, int j) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const d2* p = a.v2f_old + ((size_t)k * a.nV + j) * 2;
-        pv[k][0] = p[0];
-        pv[k][1] = p[1];
+        pv[k][0] = ld<NT>(p);
+        pv[k][1] = ld<NT>(p + 1);
         const d2* r = a.f2v_old + (size_t)e[k] * 2;
-        in[k][0] = r[0];
-        in[k][1] = r[1];
+        in[k][0] = ld<NT>(r);
+        in[k][1] = ld<NT>(r + 1);
     }
     d2 s0 = add2(add2(in[0][0], in[1][0]), add2(in[2][0], in[3][0]));
     d2 s1 = add2(add2(in[0][1], in[1][1]), add2(in[2][1], in[3][1]));
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         d2* w = a.v2f_new + ((size_t)k * a.nV + j) * 2;
-        w[0] = add2(s0, pv[k][0]);
-        w[1] = add2(s1, pv[k][1]);
+        st<NT>(w, add2(s0, pv[k][0]));
+        st<NT>(w + 1, add2(s1, pv[k][1]));
         a.cV[(size_t)k * a.nV + j] = c[k] + 1;
     }
     a.belief[j] = s0.x + s1.y;
@@ -384,34 +428,46 @@ __device__ __forceinline__ void var_E(const Args& a, size_t i) {
 // mode: 1 factor only, 2 variable only, 3 both in one launch
 template <char L>
 __global__ void __launch_bounds__(BLOCK) k_cycle(Args a, int mode) {
-    const int b = blockIdx.x;
-    const bool is_f = (mode == 1) || (mode == 3 && b < a.fblocks);
+    int b = blockIdx.x;
+    bool is_f = (mode == 1) || (mode == 3 && b < a.fblocks);
+    int vb_i = -1;
+    if (mode == 4) {  // factor and variable blocks interleaved in proportion
+        const int n = gridDim.x, nf = a.fblocks;
+        const long long f0 = (long long)b * nf / n, f1 = (long long)(b + 1) * nf / n;
+        is_f = f1 > f0;
+        vb_i = b - (int)f1;   // variable blocks before this one
+        if (is_f) b = (int)f0;
+    }
     if (is_f) {
         const int first = b * BLOCK, j = first + (int)threadIdx.x;
         if (L == 'A' || L == 'E') factor_A(a, j);
         else if (L == 'B') factor_B(a, first);
         else if (L == 'C') factor_C(a, j);
         else if (L == 'D') factor_D(a, first);
-        else if (L == 'G') factor_G(a, j);
+        else if (L == 'G') factor_G<false>(a, j);
+        else if (L == 'J') factor_G<true>(a, j);
+        else if (L == 'H') { factor_H(a, (size_t)b * BLOCK * 2 + threadIdx.x); factor_H(a, (size_t)b * BLOCK * 2 + BLOCK + threadIdx.x); }
+        else if (L == 'I') factor_H(a, (size_t)b * BLOCK + threadIdx.x);
         else factor_S(a, j);
     } else {
-        const int vb = (mode == 3) ? b - a.fblocks : b;
+        const int vb = (mode == 3) ? b - a.fblocks : (mode == 4) ? vb_i : b;
         const int j = vb * BLOCK + (int)threadIdx.x;
         if (L == 'A' || L == 'B') var_A(a, j);
         else if (L == 'E') var_E(a, (size_t)vb * BLOCK + threadIdx.x);
         else if (L == 'C' || L == 'D') var_C(a, j);
-        else if (L == 'G') var_G(a, j);
+        else if (L == 'G' || L == 'H' || L == 'I') var_G<false>(a, j);
+        else if (L == 'J') var_G<true>(a, j);
         else var_S(a, j);
     }
 }
 
 template <char L>
 static void run(const char* name, Args a, hipStream_t st, hipEvent_t e0, hipEvent_t e1, int reps) {
-    const int fb = (a.nF + BLOCK - 1) / BLOCK;
+    const int fb = L == 'I' ? (2 * a.nF + BLOCK - 1) / BLOCK : (a.nF + BLOCK - 1) / BLOCK;
     const int vb = L == 'E' ? (4 * a.nV + BLOCK - 1) / BLOCK : (a.nV + BLOCK - 1) / BLOCK;
     a.fblocks = fb;
-    float ms[4] = {0, 0, 0, 0};
-    for (int mode = 1; mode <= 3; ++mode) {
+    float ms[5] = {0, 0, 0, 0, 0};
+    for (int mode = 1; mode <= 4; ++mode) {
         const int grid = mode == 1 ? fb : mode == 2 ? vb : fb + vb;
         Args x = a;
         for (int i = 0; i < reps + 6; ++i) {
@@ -427,8 +483,8 @@ static void run(const char* name, Args a, hipStream_t st, hipEvent_t e0, hipEven
         CHECK(hipEventElapsedTime(&ms[mode], e0, e1));
     }
     printf("{\"bench\": \"pattern\", \"layout\": \"%s\", \"factors\": %d, \"vars\": %d, "
-           "\"factor_us\": %.2f, \"variable_us\": %.2f, \"fused_us\": %.2f}\n",
-           name, a.nF, a.nV, 1e3 * ms[1] / reps, 1e3 * ms[2] / reps, 1e3 * ms[3] / reps);
+           "\"factor_us\": %.2f, \"variable_us\": %.2f, \"fused_us\": %.2f, \"interleaved_us\": %.2f}\n",
+           name, a.nF, a.nV, 1e3 * ms[1] / reps, 1e3 * ms[2] / reps, 1e3 * ms[3] / reps, 1e3 * ms[4] / reps);
     fflush(stdout);
 }
 
@@ -492,6 +548,9 @@ int main() {
         run<'D'>("D split arrays, factor via LDS", a, st, e0, e1, reps);
         run<'S'>("S scatter layout", a, st, e0, e1, reps);
         run<'G'>("G gather-only layout", a, st, e0, e1, reps);
+        run<'J'>("J gather-only, non-temporal message loads/stores", a, st, e0, e1, reps);
+        run<'H'>("H gather-only, factor lane per edge (2 edges per thread, strided)", a, st, e0, e1, reps);
+        run<'I'>("I gather-only, factor lane per edge", a, st, e0, e1, reps);
         for (int b = 0; b < 2; ++b) {
             CHECK(hipFree(rec[b])); CHECK(hipFree(v2f[b])); CHECK(hipFree(f2v[b]));
         }
