@@ -27,6 +27,20 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+
+
+def measured_traffic(workload, dtype):
+    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC
+    passes (FETCH_SIZE + WRITE_SIZE, separate runs; scripts/collect_traffic.py
+    turns the committed profiles/*.csv into profiles/traffic.json).  None when
+    this workload/dtype was not profiled."""
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+        return t.get(f"{workload}/{dtype}", {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
 
 
 def make_workload(name, n_gpus=1):
@@ -99,7 +113,10 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
 
-    import torch
+    if world > 1:
+        # one HIP runtime per process: torch first, so that the engine binds to the
+        # runtime torch bundles and can share its stream / buffers with RCCL
+        import torch
     from pydcop_amd.engine import MaxSumEngine
     from pydcop_amd.graph import Params
 
@@ -121,8 +138,8 @@ def main():
         barrier = lambda: None  # noqa: E731
 
     def sync():
-        runner.sync()
-        if torch.cuda.is_available():
+        runner.sync()  # hipStreamSynchronize on the engine's stream
+        if world > 1:
             torch.cuda.synchronize()
 
     runner.run(args.warmup)
@@ -163,7 +180,8 @@ def main():
             kernel_s = event_ms * 1e-3 / args.steps
             achieved = bytes_cycle / kernel_s / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                               "traffic": measured_traffic(args.workload, args.dtype),
                                "kernel": "k_sweep", "algorithmic_bytes_per_launch": bytes_cycle,
                                "avg_launch_us": kernel_s * 1e6}
         if args.gpus == 1 and not args.no_cpu_baseline:

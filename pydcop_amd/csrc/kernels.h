@@ -599,34 +599,63 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Cla
     }
     const T* tab = a.tables + fg.tab_off;
     const int D0 = Dm[0];
-    for (int d0 = 0; d0 < D0; ++d0) {
-        const T m0 = s_msg[off[0] + d0];
-        T best0 = pos_inf<T>();
+    // sum of the others' messages for the output to variable 0: fixed per q
+    T s0[NARY_NJ];
 #pragma unroll
-        for (int j = 0; j < NARY_NJ; ++j) {
-            if (j * BLOCK >= R) break;  // uniform
-            const T t = live[j] ? tab[(int64_t)d0 * R + tid + j * BLOCK] : pos_inf<T>();
-            // to variable 0: the others are 1..A-1 in dimensions order
-            T s0 = (T)0;
+    for (int j = 0; j < NARY_NJ; ++j) {
+        T s = (T)0;
 #pragma unroll
-            for (int i = 1; i < NARY_MAX_ARITY; ++i)
-                if (i < A) s0 += ms[j][i];
-            const T c0 = t + s0;
-            if (best0 > c0) best0 = c0;
-            // to variable p >= 1: the others are 0 and the remaining ones, in order
+        for (int i = 1; i < NARY_MAX_ARITY; ++i)
+            if (i < A) s += ms[j][i];
+        s0[j] = s;
+    }
+    constexpr int UNR = 4;  // values of d0 in flight: UNR * NJ table loads per lane before any use
+    for (int d0 = 0; d0 < D0; d0 += UNR) {
+        T tv[UNR][NARY_NJ];
 #pragma unroll
-            for (int p = 1; p < NARY_MAX_ARITY; ++p)
-                if (p < A) {
-                    T sp = (T)0 + m0;
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                    for (int i = 1; i < NARY_MAX_ARITY; ++i)
-                        if (i < A && i != p) sp += ms[j][i];
-                    const T cp = t + sp;
-                    if (acc[j][p] > cp) acc[j][p] = cp;
-                }
+            for (int j = 0; j < NARY_NJ; ++j)
+                tv[u][j] = (live[j] && d0 + u < D0) ? tab[(int64_t)(d0 + u) * R + tid + j * BLOCK]
+                                                    : pos_inf<T>();
+        T best0[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const T m0 = s_msg[off[0] + (d0 + u < D0 ? d0 + u : 0)];
+            T b0 = pos_inf<T>();
+#pragma unroll
+            for (int j = 0; j < NARY_NJ; ++j) {
+                const T t = tv[u][j];
+                const T c0 = t + s0[j];  // to variable 0: the others are 1..A-1 in dimensions order
+                if (b0 > c0) b0 = c0;
+                // to variable p >= 1: the others are 0 and the remaining ones, in order
+#pragma unroll
+                for (int p = 1; p < NARY_MAX_ARITY; ++p)
+                    if (p < A) {
+                        T sp = (T)0 + m0;
+#pragma unroll
+                        for (int i = 1; i < NARY_MAX_ARITY; ++i)
+                            if (i < A && i != p) sp += ms[j][i];
+                        const T cp = t + sp;
+                        if (acc[j][p] > cp) acc[j][p] = cp;
+                    }
+            }
+            best0[u] = b0;
         }
-        best0 = wave_min(best0);
-        if ((tid & 63) == 0) atomicMin(&s_key[off[0] + d0], OrdKey<T>::enc(best0));
+        // UNR independent wavefront reductions, interleaved step by step
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const T y = __shfl(best0[u], (int)((threadIdx.x & 63) ^ sft), 64);
+                best0[u] = y < best0[u] ? y : best0[u];
+            }
+        }
+        if ((tid & 63) == 0) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+                if (d0 + u < D0) atomicMin(&s_key[off[0] + d0 + u], OrdKey<T>::enc(best0[u]));
+        }
     }
 #pragma unroll
     for (int j = 0; j < NARY_NJ; ++j)

@@ -1,7 +1,10 @@
 #!/bin/bash
-# ad-hoc GPU call: pattern bench + runtime-sharing checks
+# ad-hoc GPU call: parity tests + selected bench variants
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/${1:-quick}; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
-echo "== torch sees the GPU?"; timeout 300 python -c "import torch; print(torch.cuda.is_available(), torch.cuda.device_count(), torch.version.hip)" 2>&1 | tail -2
-echo "== pattern bench"; timeout 600 ./tools/pattern_bench 2>&1 | tee $OUT/pattern_bench.jsonl
-echo "== smoke (system runtime)"; timeout 300 python -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -3
-echo "== pytest gpu (torch runtime)"; timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -15 | tee $OUT/pytest_gpu.txt
+echo "== pytest gpu"; timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -6 | tee $OUT/pytest_gpu.txt
+: > $OUT/bench_variants.jsonl
+free -g | head -2
+for v in "" "--workload meeting_50k --steps 20 --warmup 3" "--workload meeting_50k --steps 20 --warmup 3 --dtype f32" "--workload meeting_50k --steps 20 --warmup 3 --layout-flags 16"; do
+  echo "-- $v"
+  (echo -n "{\"args\": \"$v\", \"out\": "; timeout 1200 python bench.py --no-cpu-baseline $v 2>&1 | tail -1; echo "}") | tee -a $OUT/bench_variants.jsonl | cut -c1-300
+done

@@ -18,13 +18,13 @@ echo "== bench default"
 timeout 600 python bench.py 2>&1 | tail -3 | tee $OUT/bench_default.json
 echo "== bench variants (no cpu baseline)"
 : > $OUT/bench_variants.jsonl
-for v in "--dtype f32" "--layout-flags 32" "--layout-flags 64" "--layout-flags 1" "--graph-chunk 0" \
+for v in "--dtype f32" "--layout-flags 32" "--layout-flags 64" "--graph-chunk 0" \
          "--workload coloring_10k" "--workload coloring_100k_hard" \
          "--workload ising_1024 --steps 300 --warmup 30" "--workload ising_1024 --steps 300 --warmup 30 --dtype f32" \
          "--workload ising_1024 --steps 300 --warmup 30 --layout-flags 32" "--workload ising_1024 --steps 300 --warmup 30 --layout-flags 64" \
          "--workload coloring_1m_deg6 --steps 200 --warmup 20" "--workload coloring_1m_deg6 --steps 200 --warmup 20 --dtype f32" \
-         "--workload coloring_1m_deg6 --steps 200 --warmup 20 --layout-flags 1" \
-         "--workload coloring_1m_deg6 --steps 200 --warmup 20 --layout-flags 32" "--workload coloring_1m_deg6 --steps 200 --warmup 20 --layout-flags 64"; do
+         "--workload coloring_1m_deg6 --steps 200 --warmup 20 --layout-flags 32" "--workload coloring_1m_deg6 --steps 200 --warmup 20 --layout-flags 64" \
+         "--workload meeting_50k --steps 20 --warmup 3" "--workload meeting_50k --steps 20 --warmup 3 --dtype f32"; do
   echo "-- $v"
   (echo -n "{\"args\": \"$v\", \"out\": "; timeout 600 python bench.py --no-cpu-baseline $v 2>&1 | tail -1; echo "}") | tee -a $OUT/bench_variants.jsonl
 done
@@ -42,6 +42,21 @@ for c in FETCH_SIZE WRITE_SIZE; do
   [ -n "$f" ] && (head -1 "$f"; grep k_sweep "$f" | tail -20) > $OUT/pmc_${w}_$c.csv && tail -2 $OUT/pmc_${w}_$c.csv | cut -c1-400
   rm -rf $OUT/pmc_${w}_$c
 done
+done
+echo "== pmc calibration on kernels of known traffic (tools/microbench)"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $c --output-format csv -d $OUT/cal_$c -o pmc -- $R/tools/microbench > $OUT/cal_$c.log 2>&1
+  f=$(find $OUT/cal_$c -name "*counter_collection*.csv" | head -1)
+  [ -n "$f" ] && python - "$f" $c <<'PY' | tee $OUT/pmc_calibration_$c.txt
+import csv, sys, collections
+acc = collections.OrderedDict()
+for row in csv.DictReader(open(sys.argv[1])):
+    k = (row["Kernel_Name"][:40], row["Grid_Size"])
+    acc.setdefault(k, []).append(float(row["Counter_Value"]))
+for (k, g), v in acc.items():
+    print(f"{sys.argv[2]} {k:40s} grid {g:>9s} dispatches {len(v):5d} mean_KiB {sum(v)/len(v):12.1f} last_KiB {v[-1]:12.1f}")
+PY
+  rm -rf $OUT/cal_$c
 done
 find $OUT -name "*.rocpd" -size +8M -delete 2>/dev/null
 rm -rf $OUT/prof_default

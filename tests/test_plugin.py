@@ -1,0 +1,116 @@
+"""The drop-in boundary: `maxsum_gpu` behind an UNMODIFIED pyDCOP (SURVEY.md
+section 8b).  Needs the reference checkout (build container only); the engine is
+the emulated build, because there is no GPU here -- the plumbing under test
+(plugin discovery, parameter coercion, ComputationDef -> flat arrays, proxies,
+value_selection/finished on the agents' threads, orchestrator result JSON) is
+the same with the HIP library.
+
+Mirrors the reference's own tests for this path: tests/dcop_cli/test_solve.py:39-130
+(graph_coloring1 -> v1=R, v2=G, v3=R; secp_simple1 -> l1=0, l2=3, l3=4, m1=3) and
+tests/api/test_api_solve.py:37-45.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("PYDCOP_REFERENCE", "/root/reference")
+INST = os.path.join(REF, "tests", "instances")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pydcop")),
+                                reason="the pyDCOP reference checkout is not on this machine")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    from emu.build_emu import build
+    return build()
+
+
+@pytest.fixture(scope="module")
+def pydcop_ready(emu_lib):
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pydcop_amd import plugin
+    plugin.install()
+    from pydcop.algorithms import load_algorithm_module
+    mod = load_algorithm_module("maxsum_gpu")
+    mod._ENGINE_LIB_PATH = emu_lib  # test hook: emulated engine (no GPU in this container)
+    return mod
+
+
+def test_discovered_like_a_builtin_algorithm(pydcop_ready):
+    from pydcop.algorithms import list_available_algorithms, load_algorithm_module
+    assert "maxsum_gpu" in list_available_algorithms()
+    ref = load_algorithm_module("maxsum")
+    mod = pydcop_ready
+    assert mod.GRAPH_TYPE == ref.GRAPH_TYPE == "factor_graph"
+    ref_params = {p.name: (p.type, p.values, p.default_value) for p in ref.algo_params}
+    mine = {p.name: (p.type, p.values, p.default_value) for p in mod.algo_params}
+    for name, spec in ref_params.items():  # same parameters, same defaults
+        assert mine[name] == spec
+
+
+def test_param_validation_matches_reference(pydcop_ready):
+    from pydcop.algorithms import AlgorithmDef
+    a = AlgorithmDef.build_with_default_param("maxsum_gpu", {"stop_cycle": "30", "damping": "0.7"}, mode="min")
+    assert a.params["stop_cycle"] == 30 and a.params["damping"] == 0.7
+    with pytest.raises(ValueError):
+        AlgorithmDef.build_with_default_param("maxsum_gpu", {"damping_nodes": "sometimes"})
+    with pytest.raises(ValueError):
+        AlgorithmDef.build_with_default_param("maxsum_gpu", {"no_such_param": 1})
+
+
+def test_footprint_and_load_formulas_equal_reference(pydcop_ready):
+    from pydcop.algorithms import load_algorithm_module
+    from pydcop.computations_graph import factor_graph
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    ref = load_algorithm_module("maxsum")
+    dcop = load_dcop_from_file([os.path.join(INST, "graph_coloring_tuto.yaml")])
+    cg = factor_graph.build_computation_graph(dcop)
+    for node in cg.nodes:
+        assert pydcop_ready.computation_memory(node) == ref.computation_memory(node)
+        for n in node.neighbors:
+            assert pydcop_ready.communication_load(node, n) == ref.communication_load(node, n)
+
+
+@pytest.mark.parametrize("instance,expected", [
+    ("graph_coloring1.yaml", {"v1": "R", "v2": "G", "v3": "R"}),
+    ("secp_simple1.yaml", {"l1": 0, "l2": 3, "l3": 4, "m1": 3}),
+])
+def test_api_solve(pydcop_ready, instance, expected):
+    """pydcop.infrastructure.run.solve with thread agents (reference:
+    tests/api/test_api_solve.py, tests/dcop_cli/test_solve.py)."""
+    from pydcop.algorithms import AlgorithmDef
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop.infrastructure.run import solve
+    dcop = load_dcop_from_file([os.path.join(INST, instance)])
+    algo = AlgorithmDef.build_with_default_param(
+        "maxsum_gpu", {"stop_cycle": 20, "noise": 0}, mode=dcop.objective)
+    assignment = solve(dcop, algo, "adhoc", timeout=20)
+    assert assignment == expected
+
+
+def test_cli_solve_json(emu_lib, tmp_path):
+    """`pydcop solve --algo maxsum_gpu` through the launcher, result JSON of the
+    unmodified orchestrator (docs/tutorials/analysing_results.rst:31-48)."""
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from pydcop_amd import plugin; plugin.install()\n"
+        "from pydcop.algorithms import load_algorithm_module\n"
+        "load_algorithm_module('maxsum_gpu')._ENGINE_LIB_PATH = %r\n"
+        "sys.argv = ['pydcop', '-t', '20', 'solve', '--algo', 'maxsum_gpu', '-p', 'stop_cycle:20',\n"
+        "            '-p', 'noise:0', '-d', 'adhoc', %r]\n"
+        "from pydcop import dcop_cli; dcop_cli.main()\n"
+    ) % (ROOT, REF, emu_lib, os.path.join(INST, "graph_coloring1.yaml"))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr[-2000:]
+    start = out.stdout.index("{")
+    res = json.loads(out.stdout[start:])
+    assert res["assignment"] == {"v1": "R", "v2": "G", "v3": "R"}
+    assert res["status"] == "FINISHED"
+    assert res["violation"] == 0 and abs(res["cost"] - (-0.1)) < 1e-9
+    assert res["cycle"] == 20
