@@ -159,6 +159,12 @@ int mxs_eval_cost(mxs_engine *e, const int32_t *idx, double infinity,
 int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
                     int32_t *launches_per_cycle);
 
+/* Profiling only: run ONE more cycle in which every block of the sweep launch
+ * records {start, end} (wall_clock64 ticks, 100 MHz) and its class kind;
+ * out[3*b .. 3*b+2] for block b, `cap` = blocks the buffer can hold.  out == NULL
+ * only reports the number of blocks. */
+int mxs_debug_timeline(mxs_engine *e, int64_t *out, int32_t cap, int32_t *n_blocks);
+
 /* ---- sharded (multi-GPU) operation: one engine per rank ----------------
  * A shard's graph holds its owned variables, every factor touching one of
  * them, and ghost copies (var_owned = 0) of the remote variables those cut

@@ -83,6 +83,7 @@ struct EngineBase {
     virtual int halo_bind(void* s, void* r) = 0;
     virtual int step_pack() = 0;
     virtual int step_unpack() = 0;
+    virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     Layout L;
     mxs_params params{};
     int64_t cycles = 0;
@@ -95,15 +96,16 @@ struct Engine : EngineBase {
     int device = 0;
     int cur = 0;  // buffers holding the messages of the last finished cycle
     DevBuf<T> v2f[2], f2v[2], tables, var_cost, belief, halo_send, halo_recv;
-    DevBuf<uint8_t> cF, cV, owned, fowned, vdeg8, vlane_k;
-    DevBuf<int32_t> vrowptr, vdom, init_idx, edge_gen_factor, edge_dom, sel, vell, vlane_var;
+    DevBuf<uint8_t> cF, cV, owned, fowned;
+    DevBuf<int32_t> vrowptr, vdom, init_idx, edge_gen_factor, edge_dom, sel, vell;
+    DevBuf<WaveMeta> vwave;
     DevBuf<int32_t> edge_v2f, f2v_off, vslot_f2v, vslot_v2f;
     DevBuf<int32_t> frowptr, edge_var_int, eval_idx;
-    DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off;
+    DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off, timeline;
+    bool timeline_on = false;
     DevBuf<FactorGen> fgen;
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
-    DevBuf<ClassInfo> classes_all;  // every class (indexed by BlockDesc.cls)
-    DevBuf<BlockDesc> blocks_nary;
+    DevBuf<NaryDesc> ndesc;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -139,9 +141,7 @@ struct Engine : EngineBase {
         a.vslot_f2v = vslot_f2v.p;
         a.vslot_v2f = vslot_v2f.p;
         a.vell = vell.p;
-        a.vlane_var = vlane_var.p;
-        a.vlane_k = vlane_k.p;
-        a.vdeg8 = vdeg8.p;
+        a.vwave = vwave.p;
         a.vdom = vdom.p;
         a.vcost_off = vcost_off.p;
         a.init_idx = init_idx.p;
@@ -157,6 +157,7 @@ struct Engine : EngineBase {
         a.start = start ? 1 : 0;
         a.start_mode = params.start_messages;
         a.null_f2v = (int32_t)L.null_f2v;
+        a.timeline = timeline_on ? timeline.p : nullptr;
         a.n_classes = (int32_t)L.sweep_order.size();
         for (int i = 0; i < MAX_CLASSES; ++i)
             a.block_base[i] = i < a.n_classes ? L.classes[L.sweep_order[i]].block_base : INT32_MAX;
@@ -178,9 +179,26 @@ struct Engine : EngineBase {
             }
             HIP_TRY(hipGetLastError());
         }
-        if (!L.blocks_nary.empty()) {
-            hipLaunchKernelGGL((k_factor_nary<T>), dim3((unsigned)L.blocks_nary.size()), dim3(BLOCK), 0,
-                               stream, a, (const ClassInfo*)classes_all.p, (const BlockDesc*)blocks_nary.p);
+        for (int c : L.wide_classes) {
+            const ClassInfo& ci = L.classes[c];
+            hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)),
+                               dim3(BLOCK), 0, stream, a, ci);
+            HIP_TRY(hipGetLastError());
+        }
+        for (const NaryLaunch& nl : L.nary_launches) {
+            const dim3 grid((unsigned)nl.count), block(BLOCK);
+            const NaryDesc* d = ndesc.p + nl.first;
+#define MXS_NARY_CASE(AR, NJ)                                                               \
+    case (AR) * 16 + (NJ):                                                                   \
+        hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);        \
+        break;
+            switch (nl.arity * 16 + nl.nj) {
+                MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
+                MXS_NARY_CASE(3, 1) MXS_NARY_CASE(3, 2) MXS_NARY_CASE(3, 3) MXS_NARY_CASE(3, 4)
+                MXS_NARY_CASE(4, 1) MXS_NARY_CASE(4, 2) MXS_NARY_CASE(4, 3) MXS_NARY_CASE(4, 4)
+                default: return fail(MXS_E_STATE, "no n-ary kernel for this (arity, size) group");
+            }
+#undef MXS_NARY_CASE
             HIP_TRY(hipGetLastError());
         }
         return MXS_OK;
@@ -223,9 +241,7 @@ struct Engine : EngineBase {
         HIP_TRY(cF.alloc((size_t)L.n_edges));
         HIP_TRY(cV.alloc((size_t)L.n_cv));
         HIP_TRY(vell.upload(L.vell, stream));
-        HIP_TRY(vlane_var.upload(L.vlane_var, stream));
-        HIP_TRY(vlane_k.upload(L.vlane_k, stream));
-        HIP_TRY(vdeg8.upload(L.vdeg8, stream));
+        HIP_TRY(vwave.upload(L.vwave, stream));
         HIP_TRY(owned.upload(L.owned, stream));
         HIP_TRY(fowned.upload(L.fowned, stream));
         HIP_TRY(vrowptr.upload(L.vrowptr, stream));
@@ -242,8 +258,7 @@ struct Engine : EngineBase {
             for (int c : L.sweep_order) order.push_back(L.classes[c]);
             HIP_TRY(classes.upload(order, stream));
         }
-        HIP_TRY(classes_all.upload(L.classes, stream));
-        HIP_TRY(blocks_nary.upload(L.blocks_nary, stream));
+        HIP_TRY(ndesc.upload(L.ndesc, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
         HIP_TRY(edge_var_int.upload(L.edge_var_int, stream));
@@ -253,7 +268,8 @@ struct Engine : EngineBase {
         HIP_TRY(eval_idx.alloc((size_t)L.n_vars));
         HIP_TRY(part_cost.alloc(EVAL_BLOCKS));
         HIP_TRY(part_viol.alloc(EVAL_BLOCKS));
-        launches_per_cycle = 1 + (L.blocks_nary.empty() ? 0 : 1);
+        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (int)L.nary_launches.size() +
+                             (int)L.wide_classes.size();
         return reset();
     }
 
@@ -465,6 +481,31 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    // Profiling: run ONE more cycle with per-block timestamps (wall_clock64 ticks,
+    // 100 MHz) and return {start, end, class kind} per block of the sweep launch.
+    int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) override {
+        HIP_TRY(hipSetDevice(device));
+        if (halo_ready) return fail(MXS_E_STATE, "mxs_debug_timeline: not on a sharded engine");
+        const int nb = L.n_blocks_sweep;
+        if (n_blocks) *n_blocks = nb;
+        if (!out) return MXS_OK;
+        if (cap < nb) return fail(MXS_E_INVALID, "timeline buffer too small");
+        if (timeline.n < (size_t)3 * nb) {
+            if (timeline.p) (void)hipFree(timeline.p);
+            timeline.p = nullptr;
+            HIP_TRY(timeline.alloc((size_t)3 * nb));
+        }
+        timeline_on = true;
+        int rc = launch_cycle(cur, false);
+        timeline_on = false;
+        if (rc) return rc;
+        cur ^= 1;
+        cycles += 1;
+        HIP_TRY(hipStreamSynchronize(stream));
+        HIP_TRY(copy_sync(out, timeline.p, sizeof(int64_t) * 3 * nb, hipMemcpyDeviceToHost, stream));
+        return MXS_OK;
+    }
+
     // ---- halo -------------------------------------------------------------
     int build_elem_offsets(const int32_t* edges, int64_t n, std::vector<int64_t>& out) {
         out.clear();
@@ -653,6 +694,11 @@ int mxs_stream(mxs_engine* e, void** stream) {
     CHECK_HANDLE(e);
     if (stream) *stream = (void*)e->impl->stream;
     return MXS_OK;
+}
+
+int mxs_debug_timeline(mxs_engine* e, int64_t* out, int32_t cap, int32_t* n_blocks) {
+    CHECK_HANDLE(e);
+    return e->impl->debug_timeline(out, cap, n_blocks);
 }
 
 int mxs_destroy(mxs_engine* e) {

@@ -55,10 +55,8 @@ struct SweepArgs {
     const int32_t* vrowptr;
     const int32_t* vslot_f2v;  // [n_edges] CSR slot -> F2V offset (generic variables)
     const int32_t* vslot_v2f;  // [n_edges] CSR slot -> V2F offset
-    const int32_t* vell;       // per lane of the packed variable classes: F2V offset / -1,
-    const int32_t* vlane_var;  // variable id,
-    const uint8_t* vlane_k;    // edge position in the variable
-    const uint8_t* vdeg8;  // [n_vars] degree (saturated), internal order
+    const int32_t* vell;       // per lane of the packed variable classes: F2V offset / -1
+    const WaveMeta* vwave;     // per wave of the packed variable classes
     const int32_t* vdom;
     const int64_t* vcost_off;
     const int32_t* init_idx;
@@ -74,6 +72,8 @@ struct SweepArgs {
     int32_t start;       // 1: cycle 0 (on_start), 0: regular cycle
     int32_t start_mode;  // MXS_START_*
     int32_t null_f2v;    // offset of the all-zero F2V block (padding slots)
+    int64_t* timeline;   // profiling only (mxs_debug_timeline): per block {start, end} in
+                         // wall_clock64 ticks and its class kind; NULL in normal runs
     int32_t n_classes;
     // First block of every class of the launch (in launch order; unused entries
     // hold INT32_MAX): a block finds its class with compares on kernel arguments,
@@ -301,21 +301,26 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
     const int lane_id = item + (int)threadIdx.x;
     if (lane_id >= ci.count) return;  // whole waves (count is a multiple of 64)
     const int64_t pos = ci.ell_base + lane_id;
+    // what the wave works on: one scalar load (the wave index is wave-uniform)
+    const WaveMeta wm = a.vwave[__builtin_amdgcn_readfirstlane((int)(pos >> 6))];
+    const uint32_t dn = (uint32_t)wm.deg_nv;
+    const int deg = (int)(dn & 255u), nv = (int)((dn >> 8) & 255u);
+    const int l = (int)threadIdx.x & 63;
+    const int var = (int)(((uint32_t)l * (dn >> 16)) >> 15);  // l / deg (exact for l < 64)
+    const int k = l - var * deg;                              // edge position in the variable
+    const bool has = var < nv;
+    const int v = wm.first_var + (has ? var : 0);
     const int32_t slot = a.vell[pos];
-    const int v = a.vlane_var[pos];
-    const int k = a.vlane_k[pos];
     const uint8_t cnt = a.cV[ci.cv_base + lane_id];
     T pv[D], in[D], c[D], b[D], m[D];
     const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
     Msg<T, D>::load(a.v2f_old + vo, pv);  // V->F message last sent on this edge
-    const bool has = slot >= 0;
     Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);  // F->V held from this factor
-    const int deg = a.vdeg8[v];  // the same for every lane of the wave
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)(v - ci.first) * D + d];
     int init = -1;
     if (a.start) init = a.init_idx[v];
-    const int seg = ((int)threadIdx.x & 63) - (has ? k : 0);  // first lane of the variable
+    const int seg = l - (has ? k : 0);  // first lane of the variable
     // d outer / factors inner, as the reference sums (maxsum.py:607-610, 651-665):
     // sum_cost is ONE accumulator running through all of it
     T sum_cost = (T)0;
@@ -458,7 +463,7 @@ __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& 
 }
 
 template <typename T, int DSEL>
-__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a) {
+__device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0;
 #pragma unroll
     for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
@@ -466,10 +471,10 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a
     const int item = ((int)blockIdx.x - ci.block_base) * ci.per_block;
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;
-        if (j >= ci.count) return;
+        if (j >= ci.count) return ci.kind;
         if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
         else variable_generic<T>(a, ci, j);
-        return;
+        return ci.kind;
     }
     if (DSEL != 0) {
         sweep_d<T, (DSEL != 0 ? DSEL : 2)>(a, ci, item);
@@ -480,6 +485,25 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a
             case 4: sweep_d<T, 4>(a, ci, item); break;
             default: break;
         }
+    }
+    return ci.kind;
+}
+
+template <typename T, int DSEL>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a) {
+    if (a.timeline == nullptr) {  // the normal path
+        sweep_block<T, DSEL>(a);
+        return;
+    }
+    // profiling launch: when did this block start, when were its stores done
+    const int64_t t0 = (int64_t)wall_clock64();
+    const int kind = sweep_block<T, DSEL>(a);
+    __builtin_amdgcn_s_waitcnt(0);  // loads back, stores acknowledged
+    const int64_t t1 = (int64_t)wall_clock64();
+    if (threadIdx.x == 0) {
+        a.timeline[3 * (int64_t)blockIdx.x + 0] = t0;
+        a.timeline[3 * (int64_t)blockIdx.x + 1] = t1;
+        a.timeline[3 * (int64_t)blockIdx.x + 2] = kind;
     }
 }
 
@@ -503,7 +527,7 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep(SweepArgs<T> a
 // ---------------------------------------------------------------------------
 constexpr int NARY_MAX_SUMD = 1024;  // sum of the scope's domain sizes
 constexpr int NARY_MAX_R = 1024;     // BLOCK * NARY_NJ
-constexpr int NARY_NJ = NARY_MAX_R / BLOCK;
+constexpr int NARY_MAX_NJ = NARY_MAX_R / BLOCK;
 constexpr int NARY_MAX_ARITY = 4;
 
 template <typename T>
@@ -549,96 +573,103 @@ __device__ __forceinline__ T wave_min(T x) {  // all 64 lanes get the minimum
     return x;
 }
 
-template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const ClassInfo* classes,
-                                                       const BlockDesc* blocks) {
+template <typename T, int A, int NJ>
+__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
-    __shared__ T s_msg[NARY_MAX_SUMD];
-    __shared__ U s_key[NARY_MAX_SUMD];
-    const BlockDesc bd = blocks[blockIdx.x];
-    const ClassInfo ci = classes[bd.cls];
-    const FactorGen fg = a.fgen[ci.first + bd.item];
-    const int A = fg.arity;
+    __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
+    __shared__ U s_key[NARY_MAX_SUMD];   // running minima of the outgoing messages (ordered keys)
+    __shared__ T s_prev[NARY_MAX_SUMD];  // epilogue: the messages sent last
+    __shared__ int s_nomatch[NARY_MAX_ARITY];
+    __shared__ int s_cnt[NARY_MAX_ARITY];
+    const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
     const int tid = (int)threadIdx.x;
-    int Dm[NARY_MAX_ARITY], off[NARY_MAX_ARITY];
+    int Dm[A], off[A];
     int sumd = 0;
 #pragma unroll
-    for (int i = 0; i < NARY_MAX_ARITY; ++i) {
-        Dm[i] = i < A ? a.edge_dom[fg.edge_base + i] : 1;
+    for (int i = 0; i < A; ++i) {
+        Dm[i] = fd.dom[i];
         off[i] = sumd;
-        sumd += i < A ? Dm[i] : 0;
+        sumd += Dm[i];
     }
-    // stage the incoming messages, arm the minima
+    int R = 1;
 #pragma unroll
-    for (int i = 0; i < NARY_MAX_ARITY; ++i)
-        if (i < A) {
-            const int vo = a.edge_v2f[fg.edge_base + i];
-            for (int d = tid; d < Dm[i]; d += BLOCK) {
-                s_msg[off[i] + d] = a.v2f_old[vo + d];
-                s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
-            }
+    for (int i = 1; i < A; ++i) R *= Dm[i];
+    const int D0 = Dm[0];
+    const T* tab = a.tables + fd.tab_off;
+    constexpr int UNR = 4;  // values of d0 per batch: UNR * NJ table loads per lane in flight,
+                            // and the next batch is requested before this one is reduced
+    T cur[UNR][NJ];
+#pragma unroll
+    for (int u = 0; u < UNR; ++u)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int q = tid + j * BLOCK;
+            cur[u][j] = (q < R && u < D0) ? tab[(int64_t)u * R + q] : pos_inf<T>();
         }
-    __syncthreads();
-    const int R = Dm[1] * Dm[2] * Dm[3];
-    // per owned q: its digits' messages and the running minima for p >= 1
-    T ms[NARY_NJ][NARY_MAX_ARITY], acc[NARY_NJ][NARY_MAX_ARITY];
-    int dig[NARY_NJ][NARY_MAX_ARITY];
-    bool live[NARY_NJ];
+    // stage the incoming messages, arm the minima (the table loads above are in flight)
 #pragma unroll
-    for (int j = 0; j < NARY_NJ; ++j) {
+    for (int i = 0; i < A; ++i) {
+        const int vo = fd.v2f_off[i];
+        for (int d = tid; d < Dm[i]; d += BLOCK) {
+            s_msg[off[i] + d] = a.v2f_old[vo + d];
+            s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
+        }
+    }
+    if (tid < NARY_MAX_ARITY) s_nomatch[tid] = 0;
+    __syncthreads();
+    // per owned q: its digits' messages and the running minima for p >= 1
+    T ms[NJ][A], acc[NJ][A], s0[NJ];
+    int dig[NJ][A];
+    bool live[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
         const int q = tid + j * BLOCK;
         live[j] = q < R;
         int rem = live[j] ? q : 0;
 #pragma unroll
-        for (int i = NARY_MAX_ARITY - 1; i >= 1; --i) {
+        for (int i = A - 1; i >= 1; --i) {
             dig[j][i] = rem % Dm[i];
             rem /= Dm[i];
-            ms[j][i] = i < A ? s_msg[off[i] + dig[j][i]] : (T)0;
+            ms[j][i] = s_msg[off[i] + dig[j][i]];
             acc[j][i] = pos_inf<T>();
         }
-    }
-    const T* tab = a.tables + fg.tab_off;
-    const int D0 = Dm[0];
-    // sum of the others' messages for the output to variable 0: fixed per q
-    T s0[NARY_NJ];
-#pragma unroll
-    for (int j = 0; j < NARY_NJ; ++j) {
+        // sum of the others' messages for the output to variable 0: fixed per q
         T s = (T)0;
 #pragma unroll
-        for (int i = 1; i < NARY_MAX_ARITY; ++i)
-            if (i < A) s += ms[j][i];
+        for (int i = 1; i < A; ++i) s += ms[j][i];
         s0[j] = s;
     }
-    constexpr int UNR = 4;  // values of d0 in flight: UNR * NJ table loads per lane before any use
     for (int d0 = 0; d0 < D0; d0 += UNR) {
-        T tv[UNR][NARY_NJ];
+        T nxt[UNR][NJ];
+        const bool more = d0 + UNR < D0;  // block-uniform
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int j = 0; j < NARY_NJ; ++j)
-                tv[u][j] = (live[j] && d0 + u < D0) ? tab[(int64_t)(d0 + u) * R + tid + j * BLOCK]
-                                                    : pos_inf<T>();
+            for (int j = 0; j < NJ; ++j) {
+                const int q = tid + j * BLOCK;
+                nxt[u][j] = (more && q < R && d0 + UNR + u < D0) ? tab[(int64_t)(d0 + UNR + u) * R + q]
+                                                                 : pos_inf<T>();
+            }
         T best0[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
             const T m0 = s_msg[off[0] + (d0 + u < D0 ? d0 + u : 0)];
             T b0 = pos_inf<T>();
 #pragma unroll
-            for (int j = 0; j < NARY_NJ; ++j) {
-                const T t = tv[u][j];
+            for (int j = 0; j < NJ; ++j) {
+                const T t = cur[u][j];
                 const T c0 = t + s0[j];  // to variable 0: the others are 1..A-1 in dimensions order
                 if (b0 > c0) b0 = c0;
                 // to variable p >= 1: the others are 0 and the remaining ones, in order
 #pragma unroll
-                for (int p = 1; p < NARY_MAX_ARITY; ++p)
-                    if (p < A) {
-                        T sp = (T)0 + m0;
+                for (int p = 1; p < A; ++p) {
+                    T sp = (T)0 + m0;
 #pragma unroll
-                        for (int i = 1; i < NARY_MAX_ARITY; ++i)
-                            if (i < A && i != p) sp += ms[j][i];
-                        const T cp = t + sp;
-                        if (acc[j][p] > cp) acc[j][p] = cp;
-                    }
+                    for (int i = 1; i < A; ++i)
+                        if (i != p) sp += ms[j][i];
+                    const T cp = t + sp;
+                    if (acc[j][p] > cp) acc[j][p] = cp;
+                }
             }
             best0[u] = b0;
         }
@@ -656,48 +687,221 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Cla
             for (int u = 0; u < UNR; ++u)
                 if (d0 + u < D0) atomicMin(&s_key[off[0] + d0 + u], OrdKey<T>::enc(best0[u]));
         }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) cur[u][j] = nxt[u][j];
     }
 #pragma unroll
-    for (int j = 0; j < NARY_NJ; ++j)
+    for (int j = 0; j < NJ; ++j)
         if (live[j]) {
 #pragma unroll
-            for (int p = 1; p < NARY_MAX_ARITY; ++p)
-                if (p < A) atomicMin(&s_key[off[p] + dig[j][p]], OrdKey<T>::enc(acc[j][p]));
+            for (int p = 1; p < A; ++p) atomicMin(&s_key[off[p] + dig[j][p]], OrdKey<T>::enc(acc[j][p]));
         }
     __syncthreads();
-    // apply_damping + the send rule, one thread per outgoing message
-    if (tid < A) {
-        const int e = fg.edge_base + tid;
-        const int D = Dm[tid];
-        const T* prev = a.f2v_old + a.f2v_off[e];
-        T* w = a.f2v_new + a.f2v_off[e];
-        const U* key = s_key + off[tid];
+    // apply_damping + the send rule (maxsum.py:346-377), one thread per message ELEMENT so
+    // that the previous messages arrive with one round of parallel loads.
+    // phase 1: damp, compare with the message sent last
+    for (int idx = tid; idx < sumd; idx += BLOCK) {
+        int i = 0;
+#pragma unroll
+        for (int ii = 1; ii < A; ++ii)
+            if (idx >= off[ii]) i = ii;
+        const int d = idx - off[i];
+        T m = OrdKey<T>::dec(s_key[idx]);
         if (a.start) {  // only start_messages == all makes a non-unary factor send
-            const bool sends = a.start_mode == MXS_START_ALL;
-            for (int d = 0; d < D; ++d) w[d] = sends ? OrdKey<T>::dec(key[d]) : (T)0;
-            a.cF[e] = 0;
-        } else {
-            const uint8_t cnt = a.cF[e];
-            const bool damp = cnt > 0 && a.damp_f;
-            bool match = cnt > 0;
-            for (int d = 0; d < D; ++d) {
-                T m = OrdKey<T>::dec(key[d]);
-                const T p = prev[d];
-                if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
-                if (match) match = comp_match(m, p, a.stability);
-                w[d] = m;
-            }
-            uint8_t out = 1;
-            if (match) {
-                if (cnt < SAME_COUNT) {
-                    out = (uint8_t)(cnt + 1);
-                } else {
-                    out = cnt;
-                    for (int d = 0; d < D; ++d) w[d] = prev[d];
-                }
-            }
-            a.cF[e] = out;
+            s_msg[idx] = a.start_mode == MXS_START_ALL ? m : (T)0;
+            continue;
         }
+        const T p = a.f2v_old[fd.f2v_off[i] + d];
+        const int cnt = a.cF[fd.edge_base + i];
+        if (cnt > 0 && a.damp_f) m = a.damping * p + ((T)1 - a.damping) * m;
+        if (cnt > 0 && !comp_match(m, p, a.stability)) s_nomatch[i] = 1;  // same value from all writers
+        if (d == 0) s_cnt[i] = cnt;
+        s_msg[idx] = m;
+        s_prev[idx] = p;
+    }
+    __syncthreads();
+    // phase 2: send / send again / stay silent (the receiver keeps the old message)
+    for (int idx = tid; idx < sumd; idx += BLOCK) {
+        int i = 0;
+#pragma unroll
+        for (int ii = 1; ii < A; ++ii)
+            if (idx >= off[ii]) i = ii;
+        const int d = idx - off[i];
+        const int e = fd.edge_base + i;
+        T* w = a.f2v_new + fd.f2v_off[i];
+        if (a.start) {
+            w[d] = s_msg[idx];
+            if (d == 0) a.cF[e] = 0;
+            continue;
+        }
+        const int cnt = s_cnt[i];
+        const bool match = cnt > 0 && !s_nomatch[i];
+        int out = 1;
+        T val = s_msg[idx];
+        if (match) {
+            if (cnt < SAME_COUNT) {
+                out = cnt + 1;
+            } else {
+                out = cnt;
+                val = s_prev[idx];
+            }
+        }
+        w[d] = val;
+        if (d == 0) a.cF[e] = (uint8_t)out;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// Variable side, wide class: ONE WAVE PER VARIABLE, for domains too large for the
+// packed class (5 <= D <= 256) or degrees above 64, as long as deg * D <= WIDE_MAX.
+// The incoming F->V messages are staged in LDS with one round of parallel loads;
+// lanes then run over d (beliefs, outgoing messages) or over the outgoing edges
+// (the `sum_cost` chains).  Arithmetic order is the reference's, op for op:
+//   select_value      maxsum.py:584-620   b[d] = c[d] + in_0[d] + in_1[d] + ...
+//   costs_for_factor  maxsum.py:623-676   ONE accumulator `sum_cost` runs through all
+//                     (d, f != target) in d-major order, so that chain stays serial:
+//                     one lane per outgoing edge walks it in LDS
+// Own launch (its LDS must not cap the occupancy of the register classes).
+// ---------------------------------------------------------------------------
+constexpr int WIDE_MAX = 1024;        // deg * D elements staged per variable
+constexpr int WIDE_MAX_D = 256;       // <= 4 domain values per lane
+constexpr int WIDE_VARS = BLOCK / 64;
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassInfo ci) {
+    __shared__ T s_in[WIDE_VARS][WIDE_MAX];
+    __shared__ T s_avg[WIDE_VARS][WIDE_MAX / 4];
+    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int j = (int)blockIdx.x * WIDE_VARS + w;
+    if (j >= ci.count) return;  // whole waves; only wave-level synchronisation below
+    const int v = ci.first + j;
+    const int D = a.vdom[v];
+    const int k0 = a.vrowptr[v], deg = a.vrowptr[v + 1] - k0;
+    const T* c = a.var_cost + a.vcost_off[v];
+    T* in = s_in[w];
+    constexpr int NR = WIDE_MAX_D / 64;
+    T cv[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) cv[r] = lane + 64 * r < D ? c[lane + 64 * r] : (T)0;
+    // stage the messages this variable holds: all loads in flight together
+    for (int idx = lane; idx < deg * D; idx += 64) {
+        const int k = idx / D, d = idx - k * D;
+        in[idx] = a.f2v_old[a.vslot_f2v[k0 + k] + d];
+    }
+    // the first outgoing edge's previous message and counter (needed last, requested now)
+    T pv[NR];
+    int cnt = 0;
+    if (!a.start) {
+        const int vo = a.vslot_v2f[k0];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? a.v2f_old[vo + lane + 64 * r] : (T)0;
+        cnt = a.cV[k0];
+    }
+    __builtin_amdgcn_wave_barrier();
+    // belief and selection: first index attaining the minimum
+    T bb = pos_inf<T>();
+    int bi = 0x7fffffff;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int d = lane + 64 * r;
+        if (d < D) {
+            T b = cv[r];
+            for (int k = 0; k < deg; ++k) b += in[k * D + d];
+            if (bi == 0x7fffffff || b < bb) {
+                bb = b;
+                bi = d;
+            }
+        }
+    }
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+        const T y = __shfl(bb, lane ^ sft, 64);
+        const int yi = __shfl(bi, lane ^ sft, 64);
+        if (yi != 0x7fffffff && (bi == 0x7fffffff || y < bb || (y == bb && yi < bi))) {
+            bb = y;
+            bi = yi;
+        }
+    }
+    if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+        bi = a.init_idx[v];
+        bb = (T)0;
+    }
+    if (lane == 0) {
+        a.sel[v] = bi;
+        a.belief[v] = bb;
+    }
+    // the mean of each outgoing message: one lane per target walks its serial chain
+    for (int ko = lane; ko < deg; ko += 64) {
+        T sum_cost = (T)0;
+        for (int d = 0; d < D; ++d)
+            for (int k = 0; k < deg; ++k)
+                if (k != ko) sum_cost += in[k * D + d];
+        s_avg[w][ko] = sum_cost / (T)D;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                             a.start_mode != MXS_START_LEAFS;
+    for (int ko = 0; ko < deg; ++ko) {
+        // request the next edge's previous message before working on this one
+        T pn[NR];
+        int cnt_n = 0;
+        if (!a.start && ko + 1 < deg) {
+            const int vn = a.vslot_v2f[k0 + ko + 1];
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pn[r] = lane + 64 * r < D ? a.v2f_old[vn + lane + 64 * r] : (T)0;
+            cnt_n = a.cV[k0 + ko + 1];
+        } else {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pn[r] = (T)0;
+        }
+        const T avg = s_avg[w][ko];
+        T* wout = a.v2f_new + a.vslot_v2f[k0 + ko];
+        const bool damp = cnt > 0 && a.damp_v;
+        T mv[NR];
+        int nomatch = 0;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = lane + 64 * r;
+            mv[r] = (T)0;
+            if (d < D) {
+                T m = cv[r];
+                for (int k = 0; k < deg; ++k)
+                    if (k != ko) m += in[k * D + d];
+                m = m - avg;
+                if (a.start) {
+                    m = start_sends ? m : (T)0;
+                } else {
+                    if (damp) m = a.damping * pv[r] + ((T)1 - a.damping) * m;
+                    if (!comp_match(m, pv[r], a.stability)) nomatch = 1;
+                }
+                mv[r] = m;
+            }
+        }
+#pragma unroll
+        for (int sft = 32; sft > 0; sft >>= 1) nomatch |= __shfl(nomatch, lane ^ sft, 64);
+        int out = 1;
+        bool keep_old = false;
+        if (a.start) {
+            out = 0;
+        } else if (cnt > 0 && !nomatch) {
+            if (cnt < SAME_COUNT) {
+                out = cnt + 1;
+            } else {
+                out = cnt;
+                keep_old = true;  // not sent: the receiver keeps the old message
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int d = lane + 64 * r;
+            if (d < D) wout[d] = keep_old ? pv[r] : mv[r];
+        }
+        if (lane == 0) a.cV[k0 + ko] = (uint8_t)out;
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pv[r] = pn[r];
+        cnt = cnt_n;
     }
 }
 

@@ -125,7 +125,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     sumd += Di;
                     if (i) R *= Di;
                 }
-                if (R >= 64 && R <= 1024 && sumd <= 1024) k = FKey{K_F_NARY, 0};
+                // one launch group per (arity, R / BLOCK rounded up): compile-time loop bounds
+                if (R >= 64 && R <= 1024 && sumd <= 1024)
+                    k = FKey{K_F_NARY, ar * 16 + (int)((R + BLOCK - 1) / BLOCK)};
             }
         }
         fkey[f] = k;
@@ -184,6 +186,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
             kind = K_V_PACK; sub = D;
+        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024) {
+            kind = K_V_WIDE; sub = 0;  // wave per variable, messages staged in LDS
         } else { kind = K_V_GEN; sub = 0; }
         // sort key: class, then degree (the packed class needs equal degrees side
         // by side; bit3 of layout_flags keeps the caller's order elsewhere)
@@ -202,7 +206,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     L.vslot_f2v.resize(nE);
     L.vslot_v2f.assign(nE, 0);
     L.vslot_cv.resize(nE);
-    L.vdeg8.resize(nV);
     L.vdom.resize(nV);
     L.vhalf.resize(nV);
     L.vcost_off.resize(nV);
@@ -225,7 +228,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.vslot_f2v[k] = L.f2v_off[ei];
                 L.edge_var_int[ei] = vi;
             }
-            L.vdeg8[vi] = (uint8_t)std::min(g.var_rowptr[v + 1] - g.var_rowptr[v], 255);
             L.vdom[vi] = g.dom_size[v];
             L.vhalf[vi] = L.half(g.dom_size[v]);
             L.vcost_off[vi] = coff;
@@ -267,8 +269,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         const int n = fj - fi;
         ClassInfo ci{};
         ci.kind = key.kind;
-        ci.D = key.D;
-        ci.H = key.D ? L.half(key.D) : 0;
+        ci.D = key.kind == K_F_NARY ? 0 : key.D;
+        ci.H = ci.D ? L.half(ci.D) : 0;
         ci.first = fi;
         ci.count = n;
         ci.edge_base = L.frowptr[fi];
@@ -300,12 +302,23 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
                 L.classes.push_back(ci);
                 sweep_class(cls, BLOCK);
-            } else {  // K_F_NARY: one workgroup per factor, own launch
-                ci.first = gen_base;  // index into fgen
-                ci.block_base = (int)L.blocks_nary.size();
-                ci.per_block = 1;
-                L.classes.push_back(ci);
-                for (int i = 0; i < n; ++i) L.blocks_nary.push_back(BlockDesc{cls, i});
+            } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
+                NaryLaunch nl{key.D / 16, key.D % 16, (int32_t)L.ndesc.size(), n};
+                for (int j = 0; j < n; ++j) {
+                    const int f2 = fi + j;
+                    NaryDesc d{};
+                    d.tab_off = L.eval_tab_off[f2];
+                    d.edge_base = L.frowptr[f2];
+                    d.arity = L.frowptr[f2 + 1] - L.frowptr[f2];
+                    for (int i = 0; i < 4; ++i) {
+                        const bool in = i < d.arity;
+                        d.dom[i] = in ? L.edge_dom[d.edge_base + i] : 1;
+                        d.f2v_off[i] = in ? L.f2v_off[d.edge_base + i] : 0;
+                        d.v2f_off[i] = 0;  // filled in once the variable side is laid out
+                    }
+                    L.ndesc.push_back(d);
+                }
+                L.nary_launches.push_back(nl);
             }
         }
         fi = fj;
@@ -338,6 +351,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.H = L.half(ci.D);
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
+        } else if (kind == K_V_WIDE) {
+            ci.kind = K_V_WIDE;
         } else if (kind == 80) {
             ci.kind = K_V_GEN;
             ci.start_only = 1;
@@ -360,19 +375,17 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 const int per_wave = 64 / deg;
                 for (int x = w; x < w2; x += per_wave) {  // one wave
                     const int nv = std::min(per_wave, w2 - x);
+                    L.vwave.push_back(WaveMeta{x, (int32_t)((uint32_t)deg | ((uint32_t)nv << 8) |
+                                                          ((uint32_t)((32768 + deg - 1) / deg) << 16))});
                     for (int lane = 0; lane < 64; ++lane) {
                         const int var = lane / deg, k = lane % deg;
                         if (var < nv) {
                             const int ks = L.vrowptr[x + var] + k;
                             L.vell.push_back(L.vslot_f2v[ks]);
-                            L.vlane_var.push_back(x + var);
-                            L.vlane_k.push_back((uint8_t)k);
                             L.vslot_cv[ks] = ci.cv_base + lanes;
                             L.vslot_v2f[ks] = (int32_t)(ci.v2f_base + lanes * ci.H);
                         } else {
                             L.vell.push_back(-1);
-                            L.vlane_var.push_back(x);
-                            L.vlane_k.push_back(255);
                         }
                         ++lanes;
                     }
@@ -393,12 +406,19 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (swept) {
             const int cls = (int)L.classes.size();
             L.classes.push_back(ci);
-            sweep_class(cls, BLOCK);
+            if (ci.kind == K_V_WIDE) {
+                L.classes[cls].per_block = BLOCK / 64;  // one wave per variable
+                L.wide_classes.push_back(cls);
+            } else {
+                sweep_class(cls, BLOCK);
+            }
         }
         vi = vj;
     }
     L.v2f_elems = voff;
     for (int k = 0; k < nE; ++k) L.v2f_off[L.vslot_edge[k]] = L.vslot_v2f[k];
+    for (NaryDesc& d : L.ndesc)
+        for (int i = 0; i < d.arity; ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
 
     // Launch order of the sweep classes: the longest per-thread chains first
     // (generic classes, then the gathering variable classes, then the streaming
@@ -417,7 +437,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (p.layout_flags & (32 | 64)) {  // timing experiments only (results are wrong):
             std::vector<int32_t> keep;     // bit5 = factor side only, bit6 = variable side only
             for (int c : L.sweep_order) {
-                const bool is_var = prio(c) == 0 || prio(c) == 2;
+                const int k = L.classes[c].kind;
+                const bool is_var = k == K_V_GEN || k == K_V_PACK;
                 if (((p.layout_flags & 32) && !is_var) || ((p.layout_flags & 64) && is_var)) keep.push_back(c);
             }
             L.sweep_order = keep;

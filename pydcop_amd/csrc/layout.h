@@ -49,6 +49,8 @@ enum Kind : int32_t {
                     // variables of a wave have the same degree and are packed side
                     // by side (64/deg per wave), cross-lane sums
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
+    K_V_WIDE = 7,   // 5 <= D <= 256 or deg > 64, deg * D <= 1024: wave per variable, messages
+                    // staged in LDS (own launch)
 };
 
 constexpr int BLOCK = 256;
@@ -82,9 +84,27 @@ struct ClassInfo {       // one per class, read with one scalar load
     int64_t v2f_base;    // K_V_PACK: element offset of the class in V2F
 };
 
-struct BlockDesc {  // n-ary launch only; the sweep derives (class, item) from blockIdx
-    int32_t cls;   // index into classes
-    int32_t item;  // first item (factor index within class)
+struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block
+                   // needs, read with ONE scalar load (no chain of dependent loads)
+    int64_t tab_off;     // element offset of its row-major table
+    int32_t edge_base;   // internal id of its first edge
+    int32_t arity;
+    int32_t dom[4];      // domain sizes in dimensions order (1 beyond the arity)
+    int32_t v2f_off[4];  // V2F offsets of the incoming messages
+    int32_t f2v_off[4];  // F2V offsets of the outgoing messages
+};
+
+struct NaryLaunch {  // one launch per (arity, NJ) group of K_F_NARY factors
+    int32_t arity, nj;   // nj = ceil(R / BLOCK), R = product of the dimensions after the first
+    int32_t first;       // first descriptor of the group
+    int32_t count;
+};
+
+struct WaveMeta {  // per wave of a K_V_PACK class: read with ONE scalar load, so a lane
+                   // knows its variable and edge position without per-lane tables
+    int32_t first_var;  // internal id of the variable of lane 0
+    int32_t deg_nv;     // degree of the wave's variables | number of variables << 8 |
+                        // ceil(2^15 / degree) << 16  (lane / degree = lane * that >> 15)
 };
 
 struct FactorGen {  // per factor of a generic / n-ary class
@@ -109,11 +129,13 @@ struct Layout {
     std::vector<int32_t> factor_i2e, var_i2e, edge_i2e;
     std::vector<int32_t> var_e2i, edge_e2i;
 
-    // classes; launch 0 = sweep kernel, launch 1 = n-ary kernel
+    // classes of the sweep launch (the K_F_NARY groups have their own launches)
     std::vector<ClassInfo> classes;
     std::vector<int32_t> sweep_order;  // classes of launch 0 in launch order
     int32_t n_blocks_sweep = 0;        // grid size of launch 0
-    std::vector<BlockDesc> blocks_nary;
+    std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)
+    std::vector<NaryLaunch> nary_launches;
+    std::vector<int32_t> wide_classes;    // K_V_WIDE classes: one launch each
 
     // per internal edge (factor-major)
     std::vector<int32_t> f2v_off;    // element offset of the edge's F->V message
@@ -135,12 +157,9 @@ struct Layout {
     std::vector<int32_t> vslot_f2v;  // [n_edges] F2V offset of the slot's edge
     std::vector<int32_t> vslot_v2f;  // [n_edges] V2F offset of the slot
     std::vector<int64_t> vslot_cv;   // [n_edges] position of the slot's send counter in cV
-    // per lane of the K_V_PACK classes (lane = one edge of one variable, or padding)
+    // per lane of the K_V_PACK classes (lane = var_in_wave * deg + k, or padding)
     std::vector<int32_t> vell;       // F2V offset of the lane's edge, -1 = padding lane
-    std::vector<int32_t> vlane_var;  // internal id of the lane's variable (padding: the
-                                     // wave's first variable)
-    std::vector<uint8_t> vlane_k;    // position of the edge in the variable's links order
-    std::vector<uint8_t> vdeg8;      // [n_vars] min(degree, 255), internal order
+    std::vector<WaveMeta> vwave;     // one per wave (64 lanes) of the K_V_PACK classes
     int64_t n_cv = 0;                // size of the cV array (CSR slots + padded class slots)
     int dsel = 0;                    // the one D all register/wave classes share, else 0
     std::vector<int32_t> vdom;       // [n_vars]

@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
-    "mxs_destroy", "mxs_last_error", "mxs_version",
+    "mxs_debug_timeline", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
 
 
@@ -104,6 +104,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_step_pack": ([vp], C.c_int),
         "mxs_step_unpack": ([vp], C.c_int),
         "mxs_stream": ([vp, C.POINTER(vp)], C.c_int),
+        "mxs_debug_timeline": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
         "mxs_destroy": ([vp], C.c_int),
         "mxs_last_error": ([], C.c_char_p),
         "mxs_version": ([], i32),
@@ -203,6 +204,15 @@ class MaxSumEngine:
         b, n = C.c_int64(0), C.c_int32(0)
         self._check(self._lib.mxs_cycle_bytes(self._h, C.byref(b), C.byref(n)))
         return int(b.value), int(n.value)
+
+    def debug_timeline(self) -> np.ndarray:
+        """Profiling: run one more cycle with per-block timestamps; returns an int64
+        array [n_blocks, 3] = (start tick, end tick, class kind), 100 MHz ticks."""
+        n = C.c_int32(0)
+        self._check(self._lib.mxs_debug_timeline(self._h, None, 0, C.byref(n)))
+        out = np.zeros((int(n.value), 3), dtype=np.int64)
+        self._check(self._lib.mxs_debug_timeline(self._h, out.ctypes.data, int(n.value), C.byref(n)))
+        return out
 
     # -- sharded operation ---------------------------------------------------------
     def halo_setup(self, send_edges, recv_edges):

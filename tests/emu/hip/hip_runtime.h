@@ -189,3 +189,10 @@ inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu_launch(kernel, grid, block, __VA_ARGS__)
+
+inline void __builtin_amdgcn_s_waitcnt(int) {}
+inline void __builtin_amdgcn_wave_barrier() { hipemu::yield_barrier(); }  // let the other lanes catch up
+inline unsigned long long wall_clock64() { return 0; }
+
+// ---- gfx950 builtins the kernels use -------------------------------------------
+inline int __builtin_amdgcn_readfirstlane(int x) { return x; }  // callers pass wave-uniform values

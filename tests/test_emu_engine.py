@@ -22,7 +22,8 @@ def emu_lib():
     return build()
 
 
-LAYOUTS = {"default": 0, "tight": 1, "pad64": 2, "generic": 4, "keep_order": 8}
+LAYOUTS = {"default": 0, "tight": 1, "pad64": 2, "generic": 4, "keep_order": 8,
+           "write_through": 128}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
