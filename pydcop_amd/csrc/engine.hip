@@ -186,7 +186,7 @@ struct Engine : EngineBase {
             HIP_TRY(hipGetLastError());
         }
         for (const NaryLaunch& nl : L.nary_launches) {
-            const dim3 grid((unsigned)nl.count), block(BLOCK);
+            const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
 #define MXS_NARY_CASE(AR, NJ)                                                               \
     case (AR) * 16 + (NJ):                                                                   \

@@ -573,16 +573,70 @@ __device__ __forceinline__ T wave_min(T x) {  // all 64 lanes get the minimum
     return x;
 }
 
+// min(a, b) as one instruction.  Equal to the reference's `if (best > cur) best = cur`
+// scan for every value but the sign of a zero minimum, which nothing downstream observes.
+__device__ __forceinline__ double min2(double x, double y) { return __builtin_fmin(x, y); }
+__device__ __forceinline__ float min2(float x, float y) { return __builtin_fminf(x, y); }
+
+constexpr int NARY_UNR = 4;  // values of d0 per batch: UNR * NJ table loads per lane in flight,
+                             // and the next batch is requested before this one is reduced
+
+// One batch of d0 values: `tv[u][j]` = table[d0 + u][q_j].  Every entry feeds all A outputs.
+// MASKED: some (u, j) are out of range (tail batch / q >= R) and must not count.
+template <typename T, int A, int NJ, bool MASKED>
+__device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, int D0, const T* s_m0,
+                                           const T (&ms)[NJ][A], const T (&s0)[NJ], const bool (&live)[NJ],
+                                           T (&acc)[NJ][A], typename OrdKey<T>::U* s_key0) {
+    T best0[NARY_UNR];
+#pragma unroll
+    for (int u = 0; u < NARY_UNR; ++u) {
+        const T m0 = s_m0[(!MASKED || d0 + u < D0) ? d0 + u : 0];
+        const T a0 = (T)0 + m0;
+        T b0 = pos_inf<T>();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            T t = tv[u][j];
+            if (MASKED) t = (live[j] && d0 + u < D0) ? t : pos_inf<T>();
+            b0 = min2(b0, t + s0[j]);  // to variable 0: the others are 1..A-1 in dimensions order
+            // to variable p >= 1: the others are 0 and the remaining ones, in order
+#pragma unroll
+            for (int p = 1; p < A; ++p) {
+                T sp = a0;
+#pragma unroll
+                for (int i = 1; i < A; ++i)
+                    if (i != p) sp += ms[j][i];
+                acc[j][p] = min2(acc[j][p], t + sp);
+            }
+        }
+        best0[u] = b0;
+    }
+    // UNR independent wavefront reductions, interleaved step by step
+#pragma unroll
+    for (int sft = 32; sft > 0; sft >>= 1) {
+#pragma unroll
+        for (int u = 0; u < NARY_UNR; ++u)
+            best0[u] = min2(best0[u], __shfl(best0[u], (int)((threadIdx.x & 63) ^ sft), 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int u = 0; u < NARY_UNR; ++u)
+            if (!MASKED || d0 + u < D0) atomicMin(&s_key0[d0 + u], OrdKey<T>::enc(best0[u]));
+    }
+}
+
+// blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
+// layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
 template <typename T, int A, int NJ>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
+    constexpr int UNR = NARY_UNR;
     __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
     __shared__ U s_key[NARY_MAX_SUMD];   // running minima of the outgoing messages (ordered keys)
     __shared__ T s_prev[NARY_MAX_SUMD];  // epilogue: the messages sent last
     __shared__ int s_nomatch[NARY_MAX_ARITY];
     __shared__ int s_cnt[NARY_MAX_ARITY];
     const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
-    const int tid = (int)threadIdx.x;
+    const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     int Dm[A], off[A];
     int sumd = 0;
 #pragma unroll
@@ -596,21 +650,28 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
     const T* tab = a.tables + fd.tab_off;
-    constexpr int UNR = 4;  // values of d0 per batch: UNR * NJ table loads per lane in flight,
-                            // and the next batch is requested before this one is reduced
+    // own q's (clamped into the table so that every load is in range)
+    int qc[NJ];
+    bool live[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = tid + j * NT;
+        live[j] = q < R;
+        qc[j] = live[j] ? q : R - 1;
+    }
+    const int n_full = D0 / UNR;  // batches without a masked d0
     T cur[UNR][NJ];
+    if (n_full > 0) {  // first batch: requested before anything else, independent of the messages
 #pragma unroll
-    for (int u = 0; u < UNR; ++u)
+        for (int u = 0; u < UNR; ++u)
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
-            const int q = tid + j * BLOCK;
-            cur[u][j] = (q < R && u < D0) ? tab[(int64_t)u * R + q] : pos_inf<T>();
-        }
+            for (int j = 0; j < NJ; ++j) cur[u][j] = tab[(int64_t)u * R + qc[j]];
+    }
     // stage the incoming messages, arm the minima (the table loads above are in flight)
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         const int vo = fd.v2f_off[i];
-        for (int d = tid; d < Dm[i]; d += BLOCK) {
+        for (int d = tid; d < Dm[i]; d += NT) {
             s_msg[off[i] + d] = a.v2f_old[vo + d];
             s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
         }
@@ -620,12 +681,9 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // per owned q: its digits' messages and the running minima for p >= 1
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
-    bool live[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int q = tid + j * BLOCK;
-        live[j] = q < R;
-        int rem = live[j] ? q : 0;
+        int rem = qc[j];
 #pragma unroll
         for (int i = A - 1; i >= 1; --i) {
             dig[j][i] = rem % Dm[i];
@@ -639,58 +697,36 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
         for (int i = 1; i < A; ++i) s += ms[j][i];
         s0[j] = s;
     }
-    for (int d0 = 0; d0 < D0; d0 += UNR) {
+    const bool all_live = R == NJ * NT;  // block-uniform
+    for (int b = 0; b < n_full; ++b) {
+        const int d0 = b * UNR;
         T nxt[UNR][NJ];
-        const bool more = d0 + UNR < D0;  // block-uniform
-#pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int q = tid + j * BLOCK;
-                nxt[u][j] = (more && q < R && d0 + UNR + u < D0) ? tab[(int64_t)(d0 + UNR + u) * R + q]
-                                                                 : pos_inf<T>();
-            }
-        T best0[UNR];
-#pragma unroll
-        for (int u = 0; u < UNR; ++u) {
-            const T m0 = s_msg[off[0] + (d0 + u < D0 ? d0 + u : 0)];
-            T b0 = pos_inf<T>();
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const T t = cur[u][j];
-                const T c0 = t + s0[j];  // to variable 0: the others are 1..A-1 in dimensions order
-                if (b0 > c0) b0 = c0;
-                // to variable p >= 1: the others are 0 and the remaining ones, in order
-#pragma unroll
-                for (int p = 1; p < A; ++p) {
-                    T sp = (T)0 + m0;
-#pragma unroll
-                    for (int i = 1; i < A; ++i)
-                        if (i != p) sp += ms[j][i];
-                    const T cp = t + sp;
-                    if (acc[j][p] > cp) acc[j][p] = cp;
-                }
-            }
-            best0[u] = b0;
-        }
-        // UNR independent wavefront reductions, interleaved step by step
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) {
-#pragma unroll
-            for (int u = 0; u < UNR; ++u) {
-                const T y = __shfl(best0[u], (int)((threadIdx.x & 63) ^ sft), 64);
-                best0[u] = y < best0[u] ? y : best0[u];
-            }
-        }
-        if ((tid & 63) == 0) {
+        if (b + 1 < n_full) {
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
-                if (d0 + u < D0) atomicMin(&s_key[off[0] + d0 + u], OrdKey<T>::enc(best0[u]));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) nxt[u][j] = tab[(int64_t)(d0 + UNR + u) * R + qc[j]];
+        } else {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) nxt[u][j] = pos_inf<T>();
         }
+        if (all_live) nary_batch<T, A, NJ, false>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+        else nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cur[u][j] = nxt[u][j];
+    }
+    if (n_full * UNR < D0) {  // tail batch
+        const int d0 = n_full * UNR;
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+                cur[u][j] = tab[(int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]];
+        nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
@@ -702,7 +738,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // apply_damping + the send rule (maxsum.py:346-377), one thread per message ELEMENT so
     // that the previous messages arrive with one round of parallel loads.
     // phase 1: damp, compare with the message sent last
-    for (int idx = tid; idx < sumd; idx += BLOCK) {
+    for (int idx = tid; idx < sumd; idx += NT) {
         int i = 0;
 #pragma unroll
         for (int ii = 1; ii < A; ++ii)
@@ -723,7 +759,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     }
     __syncthreads();
     // phase 2: send / send again / stay silent (the receiver keeps the old message)
-    for (int idx = tid; idx < sumd; idx += BLOCK) {
+    for (int idx = tid; idx < sumd; idx += NT) {
         int i = 0;
 #pragma unroll
         for (int ii = 1; ii < A; ++ii)

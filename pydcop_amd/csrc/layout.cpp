@@ -126,8 +126,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     if (i) R *= Di;
                 }
                 // one launch group per (arity, R / BLOCK rounded up): compile-time loop bounds
-                if (R >= 64 && R <= 1024 && sumd <= 1024)
-                    k = FKey{K_F_NARY, ar * 16 + (int)((R + BLOCK - 1) / BLOCK)};
+                if (R >= 64 && R <= 1024 && sumd <= 1024) {
+                    const int nj = (int)((R + BLOCK - 1) / BLOCK);
+                    const int waves = (int)(((R + nj - 1) / nj + 63) / 64);  // 1..4
+                    k = FKey{K_F_NARY, (ar * 16 + nj) * 16 + waves};
+                }
             }
         }
         fkey[f] = k;
@@ -303,7 +306,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.classes.push_back(ci);
                 sweep_class(cls, BLOCK);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
-                NaryLaunch nl{key.D / 16, key.D % 16, (int32_t)L.ndesc.size(), n};
+                NaryLaunch nl{key.D / 256, (key.D / 16) % 16, (key.D % 16) * 64, (int32_t)L.ndesc.size(), n};
                 for (int j = 0; j < n; ++j) {
                     const int f2 = fi + j;
                     NaryDesc d{};

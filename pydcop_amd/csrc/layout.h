@@ -94,8 +94,10 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
     int32_t f2v_off[4];  // F2V offsets of the outgoing messages
 };
 
-struct NaryLaunch {  // one launch per (arity, NJ) group of K_F_NARY factors
+struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY factors
     int32_t arity, nj;   // nj = ceil(R / BLOCK), R = product of the dimensions after the first
+    int32_t threads;     // block size: ceil(R / nj) rounded up to whole waves -- when R allows
+                         // it (R = 576 = 3 * 192) every lane owns exactly nj entries per d0
     int32_t first;       // first descriptor of the group
     int32_t count;
 };

@@ -16,7 +16,8 @@ import numpy as np
 from .graph import CGraph, CParams, FlatGraph, Params
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(_HERE, "csrc", "libmaxsum_hip.so")
+# $MAXSUM_HIP_LIB selects another build of the same library (kernel experiments)
+DEFAULT_LIB = os.environ.get("MAXSUM_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaxsum_hip.so")
 
 # every symbol include/maxsum_gpu.h declares
 ABI_SYMBOLS = (
@@ -81,7 +82,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise MaxSumGpuError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). maxsum_gpu has no CPU fallback.")
-    if os.path.basename(path) == os.path.basename(DEFAULT_LIB):
+    if os.path.basename(path).startswith("libmaxsum_hip"):
         _load_hip_runtime()  # the emulated test build carries its own fake runtime
     lib = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
