@@ -11,9 +11,14 @@ engine creation).
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
                     [--dtype f64|f32] [--no-cpu-baseline]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU);
-the factor graph is partitioned across the ranks and boundary V->F messages are
-exchanged once per cycle with an RCCL all-to-all (pydcop_amd/sharded.py).
+N > 1 is launched by the driver through torch.distributed.run (one rank per GPU):
+WEAK scaling -- ONE random 3-colouring instance of N x 100k variables (same degree,
+same cost convention) is partitioned across the ranks, 100k variables per GPU, and
+boundary V->F messages are exchanged once per cycle with an RCCL all-to-all
+(pydcop_amd/sharded.py).  `value` is then N x iterations/s: the whole job's
+throughput in iterations of a 100k-variable instance (= directed edge-messages/s
+divided by the 800k messages of one such iteration), so N = 1 is the plain metric.
+`--scaling strong` keeps the fixed 100k instance and splits it instead.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -27,6 +32,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# the launch(es) one cycle is made of, per workload (roofline.avg_launch_us covers them all)
+KERNEL_OF = {"meeting_50k": "k_factor_nary + k_variable_wide (one cycle)"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 
 
@@ -45,8 +52,8 @@ def measured_traffic(workload, dtype):
 
 def make_workload(name, n_gpus=1):
     from pydcop_amd import generators as G
-    if name == "coloring_100k":     # the metric's configuration (north-star)
-        return G.random_coloring(100_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+    if name == "coloring_100k":     # the metric's configuration (north-star); x n_gpus when weak-scaled
+        return G.random_coloring(100_000 * n_gpus, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_10k":      # BASELINE.json configs[1]
         return G.random_coloring(10_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_100k_hard":
@@ -105,13 +112,16 @@ def main():
     ap.add_argument("--layout-flags", type=int, default=0)
     ap.add_argument("--graph-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N > 1: weak = N x 100k-variable instance (default), strong = the fixed instance")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
 
     if world > 1:
         # one HIP runtime per process: torch first, so that the engine binds to the
@@ -120,7 +130,9 @@ def main():
     from pydcop_amd.engine import MaxSumEngine
     from pydcop_amd.graph import Params
 
-    graph, mode = make_workload(args.workload, args.gpus)
+    weak = args.scaling == "weak" and args.gpus > 1 and args.workload == "coloring_100k"
+    graph, mode = make_workload(args.workload, args.gpus if weak else 1)
+    units = args.gpus if weak else 1  # 100k-variable instances' worth of work per iteration
     params = Params(mode=mode, dtype=args.dtype, layout_flags=args.layout_flags,
                     graph_chunk=args.graph_chunk)
     word = 8 if args.dtype == "f64" else 4
@@ -161,18 +173,21 @@ def main():
         elapsed = float(t.item())
 
     if rank == 0:
-        its = args.steps / elapsed
+        its = units * args.steps / elapsed
         bytes_cycle = graph.cycle_bytes(word)
         out = {
             "metric": "MaxSum iterations/sec on 100k-var random graph-coloring DCOP",
             "value": its, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "weak" if (weak or args.gpus == 1) else "strong",
+            "vs_baseline": None,
             "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": args.workload, "n_vars": graph.n_vars,
+            "config": {"workload": args.workload + (f" x{args.gpus} (one {graph.n_vars}-variable instance, "
+                                                    f"100k variables per GPU)" if weak else ""),
+                       "n_vars": graph.n_vars,
                        "n_factors": graph.n_factors, "n_edges": graph.n_edges,
                        "domain": int(graph.dom_size.max()),
-                       "edge_messages_per_s": its * 2 * n_edges_total,
+                       "edge_messages_per_s": args.steps / elapsed * 2 * n_edges_total,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
                        "parallelism": f"graph-partition x{args.gpus}"},
         }
@@ -182,7 +197,8 @@ def main():
             out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                                "traffic": measured_traffic(args.workload, args.dtype),
-                               "kernel": "k_sweep", "algorithmic_bytes_per_launch": bytes_cycle,
+                               "kernel": KERNEL_OF.get(args.workload, "k_sweep"),
+                               "algorithmic_bytes_per_launch": bytes_cycle,
                                "avg_launch_us": kernel_s * 1e6}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)

@@ -1,28 +1,35 @@
-"""profiles/*pmc*FETCH_SIZE*.csv + *WRITE_SIZE*.csv -> profiles/traffic.json
+"""profiles/*_pmc_<workload>.txt (FETCH_SIZE / WRITE_SIZE per launch of the sweep kernel,
+summarised by scripts/pmc_summary.py from separate rocprofv3 --pmc passes)
+-> profiles/traffic.json, the `roofline.traffic` figure bench.py reports.
 
-Per workload/dtype: mean FETCH_SIZE and WRITE_SIZE (KiB per dispatch, rocprofv3
-counter_collection) of the dominant sweep kernel over the profiled launches,
-converted to bytes.  Calibration of the two counters on this GPU against kernels
-of known traffic is in profiles/*pmc_calibration* (tools/microbench copy/read/fill):
-see DESIGN.md section "Measured traffic".
-
-usage: python scripts/collect_traffic.py TAG workload/dtype=fetch.csv,write.csv ...
+Correction (MI355X_MICROARCH.md "HBM" + our own calibration on kernels of known
+traffic, profiles/r01_pmc_calibration_v4.txt, r01_pmc_requests_calibration_v4.txt):
+  * WRITE_SIZE is exact (k_copy / k_fill / k_gather: reported == written bytes).
+  * On gfx950 TCC_BUBBLE and TCC_EA0_RDREQ_32B read 0, so FETCH_SIZE = 64 B x
+    TCC_EA0_RDREQ.  A coalesced stream issues 128-B requests (k_copy 1 GiB ->
+    8.39 M requests) and is therefore reported at exactly 1/2; a random sub-line
+    gather issues one 64-B request per gather (k_gather: 6.0 M gathers + index
+    stream -> 6.19 M requests) and is reported in full.
+  * Hence for a sweep with G random gathers per launch (two per edge on a graph
+    without locality):  read bytes = 2 * FETCH - 64 * G ;  with locality the
+    gathers merge into line requests and 2 * FETCH is an upper bound.
+usage: python scripts/collect_traffic.py TAG workload/dtype=file.txt:n_gather ...
 """
-import csv
 import json
 import os
+import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def mean_counter(path, kernel_substr="k_sweep"):
-    vals = []
-    with open(path) as f:
-        for row in csv.DictReader(f):
-            if kernel_substr in row["Kernel_Name"]:
-                vals.append(float(row["Counter_Value"]))
-    return sum(vals) / len(vals), len(vals)
+def read_counters(path):
+    out = {}
+    for line in open(path):
+        m = re.match(r"(\S+)\s+.*k_sweep.*mean(?:_KiB)?\s+([0-9.]+)", line)
+        if m:
+            out[m.group(1)] = float(m.group(2))
+    return out
 
 
 def main():
@@ -33,14 +40,18 @@ def main():
         data = {}
     tag = sys.argv[1]
     for spec in sys.argv[2:]:
-        key, files = spec.split("=")
-        fetch, write = files.split(",")
-        fk, nf = mean_counter(fetch)
-        wk, nw = mean_counter(write)
+        key, rest = spec.split("=")
+        path, n_gather = rest.split(":")
+        n_gather = int(n_gather)
+        c = read_counters(path)
+        fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+        read_bytes = 2 * fetch - 64 * n_gather
         data[key] = {
-            "fetch_kib": fk, "write_kib": wk, "dispatches": min(nf, nw),
-            "bytes_per_launch": int((fk + wk) * 1024), "source": tag,
-            "files": [os.path.relpath(fetch, ROOT), os.path.relpath(write, ROOT)],
+            "fetch_size_bytes": int(fetch), "write_size_bytes": int(write),
+            "random_gathers_per_launch": n_gather,
+            "bytes_per_launch": int(read_bytes + write),
+            "model": "2*FETCH_SIZE - 64*gathers + WRITE_SIZE (see scripts/collect_traffic.py)",
+            "source": tag, "file": os.path.relpath(path, ROOT),
         }
     json.dump(data, open(out_path, "w"), indent=1, sort_keys=True)
     print(json.dumps(data, indent=1))
