@@ -168,7 +168,8 @@ struct Engine : EngineBase {
     // Enqueue one cycle reading buffer `from`.
     int launch_cycle(int from, bool start) {
         const SweepArgs<T> a = make_args(from, start);
-        const int nb = L.n_blocks_sweep;
+        const int nb = (start || L.sweep_regular) ? L.n_blocks_sweep : 0;  // isolated variables only
+                                                                           // act in cycle 0
         if (nb > 0) {
             const dim3 grid(nb), block(BLOCK);
             switch (L.dsel) {
@@ -181,8 +182,9 @@ struct Engine : EngineBase {
         }
         for (int c : L.wide_classes) {
             const ClassInfo& ci = L.classes[c];
-            hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)),
-                               dim3(BLOCK), 0, stream, a, ci);
+            const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
+            if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
+            else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
             HIP_TRY(hipGetLastError());
         }
         for (const NaryLaunch& nl : L.nary_launches) {

@@ -791,7 +791,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 
 // ---------------------------------------------------------------------------
 // Variable side, wide class: ONE WAVE PER VARIABLE, for domains too large for the
-// packed class (5 <= D <= 256) or degrees above 64, as long as deg * D <= WIDE_MAX.
+// packed class (5 <= D <= 256) or degrees above 64, as long as deg * D <= 1024, deg <= 256.
 // The incoming F->V messages are staged in LDS with one round of parallel loads;
 // lanes then run over d (beliefs, outgoing messages) or over the outgoing edges
 // (the `sum_cost` chains).  Arithmetic order is the reference's, op for op:
@@ -801,16 +801,80 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 //                     one lane per outgoing edge walks it in LDS
 // Own launch (its LDS must not cap the occupancy of the register classes).
 // ---------------------------------------------------------------------------
-constexpr int WIDE_MAX = 1024;        // deg * D elements staged per variable
 constexpr int WIDE_MAX_D = 256;       // <= 4 domain values per lane
 constexpr int WIDE_VARS = BLOCK / 64;
+// Two instantiations: CAP = staged elements per variable (deg * D <= CAP, deg <= CAP / 4).
+constexpr int WIDE_CAP_SMALL = 128;   // 5 KB of LDS per block: full occupancy
+constexpr int WIDE_CAP_LARGE = 1024;  // 40 KB per block
 
+// sum over t of in[..] in (d major, k minor) order, skipping edge `ko`: the serial
+// `sum_cost` chain of costs_for_factor.  Reads are issued four at a time, the adds stay
+// in order.
 template <typename T>
+__device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
+    T sc = (T)0;
+    const int n = D * deg;
+    int d = 0, k = 0, t = 0;
+    for (; t + 4 <= n; t += 4) {
+        T x[4];
+        bool use[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[u] = in[k * D + d];
+            use[u] = k != ko;
+            if (++k == deg) {
+                k = 0;
+                ++d;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (use[u]) sc += x[u];
+    }
+    for (; t < n; ++t) {
+        const T x = in[k * D + d];
+        if (k != ko) sc += x;
+        if (++k == deg) {
+            k = 0;
+            ++d;
+        }
+    }
+    return sc;
+}
+
+// c + in_0[d] + in_1[d] + ... in order, skipping edge `skip` (-1: none); reads four at a time
+template <typename T>
+__device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, int d, int skip) {
+    T acc = c;
+    int k = 0;
+    for (; k + 4 <= deg; k += 4) {
+        T x[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) x[u] = in[(k + u) * D + d];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (k + u != skip) acc += x[u];
+    }
+    for (; k < deg; ++k) {
+        const T x = in[k * D + d];
+        if (k != skip) acc += x;
+    }
+    return acc;
+}
+
+template <typename T, int CAP>
 __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassInfo ci) {
-    __shared__ T s_in[WIDE_VARS][WIDE_MAX];
-    __shared__ T s_avg[WIDE_VARS][WIDE_MAX / 4];
+    // the small footprint also stages the previous outgoing messages (one more round of
+    // parallel loads instead of a dependent load per outgoing edge)
+    constexpr bool STAGE_PREV = CAP <= WIDE_CAP_SMALL;
+    __shared__ T s_in[WIDE_VARS][CAP];
+    __shared__ T s_prev[WIDE_VARS][STAGE_PREV ? CAP : 1];
+    __shared__ T s_avg[WIDE_VARS][CAP / 4];
+    __shared__ int s_vo[WIDE_VARS][CAP / 4];   // per outgoing edge: V2F offset,
+    __shared__ int s_cn[WIDE_VARS][CAP / 4];   // send counter
     const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int j = (int)blockIdx.x * WIDE_VARS + w;
+    // wave-uniform: the variable's record comes through scalar loads
+    const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WIDE_VARS + w);
     if (j >= ci.count) return;  // whole waves; only wave-level synchronisation below
     const int v = ci.first + j;
     const int D = a.vdom[v];
@@ -821,19 +885,15 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     T cv[NR];
 #pragma unroll
     for (int r = 0; r < NR; ++r) cv[r] = lane + 64 * r < D ? c[lane + 64 * r] : (T)0;
-    // stage the messages this variable holds: all loads in flight together
+    // stage what this variable holds: every load of a round is in flight together
     for (int idx = lane; idx < deg * D; idx += 64) {
         const int k = idx / D, d = idx - k * D;
         in[idx] = a.f2v_old[a.vslot_f2v[k0 + k] + d];
+        if (STAGE_PREV) s_prev[w][idx] = a.start ? (T)0 : a.v2f_old[a.vslot_v2f[k0 + k] + d];
     }
-    // the first outgoing edge's previous message and counter (needed last, requested now)
-    T pv[NR];
-    int cnt = 0;
-    if (!a.start) {
-        const int vo = a.vslot_v2f[k0];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? a.v2f_old[vo + lane + 64 * r] : (T)0;
-        cnt = a.cV[k0];
+    for (int k = lane; k < deg; k += 64) {
+        s_vo[w][k] = a.vslot_v2f[k0 + k];
+        s_cn[w][k] = a.start ? 0 : (int)a.cV[k0 + k];
     }
     __builtin_amdgcn_wave_barrier();
     // belief and selection: first index attaining the minimum
@@ -843,8 +903,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     for (int r = 0; r < NR; ++r) {
         const int d = lane + 64 * r;
         if (d < D) {
-            T b = cv[r];
-            for (int k = 0; k < deg; ++k) b += in[k * D + d];
+            const T b = wide_sum_edges<T>(cv[r], in, D, deg, d, -1);
             if (bi == 0x7fffffff || b < bb) {
                 bb = b;
                 bi = d;
@@ -869,59 +928,54 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
         a.belief[v] = bb;
     }
     // the mean of each outgoing message: one lane per target walks its serial chain
-    for (int ko = lane; ko < deg; ko += 64) {
-        T sum_cost = (T)0;
-        for (int d = 0; d < D; ++d)
-            for (int k = 0; k < deg; ++k)
-                if (k != ko) sum_cost += in[k * D + d];
-        s_avg[w][ko] = sum_cost / (T)D;
-    }
+    for (int ko = lane; ko < deg; ko += 64) s_avg[w][ko] = wide_sum_cost<T>(in, D, deg, ko) / (T)D;
     __builtin_amdgcn_wave_barrier();
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
                              a.start_mode != MXS_START_LEAFS;
+    T pv[NR], pn[NR];
+#pragma unroll
+    for (int r = 0; r < NR; ++r) pv[r] = pn[r] = (T)0;
+    if (!STAGE_PREV && !a.start) {  // the first outgoing edge's previous message
+        const int vo = s_vo[w][0];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? a.v2f_old[vo + lane + 64 * r] : (T)0;
+    }
     for (int ko = 0; ko < deg; ++ko) {
-        // request the next edge's previous message before working on this one
-        T pn[NR];
-        int cnt_n = 0;
-        if (!a.start && ko + 1 < deg) {
-            const int vn = a.vslot_v2f[k0 + ko + 1];
+        if (STAGE_PREV) {
+#pragma unroll
+            for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? s_prev[w][ko * D + lane + 64 * r] : (T)0;
+        } else if (!a.start && ko + 1 < deg) {  // request the next edge's before working on this one
+            const int vn = s_vo[w][ko + 1];
 #pragma unroll
             for (int r = 0; r < NR; ++r) pn[r] = lane + 64 * r < D ? a.v2f_old[vn + lane + 64 * r] : (T)0;
-            cnt_n = a.cV[k0 + ko + 1];
-        } else {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) pn[r] = (T)0;
         }
         const T avg = s_avg[w][ko];
-        T* wout = a.v2f_new + a.vslot_v2f[k0 + ko];
+        const int cnt = s_cn[w][ko];
+        T* wout = a.v2f_new + s_vo[w][ko];
         const bool damp = cnt > 0 && a.damp_v;
         T mv[NR];
-        int nomatch = 0;
+        bool nomatch = false;
 #pragma unroll
         for (int r = 0; r < NR; ++r) {
             const int d = lane + 64 * r;
             mv[r] = (T)0;
             if (d < D) {
-                T m = cv[r];
-                for (int k = 0; k < deg; ++k)
-                    if (k != ko) m += in[k * D + d];
-                m = m - avg;
+                T m = wide_sum_edges<T>(cv[r], in, D, deg, d, ko) - avg;
                 if (a.start) {
                     m = start_sends ? m : (T)0;
                 } else {
                     if (damp) m = a.damping * pv[r] + ((T)1 - a.damping) * m;
-                    if (!comp_match(m, pv[r], a.stability)) nomatch = 1;
+                    if (!comp_match(m, pv[r], a.stability)) nomatch = true;
                 }
                 mv[r] = m;
             }
         }
-#pragma unroll
-        for (int sft = 32; sft > 0; sft >>= 1) nomatch |= __shfl(nomatch, lane ^ sft, 64);
+        const bool any_nomatch = __ballot(nomatch ? 1 : 0) != 0;  // over the wave
         int out = 1;
         bool keep_old = false;
         if (a.start) {
             out = 0;
-        } else if (cnt > 0 && !nomatch) {
+        } else if (cnt > 0 && !any_nomatch) {
             if (cnt < SAME_COUNT) {
                 out = cnt + 1;
             } else {
@@ -935,9 +989,10 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
             if (d < D) wout[d] = keep_old ? pv[r] : mv[r];
         }
         if (lane == 0) a.cV[k0 + ko] = (uint8_t)out;
+        if (!STAGE_PREV) {
 #pragma unroll
-        for (int r = 0; r < NR; ++r) pv[r] = pn[r];
-        cnt = cnt_n;
+            for (int r = 0; r < NR; ++r) pv[r] = pn[r];
+        }
     }
 }
 

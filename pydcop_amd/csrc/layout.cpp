@@ -189,8 +189,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
             kind = K_V_PACK; sub = D;
-        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024) {
-            kind = K_V_WIDE; sub = 0;  // wave per variable, messages staged in LDS
+        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
+            kind = K_V_WIDE;  // wave per variable, messages staged in LDS; two LDS footprints
+            sub = ((int64_t)deg * D <= 128 && deg <= 32) ? 0 : 1;
         } else { kind = K_V_GEN; sub = 0; }
         // sort key: class, then degree (the packed class needs equal degrees side
         // by side; bit3 of layout_flags keeps the caller's order elsewhere)
@@ -356,6 +357,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.kind = K_V_GEN;
         } else if (kind == K_V_WIDE) {
             ci.kind = K_V_WIDE;
+            ci.D = sub;  // 0: small LDS footprint, 1: large
         } else if (kind == 80) {
             ci.kind = K_V_GEN;
             ci.start_only = 1;
@@ -454,6 +456,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             nb += (ci.count + ci.per_block - 1) / ci.per_block;
         }
         L.n_blocks_sweep = nb;
+        for (int c : L.sweep_order)
+            if (!L.classes[c].start_only) L.sweep_regular = true;
         // one compile-time D for every register / wave class -> leaner kernel
         int dsel = -1;
         for (int c : L.sweep_order) {

@@ -135,6 +135,7 @@ struct Layout {
     std::vector<ClassInfo> classes;
     std::vector<int32_t> sweep_order;  // classes of launch 0 in launch order
     int32_t n_blocks_sweep = 0;        // grid size of launch 0
+    bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)
     std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)
     std::vector<NaryLaunch> nary_launches;
     std::vector<int32_t> wide_classes;    // K_V_WIDE classes: one launch each

@@ -170,6 +170,19 @@ inline V __shfl(V var, int src_lane, int width = 64) {
     return out;
 }
 
+// 64-bit mask of the lanes of the wave whose predicate is non-zero
+inline unsigned long long __ballot(int pred) {
+    const unsigned t = threadIdx.x;
+    hipemu::g_xchg[t] = pred ? 1ull : 0ull;
+    hipemu::yield_barrier();
+    const unsigned wave_base = t - t % 64;
+    unsigned long long mask = 0;
+    for (unsigned l = 0; l < 64 && wave_base + l < blockDim.x; ++l)
+        if (hipemu::g_xchg[wave_base + l]) mask |= 1ull << l;
+    hipemu::yield_barrier();
+    return mask;
+}
+
 template <typename U>
 inline U atomicMin(U* addr, U val) {  // fibers run one at a time: plain read-modify-write
     const U old = *addr;

@@ -69,12 +69,12 @@ def parity_cases():
         g.init_idx = init.astype(np.int32)
         return g
 
-    def hub(seed):
-        # one variable in 40 factors (generic variable class), some isolated variables
-        g = G.random_coloring(60, avg_degree=3, seed=seed)
+    def hub(seed, nf=40, n=60):
+        # one variable in nf more factors (packed class up to degree 64, wide class above),
+        # some isolated variables
+        g = G.random_coloring(n, avg_degree=3, seed=seed)
         rng = np.random.default_rng(seed)
-        nf = 40
-        others = rng.choice(np.arange(1, 50), size=nf, replace=False)
+        others = rng.choice(np.arange(1, n - 10), size=nf, replace=False)
         edge_var = np.concatenate([g.edge_var, np.stack([np.zeros(nf, int), others], 1).reshape(-1)])
         rowptr = np.concatenate([g.factor_rowptr, g.factor_rowptr[-1] + 2 * np.arange(1, nf + 1)])
         tables = np.concatenate([g.tables, rng.integers(0, 10, nf * 9).astype(float)])
@@ -113,5 +113,8 @@ def parity_cases():
         ("nary_binary_d70", lambda: G.meeting_like(16, n_factors=12, dom=70, arity=2, seed=17), {}),
         ("nary_arity4_d5", lambda: G.meeting_like(25, n_factors=15, dom=5, arity=4, seed=18),
          {"damping_nodes": "factors"}),
+        # wave-per-variable kernel, large LDS footprint: deg * D > 128 and degree > 64
+        ("wide_coloring6_deg30", lambda: G.random_coloring(60, avg_degree=30, n_colors=6, seed=20), {}),
+        ("wide_hub_deg100", lambda: hub(21, nf=100, n=150), {"start_messages": "leafs_vars"}),
         ("nary_mixed_dims", lambda: G.random_mixed(40, 50, seed=19, max_arity=4, dom_choices=(3, 7, 10, 12)), {}),
     ]
