@@ -184,12 +184,22 @@ int mxs_halo_buffers(mxs_engine *e, void **send_dev, int64_t *send_bytes,
  * sizes as reported by mxs_halo_buffers.  Call after mxs_halo_setup; the
  * current messages are packed into the new send buffer. */
 int mxs_halo_bind(mxs_engine *e, void *send_dev, void *recv_dev);
-/* One cycle split around the exchange:  step_pack = sweep + pack (async on
- * the engine stream), then the host runs the collective on the same stream
- * (mxs_stream), then step_unpack scatters the received messages. */
+/* One sharded cycle, split so that the exchange of cycle t hides behind the part
+ * of cycle t+1 that does not need it.  Per cycle the host calls, in this order:
+ *   mxs_step_compute  compute stream: variables + interior factors of cycle t,
+ *                     then (after the unpack of cycle t-1) the cut factors --
+ *                     the only readers of ghost messages;
+ *   mxs_step_pack     comm stream: waits for the variables of cycle t, gathers
+ *                     the owned cut-edge V->F messages into the send buffer;
+ *   <collective>      enqueued by the host on the comm stream (mxs_stream);
+ *   mxs_step_unpack   comm stream: scatters the received messages into the
+ *                     ghost slots.
+ * Nothing blocks the host; mxs_sync waits for both streams. */
+int mxs_step_compute(mxs_engine *e);
 int mxs_step_pack(mxs_engine *e);
 int mxs_step_unpack(mxs_engine *e);
-/* The engine's hipStream_t, as an opaque pointer. */
+/* The engine's comm hipStream_t (the stream the collective has to be enqueued
+ * on), as an opaque pointer. */
 int mxs_stream(mxs_engine *e, void **stream);
 
 int mxs_destroy(mxs_engine *e);

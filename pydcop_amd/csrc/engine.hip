@@ -81,13 +81,15 @@ struct EngineBase {
     virtual int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) = 0;
     virtual int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) = 0;
     virtual int halo_bind(void* s, void* r) = 0;
+    virtual int step_compute() = 0;
     virtual int step_pack() = 0;
     virtual int step_unpack() = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     Layout L;
     mxs_params params{};
     int64_t cycles = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // compute stream
+    hipStream_t comm = nullptr;    // sharded operation: pack / collective / unpack
     int launches_per_cycle = 1;
 };
 
@@ -105,10 +107,14 @@ struct Engine : EngineBase {
     bool timeline_on = false;
     DevBuf<FactorGen> fgen;
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
+    DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
     DevBuf<NaryDesc> ndesc;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
+    hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
+    bool halo_pending = false;
     hipGraphExec_t graph_exec = nullptr;
     int graph_cycles = 0;  // cycles per replay (even), 0 = no graph
     bool graph_tried = false;
@@ -122,10 +128,13 @@ struct Engine : EngineBase {
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
+        if (ev_p1) (void)hipEventDestroy(ev_p1);
+        if (ev_halo) (void)hipEventDestroy(ev_halo);
+        if (comm) (void)hipStreamDestroy(comm);
         if (stream) (void)hipStreamDestroy(stream);
     }
 
-    SweepArgs<T> make_args(int from, bool start) const {
+    SweepArgs<T> make_args(int from, bool start, int phase = 1) const {
         SweepArgs<T> a{};
         a.v2f_old = v2f[from].p;
         a.v2f_new = v2f[from ^ 1].p;
@@ -158,36 +167,30 @@ struct Engine : EngineBase {
         a.start_mode = params.start_messages;
         a.null_f2v = (int32_t)L.null_f2v;
         a.timeline = timeline_on ? timeline.p : nullptr;
-        a.n_classes = (int32_t)L.sweep_order.size();
+        const std::vector<int32_t>& order = phase == 1 ? L.sweep_order : L.sweep_order2;
+        a.n_classes = (int32_t)order.size();
         for (int i = 0; i < MAX_CLASSES; ++i)
-            a.block_base[i] = i < a.n_classes ? L.classes[L.sweep_order[i]].block_base : INT32_MAX;
-        a.classes = classes.p;
+            a.block_base[i] = i < a.n_classes ? L.classes[order[i]].block_base : INT32_MAX;
+        a.classes = phase == 1 ? classes.p : classes2.p;
         return a;
     }
 
-    // Enqueue one cycle reading buffer `from`.
-    int launch_cycle(int from, bool start) {
-        const SweepArgs<T> a = make_args(from, start);
-        const int nb = (start || L.sweep_regular) ? L.n_blocks_sweep : 0;  // isolated variables only
-                                                                           // act in cycle 0
-        if (nb > 0) {
-            const dim3 grid(nb), block(BLOCK);
-            switch (L.dsel) {
-                case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
-                case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
-                case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
-                default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
-            }
-            HIP_TRY(hipGetLastError());
+    int launch_sweep(const SweepArgs<T>& a, int nb) {
+        if (nb <= 0) return MXS_OK;
+        const dim3 grid(nb), block(BLOCK);
+        switch (L.dsel) {
+            case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
+            case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
+            case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
+            default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
         }
-        for (int c : L.wide_classes) {
-            const ClassInfo& ci = L.classes[c];
-            const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
-            if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
-            else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
-            HIP_TRY(hipGetLastError());
-        }
+        HIP_TRY(hipGetLastError());
+        return MXS_OK;
+    }
+
+    int launch_nary(const SweepArgs<T>& a, int cut) {
         for (const NaryLaunch& nl : L.nary_launches) {
+            if (nl.cut != cut) continue;
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
 #define MXS_NARY_CASE(AR, NJ)                                                               \
@@ -204,6 +207,37 @@ struct Engine : EngineBase {
             HIP_TRY(hipGetLastError());
         }
         return MXS_OK;
+    }
+
+    // Enqueue (part of) one cycle reading buffer `from` on the compute stream.
+    //   phase 1: every variable class and every factor class that reads owned variables only
+    //   phase 2: the cut factor classes of a shard (they read ghost messages, i.e. they are
+    //            the only work that depends on the halo exchange of the previous cycle)
+    // A single-GPU engine has no phase-2 work.
+    int launch_phase(int from, bool start, int phase) {
+        const SweepArgs<T> a = make_args(from, start, phase);
+        if (phase == 1) {
+            // isolated variables only act in cycle 0
+            int rc = launch_sweep(a, (start || L.sweep_regular) ? L.n_blocks_sweep : 0);
+            if (rc) return rc;
+            for (int c : L.wide_classes) {
+                const ClassInfo& ci = L.classes[c];
+                const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
+                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
+                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
+                HIP_TRY(hipGetLastError());
+            }
+            return launch_nary(a, 0);
+        }
+        int rc = launch_sweep(a, L.n_blocks_sweep2);
+        if (rc) return rc;
+        return launch_nary(a, 1);
+    }
+
+    int launch_cycle(int from, bool start) {
+        int rc = launch_phase(from, start, 1);
+        if (rc) return rc;
+        return launch_phase(from, start, 2);
     }
 
     int init(const mxs_graph& g, const mxs_params& p, int dev) override {
@@ -224,6 +258,9 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_p1, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
 
         auto conv = [](const std::vector<double>& src) {
             std::vector<T> out(src.size());
@@ -259,6 +296,9 @@ struct Engine : EngineBase {
             std::vector<ClassInfo> order;
             for (int c : L.sweep_order) order.push_back(L.classes[c]);
             HIP_TRY(classes.upload(order, stream));
+            order.clear();
+            for (int c : L.sweep_order2) order.push_back(L.classes[c]);
+            HIP_TRY(classes2.upload(order, stream));
         }
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         // solution_cost data
@@ -270,8 +310,8 @@ struct Engine : EngineBase {
         HIP_TRY(eval_idx.alloc((size_t)L.n_vars));
         HIP_TRY(part_cost.alloc(EVAL_BLOCKS));
         HIP_TRY(part_viol.alloc(EVAL_BLOCKS));
-        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (int)L.nary_launches.size() +
-                             (int)L.wide_classes.size();
+        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
+                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
         return reset();
     }
 
@@ -291,12 +331,13 @@ struct Engine : EngineBase {
         int rc = launch_cycle(cur, true);
         if (rc) return rc;
         cur ^= 1;
+        halo_pending = false;
+        HIP_TRY(hipEventRecord(ev_p1, stream));
         if (halo_ready) {  // the start messages have to cross too
             rc = pack();
             if (rc) return rc;
         }
-        HIP_TRY(hipStreamSynchronize(stream));
-        return MXS_OK;
+        return sync();
     }
 
     // Capture `chunk` (even) cycles into a hipGraph: launch-bound loops replay it.
@@ -336,7 +377,7 @@ struct Engine : EngineBase {
         if (n < 0) return fail(MXS_E_INVALID, "n_cycles must be >= 0");
         HIP_TRY(hipSetDevice(device));
         if (halo_ready)
-            return fail(MXS_E_STATE, "a sharded engine must be stepped with mxs_step_pack/unpack");
+            return fail(MXS_E_STATE, "a sharded engine must be stepped with mxs_step_compute/pack/unpack");
         int left = n;
         if (left > 0 && cur != 0) {  // align to the parity the graph was captured with
             int rc = launch_cycle(cur, false);
@@ -361,6 +402,7 @@ struct Engine : EngineBase {
 
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
+        if (comm) HIP_TRY(hipStreamSynchronize(comm));
         return MXS_OK;
     }
 
@@ -382,7 +424,7 @@ struct Engine : EngineBase {
 
     int get_assignment(int32_t* idx, double* bel) override {
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamSynchronize(stream));
+        { int rc = sync(); if (rc) return rc; }
         const int nV = L.n_vars;
         std::vector<int32_t> hs(nV);
         std::vector<T> hb(nV);
@@ -401,7 +443,7 @@ struct Engine : EngineBase {
 
     int get_messages(double* v2f_out, double* f2v_out, uint8_t* cv, uint8_t* cf) override {
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamSynchronize(stream));
+        { int rc = sync(); if (rc) return rc; }
         const int nE = L.n_edges;
         std::vector<T> hv((size_t)L.v2f_elems), hf((size_t)L.f2v_elems);
         std::vector<uint8_t> hcF(nE), hcV((size_t)L.n_cv);
@@ -433,7 +475,7 @@ struct Engine : EngineBase {
 
     int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) override {
         HIP_TRY(hipSetDevice(device));
-        HIP_TRY(hipStreamSynchronize(stream));
+        { int rc = sync(); if (rc) return rc; }
         const int nV = L.n_vars;
         const int32_t* didx = sel.p;
         if (idx) {
@@ -537,13 +579,17 @@ struct Engine : EngineBase {
         recv_buf = halo_recv.p;
         halo_ready = true;
         // the start messages of cycle 0 have to cross too: pack them now
+        HIP_TRY(hipEventRecord(ev_p1, stream));
         return pack();
     }
 
+    // comm stream: wait until the variables of the current cycle are done, then gather the
+    // V->F messages of the cut edges this shard owns into the send buffer
     int pack() {
+        HIP_TRY(hipStreamWaitEvent(comm, ev_p1, 0));
         if (n_halo_send > 0) {
             const int nb = (int)((n_halo_send + BLOCK - 1) / BLOCK);
-            hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, stream,
+            hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, comm,
                                (const T*)v2f[cur].p, (const int64_t*)halo_send_off.p, send_buf,
                                n_halo_send);
             HIP_TRY(hipGetLastError());
@@ -568,12 +614,28 @@ struct Engine : EngineBase {
         return pack();
     }
 
-    int step_pack() override {
+    // One sharded cycle, split so that the halo exchange of cycle t hides behind the work
+    // of cycle t+1 that does not need it:
+    //   compute stream   phase 1 (t): variables + interior factors      [record ev_p1]
+    //                    wait ev_halo (exchange of t-1 unpacked)
+    //                    phase 2 (t): cut factors -- the only readers of ghost messages
+    //   comm stream      wait ev_p1 ; pack (t) ; <the host's collective> ; unpack (t) [record ev_halo]
+    // Ping-pong buffers keep the two streams on disjoint data.
+    int step_compute() override {
         HIP_TRY(hipSetDevice(device));
-        int rc = launch_cycle(cur, false);
+        int rc = launch_phase(cur, false, 1);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(ev_p1, stream));
+        if (halo_pending) HIP_TRY(hipStreamWaitEvent(stream, ev_halo, 0));
+        rc = launch_phase(cur, false, 2);
         if (rc) return rc;
         cur ^= 1;
         cycles += 1;
+        return MXS_OK;
+    }
+
+    int step_pack() override {
+        HIP_TRY(hipSetDevice(device));
         return pack();
     }
 
@@ -581,10 +643,12 @@ struct Engine : EngineBase {
         HIP_TRY(hipSetDevice(device));
         if (n_halo_recv > 0) {
             const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
-            hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, stream, v2f[cur].p,
+            hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, comm, v2f[cur].p,
                                (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv);
             HIP_TRY(hipGetLastError());
         }
+        HIP_TRY(hipEventRecord(ev_halo, comm));
+        halo_pending = true;
         return MXS_OK;
     }
 };
@@ -689,12 +753,13 @@ int mxs_halo_buffers(mxs_engine* e, void** s, int64_t* sb, void** r, int64_t* rb
 
 int mxs_halo_bind(mxs_engine* e, void* s, void* r) { CHECK_HANDLE(e); return e->impl->halo_bind(s, r); }
 
+int mxs_step_compute(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_compute(); }
 int mxs_step_pack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_pack(); }
 int mxs_step_unpack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_unpack(); }
 
 int mxs_stream(mxs_engine* e, void** stream) {
     CHECK_HANDLE(e);
-    if (stream) *stream = (void*)e->impl->stream;
+    if (stream) *stream = (void*)e->impl->comm;
     return MXS_OK;
 }
 

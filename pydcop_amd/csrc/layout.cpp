@@ -25,8 +25,11 @@ namespace {
 
 struct FKey {
     int kind, D;
-    bool operator<(const FKey& o) const { return kind != o.kind ? kind < o.kind : D < o.D; }
-    bool operator==(const FKey& o) const { return kind == o.kind && D == o.D; }
+    int cut = 0;  // 1: the factor reads a ghost variable's message (sharded operation)
+    bool operator<(const FKey& o) const {
+        return cut != o.cut ? cut < o.cut : kind != o.kind ? kind < o.kind : D < o.D;
+    }
+    bool operator==(const FKey& o) const { return kind == o.kind && D == o.D && cut == o.cut; }
 };
 
 std::string validate(const mxs_graph& g) {
@@ -133,6 +136,12 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 }
             }
         }
+        // Sharded operation: a factor that reads a ghost variable's V->F message has to
+        // wait for the halo exchange; such "cut" factors form classes of their own, swept in
+        // a second launch (see engine.hip, step_compute).
+        if (g.var_owned)
+            for (int i = 0; i < ar; ++i)
+                if (!g.var_owned[g.edge_var[e0 + i]]) k.cut = 1;
         fkey[f] = k;
     }
     L.factor_i2e.resize(nF);
@@ -262,9 +271,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         std::copy(g.tables + g.table_off[f], g.tables + g.table_off[f + 1],
                   L.eval_tables.begin() + L.eval_tab_off[fi]);
     }
-    auto sweep_class = [&](int cls, int per_block) {  // blocks are derived from blockIdx
+    auto sweep_class = [&](int cls, int per_block, int cut = 0) {  // blocks are derived from blockIdx
         L.classes[cls].per_block = per_block;
-        L.sweep_order.push_back(cls);
+        (cut ? L.sweep_order2 : L.sweep_order).push_back(cls);
     };
     for (int fi = 0; fi < nF;) {
         const FKey key = fkey[L.factor_i2e[fi]];
@@ -290,7 +299,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     L.tables[ci.tab_base + (int64_t)k * n + j] = sign * src[k];
             }
             L.classes.push_back(ci);
-            sweep_class(cls, BLOCK);
+            sweep_class(cls, BLOCK, key.cut);
         } else {
             const int gen_base = (int)L.fgen.size();
             for (int j = 0; j < n; ++j) {
@@ -305,9 +314,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (key.kind == K_F_GEN) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
                 L.classes.push_back(ci);
-                sweep_class(cls, BLOCK);
+                sweep_class(cls, BLOCK, key.cut);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
-                NaryLaunch nl{key.D / 256, (key.D / 16) % 16, (key.D % 16) * 64, (int32_t)L.ndesc.size(), n};
+                NaryLaunch nl{key.D / 256, (key.D / 16) % 16, (key.D % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut};
                 for (int j = 0; j < n; ++j) {
                     const int f2 = fi + j;
                     NaryDesc d{};
@@ -447,8 +456,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 if (((p.layout_flags & 32) && !is_var) || ((p.layout_flags & 64) && is_var)) keep.push_back(c);
             }
             L.sweep_order = keep;
+            if (p.layout_flags & 64) L.sweep_order2.clear();
         }
-        if ((int)L.sweep_order.size() > MAX_CLASSES) return "too many kernel classes";
+        if ((int)L.sweep_order.size() > MAX_CLASSES || (int)L.sweep_order2.size() > MAX_CLASSES)
+            return "too many kernel classes";
         int nb = 0;
         for (int c : L.sweep_order) {
             ClassInfo& ci = L.classes[c];
@@ -456,11 +467,20 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             nb += (ci.count + ci.per_block - 1) / ci.per_block;
         }
         L.n_blocks_sweep = nb;
+        nb = 0;
+        for (int c : L.sweep_order2) {  // the cut factor classes: their own launch
+            ClassInfo& ci = L.classes[c];
+            ci.block_base = nb;
+            nb += (ci.count + ci.per_block - 1) / ci.per_block;
+        }
+        L.n_blocks_sweep2 = nb;
         for (int c : L.sweep_order)
             if (!L.classes[c].start_only) L.sweep_regular = true;
         // one compile-time D for every register / wave class -> leaner kernel
         int dsel = -1;
-        for (int c : L.sweep_order) {
+        std::vector<int32_t> both = L.sweep_order;
+        both.insert(both.end(), L.sweep_order2.begin(), L.sweep_order2.end());
+        for (int c : both) {
             const ClassInfo& ci = L.classes[c];
             if (ci.D == 0) continue;
             if (dsel == -1) dsel = ci.D;

@@ -100,6 +100,7 @@ struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY fa
                          // it (R = 576 = 3 * 192) every lane owns exactly nj entries per d0
     int32_t first;       // first descriptor of the group
     int32_t count;
+    int32_t cut;         // 1: factors reading ghost variables (second phase of a sharded cycle)
 };
 
 struct WaveMeta {  // per wave of a K_V_PACK class: read with ONE scalar load, so a lane
@@ -133,7 +134,9 @@ struct Layout {
 
     // classes of the sweep launch (the K_F_NARY groups have their own launches)
     std::vector<ClassInfo> classes;
-    std::vector<int32_t> sweep_order;  // classes of launch 0 in launch order
+    std::vector<int32_t> sweep_order;  // classes of the sweep launch in launch order
+    std::vector<int32_t> sweep_order2; // classes of the second sweep launch: cut factors (sharded)
+    int32_t n_blocks_sweep2 = 0;
     int32_t n_blocks_sweep = 0;        // grid size of launch 0
     bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)
     std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)

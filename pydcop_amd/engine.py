@@ -24,7 +24,7 @@ ABI_SYMBOLS = (
     "mxs_device_count", "mxs_create", "mxs_reset", "mxs_run", "mxs_run_timed",
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
-    "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
+    "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
     "mxs_debug_timeline", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
 
@@ -102,6 +102,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
         "mxs_halo_bind": ([vp, vp, vp], C.c_int),
+        "mxs_step_compute": ([vp], C.c_int),
         "mxs_step_pack": ([vp], C.c_int),
         "mxs_step_unpack": ([vp], C.c_int),
         "mxs_stream": ([vp, C.POINTER(vp)], C.c_int),
@@ -233,6 +234,9 @@ class MaxSumEngine:
         """Pack into / unpack from caller-owned device buffers (the tensors the
         collective runs on)."""
         self._check(self._lib.mxs_halo_bind(self._h, C.c_void_p(send_ptr), C.c_void_p(recv_ptr)))
+
+    def step_compute(self):
+        self._check(self._lib.mxs_step_compute(self._h))
 
     def step_pack(self):
         self._check(self._lib.mxs_step_pack(self._h))

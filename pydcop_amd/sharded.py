@@ -6,14 +6,17 @@ The reference's counterpart is message passing between agents
 (pydcop/infrastructure/communication.py:588-698); here the only messages that
 leave a GPU are those of cut factors' remote variables:
 
-    cycle t:   sweep + pack   (engine stream; kernels of pydcop_amd/csrc)
-               all-to-all     (torch.distributed; backend "nccl" = RCCL over xGMI,
-                               enqueued behind the pack on the same stream)
-               unpack         (engine stream; scatters into the ghost records)
+    cycle t:   compute stream   variables + interior factors of cycle t, then -- once
+                                the exchange of cycle t-1 is unpacked -- the cut factors
+               comm stream      pack (after the variables of cycle t) -> all-to-all
+                                (torch.distributed; backend "nccl" = RCCL over xGMI)
+                                -> unpack into the ghost slots
 
 Both message directions of cycle t read only cycle t-1 (Jacobi schedule), so one
-exchange per cycle is enough and a suppressed (unsent) message needs no special
-case: the sender's record simply still holds the old value.
+exchange per cycle is enough, a suppressed (unsent) message needs no special case
+(the sender's record simply still holds the old value), and -- because only the cut
+factors of cycle t+1 read what the exchange of cycle t delivers -- the exchange has
+a whole cycle of other work to hide behind.
 """
 from typing import Optional, Tuple
 
@@ -59,7 +62,7 @@ class ShardedMaxSum:
         self._stream_ctx = None
         if self._on_gpu:
             # torch's collectives order themselves against the *current* stream:
-            # make that the engine's own stream
+            # make that the engine's comm stream
             self._ext_stream = torch.cuda.ExternalStream(self.engine.stream(), device=tdev)
         if self._on_gpu:
             torch.cuda.synchronize(tdev)
@@ -84,6 +87,7 @@ class ShardedMaxSum:
 
     def run_async(self, n_cycles: int):
         for _ in range(int(n_cycles)):
+            self.engine.step_compute()
             self.engine.step_pack()
             self._exchange()
             self.engine.step_unpack()

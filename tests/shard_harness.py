@@ -78,6 +78,7 @@ class LocalShards:
     def run(self, n):
         for _ in range(n):
             for e in self.engines:
+                e.step_compute()
                 e.step_pack()
             self._exchange()
 
