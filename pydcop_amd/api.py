@@ -1,0 +1,72 @@
+"""Direct API: solve a pyDCOP `DCOP` object (or a YAML file) on the GPU without agents.
+
+`pydcop.infrastructure.run.solve` (pydcop/infrastructure/run.py:49) deploys one
+computation per node on agent threads and lets an orchestrator collect the values;
+with `maxsum_gpu` those computations are proxies and the work is one engine anyway
+(pydcop_amd/algorithms/maxsum_gpu.py).  This entry point goes straight from the DCOP
+to the engine -- O(E) graph build, flat arrays, T cycles, values back -- and reports
+with the reference's own `DCOP.solution_cost` (pydcop/dcop/dcop.py:308-367).
+pyDCOP must be importable; nothing of it is modified.
+"""
+from typing import Dict, List, Optional, Tuple
+
+import numpy as np
+
+from .compile import assignment_to_values, compile_nodes
+from .graph import FlatGraph, Params
+
+
+def compile_dcop(dcop, noise: float = 0.0, seed: int = 0) -> FlatGraph:
+    """DCOP -> FlatGraph in the node / links order the reference's factor graph has
+    (pydcop/computations_graph/factor_graph.py:245-296), built in O(E)."""
+    from . import plugin
+    plugin.install()
+    from pydcop.computations_graph import factor_graph_fast
+    cg = factor_graph_fast.build_computation_graph(dcop)
+    var_nodes = [n for n in cg.nodes if n.type == "VariableComputation"]
+    factor_nodes = [n for n in cg.nodes if n.type == "FactorComputation"]
+    return compile_nodes(var_nodes, factor_nodes, noise=noise, rng=np.random.default_rng(seed))
+
+
+def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: str = "both",
+               stability: float = 0.1, noise: float = 0.01, start_messages: str = "leafs",
+               precision: str = "f64", seed: int = 0, infinity: float = 10000, device: int = 0,
+               cost_every: int = 0, lib_path: Optional[str] = None) -> Dict:
+    """Synchronous Max-Sum for exactly `cycles` cycles; parameters and defaults are those
+    of `pydcop.algorithms.maxsum` (maxsum.py:212-220), `infinity` that of
+    `pydcop.infrastructure.run.solve` (run.py:49).
+
+    Returns {"assignment", "cost", "violation", "cycle", "cost_curve"}: the first three
+    as `DCOP.solution_cost` computes them for the selected values; `cost_curve` (when
+    `cost_every` > 0) = [(cycle, cost, violations)] evaluated on the device every
+    `cost_every` cycles (the reference's `--collect_on cycle_change`,
+    pydcop/commands/solve.py:356-376, without leaving the GPU)."""
+    from .engine import MaxSumEngine
+    graph = compile_dcop(dcop, noise=noise, seed=seed)
+    params = Params(mode=dcop.objective, damping=damping, damping_nodes=damping_nodes,
+                    stability=stability, start_messages=start_messages, dtype=precision)
+    curve: List[Tuple[int, float, int]] = []
+    with MaxSumEngine(graph, params, device=device, lib_path=lib_path) as eng:
+        done = 0
+        while done < cycles:
+            n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
+            eng.run(n)
+            done += n
+            if cost_every > 0:
+                c, v = eng.eval_cost(infinity=infinity)
+                curve.append((done, c, v))
+        idx, _ = eng.assignment()
+    assignment = assignment_to_values(graph, idx)
+    violation, cost = dcop.solution_cost(assignment, infinity)
+    return {"assignment": assignment, "cost": cost, "violation": violation, "cycle": cycles,
+            "cost_curve": curve}
+
+
+def solve_yaml(paths, cycles: int = 30, **kw) -> Dict:
+    """`solve_dcop` on DCOP YAML file(s) (pydcop/dcop/yamldcop.py:96)."""
+    from . import plugin
+    plugin.install()
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    if isinstance(paths, str):
+        paths = [paths]
+    return solve_dcop(load_dcop_from_file(list(paths)), cycles, **kw)

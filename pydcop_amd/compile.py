@@ -14,22 +14,98 @@ import numpy as np
 from .graph import FlatGraph
 
 
+_TABLE_CACHE = {}       # (code of the cost function, domains in scope order) -> table
+_TABLE_CACHE_MAX = 4096
+
+
+def _function_key(constraint, dims):
+    """Identity of an intentional constraint up to the NAMES of its variables: two
+    constraints whose cost functions have the same code, the same constants and
+    globals, the same fixed parameters and the same domains in scope order have the
+    same table (a 200 000-factor colouring instance has one `1 if a == b else 0`)."""
+    f = getattr(constraint, "_f", None)
+    fn = getattr(f, "exp_func", None)
+    code = getattr(fn, "__code__", None)
+    if code is None or getattr(fn, "__closure__", None):
+        return None
+    try:
+        argnames = code.co_varnames[:code.co_argcount]
+        pos = {v.name: i for i, v in enumerate(dims)}
+        if set(argnames) != set(pos) or getattr(f, "_fixed_vars", None):
+            return None
+        # scope position of every argument: the function sees the domains in that order
+        arg_pos = tuple(pos[a] for a in argnames)
+        doms = tuple(tuple(v.domain) for v in dims)
+        return (code.co_code, code.co_consts, code.co_names, arg_pos, doms,
+                getattr(f, "_source_file", None))
+    except TypeError:  # unhashable domain values
+        return None
+
+
+def _vectorised_table(constraint, dims, shape):
+    """Evaluate an expression-based constraint on broadcast numpy arrays of the domain
+    values (one call instead of one per entry).  Returns None when the expression
+    does not vectorise (conditional expressions, non-numeric domains, ...); the result
+    is checked against scalar evaluation on sampled entries before it is trusted."""
+    f = getattr(constraint, "_f", None)
+    fn = getattr(f, "exp_func", None)
+    if fn is None or getattr(f, "_fixed_vars", None):
+        return None
+    try:
+        grids = {}
+        for i, v in enumerate(dims):
+            vals = np.asarray(list(v.domain))
+            if vals.dtype.kind not in "iuf":
+                return None
+            sh = [1] * len(dims)
+            sh[i] = len(vals)
+            grids[v.name] = vals.reshape(sh).astype(np.float64 if vals.dtype.kind == "f" else np.int64)
+        with np.errstate(all="ignore"):
+            out = fn(**grids)
+        out = np.broadcast_to(np.asarray(out, dtype=np.float64), shape).copy()
+    except Exception:
+        return None
+    # trust, but verify: corners + a few pseudo-random entries through the scalar path
+    names = [v.name for v in dims]
+    size = int(np.prod(shape))
+    probe = {0, size - 1} | {(k * 2654435761) % size for k in range(1, 15)}
+    for lin in probe:
+        idx = np.unravel_index(lin, shape)
+        want = constraint(**{n: dims[i].domain[int(j)] for i, (n, j) in enumerate(zip(names, idx))})
+        got = out[idx]
+        if not (got == want or (np.isnan(got) and want != want)):
+            return None
+    return out
+
+
 def tensorise_constraint(constraint) -> np.ndarray:
     """Dense cost tensor of a constraint, row-major over `constraint.dimensions`
     (pydcop/dcop/relations.py:682-690).  Extensional relations expose their
-    ndarray; anything else is enumerated once through `constraint(**assignment)`
-    (NB: the dimension order of an ExpressionFunction constraint is set order,
-    pydcop/utils/expressionfunction.py:74 -- always read `.dimensions`)."""
+    ndarray.  Intentional ones (NAryFunctionRelation, relations.py:456) are looked up
+    in a cache keyed by the function's code and the scope's domains, else evaluated on
+    broadcast arrays when the expression allows it, else enumerated once through
+    `constraint(**assignment)` -- the reference evaluates them that way on EVERY
+    message (relations.py:735-810).  NB: the dimension order of an ExpressionFunction
+    constraint is set order, pydcop/utils/expressionfunction.py:74: always read
+    `.dimensions`."""
     dims = list(constraint.dimensions)
     shape = tuple(len(v.domain) for v in dims)
     m = getattr(constraint, "_m", None)
     if isinstance(m, np.ndarray) and m.shape == shape:
         return np.ascontiguousarray(m, dtype=np.float64)
-    names = [v.name for v in dims]
-    out = np.empty(shape, dtype=np.float64)
-    flat = out.reshape(-1)
-    for i, values in enumerate(itertools.product(*[list(v.domain) for v in dims])):
-        flat[i] = constraint(**dict(zip(names, values)))
+    key = _function_key(constraint, dims)
+    if key is not None and key in _TABLE_CACHE:
+        return _TABLE_CACHE[key]
+    out = _vectorised_table(constraint, dims, shape)
+    if out is None:
+        names = [v.name for v in dims]
+        out = np.empty(shape, dtype=np.float64)
+        flat = out.reshape(-1)
+        for i, values in enumerate(itertools.product(*[list(v.domain) for v in dims])):
+            flat[i] = constraint(**dict(zip(names, values)))
+    if key is not None and len(_TABLE_CACHE) < _TABLE_CACHE_MAX:
+        out.setflags(write=False)
+        _TABLE_CACHE[key] = out
     return out
 
 

@@ -53,7 +53,10 @@ enum Kind : int32_t {
                     // staged in LDS (own launch)
 };
 
-constexpr int BLOCK = 256;
+#ifndef MXS_BLOCK
+#define MXS_BLOCK 256  // threads per workgroup of the sweep (other values: experiments only)
+#endif
+constexpr int BLOCK = MXS_BLOCK;
 constexpr int MAX_REG_D = 4;
 constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments

@@ -41,13 +41,28 @@ def _compat_shims():
                 sys.modules[mod] = _Permissive(mod)
 
 
-def install():
-    """Append pydcop_amd/algorithms to pydcop.algorithms.__path__ (idempotent)."""
+def install(fast_graph=None):
+    """Append pydcop_amd/algorithms to pydcop.algorithms.__path__ and
+    pydcop_amd/computations_graph to pydcop.computations_graph.__path__ (idempotent).
+
+    fast_graph=True (or $MAXSUM_GPU_GRAPH=fast) makes `maxsum_gpu` use the O(E)
+    builder `factor_graph_fast` instead of the reference's O(V*F)
+    `factor_graph.build_computation_graph`; the graph it returns is the same."""
     _compat_shims()
     import pydcop.algorithms as algos
-    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "algorithms")
+    import pydcop.computations_graph as graphs
+    base = os.path.dirname(os.path.abspath(__file__))
+    here = os.path.join(base, "algorithms")
     if here not in list(algos.__path__):
         algos.__path__.append(here)
+    gdir = os.path.join(base, "computations_graph")
+    if gdir not in list(graphs.__path__):
+        graphs.__path__.append(gdir)
+    if fast_graph is None:
+        fast_graph = os.environ.get("MAXSUM_GPU_GRAPH", "") == "fast"
+    if fast_graph:
+        from pydcop.algorithms import load_algorithm_module
+        load_algorithm_module("maxsum_gpu").GRAPH_TYPE = "factor_graph_fast"
     return here
 
 

@@ -1,0 +1,149 @@
+"""SURVEY.md section 8(f).1 -- the O(E) front-end: `factor_graph_fast` builds the SAME
+computation graph as the reference's O(V*F) builder, tensorisation through the cache /
+vectorised path gives the same tables as entry-by-entry evaluation, and the direct API
+reproduces the reference's results (emulated engine: no GPU here).  Needs the reference
+checkout (build container only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("PYDCOP_REFERENCE", "/root/reference")
+INST = os.path.join(REF, "tests", "instances")
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pydcop")),
+                                reason="the pyDCOP reference checkout is not on this machine")
+
+INSTANCES = ["graph_coloring1.yaml", "graph_coloring_tuto.yaml", "secp_simple1.yaml",
+             "graph_coloring_10_4_15_0.1.yml", "graph_coloring_3agts_10vars.yaml"]
+
+
+@pytest.fixture(scope="module")
+def pydcop_ready():
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+    from pydcop_amd import plugin
+    plugin.install()
+    return plugin
+
+
+def _load(name):
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    return load_dcop_from_file([os.path.join(INST, name)])
+
+
+@pytest.mark.parametrize("name", INSTANCES)
+def test_fast_graph_equals_reference_graph(pydcop_ready, name):
+    from pydcop.computations_graph import factor_graph, factor_graph_fast
+    dcop = _load(name)
+    ref = factor_graph.build_computation_graph(dcop)
+    fast = factor_graph_fast.build_computation_graph(dcop)
+    assert [n.name for n in fast.nodes] == [n.name for n in ref.nodes]
+    for a, b in zip(fast.nodes, ref.nodes):
+        assert type(a) is type(b) and a.type == b.type
+        assert [(l.factor_node, l.variable_node) for l in a.links] == \
+               [(l.factor_node, l.variable_node) for l in b.links]
+        assert list(a.neighbors) == list(b.neighbors)
+        assert fast.computation(a.name) is a
+        assert list(fast.neighbors(a.name)) == list(ref.neighbors(a.name))
+        assert list(fast.links_for_node(a.name)) == list(ref.links_for_node(a.name))
+    assert fast.links == ref.links and fast.density() == ref.density()
+    with pytest.raises(KeyError):
+        fast.computation("no_such_node")
+
+
+def test_fast_graph_argument_contract(pydcop_ready):
+    from pydcop.computations_graph import factor_graph_fast
+    dcop = _load("graph_coloring1.yaml")
+    with pytest.raises(ValueError):
+        factor_graph_fast.build_computation_graph(dcop, variables=list(dcop.variables.values()))
+    with pytest.raises(ValueError):
+        factor_graph_fast.build_computation_graph(None, variables=list(dcop.variables.values()))
+    g = factor_graph_fast.build_computation_graph(None, variables=dcop.variables.values(),
+                                                  constraints=dcop.constraints.values())
+    assert len(g.nodes) == len(dcop.variables) + len(dcop.constraints)
+
+
+@pytest.mark.parametrize("name", INSTANCES)
+def test_tensorisation_paths_agree(pydcop_ready, name):
+    """cache / vectorised evaluation == the reference's entry-by-entry evaluation."""
+    import itertools
+    from pydcop_amd import compile as comp
+    dcop = _load(name)
+    comp._TABLE_CACHE.clear()
+    for _ in range(2):  # second pass is served from the cache
+        for c in dcop.constraints.values():
+            t = comp.tensorise_constraint(c)
+            dims = list(c.dimensions)
+            assert t.shape == tuple(len(v.domain) for v in dims)
+            for idx in itertools.islice(itertools.product(*[range(len(v.domain)) for v in dims]), 0, 700):
+                want = c(**{v.name: v.domain[i] for v, i in zip(dims, idx)})
+                assert t[idx] == want
+
+
+def test_vectorised_expression_and_cache_key(pydcop_ready):
+    from pydcop.dcop.objects import Domain, Variable
+    from pydcop.dcop.relations import constraint_from_str
+    from pydcop_amd import compile as comp
+    d = Domain("d", "", [0, 1, 2, 3, 4, 5])
+    x, y, z, w = (Variable(n, d) for n in "xyzw")
+    comp._TABLE_CACHE.clear()
+    c1 = constraint_from_str("c1", "abs(x - y) * 0.5 + x", [x, y])
+    t1 = comp.tensorise_constraint(c1)          # arithmetic: goes through numpy broadcasting
+    pos = {v.name: i for i, v in enumerate(c1.dimensions)}
+    for a in range(6):
+        for b in range(6):
+            idx = [0, 0]
+            idx[pos["x"]], idx[pos["y"]] = a, b
+            assert t1[tuple(idx)] == abs(a - b) * 0.5 + a
+    n_before = len(comp._TABLE_CACHE)
+    same = constraint_from_str("c1b", "abs(x - y) * 0.5 + x", [Variable("x", d), Variable("y", d)])
+    assert comp.tensorise_constraint(same) is t1                     # same code + domains: cache hit
+    assert len(comp._TABLE_CACHE) == n_before
+    c2 = constraint_from_str("c2", "abs(z - w) * 0.5 + z", [z, w])   # other names (maybe other
+    t2 = comp.tensorise_constraint(c2)                               # argument order): still right
+    posz = {v.name: i for i, v in enumerate(c2.dimensions)}
+    for a in range(6):
+        for b in range(6):
+            idx = [0, 0]
+            idx[posz["z"]], idx[posz["w"]] = a, b
+            assert t2[tuple(idx)] == abs(a - b) * 0.5 + a
+    c3 = constraint_from_str("c3", "10 if x == y else 0", [x, y])    # does not vectorise
+    t3 = comp.tensorise_constraint(c3)
+    assert np.array_equal(t3, 10.0 * np.eye(6))
+
+
+@pytest.mark.parametrize("name,expected,cost", [
+    ("graph_coloring1.yaml", {"v1": "R", "v2": "G", "v3": "R"}, -0.1),
+    ("secp_simple1.yaml", {"l1": 0, "l2": 3, "l3": 4, "m1": 3}, None),
+    ("graph_coloring_tuto.yaml", None, 12),
+])
+def test_direct_api_reproduces_reference_results(pydcop_ready, name, expected, cost):
+    """SURVEY.md section 8c golden results through pydcop_amd.api (emulated engine)."""
+    from emu.build_emu import build
+    from pydcop_amd.api import solve_yaml
+    res = solve_yaml(os.path.join(INST, name), cycles=20, noise=0, lib_path=build(),
+                     cost_every=5, infinity=float("inf"))
+    if expected is not None:
+        assert res["assignment"] == expected
+    if cost is not None:
+        assert abs(res["cost"] - cost) < 1e-9
+    assert res["violation"] == 0 and res["cycle"] == 20
+    assert [c[0] for c in res["cost_curve"]] == [5, 10, 15, 20]
+    assert abs(res["cost_curve"][-1][1] - res["cost"]) < 1e-9   # device cost == DCOP.solution_cost
+
+
+def test_plugin_uses_fast_graph_when_asked(pydcop_ready):
+    from pydcop.algorithms import load_algorithm_module
+    mod = load_algorithm_module("maxsum_gpu")
+    old = mod.GRAPH_TYPE
+    try:
+        pydcop_ready.install(fast_graph=True)
+        assert mod.GRAPH_TYPE == "factor_graph_fast"
+        from importlib import import_module
+        gm = import_module("pydcop.computations_graph." + mod.GRAPH_TYPE)
+        assert hasattr(gm, "build_computation_graph")
+    finally:
+        mod.GRAPH_TYPE = old
