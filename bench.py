@@ -142,6 +142,10 @@ def main():
         from pydcop_amd.sharded import ShardedMaxSum
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        # one node: RCCL bootstraps over loopback, no InfiniBand probing (the container's
+        # hostname may not resolve); respected only if the launcher did not set them
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group("nccl")
         runner = ShardedMaxSum(graph, params, rank, world, device=local_rank)
         barrier = dist.barrier

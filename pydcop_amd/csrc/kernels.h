@@ -739,17 +739,21 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // that the previous messages arrive with one round of parallel loads.
     // phase 1: damp, compare with the message sent last
     for (int idx = tid; idx < sumd; idx += NT) {
-        int i = 0;
-#pragma unroll
+        int i = 0, off_i = 0, fo_i = fd.f2v_off[0];  // selects, not indexed loads: the
+#pragma unroll                                       // descriptor stays in registers
         for (int ii = 1; ii < A; ++ii)
-            if (idx >= off[ii]) i = ii;
-        const int d = idx - off[i];
+            if (idx >= off[ii]) {
+                i = ii;
+                off_i = off[ii];
+                fo_i = fd.f2v_off[ii];
+            }
+        const int d = idx - off_i;
         T m = OrdKey<T>::dec(s_key[idx]);
         if (a.start) {  // only start_messages == all makes a non-unary factor send
             s_msg[idx] = a.start_mode == MXS_START_ALL ? m : (T)0;
             continue;
         }
-        const T p = a.f2v_old[fd.f2v_off[i] + d];
+        const T p = a.f2v_old[fo_i + d];
         const int cnt = a.cF[fd.edge_base + i];
         if (cnt > 0 && a.damp_f) m = a.damping * p + ((T)1 - a.damping) * m;
         if (cnt > 0 && !comp_match(m, p, a.stability)) s_nomatch[i] = 1;  // same value from all writers
@@ -760,13 +764,17 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     __syncthreads();
     // phase 2: send / send again / stay silent (the receiver keeps the old message)
     for (int idx = tid; idx < sumd; idx += NT) {
-        int i = 0;
+        int i = 0, off_i = 0, fo_i = fd.f2v_off[0];
 #pragma unroll
         for (int ii = 1; ii < A; ++ii)
-            if (idx >= off[ii]) i = ii;
-        const int d = idx - off[i];
+            if (idx >= off[ii]) {
+                i = ii;
+                off_i = off[ii];
+                fo_i = fd.f2v_off[ii];
+            }
+        const int d = idx - off_i;
         const int e = fd.edge_base + i;
-        T* w = a.f2v_new + fd.f2v_off[i];
+        T* w = a.f2v_new + fo_i;
         if (a.start) {
             w[d] = s_msg[idx];
             if (d == 0) a.cF[e] = 0;
@@ -869,6 +877,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     constexpr bool STAGE_PREV = CAP <= WIDE_CAP_SMALL;
     __shared__ T s_in[WIDE_VARS][CAP];
     __shared__ T s_prev[WIDE_VARS][STAGE_PREV ? CAP : 1];
+    __shared__ T s_c[WIDE_VARS][WIDE_MAX_D];   // the variable's own costs
     __shared__ T s_avg[WIDE_VARS][CAP / 4];
     __shared__ int s_vo[WIDE_VARS][CAP / 4];   // per outgoing edge: V2F offset,
     __shared__ int s_cn[WIDE_VARS][CAP / 4];   // send counter
@@ -881,11 +890,9 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     const int k0 = a.vrowptr[v], deg = a.vrowptr[v + 1] - k0;
     const T* c = a.var_cost + a.vcost_off[v];
     T* in = s_in[w];
-    constexpr int NR = WIDE_MAX_D / 64;
-    T cv[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) cv[r] = lane + 64 * r < D ? c[lane + 64 * r] : (T)0;
     // stage what this variable holds: every load of a round is in flight together
+    // (no per-lane arrays anywhere below: everything indexed lives in LDS)
+    for (int d = lane; d < D; d += 64) s_c[w][d] = c[d];
     for (int idx = lane; idx < deg * D; idx += 64) {
         const int k = idx / D, d = idx - k * D;
         in[idx] = a.f2v_old[a.vslot_f2v[k0 + k] + d];
@@ -899,15 +906,11 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     // belief and selection: first index attaining the minimum
     T bb = pos_inf<T>();
     int bi = 0x7fffffff;
-#pragma unroll
-    for (int r = 0; r < NR; ++r) {
-        const int d = lane + 64 * r;
-        if (d < D) {
-            const T b = wide_sum_edges<T>(cv[r], in, D, deg, d, -1);
-            if (bi == 0x7fffffff || b < bb) {
-                bb = b;
-                bi = d;
-            }
+    for (int d = lane; d < D; d += 64) {
+        const T b = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, -1);
+        if (bi == 0x7fffffff || b < bb) {
+            bb = b;
+            bi = d;
         }
     }
 #pragma unroll
@@ -932,43 +935,27 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
     __builtin_amdgcn_wave_barrier();
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
                              a.start_mode != MXS_START_LEAFS;
-    T pv[NR], pn[NR];
-#pragma unroll
-    for (int r = 0; r < NR; ++r) pv[r] = pn[r] = (T)0;
-    if (!STAGE_PREV && !a.start) {  // the first outgoing edge's previous message
-        const int vo = s_vo[w][0];
-#pragma unroll
-        for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? a.v2f_old[vo + lane + 64 * r] : (T)0;
-    }
+    const bool single = D <= 64;  // one domain value per lane: the new message stays in a register
     for (int ko = 0; ko < deg; ++ko) {
-        if (STAGE_PREV) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) pv[r] = lane + 64 * r < D ? s_prev[w][ko * D + lane + 64 * r] : (T)0;
-        } else if (!a.start && ko + 1 < deg) {  // request the next edge's before working on this one
-            const int vn = s_vo[w][ko + 1];
-#pragma unroll
-            for (int r = 0; r < NR; ++r) pn[r] = lane + 64 * r < D ? a.v2f_old[vn + lane + 64 * r] : (T)0;
-        }
         const T avg = s_avg[w][ko];
         const int cnt = s_cn[w][ko];
-        T* wout = a.v2f_new + s_vo[w][ko];
+        const int vo = s_vo[w][ko];
         const bool damp = cnt > 0 && a.damp_v;
-        T mv[NR];
+        // pass 1: the new message, damped, against the one sent last
         bool nomatch = false;
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int d = lane + 64 * r;
-            mv[r] = (T)0;
-            if (d < D) {
-                T m = wide_sum_edges<T>(cv[r], in, D, deg, d, ko) - avg;
-                if (a.start) {
-                    m = start_sends ? m : (T)0;
-                } else {
-                    if (damp) m = a.damping * pv[r] + ((T)1 - a.damping) * m;
-                    if (!comp_match(m, pv[r], a.stability)) nomatch = true;
-                }
-                mv[r] = m;
+        T m_keep = (T)0, p_keep = (T)0;
+        for (int d = lane; d < D; d += 64) {
+            T m = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, ko) - avg;
+            T p = (T)0;
+            if (a.start) {
+                m = start_sends ? m : (T)0;
+            } else {
+                p = STAGE_PREV ? s_prev[w][ko * D + d] : a.v2f_old[vo + d];
+                if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+                if (!comp_match(m, p, a.stability)) nomatch = true;
             }
+            m_keep = m;
+            p_keep = p;
         }
         const bool any_nomatch = __ballot(nomatch ? 1 : 0) != 0;  // over the wave
         int out = 1;
@@ -983,16 +970,23 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassIn
                 keep_old = true;  // not sent: the receiver keeps the old message
             }
         }
-#pragma unroll
-        for (int r = 0; r < NR; ++r) {
-            const int d = lane + 64 * r;
-            if (d < D) wout[d] = keep_old ? pv[r] : mv[r];
+        // pass 2: write what the receiver holds after this cycle (wider domains recompute
+        // the element: same expression, same bits)
+        T* wout = a.v2f_new + vo;
+        for (int d = lane; d < D; d += 64) {
+            T m = m_keep, p = p_keep;
+            if (!single) {
+                m = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, ko) - avg;
+                if (a.start) {
+                    m = start_sends ? m : (T)0;
+                } else {
+                    p = STAGE_PREV ? s_prev[w][ko * D + d] : a.v2f_old[vo + d];
+                    if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+                }
+            }
+            wout[d] = keep_old ? p : m;
         }
         if (lane == 0) a.cV[k0 + ko] = (uint8_t)out;
-        if (!STAGE_PREV) {
-#pragma unroll
-            for (int r = 0; r < NR; ++r) pv[r] = pn[r];
-        }
     }
 }
 

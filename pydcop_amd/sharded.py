@@ -47,7 +47,8 @@ class ShardedMaxSum:
         self.shard: Shard = build_shard(graph, self.part, rank, world)
         self.engine = MaxSumEngine(self.shard.graph, self.params, device=device, lib_path=lib_path)
         self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
-        backend = dist.get_backend(group) if world > 1 else "none"
+        backend = dist.get_backend(group) if dist.is_initialized() else "none"
+        self._backend = backend
         self._on_gpu = backend == "nccl"
         tdtype = torch.float64 if self.params.dtype == "f64" else torch.float32
         tdev = torch.device("cuda", device) if self._on_gpu else torch.device("cpu")
@@ -73,17 +74,24 @@ class ShardedMaxSum:
 
     # -- the per-cycle exchange ------------------------------------------------------
     def _exchange(self):
-        if self.world == 1:
-            return
+        if self._backend == "none":
+            return  # a single engine without torch.distributed: nothing crosses
         torch, dist = self._torch, self._dist
         send = self._send[:self._n_send]
         recv = self._recv[:self._n_recv]
+        if self.world == 1:
+            # nothing crosses either, but keep the collective in the stream (one padding
+            # element to itself): the single-GPU test then runs the same RCCL code path
+            send, recv = self._send[:1], self._recv[:1]
+            splits = ([1], [1])
+        else:
+            splits = (self._recv_splits, self._send_splits)
         if self._on_gpu:
             with torch.cuda.stream(self._ext_stream):
-                dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
+                dist.all_to_all_single(recv, send, splits[0], splits[1], group=self.group)
         else:
             self.engine.sync()
-            dist.all_to_all_single(recv, send, self._recv_splits, self._send_splits, group=self.group)
+            dist.all_to_all_single(recv, send, splits[0], splits[1], group=self.group)
 
     def run_async(self, n_cycles: int):
         for _ in range(int(n_cycles)):

@@ -114,6 +114,9 @@ def rank_main(argv):
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":
         torch.cuda.set_device(0)
+        # single node: bootstrap over loopback, no InfiniBand probing
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
     dist.init_process_group(backend, rank=rank, world_size=world)
     g, kw = make_case(case)
     run = ShardedMaxSum(g, Params(**kw), rank, world, device=0, lib_path=lib)

@@ -45,3 +45,27 @@ def test_product_does_not_import_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
                 assert "maxsum_oracle" not in src.replace("oracle/maxsum_oracle.c", ""), f
+
+
+def test_no_kernel_uses_scratch():
+    """all per-item state lives in registers / LDS.  A kernel that
+    indexes a local array dynamically silently gets scratch memory (= extra HBM traffic:
+    the n-ary kernel once wrote 644 MB per cycle that way); the compiler's resource
+    report must show 0 bytes for every kernel."""
+    import re
+    import shutil
+    import subprocess
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    csrc = os.path.join(ROOT, "pydcop_amd", "csrc")
+    out = subprocess.run(
+        [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+         "-fno-fast-math", "-Rpass-analysis=kernel-resource-usage", "-c", "engine.hip", "-o", os.devnull],
+        cwd=csrc, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-2000:]
+    names = re.findall(r"Function Name: (\S+)", out.stderr)
+    scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) and len(names) >= 20
+    bad = [(n, s) for n, s in zip(names, scratch) if s != 0]
+    assert not bad, f"kernels using scratch: {bad}"
