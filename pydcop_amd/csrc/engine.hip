@@ -178,11 +178,20 @@ struct Engine : EngineBase {
     int launch_sweep(const SweepArgs<T>& a, int nb) {
         if (nb <= 0) return MXS_OK;
         const dim3 grid(nb), block(BLOCK);
-        switch (L.dsel) {
-            case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
-            case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
-            case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
-            default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
+        if (a.timeline != nullptr) {  // profiling twin
+            switch (L.dsel) {
+                case 2: hipLaunchKernelGGL((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
+                default: hipLaunchKernelGGL((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
+            }
+        } else {
+            switch (L.dsel) {
+                case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
+                default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
+            }
         }
         HIP_TRY(hipGetLastError());
         return MXS_OK;
