@@ -159,6 +159,12 @@ int mxs_eval_cost(mxs_engine *e, const int32_t *idx, double infinity,
 int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
                     int32_t *launches_per_cycle);
 
+/* Replace the cost table of factor `factor` (caller's factor index) by one of the
+ * same shape, row-major over its scope; messages, counters and the selection
+ * carry on from where they are: change_factor_function of
+ * pydcop/algorithms/maxsum_dynamic.py:80-104 without rebuilding the graph. */
+int mxs_update_factor_table(mxs_engine *e, int32_t factor, const double *table, int64_t n_entries);
+
 /* Profiling only: run ONE more cycle in which every block of the sweep launch
  * records {start, end} (wall_clock64 ticks, 100 MHz) and its class kind;
  * out[3*b .. 3*b+2] for block b, `cap` = blocks the buffer can hold.  out == NULL

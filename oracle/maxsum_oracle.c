@@ -369,6 +369,16 @@ void mso_set_v2f(mso_state *s, int32_t e, const double *msg, uint8_t cnt) {
     s->cnt_v[s->cur][e] = cnt;
 }
 
+/* change_factor_function, pydcop/algorithms/maxsum_dynamic.py:80-104: same scope,
+ * new costs; the messages carry on. */
+void mso_update_table(mso_state *s, int32_t f, const double *table) {
+    const int64_t lo = s->table_off[f], hi = s->table_off[f + 1];
+    for (int64_t k = lo; k < hi; ++k) {
+        s->tables64[k] = table[k - lo];
+        s->tables[k] = (real)table[k - lo];
+    }
+}
+
 /* solution_cost, pydcop/dcop/dcop.py:319-367: always f64, host tables. */
 void mso_eval_cost(const mso_state *s, const int32_t *idx, double infinity, double *cost,
                    int64_t *violations) {

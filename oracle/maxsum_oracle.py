@@ -44,6 +44,7 @@ def _lib(dtype):
         lib.mso_set_v2f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint8]
         lib.mso_eval_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_double,
                                       C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.mso_update_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         lib.mso_destroy.argtypes = [C.c_void_p]
         _LIBS[dtype] = lib
     return _LIBS[dtype]
@@ -88,6 +89,10 @@ class OracleMaxSum:
     def set_v2f(self, edge: int, msg, cnt: int):
         msg = np.ascontiguousarray(msg, dtype=np.float64)
         self._lib.mso_set_v2f(self._h, int(edge), msg.ctypes.data, int(cnt))
+
+    def update_factor_table(self, factor: int, table):
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        self._lib.mso_update_table(self._h, int(factor), t.ctypes.data)
 
     def eval_cost(self, idx=None, infinity=float("inf")):
         cost, viol = C.c_double(), C.c_int64()

@@ -177,6 +177,17 @@ class _Session:
             if self.error:
                 raise self.error
 
+    def update_factor(self, name, old, fn):
+        """Tensorise `fn` in the scope order of the factor it replaces and upload it."""
+        from pydcop_amd.compile import tensorise_constraint
+        with self.lock:
+            if self.engine is None:
+                raise ComputationException("maxsum_gpu: the engine is not running")
+            t = tensorise_constraint(fn)
+            src = [v.name for v in fn.dimensions]
+            t = np.transpose(t, [src.index(v.name) for v in old.dimensions])
+            self.engine.update_factor_table(self.graph.factor_names.index(name), t)
+
     def value_of(self, name):
         i = self.var_index[name]
         return self.graph.domains[i][int(self.idx[i])], float(self.belief[i])
@@ -267,6 +278,17 @@ class MaxSumGpuFactorComputation(_ProxyMixin, DcopComputation):
     def __init__(self, comp_def: ComputationDef):
         super().__init__(comp_def.node.factor.name, comp_def)
         self._init_proxy(comp_def)
+
+    def change_factor_function(self, fn):
+        """New cost function over the same variables
+        (pydcop/algorithms/maxsum_dynamic.py:80-104): its table replaces the old one on
+        the device, the iteration carries on."""
+        factor = self.computation_def.node.factor
+        if len(factor.dimensions) != len(fn.dimensions) or \
+                {v.name for v in factor.dimensions} != {v.name for v in fn.dimensions}:
+            raise ValueError("Dimensions must be the same when changing function in "
+                             "MaxSumGpuFactorComputation")
+        self._session.update_factor(self.name, factor, fn)
 
 
 class MaxSumGpuVariableComputation(_ProxyMixin, VariableComputation):

@@ -85,6 +85,7 @@ struct EngineBase {
     virtual int step_pack() = 0;
     virtual int step_unpack() = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
+    virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
     Layout L;
     mxs_params params{};
     int64_t cycles = 0;
@@ -559,6 +560,28 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    // change_factor_function (pydcop/algorithms/maxsum_dynamic.py:80-104): a factor gets a
+    // new cost table of the same shape; messages, counters and selections carry on.
+    int update_table(int32_t factor, const double* table, int64_t n) override {
+        HIP_TRY(hipSetDevice(device));
+        if (factor < 0 || factor >= L.n_factors) return fail(MXS_E_INVALID, "factor out of range");
+        const int fi = L.factor_e2i[factor];
+        const int64_t want = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
+        if (!table || n != want) return fail(MXS_E_INVALID, "the new table must have the shape of the old one");
+        { int rc = sync(); if (rc) return rc; }
+        const double sign = L.is_max ? -1.0 : 1.0;
+        std::vector<T> h((size_t)n);
+        for (int64_t k = 0; k < n; ++k) h[k] = (T)(sign * table[k]);
+        DevBuf<T> staging;
+        HIP_TRY(staging.upload(h, stream));
+        hipLaunchKernelGGL((k_table_update<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
+                           tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi], (const T*)staging.p, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(copy_sync(eval_tables.p + L.eval_tab_off[fi], table, sizeof(double) * (size_t)n,
+                          hipMemcpyHostToDevice, stream));  // also waits for the kernel above
+        return MXS_OK;
+    }
+
     // ---- halo -------------------------------------------------------------
     int build_elem_offsets(const int32_t* edges, int64_t n, std::vector<int64_t>& out) {
         out.clear();
@@ -775,6 +798,11 @@ int mxs_stream(mxs_engine* e, void** stream) {
 int mxs_debug_timeline(mxs_engine* e, int64_t* out, int32_t cap, int32_t* n_blocks) {
     CHECK_HANDLE(e);
     return e->impl->debug_timeline(out, cap, n_blocks);
+}
+
+int mxs_update_factor_table(mxs_engine* e, int32_t factor, const double* table, int64_t n) {
+    CHECK_HANDLE(e);
+    return e->impl->update_table(factor, table, n);
 }
 
 int mxs_destroy(mxs_engine* e) {

@@ -1110,6 +1110,14 @@ __global__ void __launch_bounds__(BLOCK) k_eval(EvalArgs a) {
 // dense send buffer / scatter the received ones into the ghost records.
 // One thread per (edge, d) element; `elem_edge`/`elem_d` are precomputed.
 // ---------------------------------------------------------------------------
+// mxs_update_factor_table: entry k of the new table -> tables[base + k * stride]
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_table_update(T* tables, int64_t base, int64_t stride,
+                                                        const T* src, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) tables[base + k * stride] = src[k];
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_halo_pack(const T* rec, const int64_t* elem_off, T* out,
                                                      int64_t n) {

@@ -149,6 +149,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(),
                      [&](int a, int b) { return fkey[a] < fkey[b]; });
 
+    L.factor_e2i.resize(nF);
+    for (int fi = 0; fi < nF; ++fi) L.factor_e2i[L.factor_i2e[fi]] = fi;
+    L.f_tab_base.assign(nF, 0);
+    L.f_tab_stride.assign(nF, 1);
+
     // ---- internal edges, F2V array (factor-major) ------------------------------
     L.edge_i2e.resize(nE);
     L.edge_e2i.resize(nE);
@@ -297,6 +302,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 const double* src = L.eval_tables.data() + L.eval_tab_off[fi + j];
                 for (int k = 0; k < entries; ++k)
                     L.tables[ci.tab_base + (int64_t)k * n + j] = sign * src[k];
+                L.f_tab_base[fi + j] = ci.tab_base + j;
+                L.f_tab_stride[fi + j] = n;
             }
             L.classes.push_back(ci);
             sweep_class(cls, BLOCK, key.cut);
@@ -308,6 +315,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 for (int e = L.frowptr[f2]; e < L.frowptr[f2 + 1]; ++e)
                     L.edge_gen_factor[e] = gen_base + j;
                 L.fgen.push_back(fg);
+                L.f_tab_base[f2] = L.eval_tab_off[f2];
+                L.f_tab_stride[f2] = 1;
                 for (int64_t k = L.eval_tab_off[f2]; k < L.eval_tab_off[f2 + 1]; ++k)
                     L.tables[k] = sign * L.eval_tables[k];
             }

@@ -133,6 +133,11 @@ struct Layout {
 
     // permutations (internal -> external)
     std::vector<int32_t> factor_i2e, var_i2e, edge_i2e;
+    std::vector<int32_t> factor_e2i;
+    // where entry k of internal factor fi lives in the device table image:
+    // f_tab_base[fi] + k * f_tab_stride[fi]  (mxs_update_factor_table)
+    std::vector<int64_t> f_tab_base;
+    std::vector<int32_t> f_tab_stride;
     std::vector<int32_t> var_e2i, edge_e2i;
 
     // classes of the sweep launch (the K_F_NARY groups have their own launches)

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
-    "mxs_debug_timeline", "mxs_destroy", "mxs_last_error", "mxs_version",
+    "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
 
 
@@ -107,6 +107,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_step_unpack": ([vp], C.c_int),
         "mxs_stream": ([vp, C.POINTER(vp)], C.c_int),
         "mxs_debug_timeline": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
+        "mxs_update_factor_table": ([vp, i32, vp, i64], C.c_int),
         "mxs_destroy": ([vp], C.c_int),
         "mxs_last_error": ([], C.c_char_p),
         "mxs_version": ([], i32),
@@ -206,6 +207,14 @@ class MaxSumEngine:
         b, n = C.c_int64(0), C.c_int32(0)
         self._check(self._lib.mxs_cycle_bytes(self._h, C.byref(b), C.byref(n)))
         return int(b.value), int(n.value)
+
+    def update_factor_table(self, factor: int, table):
+        """New cost table (same shape, row-major over the scope) for one factor; the
+        iteration carries on (maxsum_dynamic.py:80-104, change_factor_function)."""
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        self._check(self._lib.mxs_update_factor_table(self._h, int(factor), t.ctypes.data, t.shape[0]))
+        lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
+        self.graph.tables[lo:hi] = t  # keep the host copy of the graph in step
 
     def debug_timeline(self) -> np.ndarray:
         """Profiling: run one more cycle with per-block timestamps; returns an int64

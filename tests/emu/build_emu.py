@@ -17,7 +17,7 @@ def build(force=False):
             os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
-    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+    cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
            "-I", HERE, "-x", "c++", srcs[0], srcs[1], "-o", OUT]
     subprocess.check_call(cmd)
     return OUT

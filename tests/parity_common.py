@@ -118,3 +118,35 @@ def parity_cases():
         ("wide_hub_deg100", lambda: hub(21, nf=100, n=150), {"start_messages": "leafs_vars"}),
         ("nary_mixed_dims", lambda: G.random_mixed(40, 50, seed=19, max_arity=4, dom_choices=(3, 7, 10, 12)), {}),
     ]
+
+
+def check_table_updates(oracle_mod, graph, params: Params, lib_path=None, seed=0):
+    """mxs_update_factor_table (maxsum_dynamic.py:80-104, change_factor_function): new
+    tables for a tenth of the factors in the middle of a run, engine == oracle before and
+    after, and the solution cost follows the new tables."""
+    rng = np.random.default_rng(seed)
+    eng = MaxSumEngine(graph, params, lib_path=lib_path)
+    ora = oracle_mod.OracleMaxSum(graph, params)
+    eng.run(4), ora.run(4)
+    picks = rng.choice(graph.n_factors, size=max(1, graph.n_factors // 10), replace=False)
+    for f in picks:
+        n = int(graph.table_off[f + 1] - graph.table_off[f])
+        t = rng.integers(-5, 15, n).astype(np.float64)
+        eng.update_factor_table(int(f), t)
+        ora.update_factor_table(int(f), t)
+    for n in (1, 7):
+        eng.run(n), ora.run(n)
+        for x, y in zip(eng.messages(), ora.messages()):
+            np.testing.assert_array_equal(x, y)
+        np.testing.assert_array_equal(eng.assignment()[0], ora.assignment()[0])
+        np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
+        ce, co = eng.eval_cost(), ora.eval_cost()
+        assert ce[1] == co[1] and abs(ce[0] - co[0]) <= 1e-9 * max(1.0, abs(co[0]))
+    import pytest
+    from pydcop_amd.engine import MaxSumGpuError
+    with pytest.raises(MaxSumGpuError):
+        eng.update_factor_table(0, np.zeros(int(graph.table_off[1] - graph.table_off[0]) + 1))
+    with pytest.raises(MaxSumGpuError):
+        eng.update_factor_table(graph.n_factors, np.zeros(1))
+    eng.close()
+    ora.close()

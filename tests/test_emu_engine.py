@@ -12,7 +12,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_files, load_golden
-from parity_common import check_golden, compare_with_oracle, parity_cases
+from parity_common import check_table_updates, check_golden, compare_with_oracle, parity_cases
 from pydcop_amd.graph import Params
 
 
@@ -79,3 +79,11 @@ def test_emu_errors(emu_lib):
         e.eval_cost(np.full(g.n_vars, 7))
     with pytest.raises(MaxSumGpuError):
         e.run(-1)
+
+
+@pytest.mark.parametrize("case", [c for c in parity_cases() if c[0] in
+                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims")],
+                         ids=lambda c: c[0])
+def test_emu_table_updates(case, emu_lib, oracle_built):
+    name, make, kw = case
+    check_table_updates(oracle_built, make(), Params(**kw), lib_path=emu_lib)

@@ -13,7 +13,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_files, load_golden
-from parity_common import check_golden, compare_with_oracle, parity_cases
+from parity_common import check_table_updates, check_golden, compare_with_oracle, parity_cases
 from pydcop_amd import generators as G
 from pydcop_amd.engine import MaxSumEngine
 from pydcop_amd.graph import Params
@@ -122,3 +122,13 @@ def test_max_mode_is_negated_min_mode():
     a.run(30), b.run(30)
     np.testing.assert_array_equal(a.assignment()[0], b.assignment()[0])
     np.testing.assert_array_equal(a.assignment()[1], -b.assignment()[1])
+
+
+@pytest.mark.parametrize("case", [c for c in parity_cases() if c[0] in
+                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims")],
+                         ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_table_updates(case, dtype, oracle_built):
+    """change_factor_function (maxsum_dynamic.py:80-104) through mxs_update_factor_table."""
+    name, make, kw = case
+    check_table_updates(oracle_built, make(), Params(dtype=dtype, **kw))
