@@ -100,7 +100,12 @@ typedef struct mxs_params {
     double  stability;       /* maxsum.py:217, default 0.1                    */
     int32_t graph_chunk;     /* cycles captured per hipGraph replay; 0 = eager
                                 launches; <0 = engine default                 */
-    int32_t layout_flags;    /* tuning knobs (0 = default), see DESIGN.md     */
+    int32_t layout_flags;    /* 0 = default.  Testing / measurement knobs:
+                                bit2 (4)  generic kernels only (no specialised classes)
+                                bit3 (8)  keep the caller's variable order where possible
+                                bit4 (16) no workgroup-per-factor kernel
+                                bit5 (32) variable side only, bit6 (64) factor side
+                                          only: TIMING ONLY, results are wrong      */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;

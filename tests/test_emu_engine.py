@@ -22,8 +22,7 @@ def emu_lib():
     return build()
 
 
-LAYOUTS = {"default": 0, "tight": 1, "pad64": 2, "generic": 4, "keep_order": 8,
-           "write_through": 128}
+LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
