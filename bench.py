@@ -204,6 +204,13 @@ def main():
                                "kernel": KERNEL_OF.get(args.workload, "k_sweep"),
                                "algorithmic_bytes_per_launch": bytes_cycle,
                                "avg_launch_us": kernel_s * 1e6}
+        else:  # N > 1: per-GPU figure from the wall clock of the whole sharded cycle
+            per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
+            out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS,
+                               "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None,
+                               "kernel": "k_sweep x2 + halo pack/unpack + all_to_all (one sharded cycle)",
+                               "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
+                               "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True}
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)
         print(json.dumps(out), flush=True)
