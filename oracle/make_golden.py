@@ -91,7 +91,58 @@ def synthetic_cases():
             save(f"syn_{name}_T{T}", graph, mode, params, T, vals, costs, sol)
 
 
+def generator_cases():
+    """Instances produced by the reference's OWN generators
+    (pydcop/commands/generators/{ising,graphcoloring,meetingscheduling}.py), i.e. the DCOP
+    objects `pydcop generate ...` would write, solved by the reference's Max-Sum."""
+    import random
+    install_shims()
+    from pydcop.commands.generators import graphcoloring as gc
+    from pydcop.commands.generators import ising, meetingscheduling as ms
+    from pydcop.computations_graph import factor_graph
+    from pydcop.dcop.dcop import DCOP
+    from pydcop.dcop.objects import Variable, VariableDomain
+
+    def emit(name, dcop, Ts, params=None):
+        cg = factor_graph.build_computation_graph(dcop)
+        graph = compile_computation_graph(cg)
+        for T in Ts:
+            vals, costs = run_reference_maxsum(dcop, T, params or {}, cg=cg)
+            sol = dcop.solution_cost(vals, float("inf"))
+            save(f"gen_{name}_T{T}", graph, dcop.objective, params or {}, T, vals, costs, sol)
+
+    random.seed(20260923)
+    # pydcop generate ising --row_count 5 --col_count 4 [--intentional]   (ising.py:274-331)
+    for label, extensive in (("ext", True), ("int", False)):
+        dcop, _, _ = ising.generate_ising(5, 4, 1.6, 0.05, extensive, True, False, False)
+        emit(f"ising_5x4_{label}", dcop, (3, 20))
+    # pydcop generate graph_coloring -v 24 -c 3 --graph random --p_edge 0.15 --soft [--intentional]
+    # and --graph scalefree --m_edge 2  (graphcoloring.py:238-306, 355-413)
+    def coloring(graph, soft, intentional, colors=3):
+        domain = VariableDomain("colors", "color", gc.COLORS[:colors])
+        variables = {node: Variable(f"v{i:02d}", domain) for i, node in enumerate(sorted(graph.nodes))}
+        make = gc.generate_soft_constraints if soft else gc.generate_hard_constraints
+        return DCOP("gc", domains={"colors": domain},
+                    variables={v.name: v for v in variables.values()}, agents={},
+                    constraints=make(graph, variables, intentional))
+    emit("coloring_random_soft_ext", coloring(gc.generate_random_graph(24, 0.15, True), True, False), (3, 20))
+    emit("coloring_random_hard_int", coloring(gc.generate_random_graph(24, 0.15, True), False, True), (20,),
+         {"damping_nodes": "vars"})
+    emit("coloring_scalefree_hard", coloring(gc.generate_scalefree_graph(30, 2, True), False, True, 4), (20,),
+         {"start_messages": "leafs_vars"})
+    # pydcop generate meetings --slots_count 5 --events_count 5 --resources_count 4 ...
+    # (meetingscheduling.py:210-226, 317-365: PEAV model, objective max)
+    slots, events, resources = ms.generate_problem_definition(5, 4, 8, 5, 2, 3)
+    variables, constraints, _ = ms.peav_model(slots, events, resources, 8 * 5 * 4)
+    dcop = DCOP("meetings", objective="max",
+                domains={v.domain.name: v.domain for v in variables.values()},
+                variables={v.name: v for v in variables.values()}, constraints=constraints, agents={})
+    emit("meetings_peav", dcop, (5, 20))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    yaml_cases()
-    synthetic_cases()
+    if "--only-generators" not in sys.argv:
+        yaml_cases()
+        synthetic_cases()
+    generator_cases()

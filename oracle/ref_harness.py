@@ -71,24 +71,21 @@ def _patch_itemset():
         return
     import numpy as np
 
-    if hasattr(np.ndarray, "itemset"):
+    if hasattr(np.zeros(1), "itemset"):  # numpy 2 keeps a class attribute that raises on instances
         return
 
     def set_value_for_assignment(self, var_values, rel_value):
-        if isinstance(var_values, list):
-            _, s = self._slice_matrix(var_values)
-            matrix = self._m.copy()
-            matrix[s] = rel_value
-            return R.NAryMatrixRelation(self._variables, matrix, name=self.name)
-        elif isinstance(var_values, dict):
-            values = []
-            for v in self._variables:
-                values.append(var_values[v.name])
-            _, s = self._slice_matrix(values)
-            matrix = self._m.copy()
-            matrix[s] = rel_value
-            return R.NAryMatrixRelation(self._variables, matrix, name=self.name)
-        raise ValueError("Could not set value, must be list or dict")
+        # numpy-2 stand-in: same contract (a NEW relation with one entry changed), the
+        # entry addressed through the relation's own _slice_matrix
+        names = [v.name for v in self._variables]
+        if isinstance(var_values, dict):
+            var_values = [var_values[n] for n in names]
+        elif not isinstance(var_values, list):
+            raise ValueError("Could not set value, must be list or dict")
+        _, where = self._slice_matrix(names, var_values)
+        changed = np.array(self._m, copy=True)
+        changed[where] = rel_value
+        return R.NAryMatrixRelation(self._variables, changed, name=self.name)
 
     R.NAryMatrixRelation.set_value_for_assignment = set_value_for_assignment
     R.NAryMatrixRelation._graft_patched = True
