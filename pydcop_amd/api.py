@@ -70,3 +70,41 @@ def solve_yaml(paths, cycles: int = 30, **kw) -> Dict:
     if isinstance(paths, str):
         paths = [paths]
     return solve_dcop(load_dcop_from_file(list(paths)), cycles, **kw)
+
+
+def main(argv=None):
+    """`python -m pydcop_amd.api [-c CYCLES] [-p name:value ...] dcop.yaml ...` -- solve
+    without agents and print a result in the schema of `pydcop solve`
+    (docs/tutorials/analysing_results.rst:31-48; no agent metrics: there are no agents)."""
+    import argparse
+    import json
+    import time
+    ap = argparse.ArgumentParser(prog="python -m pydcop_amd.api")
+    ap.add_argument("dcop_files", nargs="+")
+    ap.add_argument("-c", "--cycles", type=int, default=30)
+    ap.add_argument("-p", "--algo_params", action="append", default=[],
+                    help="name:value, e.g. damping:0.7 noise:0 precision:f32 (maxsum.py:212-220)")
+    ap.add_argument("--infinity", type=float, default=float("inf"))   # pydcop/commands/solve.py:316-324
+    ap.add_argument("--cost_every", type=int, default=0)
+    args = ap.parse_args(argv)
+    kinds = {"damping": float, "stability": float, "noise": float, "seed": int,
+             "damping_nodes": str, "start_messages": str, "precision": str}
+    kw = {}
+    for item in args.algo_params:
+        name, _, value = item.partition(":")
+        if name not in kinds:
+            raise SystemExit(f"Error: unknown parameter {name!r} (one of {sorted(kinds)})")
+        kw[name] = kinds[name](value)
+    t0 = time.perf_counter()
+    res = solve_yaml(args.dcop_files, args.cycles, infinity=args.infinity,
+                     cost_every=args.cost_every, **kw)
+    out = {"assignment": res["assignment"], "cost": res["cost"], "violation": res["violation"],
+           "cycle": res["cycle"], "status": "FINISHED", "time": time.perf_counter() - t0,
+           "msg_count": 0, "msg_size": 0, "agt_metrics": {}}
+    if res["cost_curve"]:
+        out["cost_curve"] = res["cost_curve"]
+    print(json.dumps(out, sort_keys=True, indent="  "))
+
+
+if __name__ == "__main__":
+    main()
