@@ -99,7 +99,9 @@ typedef struct mxs_params {
     double  damping;         /* maxsum.py:213, default 0.5                    */
     double  stability;       /* maxsum.py:217, default 0.1                    */
     int32_t graph_chunk;     /* cycles captured per hipGraph replay; 0 = eager
-                                launches; <0 = engine default                 */
+                                launches; <0 = engine default: replay tiny
+                                graphs (< 4 MB per cycle), launch the rest
+                                eagerly (replay slows long kernels down)      */
     int32_t layout_flags;    /* 0 = default.  Testing / measurement knobs:
                                 bit2 (4)  generic kernels only (no specialised classes)
                                 bit3 (8)  keep the caller's variable order where possible

@@ -255,6 +255,12 @@ struct Engine : EngineBase {
         device = dev;
         std::string e = build_layout(g, p, L);
         if (!e.empty()) return fail(MXS_E_INVALID, e);
+        // hipGraph replay pays off only when a cycle is shorter than a launch: measured on
+        // MI355X it changes nothing from 8 MB per cycle up (7.8 vs 7.9 us at 10k variables,
+        // 26.8 vs 27.1 at 100k) and SLOWS long kernels down (Ising 1024^2: 182 vs 133 us,
+        // 1M-variable colouring 434 vs 370 us, meeting_50k 1351 vs 1176 us per cycle).
+        // Default (graph_chunk < 0): graphs of 32 cycles below 4 MB per cycle, eager above.
+        if (params.graph_chunk < 0) params.graph_chunk = L.algorithmic_bytes < (4 << 20) ? 32 : 0;
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
             return fail(MXS_E_NODEVICE, "no HIP device visible: the Max-Sum engine has no CPU fallback");
