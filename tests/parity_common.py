@@ -69,6 +69,13 @@ def parity_cases():
         g.init_idx = init.astype(np.int32)
         return g
 
+    def with_inf(g, seed):
+        rng = np.random.default_rng(seed)
+        t = g.tables.copy()
+        t[rng.random(t.shape[0]) < 0.15] = np.inf
+        g.tables = t
+        return g
+
     def hub(seed, nf=40, n=60):
         # one variable in nf more factors (packed class up to degree 64, wide class above),
         # some isolated variables
@@ -116,6 +123,13 @@ def parity_cases():
         # wave-per-variable kernel, large LDS footprint: deg * D > 128 and degree > 64
         ("wide_coloring6_deg30", lambda: G.random_coloring(60, avg_degree=30, n_colors=6, seed=20), {}),
         ("wide_hub_deg100", lambda: hub(21, nf=100, n=150), {"start_messages": "leafs_vars"}),
+        # corners: singleton domains, arity 6 (generic factor), a 300-value domain (generic
+        # variable), tables with +inf entries (hard constraints as the reference writes them)
+        ("corner_singletons_arity6", lambda: G.random_mixed(30, 25, seed=22, max_arity=6,
+                                                            dom_choices=(1, 2, 3)), {}),
+        ("corner_domain300", lambda: G.random_mixed(6, 8, seed=23, max_arity=2, dom_choices=(300, 3)),
+         {"mode": "max"}),
+        ("corner_inf_tables", lambda: with_inf(G.random_coloring(150, seed=24), 24), {}),
         ("nary_mixed_dims", lambda: G.random_mixed(40, 50, seed=19, max_arity=4, dom_choices=(3, 7, 10, 12)), {}),
     ]
 

@@ -13,6 +13,7 @@ import pytest
 
 from conftest import golden_files, load_golden
 from parity_common import check_table_updates, check_golden, compare_with_oracle, parity_cases
+from pydcop_amd.engine import MaxSumEngine
 from pydcop_amd.graph import Params
 
 
@@ -86,3 +87,31 @@ def test_emu_errors(emu_lib):
 def test_emu_table_updates(case, emu_lib, oracle_built):
     name, make, kw = case
     check_table_updates(oracle_built, make(), Params(**kw), lib_path=emu_lib)
+
+
+def _empty_graph_checks(oracle_mod, lib_path=None):
+    """Empty and degenerate inputs: no factors, no variables, invalid graphs fail loudly."""
+    from pydcop_amd.engine import MaxSumGpuError
+    from pydcop_amd.graph import FlatGraph
+    g = FlatGraph(dom_size=[3, 2, 4], var_cost=np.arange(9.0)[::-1].copy(), factor_rowptr=[0],
+                  edge_var=[], table_off=[0], tables=[], var_rowptr=[0, 0, 0, 0], var_edges=[]).validate()
+    eng, ora = MaxSumEngine(g, Params(), lib_path=lib_path), oracle_mod.OracleMaxSum(g, Params())
+    eng.run(5), ora.run(5)
+    np.testing.assert_array_equal(eng.assignment()[0], ora.assignment()[0])
+    np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
+    assert eng.eval_cost() == ora.eval_cost() == (10.0, 0) and eng.cycle_count == 5
+    g0 = FlatGraph(dom_size=[], var_cost=[], factor_rowptr=[0], edge_var=[], table_off=[0],
+                   tables=[], var_rowptr=[0], var_edges=[]).validate()
+    e0 = MaxSumEngine(g0, Params(), lib_path=lib_path)
+    e0.run(3)
+    assert e0.assignment()[0].shape == (0,) and e0.eval_cost() == (0.0, 0)
+    bad = FlatGraph(dom_size=[2, 2], var_cost=np.zeros(4), factor_rowptr=[0, 2], edge_var=[0, 0],
+                    table_off=[0, 4], tables=np.zeros(4), var_rowptr=[0, 2, 2], var_edges=[0, 1])
+    with pytest.raises(MaxSumGpuError):  # a factor listing the same variable twice
+        MaxSumEngine(bad, Params(), lib_path=lib_path)
+    with pytest.raises(ValueError):
+        Params(mode="sideways").to_c()
+
+
+def test_emu_empty_and_invalid_graphs(emu_lib, oracle_built):
+    _empty_graph_checks(oracle_built, emu_lib)

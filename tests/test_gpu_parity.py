@@ -132,3 +132,31 @@ def test_table_updates(case, dtype, oracle_built):
     """change_factor_function (maxsum_dynamic.py:80-104) through mxs_update_factor_table."""
     name, make, kw = case
     check_table_updates(oracle_built, make(), Params(dtype=dtype, **kw))
+
+
+def _empty_graph_checks(oracle_mod, lib_path=None):
+    """Empty and degenerate inputs: no factors, no variables, invalid graphs fail loudly."""
+    from pydcop_amd.engine import MaxSumGpuError
+    from pydcop_amd.graph import FlatGraph
+    g = FlatGraph(dom_size=[3, 2, 4], var_cost=np.arange(9.0)[::-1].copy(), factor_rowptr=[0],
+                  edge_var=[], table_off=[0], tables=[], var_rowptr=[0, 0, 0, 0], var_edges=[]).validate()
+    eng, ora = MaxSumEngine(g, Params(), lib_path=lib_path), oracle_mod.OracleMaxSum(g, Params())
+    eng.run(5), ora.run(5)
+    np.testing.assert_array_equal(eng.assignment()[0], ora.assignment()[0])
+    np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
+    assert eng.eval_cost() == ora.eval_cost() == (10.0, 0) and eng.cycle_count == 5
+    g0 = FlatGraph(dom_size=[], var_cost=[], factor_rowptr=[0], edge_var=[], table_off=[0],
+                   tables=[], var_rowptr=[0], var_edges=[]).validate()
+    e0 = MaxSumEngine(g0, Params(), lib_path=lib_path)
+    e0.run(3)
+    assert e0.assignment()[0].shape == (0,) and e0.eval_cost() == (0.0, 0)
+    bad = FlatGraph(dom_size=[2, 2], var_cost=np.zeros(4), factor_rowptr=[0, 2], edge_var=[0, 0],
+                    table_off=[0, 4], tables=np.zeros(4), var_rowptr=[0, 2, 2], var_edges=[0, 1])
+    with pytest.raises(MaxSumGpuError):  # a factor listing the same variable twice
+        MaxSumEngine(bad, Params(), lib_path=lib_path)
+    with pytest.raises(ValueError):
+        Params(mode="sideways").to_c()
+
+
+def test_empty_and_invalid_graphs(oracle_built):
+    _empty_graph_checks(oracle_built)
