@@ -201,9 +201,10 @@ int mxs_halo_bind(mxs_engine *e, void *send_dev, void *recv_dev);
  * of cycle t+1 that does not need it.  Per cycle the host calls, in this order:
  *   mxs_step_compute  compute stream: variables + interior factors of cycle t,
  *                     then (after the unpack of cycle t-1) the cut factors --
- *                     the only readers of ghost messages;
- *   mxs_step_pack     comm stream: waits for the variables of cycle t, gathers
- *                     the owned cut-edge V->F messages into the send buffer;
+ *                     the only readers of ghost messages; comm stream: waits
+ *                     for the variables of cycle t, gathers the owned cut-edge
+ *                     V->F messages into the send buffer (mxs_step_pack does
+ *                     only that part, e.g. after mxs_halo_bind);
  *   <collective>      enqueued by the host on the comm stream (mxs_stream);
  *   mxs_step_unpack   comm stream: scatters the received messages into the
  *                     ghost slots.

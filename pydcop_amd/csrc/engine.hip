@@ -669,10 +669,10 @@ struct Engine : EngineBase {
         if (rc) return rc;
         cur ^= 1;
         cycles += 1;
-        return MXS_OK;
+        return pack();  // comm stream, behind ev_p1: one host call per cycle before the collective
     }
 
-    int step_pack() override {
+    int step_pack() override {  // kept for callers that pack separately: packs again (idempotent)
         HIP_TRY(hipSetDevice(device));
         return pack();
     }

@@ -94,11 +94,23 @@ class ShardedMaxSum:
             dist.all_to_all_single(recv, send, splits[0], splits[1], group=self.group)
 
     def run_async(self, n_cycles: int):
+        step, unpack = self.engine.step_compute, self.engine.step_unpack  # compute + pack
+        if self._on_gpu and self.world > 1:
+            # the host loop is on the critical path of short cycles: enter the comm-stream
+            # context once and call the collective with pre-bound arguments
+            torch, dist = self._torch, self._dist
+            send, recv = self._send[:self._n_send], self._recv[:self._n_recv]
+            rs, ss, group = self._recv_splits, self._send_splits, self.group
+            with torch.cuda.stream(self._ext_stream):
+                for _ in range(int(n_cycles)):
+                    step()
+                    dist.all_to_all_single(recv, send, rs, ss, group=group)
+                    unpack()
+            return
         for _ in range(int(n_cycles)):
-            self.engine.step_compute()
-            self.engine.step_pack()
+            step()
             self._exchange()
-            self.engine.step_unpack()
+            unpack()
 
     def sync(self):
         self.engine.sync()

@@ -78,8 +78,7 @@ class LocalShards:
     def run(self, n):
         for _ in range(n):
             for e in self.engines:
-                e.step_compute()
-                e.step_pack()
+                e.step_compute()   # compute + pack
             self._exchange()
 
     def assignment(self):

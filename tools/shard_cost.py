@@ -24,7 +24,7 @@ e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
 e.halo_setup(sh.send_edges, sh.recv_edges)
 def cycles(n):
     for _ in range(n):
-        e.step_compute(); e.step_pack(); e.step_unpack()
+        e.step_compute(); e.step_unpack()
     e.sync()
 cycles(200)
 t3 = time.perf_counter(); cycles(2000); t4 = time.perf_counter()
