@@ -482,10 +482,14 @@ struct Engine : EngineBase {
                 if (v2f_out) v2f_out[ext_off[e] + d] = sign * (double)hv[L.v2f_off[ei] + d];
                 if (f2v_out) f2v_out[ext_off[e] + d] = sign * (double)hf[L.f2v_off[ei] + d];
             }
-            if (cf) cf[e] = hcF[ei];
+            if (cf) cf[e] = L.edge_fcim[ei] ? (uint8_t)(int)hf[L.f2v_off[ei] + D] : hcF[ei];
         }
         if (cv)
-            for (int k = 0; k < nE; ++k) cv[L.edge_i2e[L.vslot_edge[k]]] = hcV[L.vslot_cv[k]];
+            for (int k = 0; k < nE; ++k) {
+                const int ei = L.vslot_edge[k];
+                cv[L.edge_i2e[ei]] = L.edge_vcim[ei] ? (uint8_t)(int)hv[L.v2f_off[ei] + L.edge_dom[ei]]
+                                                     : hcV[L.vslot_cv[k]];
+            }
         return MXS_OK;
     }
 

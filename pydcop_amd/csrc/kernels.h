@@ -171,6 +171,26 @@ struct Msg {
 #pragma unroll
         for (int d = 0; d < H; ++d) q[d] = d < D ? m[d < D ? d : 0] : (T)0;
     }
+    // A record with padding (H > D, e.g. D = 3) keeps the SEND COUNTER of its message in the
+    // first padding element (a small integer, exact in T): the owner of the record reads
+    // and writes it with the message itself -- no separate one-byte load and store per
+    // edge.  The other side gathers only the D values.  Records without padding use the
+    // counter arrays cF / cV.
+    static constexpr bool CNT_IN_MSG = H > D;
+    static __device__ __forceinline__ uint8_t load_c(const T* p, T (&m)[D]) {
+        const T* q = (const T*)__builtin_assume_aligned(p, ALIGN);
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = q[d];
+        return (uint8_t)(int)q[D < H ? D : 0];
+    }
+    static __device__ __forceinline__ T padded(const T (&m)[D], uint8_t cnt, int d) {
+        return d < D ? m[d < D ? d : 0] : (d == D ? (T)(int)cnt : (T)0);
+    }
+    static __device__ __forceinline__ void store_c(T* p, const T (&m)[D], uint8_t cnt) {
+        T* q = (T*)__builtin_assume_aligned(p, ALIGN);
+#pragma unroll
+        for (int d = 0; d < H; ++d) q[d] = padded(m, cnt, d);
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -183,16 +203,26 @@ __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassI
     constexpr int H = Msg<T, D>::H;
     const int64_t fo = ci.f2v_base + (int64_t)j * H;
     const int e = ci.edge_base + j;
+    constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     T out[D], prev[D];
-    Msg<T, D>::load(a.f2v_old + fo, prev);
+    uint8_t cn;
+    if constexpr (CIM) cn = Msg<T, D>::load_c(a.f2v_old + fo, prev);
+    else {
+        Msg<T, D>::load(a.f2v_old + fo, prev);
+        cn = a.cF[e];
+    }
 #pragma unroll
     for (int d = 0; d < D; ++d)  // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
         out[d] = a.tables[ci.tab_base + (int64_t)d * ci.count + j] + (T)0;
     uint8_t c = 0;
     if (!a.start)  // on_start (maxsum.py:311-319): unary factors send in every mode, counter stays 0
-        c = damp_and_filter<T, D>(out, prev, a.cF[e], a.damp_f != 0, a.damping, a.stability);
-    Msg<T, D>::store(a.f2v_new + fo, out);
-    a.cF[e] = c;
+        c = damp_and_filter<T, D>(out, prev, cn, a.damp_f != 0, a.damping, a.stability);
+    if constexpr (CIM) {
+        Msg<T, D>::store_c(a.f2v_new + fo, out, c);
+    } else {
+        Msg<T, D>::store(a.f2v_new + fo, out);
+        a.cF[e] = c;
+    }
 }
 
 template <typename T, int D>
@@ -201,11 +231,19 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
     const int e = ci.edge_base + 2 * j;
     const int64_t fo = ci.f2v_base + (int64_t)j * 2 * H;  // both messages of the factor
     // everything addressed by j: coalesced
+    constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     const int v0 = a.edge_v2f[e], v1 = a.edge_v2f[e + 1];
-    const uint8_t cn0 = a.cF[e], cn1 = a.cF[e + 1];
+    uint8_t cn0, cn1;
     T m0[D], p0[D], m1[D], p1[D], tab[D * D];
-    Msg<T, D>::load(a.f2v_old + fo, p0);      // F->V message last sent to variable 0
-    Msg<T, D>::load(a.f2v_old + fo + H, p1);
+    if constexpr (CIM) {
+        cn0 = Msg<T, D>::load_c(a.f2v_old + fo, p0);      // F->V message last sent to variable 0
+        cn1 = Msg<T, D>::load_c(a.f2v_old + fo + H, p1);  // (+ its send counter)
+    } else {
+        cn0 = a.cF[e];
+        cn1 = a.cF[e + 1];
+        Msg<T, D>::load(a.f2v_old + fo, p0);
+        Msg<T, D>::load(a.f2v_old + fo + H, p1);
+    }
 #pragma unroll
     for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
     // the two gathers
@@ -242,16 +280,18 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         T full[2 * H];
 #pragma unroll
         for (int d = 0; d < H; ++d) {
-            full[d] = d < D ? o0[d < D ? d : 0] : (T)0;
-            full[H + d] = d < D ? o1[d < D ? d : 0] : (T)0;
+            full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
+            full[H + d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
         }
         wave_store_linear<T, 2 * H>(a.f2v_new, fo - (int64_t)lw * 2 * H, full);
     } else {
-        Msg<T, D>::store(a.f2v_new + fo, o0);
-        Msg<T, D>::store(a.f2v_new + fo + H, o1);
+        Msg<T, D>::store_c(a.f2v_new + fo, o0, CIM ? c0 : 0);
+        Msg<T, D>::store_c(a.f2v_new + fo + H, o1, CIM ? c1 : 0);
     }
-    a.cF[e] = c0;
-    a.cF[e + 1] = c1;
+    if constexpr (!CIM) {
+        a.cF[e] = c0;
+        a.cF[e + 1] = c1;
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -352,10 +392,15 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
     const bool has = var < nv;
     const int v = wm.first_var + (has ? var : 0);
     const int32_t slot = a.vell[pos];
-    const uint8_t cnt = a.cV[ci.cv_base + lane_id];
+    constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     T pv[D], in[D], c[D], b[D], m[D];
     const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
-    Msg<T, D>::load(a.v2f_old + vo, pv);  // V->F message last sent on this edge
+    uint8_t cnt;
+    if constexpr (CIM) cnt = Msg<T, D>::load_c(a.v2f_old + vo, pv);  // V->F message last sent on
+    else {                                                            // this edge (+ its counter)
+        cnt = a.cV[ci.cv_base + lane_id];
+        Msg<T, D>::load(a.v2f_old + vo, pv);
+    }
     Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);  // F->V held from this factor
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)(v - ci.first) * D + d];
@@ -415,12 +460,12 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
     if constexpr ((H * sizeof(T)) % 16 == 0) {  // the whole wave is here (count is a multiple of 64)
         T full[H];
 #pragma unroll
-        for (int d = 0; d < H; ++d) full[d] = d < D ? m[d < D ? d : 0] : (T)0;
+        for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(m, CIM ? co : 0, d);
         wave_store_linear<T, H>(a.v2f_new, vo - (int64_t)l * H, full);
     } else {
         Msg<T, D>::store(a.v2f_new + vo, m);
     }
-    a.cV[ci.cv_base + lane_id] = co;
+    if constexpr (!CIM) a.cV[ci.cv_base + lane_id] = co;
 }
 
 // Variable side, generic class: thread per variable, any domain size / degree,

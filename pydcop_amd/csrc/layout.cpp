@@ -163,6 +163,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     L.edge_dom.resize(nE);
     L.edge_half.resize(nE);
     L.edge_gen_factor.assign(nE, -1);
+    L.edge_fcim.assign(nE, 0);
+    L.edge_vcim.assign(nE, 0);
     {
         int ei = 0;
         int64_t off = 0;
@@ -305,6 +307,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.f_tab_base[fi + j] = ci.tab_base + j;
                 L.f_tab_stride[fi + j] = n;
             }
+            if (ci.H > ci.D)  // counters ride in the records' padding (kernels.h, Msg::CNT_IN_MSG)
+                for (int e = L.frowptr[fi]; e < L.frowptr[fj]; ++e) L.edge_fcim[e] = 1;
             L.classes.push_back(ci);
             sweep_class(cls, BLOCK, key.cut);
         } else {
@@ -407,6 +411,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                             L.vell.push_back(L.vslot_f2v[ks]);
                             L.vslot_cv[ks] = ci.cv_base + lanes;
                             L.vslot_v2f[ks] = (int32_t)(ci.v2f_base + lanes * ci.H);
+                            if (ci.H > ci.D) L.edge_vcim[L.vslot_edge[ks]] = 1;
                         } else {
                             L.vell.push_back(-1);
                         }

@@ -158,6 +158,9 @@ struct Layout {
     std::vector<int32_t> edge_half;  // H of its messages
     std::vector<int32_t> edge_gen_factor;  // generic classes: index into fgen
     std::vector<int32_t> edge_var_int;     // internal variable id of the edge
+    // 1: the send counter of the edge's F->V / V->F message lives in the first padding
+    // element of the message record (register classes with H > D), not in cF / cV
+    std::vector<uint8_t> edge_fcim, edge_vcim;
     int64_t f2v_elems = 0, v2f_elems = 0;  // elements per buffer
     int64_t null_f2v = 0;            // offset of an all-zero block in F2V nobody writes
                                      // (padding slots gather it: adding 0.0 is exact)
