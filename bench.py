@@ -15,7 +15,9 @@ N > 1 is launched by the driver through torch.distributed.run (one rank per GPU)
 WEAK scaling -- ONE random 3-colouring instance of N x 100k variables (same degree,
 same cost convention) is partitioned across the ranks, 100k variables per GPU, and
 boundary V->F messages are exchanged once per cycle with an RCCL all-to-all
-(pydcop_amd/sharded.py).  `value` is then N x iterations/s: the whole job's
+(grouped ncclSend/ncclRecv issued by the engine itself, the cycle loop stays in the
+library: pydcop_amd/sharded.py; MAXSUM_COLLECTIVE=torch selects
+torch.distributed.all_to_all_single instead).  `value` is then N x iterations/s: the whole job's
 throughput in iterations of a 100k-variable instance (= directed edge-messages/s
 divided by the 800k messages of one such iteration), so N = 1 is the plain metric.
 `--scaling strong` keeps the fixed 100k instance and splits it instead.
@@ -193,7 +195,8 @@ def main():
                        "domain": int(graph.dom_size.max()),
                        "edge_messages_per_s": args.steps / elapsed * 2 * n_edges_total,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
-                       "parallelism": f"graph-partition x{args.gpus}"},
+                       "parallelism": f"graph-partition x{args.gpus}"
+                                      + (f", exchange: {runner.collective}" if world > 1 else "")},
         }
         if event_ms is not None:
             kernel_s = event_ms * 1e-3 / args.steps
@@ -208,7 +211,7 @@ def main():
             per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None,
-                               "kernel": "k_sweep x2 + halo pack/unpack + all_to_all (one sharded cycle)",
+                               "kernel": "k_sweep x2 + halo pack/unpack + RCCL all-to-all (one sharded cycle)",
                                "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
                                "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True}
         if args.gpus == 1 and not args.no_cpu_baseline:

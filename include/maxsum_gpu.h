@@ -47,6 +47,7 @@ extern "C" {
 #define MXS_E_HIP        -3  /* a HIP call failed (see mxs_last_error)       */
 #define MXS_E_NOMEM      -4
 #define MXS_E_STATE      -5  /* call not valid in the engine's current state */
+#define MXS_E_COMM       -6  /* RCCL missing or a RCCL call failed               */
 
 /* dcop.objective, AlgorithmDef.mode (pydcop/algorithms/__init__.py:141) */
 #define MXS_MODE_MIN 0
@@ -215,6 +216,30 @@ int mxs_step_unpack(mxs_engine *e);
 /* The engine's comm hipStream_t (the stream the collective has to be enqueued
  * on), as an opaque pointer. */
 int mxs_stream(mxs_engine *e, void **stream);
+
+/* ---- native exchange: the engine calls RCCL itself ------------------------
+ * Replaces the agents' message transport for boundary messages
+ * (pydcop/infrastructure/communication.py:588-698) without an interpreter
+ * between two cycles: one exchange = one group of ncclSend / ncclRecv per
+ * peer (an all-to-all with the fixed counts of the partition) on the comm
+ * stream.  RCCL is dlopen'ed from `rccl_path` (NULL = "librccl.so"); a process
+ * must hold ONE copy, so pass the one torch bundles when torch is loaded. */
+#define MXS_UNIQUE_ID_BYTES 128
+/* ncclGetUniqueId: called by rank 0, the launcher hands the bytes to every
+ * other rank (torch.distributed store, MPI, a file ...). */
+int mxs_comm_unique_id(const char *rccl_path, uint8_t *id /* [128] */);
+/* ncclCommInitRank on the engine's device (collective over all ranks).  Call
+ * after mxs_halo_setup.  send_counts[q] / recv_counts[q] = ELEMENTS of the packed
+ * send / receive buffer exchanged with rank q, peers in ascending order (the
+ * order of the edge lists given to mxs_halo_setup); [rank] must be 0 when world > 1. */
+int mxs_comm_init(mxs_engine *e, const char *rccl_path, int32_t rank, int32_t world,
+                  const uint8_t *id, const int64_t *send_counts, const int64_t *recv_counts);
+/* Enqueue one exchange on the comm stream (between pack and unpack; used for the
+ * start messages of cycle 0 and after mxs_reset). */
+int mxs_comm_exchange(mxs_engine *e);
+/* n sharded cycles, each mxs_step_compute -> exchange -> mxs_step_unpack, enqueued
+ * by the library; does not wait (mxs_sync does). */
+int mxs_run_sharded(mxs_engine *e, int32_t n_cycles);
 
 int mxs_destroy(mxs_engine *e);
 

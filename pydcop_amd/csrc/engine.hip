@@ -9,12 +9,15 @@
 //   get_*    copy back, undo the internal permutation (and the max-mode negation)
 // There is no host fallback: every cycle runs on the device.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <climits>
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,6 +47,73 @@ static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyK
         hipError_t _e = (expr);                                                             \
         if (_e != hipSuccess)                                                               \
             return fail(MXS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));      \
+    } while (0)
+
+// ---- RCCL, bound at run time -------------------------------------------------------
+// The sharded cycle loop calls RCCL itself (grouped ncclSend / ncclRecv per peer = an
+// all-to-all with fixed counts) so that no interpreter sits between two cycles.  The
+// library is dlopen'ed from the path the host gives (the copy torch bundles when torch
+// is in the process, else /opt/rocm/lib/librccl.so): like the HIP runtime, there must
+// be one copy per process.  Only the handful of entry points used here are declared;
+// the types mirror rccl.h (ncclUniqueId = 128 opaque bytes passed by value).
+struct NcclUniqueId {
+    char internal[MXS_UNIQUE_ID_BYTES];
+};
+struct Rccl {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(void**, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+constexpr int NCCL_F32 = 7, NCCL_F64 = 8;  // ncclFloat32 / ncclFloat64 (rccl.h)
+
+static const Rccl* load_rccl(const char* path, std::string& err) {
+    static std::mutex mu;
+    static std::map<std::string, std::unique_ptr<Rccl>> libs;
+    const std::string key = path && *path ? path : "librccl.so";
+    std::lock_guard<std::mutex> lock(mu);
+    auto it = libs.find(key);
+    if (it != libs.end()) return it->second.get();
+    std::unique_ptr<Rccl> r(new Rccl());
+    r->handle = dlopen(key.c_str(), RTLD_NOW | RTLD_GLOBAL);
+    if (!r->handle) {
+        const char* m = dlerror();
+        err = "cannot load RCCL (" + key + "): " + (m ? m : "?");
+        return nullptr;
+    }
+    bool ok = true;
+    auto sym = [&](const char* name) {
+        void* p = dlsym(r->handle, name);
+        if (!p) {
+            ok = false;
+            err = std::string("RCCL library misses ") + name;
+        }
+        return p;
+    };
+    r->GetUniqueId = (int (*)(NcclUniqueId*))sym("ncclGetUniqueId");
+    r->CommInitRank = (int (*)(void**, int, NcclUniqueId, int))sym("ncclCommInitRank");
+    r->CommDestroy = (int (*)(void*))sym("ncclCommDestroy");
+    r->Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))sym("ncclSend");
+    r->Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))sym("ncclRecv");
+    r->GroupStart = (int (*)())sym("ncclGroupStart");
+    r->GroupEnd = (int (*)())sym("ncclGroupEnd");
+    r->GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+    if (!ok) return nullptr;
+    const Rccl* out = r.get();
+    libs[key] = std::move(r);
+    return out;
+}
+
+#define NCCL_TRY(expr)                                                                      \
+    do {                                                                                    \
+        int _r = (expr);                                                                    \
+        if (_r != 0)                                                                        \
+            return fail(MXS_E_COMM, std::string(#expr) + ": " + rccl->GetErrorString(_r));  \
     } while (0)
 
 template <typename U>
@@ -84,6 +154,10 @@ struct EngineBase {
     virtual int step_compute() = 0;
     virtual int step_pack() = 0;
     virtual int step_unpack() = 0;
+    virtual int comm_init(const char* path, int rank, int world, const uint8_t* id,
+                          const int64_t* sc, const int64_t* rc) = 0;
+    virtual int comm_exchange() = 0;
+    virtual int run_sharded(int n) = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
     Layout L;
@@ -126,6 +200,10 @@ struct Engine : EngineBase {
     static constexpr int EVAL_BLOCKS = 1024;
 
     ~Engine() override {
+        if (nccl_comm) {
+            if (comm) (void)hipStreamSynchronize(comm);
+            (void)rccl->CommDestroy(nccl_comm);
+        }
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
@@ -693,6 +771,87 @@ struct Engine : EngineBase {
         halo_pending = true;
         return MXS_OK;
     }
+
+    // ---- native exchange: the engine calls RCCL itself -----------------------------------
+    // One exchange = one group of ncclSend / ncclRecv per peer with the fixed counts of the
+    // partition (an all-to-all with unequal splits) on the comm stream, between the pack and
+    // the unpack of the cycle.  The cycle loop of a sharded run then stays in this library.
+    const Rccl* rccl = nullptr;
+    void* nccl_comm = nullptr;
+    int comm_rank = 0, comm_world = 0;
+    std::vector<int64_t> send_cnt, recv_cnt, send_at, recv_at;  // elements, per peer
+    DevBuf<T> self_pad;  // world 1: one padding element sent to ourselves
+
+    int comm_init(const char* path, int rank, int world, const uint8_t* id, const int64_t* sc,
+                  const int64_t* rc) override {
+        if (!halo_ready) return fail(MXS_E_STATE, "mxs_comm_init needs mxs_halo_setup first");
+        if (nccl_comm) return fail(MXS_E_STATE, "the communicator of this engine exists already");
+        if (world < 1 || rank < 0 || rank >= world || !id || !sc || !rc)
+            return fail(MXS_E_INVALID, "mxs_comm_init: bad rank / world / counts");
+        int64_t ts = 0, tr = 0;
+        for (int q = 0; q < world; ++q) {
+            if (sc[q] < 0 || rc[q] < 0) return fail(MXS_E_INVALID, "mxs_comm_init: negative count");
+            ts += sc[q];
+            tr += rc[q];
+        }
+        // (a rank exchanges nothing with itself; only the one-rank communicator of
+        // tools/shard_cost.py loops a shard's whole halo back to measure the exchange)
+        if (ts != n_halo_send || tr != n_halo_recv || (world > 1 && (sc[rank] != 0 || rc[rank] != 0)))
+            return fail(MXS_E_INVALID, "mxs_comm_init: counts do not match the halo lists of mxs_halo_setup");
+        std::string err;
+        rccl = load_rccl(path, err);
+        if (!rccl) return fail(MXS_E_COMM, err);
+        HIP_TRY(hipSetDevice(device));
+        HIP_TRY(self_pad.alloc(64));
+        NcclUniqueId uid;
+        std::memcpy(uid.internal, id, MXS_UNIQUE_ID_BYTES);
+        NCCL_TRY(rccl->CommInitRank(&nccl_comm, world, uid, rank));
+        comm_rank = rank;
+        comm_world = world;
+        send_cnt.assign(sc, sc + world);
+        recv_cnt.assign(rc, rc + world);
+        send_at.assign(world, 0);
+        recv_at.assign(world, 0);
+        for (int q = 1; q < world; ++q) {
+            send_at[q] = send_at[q - 1] + send_cnt[q - 1];
+            recv_at[q] = recv_at[q - 1] + recv_cnt[q - 1];
+        }
+        return MXS_OK;
+    }
+
+    int comm_exchange() override {
+        if (!nccl_comm) return fail(MXS_E_STATE, "no communicator: call mxs_comm_init first");
+        HIP_TRY(hipSetDevice(device));
+        const int dt = sizeof(T) == 8 ? NCCL_F64 : NCCL_F32;
+        NCCL_TRY(rccl->GroupStart());
+        if (comm_world == 1 && send_cnt[0] == 0) {
+            // nothing crosses; one padding element to ourselves keeps the very call sequence
+            // of a multi-GPU run testable on a one-GPU box
+            NCCL_TRY(rccl->Send(self_pad.p, 1, dt, 0, nccl_comm, comm));
+            NCCL_TRY(rccl->Recv(self_pad.p + 32, 1, dt, 0, nccl_comm, comm));
+        }
+        for (int q = 0; q < comm_world; ++q) {
+            if (send_cnt[q])
+                NCCL_TRY(rccl->Send(send_buf + send_at[q], (size_t)send_cnt[q], dt, q, nccl_comm, comm));
+            if (recv_cnt[q])
+                NCCL_TRY(rccl->Recv(recv_buf + recv_at[q], (size_t)recv_cnt[q], dt, q, nccl_comm, comm));
+        }
+        NCCL_TRY(rccl->GroupEnd());
+        return MXS_OK;
+    }
+
+    int run_sharded(int n) override {
+        if (n < 0) return fail(MXS_E_INVALID, "n_cycles must be >= 0");
+        for (int i = 0; i < n; ++i) {
+            int rc = step_compute();  // both phases + pack
+            if (rc) return rc;
+            rc = comm_exchange();
+            if (rc) return rc;
+            rc = step_unpack();
+            if (rc) return rc;
+        }
+        return MXS_OK;
+    }
 };
 
 }  // namespace mxs
@@ -799,6 +958,27 @@ int mxs_step_compute(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_comp
 int mxs_step_pack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_pack(); }
 int mxs_step_unpack(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->step_unpack(); }
 
+int mxs_comm_unique_id(const char* rccl_path, uint8_t* id) {
+    if (!id) return fail(MXS_E_INVALID, "null argument");
+    std::string err;
+    const mxs::Rccl* rccl = mxs::load_rccl(rccl_path, err);
+    if (!rccl) return fail(MXS_E_COMM, err);
+    mxs::NcclUniqueId uid;
+    int r = rccl->GetUniqueId(&uid);
+    if (r != 0) return fail(MXS_E_COMM, std::string("ncclGetUniqueId: ") + rccl->GetErrorString(r));
+    std::memcpy(id, uid.internal, MXS_UNIQUE_ID_BYTES);
+    return MXS_OK;
+}
+
+int mxs_comm_init(mxs_engine* e, const char* rccl_path, int32_t rank, int32_t world, const uint8_t* id,
+                  const int64_t* send_counts, const int64_t* recv_counts) {
+    CHECK_HANDLE(e);
+    return e->impl->comm_init(rccl_path, rank, world, id, send_counts, recv_counts);
+}
+
+int mxs_comm_exchange(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->comm_exchange(); }
+int mxs_run_sharded(mxs_engine* e, int32_t n) { CHECK_HANDLE(e); return e->impl->run_sharded(n); }
+
 int mxs_stream(mxs_engine* e, void** stream) {
     CHECK_HANDLE(e);
     if (stream) *stream = (void*)e->impl->comm;
@@ -823,6 +1003,6 @@ int mxs_destroy(mxs_engine* e) {
 
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
-int32_t mxs_version(void) { return 100; }
+int32_t mxs_version(void) { return 101; }
 
 }  // extern "C"

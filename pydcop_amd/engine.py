@@ -25,6 +25,7 @@ ABI_SYMBOLS = (
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
+    "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
 
@@ -106,6 +107,10 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_step_pack": ([vp], C.c_int),
         "mxs_step_unpack": ([vp], C.c_int),
         "mxs_stream": ([vp, C.POINTER(vp)], C.c_int),
+        "mxs_comm_unique_id": ([C.c_char_p, vp], C.c_int),
+        "mxs_comm_init": ([vp, C.c_char_p, i32, i32, vp, vp, vp], C.c_int),
+        "mxs_comm_exchange": ([vp], C.c_int),
+        "mxs_run_sharded": ([vp, i32], C.c_int),
         "mxs_debug_timeline": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
         "mxs_update_factor_table": ([vp, i32, vp, i64], C.c_int),
         "mxs_destroy": ([vp], C.c_int),
@@ -118,6 +123,39 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         fn.restype = restype
     _libs[path] = lib
     return lib
+
+
+def rccl_path() -> str:
+    """The RCCL library this process uses for the native exchange of the sharded path:
+    $MAXSUM_RCCL_LIB, the copy bundled with an already imported torch (one copy per
+    process, like the HIP runtime), then the system ROCm."""
+    env = os.environ.get("MAXSUM_RCCL_LIB")
+    if env:
+        return env
+    torch = sys.modules.get("torch")
+    if torch is not None:
+        cand = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        if os.path.exists(cand):
+            return cand
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    for name in ("librccl.so", "librccl.so.1"):
+        cand = os.path.join(rocm, "lib", name)
+        if os.path.exists(cand):
+            return cand
+    return "librccl.so"
+
+
+UNIQUE_ID_BYTES = 128
+
+
+def comm_unique_id(lib_path: Optional[str] = None, rccl: Optional[str] = None) -> bytes:
+    """ncclGetUniqueId (rank 0 calls it and hands the bytes to the other ranks)."""
+    lib = load_library(lib_path)
+    buf = C.create_string_buffer(UNIQUE_ID_BYTES)
+    rc = lib.mxs_comm_unique_id((rccl or rccl_path()).encode(), C.cast(buf, C.c_void_p))
+    if rc != 0:
+        raise MaxSumGpuError(f"maxsum_gpu error {rc}: {lib.mxs_last_error().decode()}")
+    return buf.raw
 
 
 def device_count(lib_path: Optional[str] = None) -> int:
@@ -252,6 +290,27 @@ class MaxSumEngine:
 
     def step_unpack(self):
         self._check(self._lib.mxs_step_unpack(self._h))
+
+    def comm_init(self, rank: int, world: int, unique_id: bytes, send_counts, recv_counts,
+                  rccl: Optional[str] = None):
+        """Join the RCCL communicator of the sharded run (collective over all ranks);
+        counts in ELEMENTS per peer, as given by `Shard.send_counts / recv_counts`."""
+        if len(unique_id) != UNIQUE_ID_BYTES:
+            raise ValueError("unique_id must be the 128 bytes of comm_unique_id()")
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        if sc.shape != (world,) or rc.shape != (world,):
+            raise ValueError("one count per rank")
+        uid = C.create_string_buffer(bytes(unique_id), UNIQUE_ID_BYTES)
+        self._check(self._lib.mxs_comm_init(self._h, (rccl or rccl_path()).encode(), int(rank), int(world),
+                                            C.cast(uid, C.c_void_p), sc.ctypes.data, rc.ctypes.data))
+
+    def comm_exchange(self):
+        self._check(self._lib.mxs_comm_exchange(self._h))
+
+    def run_sharded(self, n_cycles: int):
+        """n sharded cycles (compute, RCCL exchange, unpack) enqueued by the library."""
+        self._check(self._lib.mxs_run_sharded(self._h, int(n_cycles)))
 
     def stream(self) -> int:
         s = C.c_void_p()

@@ -9,8 +9,15 @@ leave a GPU are those of cut factors' remote variables:
     cycle t:   compute stream   variables + interior factors of cycle t, then -- once
                                 the exchange of cycle t-1 is unpacked -- the cut factors
                comm stream      pack (after the variables of cycle t) -> all-to-all
-                                (torch.distributed; backend "nccl" = RCCL over xGMI)
-                                -> unpack into the ghost slots
+                                (RCCL over xGMI) -> unpack into the ghost slots
+
+The all-to-all is one group of ncclSend / ncclRecv per peer with the fixed counts of
+the partition.  On GPUs the engine calls RCCL itself (`collective="rccl"`: the whole
+cycle loop stays inside libmaxsum_hip.so, mxs_run_sharded -- no interpreter between
+two 50-microsecond cycles; torch.distributed only bootstraps the communicator and
+gathers results); `collective="torch"` runs the same exchange as
+torch.distributed.all_to_all_single on the engine's comm stream (any backend; what the
+gloo CPU tests use, and the fallback when RCCL cannot be loaded).
 
 Both message directions of cycle t read only cycle t-1 (Jacobi schedule), so one
 exchange per cycle is enough, a suppressed (unsent) message needs no special case
@@ -18,11 +25,13 @@ exchange per cycle is enough, a suppressed (unsent) message needs no special cas
 factors of cycle t+1 read what the exchange of cycle t delivers -- the exchange has
 a whole cycle of other work to hide behind.
 """
+import os
+import warnings
 from typing import Optional, Tuple
 
 import numpy as np
 
-from .engine import MaxSumEngine
+from .engine import MaxSumEngine, MaxSumGpuError, comm_unique_id
 from .graph import FlatGraph, Params
 from .partition import Shard, build_shard, partition_variables
 
@@ -36,7 +45,8 @@ class ShardedMaxSum:
 
     def __init__(self, graph: FlatGraph, params: Optional[Params], rank: int, world: int,
                  device: int = 0, part: Optional[np.ndarray] = None,
-                 lib_path: Optional[str] = None, group=None):
+                 lib_path: Optional[str] = None, group=None, collective: str = "auto",
+                 rccl: Optional[str] = None):
         import torch
         import torch.distributed as dist
         self._torch, self._dist = torch, dist
@@ -50,6 +60,18 @@ class ShardedMaxSum:
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
         self._backend = backend
         self._on_gpu = backend == "nccl"
+        collective = os.environ.get("MAXSUM_COLLECTIVE") or collective
+        if collective == "auto":
+            collective = "rccl" if self._on_gpu else "torch"
+        if collective not in ("rccl", "torch"):
+            raise ValueError("collective must be 'auto', 'rccl' or 'torch'")
+        self._native = collective == "rccl" and self._init_native(lib_path, rccl)
+        self.collective = "rccl" if self._native else "torch"
+        if self._native:
+            self.engine.comm_exchange()  # the start messages of cycle 0
+            self.engine.step_unpack()
+            self.engine.sync()
+            return
         tdtype = torch.float64 if self.params.dtype == "f64" else torch.float32
         tdev = torch.device("cuda", device) if self._on_gpu else torch.device("cpu")
         n_send, n_recv = int(self.shard.send_counts.sum()), int(self.shard.recv_counts.sum())
@@ -72,8 +94,39 @@ class ShardedMaxSum:
         self.engine.step_unpack()
         self.engine.sync()
 
+    def _init_native(self, lib_path, rccl) -> bool:
+        """Create the engine's own RCCL communicator.  Every rank first checks that it can
+        load RCCL, and only if ALL can do they enter ncclCommInitRank (a rank that failed
+        on its own would leave the others waiting inside it)."""
+        dist = self._dist
+        multi = self.world > 1 and self._backend != "none"
+        uid, err = None, None
+        try:
+            uid = comm_unique_id(lib_path, rccl)  # rank 0's is the one used
+        except MaxSumGpuError as e:
+            err = str(e)
+        if multi:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err is None, group=self.group)
+            box = [uid]
+            dist.broadcast_object_list(box, src=0, group=self.group)
+            uid = box[0]
+            ok = all(oks)
+        else:
+            ok = err is None
+        if not ok:
+            warnings.warn(f"native RCCL exchange unavailable ({err or 'another rank failed'}); "
+                          "falling back to torch.distributed.all_to_all_single")
+            return False
+        self.engine.comm_init(self.rank, self.world, uid, self.shard.send_counts,
+                              self.shard.recv_counts, rccl=rccl)
+        return True
+
     # -- the per-cycle exchange ------------------------------------------------------
     def _exchange(self):
+        if self._native:
+            self.engine.comm_exchange()
+            return
         if self._backend == "none":
             return  # a single engine without torch.distributed: nothing crosses
         torch, dist = self._torch, self._dist
@@ -94,6 +147,9 @@ class ShardedMaxSum:
             dist.all_to_all_single(recv, send, splits[0], splits[1], group=self.group)
 
     def run_async(self, n_cycles: int):
+        if self._native:
+            self.engine.run_sharded(n_cycles)  # the loop is in the library
+            return
         step, unpack = self.engine.step_compute, self.engine.step_unpack  # compute + pack
         if self._on_gpu and self.world > 1:
             # the host loop is on the critical path of short cycles: enter the comm-stream

@@ -18,10 +18,38 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
-           "-I", HERE, "-x", "c++", srcs[0], srcs[1], "-o", OUT]
+           "-I", HERE, "-x", "c++", srcs[0], srcs[1], "-o", OUT, "-ldl"]
     subprocess.check_call(cmd)
     return OUT
 
 
+FAKE_RCCL = os.path.join(HERE, "_build", "libfake_rccl.so")
+
+
+def build_fake_rccl(force=False):
+    """tests/emu/fake_rccl: the RCCL entry points the engine binds, over files (TEST ONLY)."""
+    src = os.path.join(HERE, "fake_rccl", "fake_rccl.cpp")
+    if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(FAKE_RCCL) >= os.path.getmtime(src):
+        return FAKE_RCCL
+    os.makedirs(os.path.dirname(FAKE_RCCL), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", FAKE_RCCL])
+    return FAKE_RCCL
+
+
+FAKE_RCCL = os.path.join(HERE, "_build", "libfake_rccl.so")
+
+
+def build_fake_rccl(force=False):
+    """tests/emu/fake_rccl: the RCCL entry points the engine binds, over files (TEST ONLY)."""
+    src = os.path.join(HERE, "fake_rccl", "fake_rccl.cpp")
+    if not force and os.path.exists(FAKE_RCCL) and os.path.getmtime(FAKE_RCCL) >= os.path.getmtime(src):
+        return FAKE_RCCL
+    os.makedirs(os.path.dirname(FAKE_RCCL), exist_ok=True)
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-pthread", src, "-o", FAKE_RCCL])
+    return FAKE_RCCL
+
+
 if __name__ == "__main__":
+    print(build_fake_rccl(force=True))
+    print(build_fake_rccl(force=True))
     print(build(force=True))

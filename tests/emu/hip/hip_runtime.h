@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <tuple>
 #include <vector>
 
@@ -193,9 +194,19 @@ inline U atomicMin(U* addr, U val) {  // fibers run one at a time: plain read-mo
     return old;
 }
 
+namespace hipemu {
+inline std::mutex& launch_mutex() {
+    static std::mutex m;
+    return m;
+}
+}  // namespace hipemu
+
 template <typename K, typename... A>
 inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
     hipemu::Call<K, A...> call{kernel, std::tuple<A...>(args...)};
+    // __shared__ arrays are plain statics here: one emulated kernel at a time per process
+    // (engines of several "ranks" may be driven from parallel host threads)
+    std::lock_guard<std::mutex> one_kernel(hipemu::launch_mutex());
     gridDim = grid;
     blockDim = block;
     for (unsigned b = 0; b < grid.x; ++b) {

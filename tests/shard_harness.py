@@ -129,6 +129,7 @@ def rank_main(argv):
         res[f"idx_{done}"], res[f"bel_{done}"] = idx, bel
         res[f"cost_{done}"] = np.array([cost, viol])
     assert run.cycle_count == done
+    res["collective"] = np.array(run.collective)
     if rank == 0:
         np.savez(out, **res)
     run.close()

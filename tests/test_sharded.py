@@ -97,11 +97,12 @@ def test_local_shards_parity_cases_emu(emu_lib):
         _check_against_single(make(), kw, 3, emu_lib, steps=(1, 6))
 
 
-def _run_ranks(world, lib, case, steps, tmp_path, timeout=600):
+def _run_ranks(world, lib, case, steps, tmp_path, timeout=600, extra_env=None):
     port = _free_port()
     out = str(tmp_path / "sharded.npz")
     procs = []
     env = dict(os.environ, OMP_NUM_THREADS="1")
+    env.update(extra_env or {})
     for r in range(world):
         cmd = [sys.executable, os.path.join(ROOT, "tests", "shard_harness.py"), str(world), str(r),
                str(port), lib or "-", out, case] + [str(s) for s in steps]
@@ -137,6 +138,102 @@ def test_gloo_two_ranks_equal_single_engine(case, emu_lib, tmp_path):
         assert z[f"cost_{done}"][1] == v and abs(z[f"cost_{done}"][0] - c) <= 1e-9 * max(1, abs(c))
 
 
+# ---- the native exchange (the engine calls RCCL itself; here: tests/emu/fake_rccl) --------
+
+@pytest.fixture(scope="session")
+def fake_rccl():
+    from emu.build_emu import build_fake_rccl
+    return build_fake_rccl()
+
+
+@pytest.mark.parametrize("case,k", [("coloring", 3), ("mixed_max", 2), ("ising", 4)])
+def test_native_exchange_thread_ranks_emu(case, k, emu_lib, fake_rccl, tmp_path, monkeypatch):
+    """mxs_comm_init / mxs_run_sharded: k ranks as k threads of this process, every one
+    stepping its own engine through the library's cycle loop."""
+    import threading
+    from pydcop_amd.engine import comm_unique_id
+    monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    g, kw = make_case(case)
+    p = Params(**kw)
+    part = partition_variables(g, k)
+    shards = [build_shard(g, part, r, k) for r in range(k)]
+    uid = comm_unique_id(emu_lib, fake_rccl)
+    steps = (1, 2, 9)
+    results, errors = [None] * k, []
+
+    def rank_main(r):
+        try:
+            s = shards[r]
+            e = MaxSumEngine(s.graph, p, lib_path=emu_lib)
+            e.halo_setup(s.send_edges, s.recv_edges)
+            e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=fake_rccl)
+            e.comm_exchange()
+            e.step_unpack()
+            out = []
+            for n in steps:
+                e.run_sharded(n)
+                e.sync()
+                out.append(e.assignment())
+            assert e.cycle_count == sum(steps)
+            results[r] = out
+            e.close()
+        except Exception as ex:  # surfaced in the main thread
+            errors.append((r, repr(ex)))
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(k)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    one = MaxSumEngine(g, p, lib_path=emu_lib)
+    for i, n in enumerate(steps):
+        one.run(n)
+        i1, b1 = one.assignment()
+        for r, s in enumerate(shards):
+            np.testing.assert_array_equal(results[r][i][0][:s.n_owned], i1[s.local_vars[:s.n_owned]])
+            np.testing.assert_array_equal(results[r][i][1][:s.n_owned], b1[s.local_vars[:s.n_owned]])
+    one.close()
+
+
+def test_native_exchange_rejects_bad_counts(emu_lib, fake_rccl, tmp_path, monkeypatch):
+    from pydcop_amd.engine import MaxSumGpuError, comm_unique_id
+    monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    g, kw = make_case("coloring")
+    part = partition_variables(g, 2)
+    s = build_shard(g, part, 0, 2)
+    e = MaxSumEngine(s.graph, Params(**kw), lib_path=emu_lib)
+    uid = comm_unique_id(emu_lib, fake_rccl)
+    with pytest.raises(MaxSumGpuError, match="halo_setup"):
+        e.comm_init(0, 2, uid, s.send_counts, s.recv_counts, rccl=fake_rccl)
+    with pytest.raises(MaxSumGpuError, match="no communicator"):
+        e.halo_setup(s.send_edges, s.recv_edges)
+        e.run_sharded(1)
+    with pytest.raises(MaxSumGpuError, match="counts"):
+        e.comm_init(0, 2, uid, s.send_counts + 1, s.recv_counts, rccl=fake_rccl)
+    with pytest.raises(MaxSumGpuError, match="cannot load RCCL"):
+        e.comm_init(0, 2, uid, s.send_counts, s.recv_counts, rccl=str(tmp_path / "nope.so"))
+    e.close()
+
+
+def test_gloo_two_ranks_native_exchange(emu_lib, fake_rccl, tmp_path):
+    """ShardedMaxSum(collective="rccl") end to end in two processes: unique id handed over
+    through torch.distributed, communicator created by the engine, cycle loop in the library."""
+    steps = [2, 11]
+    env = {"MAXSUM_COLLECTIVE": "rccl", "MAXSUM_RCCL_LIB": fake_rccl, "FAKE_RCCL_DIR": str(tmp_path)}
+    z = _run_ranks(2, emu_lib, "mixed_max", steps, tmp_path, extra_env=env)
+    assert str(z["collective"]) == "rccl"
+    g, kw = make_case("mixed_max")
+    one = MaxSumEngine(g, Params(**kw), lib_path=emu_lib)
+    done = 0
+    for n in steps:
+        one.run(n)
+        done += n
+        i1, b1 = one.assignment()
+        np.testing.assert_array_equal(z[f"idx_{done}"], i1)
+        np.testing.assert_array_equal(z[f"bel_{done}"], b1)
+
+
 # ---- on a real MI355X -----------------------------------------------------------
 
 @pytest.mark.gpu
@@ -151,10 +248,14 @@ def test_local_shards_equal_single_engine_gpu(k, dtype):
 
 
 @pytest.mark.gpu
-def test_nccl_world1_code_path(tmp_path):
-    """ShardedMaxSum with backend nccl (RCCL): external stream + torch-owned halo
-    tensors bound to the engine; world_size 1 (one GPU on the test box)."""
-    z = _run_ranks(1, None, "coloring_50k", [25], tmp_path)
+@pytest.mark.parametrize("collective", ["rccl", "torch"])
+def test_nccl_world1_code_path(collective, tmp_path):
+    """ShardedMaxSum with backend nccl (RCCL) at world_size 1 (one GPU on the test box).
+    rccl: the engine's own communicator (real librccl: ncclCommInitRank, grouped
+    ncclSend / ncclRecv on the comm stream, cycle loop in the library); torch: external
+    stream + torch-owned halo tensors bound to the engine."""
+    z = _run_ranks(1, None, "coloring_50k", [25], tmp_path, extra_env={"MAXSUM_COLLECTIVE": collective})
+    assert str(z["collective"]) == collective
     g, kw = make_case("coloring_50k")
     one = MaxSumEngine(g, Params(**kw))
     one.run(25)

@@ -1,18 +1,28 @@
 """What one rank of the weak-scaling bench computes per cycle (profiling, one GPU):
 build the N x 100k-variable instance, partition it N-way, create the engine of shard 0
-and step it WITHOUT the collective (pack / unpack still run).  Prints cut statistics,
-halo volume and the per-cycle time of the shard.
+and step it
+  (a) WITHOUT any collective (compute + pack + unpack),
+  (b) through the library's own cycle loop with a one-rank RCCL communicator that loops
+      the shard's whole halo back to itself (mxs_run_sharded: real ncclSend/ncclRecv of
+      the real volume, no interpreter in the loop),
+  (c) through torch.distributed.all_to_all_single of the same volume on the comm stream
+      (one Python iteration per cycle),
+so that the cost of the exchange and of the host loop can be told apart on a box with a
+single GPU.  Values of (b)/(c) runs are meaningless (the halo is looped back), times are not.
 usage: python tools/shard_cost.py [N] [dtype]"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
+import torch
+import torch.distributed as dist
 from bench import make_workload
-from pydcop_amd.engine import MaxSumEngine
+from pydcop_amd.engine import MaxSumEngine, comm_unique_id
 from pydcop_amd.graph import Params
 from pydcop_amd.partition import build_shard, cut_statistics, partition_variables
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = sys.argv[2] if len(sys.argv) > 2 else "f64"
+STEPS = 2000
 g, mode = make_workload("coloring_100k", N)
 t0 = time.perf_counter()
 part = partition_variables(g, N)
@@ -20,18 +30,60 @@ t1 = time.perf_counter()
 st = cut_statistics(g, part)
 sh = build_shard(g, part, 0, N)
 t2 = time.perf_counter()
+word = 8 if dt == "f64" else 4
+n_send, n_recv = int(sh.send_counts.sum()), int(sh.recv_counts.sum())
+out = {"ranks": N, "n_vars": g.n_vars, "partition_s": t1 - t0, "build_shard_s": t2 - t1,
+       "cut_fraction": st["cut_fraction"], "edge_imbalance": st["edge_imbalance"],
+       "shard_vars_owned": sh.n_owned, "shard_vars_ghost": int(sh.graph.n_vars - sh.n_owned),
+       "shard_factors": sh.graph.n_factors,
+       "halo_send_bytes": n_send * word, "halo_recv_bytes": n_recv * word}
+
+
+def timed(fn, sync):
+    fn(200); sync()
+    t = time.perf_counter(); fn(STEPS); sync()
+    return 1e6 * (time.perf_counter() - t) / STEPS
+
+
+# (a) no collective
 e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
 e.halo_setup(sh.send_edges, sh.recv_edges)
-def cycles(n):
+def cycles_a(n):
     for _ in range(n):
         e.step_compute(); e.step_unpack()
-    e.sync()
-cycles(200)
-t3 = time.perf_counter(); cycles(2000); t4 = time.perf_counter()
-word = 8 if dt == "f64" else 4
-print(json.dumps({"ranks": N, "n_vars": g.n_vars, "partition_s": t1 - t0, "build_shard_s": t2 - t1,
-                  "cut_fraction": st["cut_fraction"], "edge_imbalance": st["edge_imbalance"],
-                  "shard_vars_owned": sh.n_owned, "shard_vars_ghost": int(sh.graph.n_vars - sh.n_owned),
-                  "shard_factors": sh.graph.n_factors,
-                  "halo_send_bytes": int(sh.send_counts.sum()) * word, "halo_recv_bytes": int(sh.recv_counts.sum()) * word,
-                  "shard_cycle_us_without_collective": 1e6 * (t4 - t3) / 2000}))
+out["shard_cycle_us_without_collective"] = timed(cycles_a, e.sync)
+e.close()
+
+# (b) library loop + real RCCL, halo looped back (needs n_send == n_recv)
+if n_send == n_recv:
+    e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
+    e.halo_setup(sh.send_edges, sh.recv_edges)
+    e.comm_init(0, 1, comm_unique_id(), [n_send], [n_recv])
+    out["shard_cycle_us_native_rccl_loopback"] = timed(e.run_sharded, e.sync)
+    e.close()
+
+# (c) torch.distributed on the comm stream, same volume
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo"); os.environ.setdefault("NCCL_IB_DISABLE", "1")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1)
+e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
+e.halo_setup(sh.send_edges, sh.recv_edges)
+tdt = torch.float64 if dt == "f64" else torch.float32
+send = torch.zeros(max(n_send, 1), dtype=tdt, device="cuda")
+recv = torch.zeros(max(n_recv, 1), dtype=tdt, device="cuda")
+torch.cuda.synchronize()
+e.halo_bind(send.data_ptr(), recv.data_ptr())
+ext = torch.cuda.ExternalStream(e.stream(), device=torch.device("cuda", 0))
+def cycles_c(n):
+    with torch.cuda.stream(ext):
+        for _ in range(n):
+            e.step_compute()
+            dist.all_to_all_single(recv, send, [n_recv], [n_send])
+            e.step_unpack()
+def sync_c():
+    e.sync(); torch.cuda.synchronize()
+out["shard_cycle_us_torch_all_to_all_loopback"] = timed(cycles_c, sync_c)
+e.close()
+dist.destroy_process_group()
+print(json.dumps(out))
