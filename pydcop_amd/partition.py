@@ -6,11 +6,16 @@ balanced split of the *edges* with few cut factors, because every cut factor is
 replicated on the shards that own one of its variables and its remote variables'
 V->F messages have to cross once per cycle.
 
-METIS is not available in this environment, so `partition_variables` is a small
-O(E) heuristic of its own: breadth-first order over the bipartite graph (locality)
-cut into k chunks of equal edge weight, then a few rounds of balanced label
-propagation that move a variable to the part holding most of its neighbours.
+METIS is not available in this environment, so `partition_variables` calls a
+multilevel partitioner of its own (heavy-edge matching, greedy growing, boundary FM
+refinement, recursive bisection: pydcop_amd/csrc/partition.cpp, C-ABI
+include/maxsum_partition.h).  The first version -- breadth-first order cut into k
+chunks of equal weight + balanced label propagation, numpy only -- is kept as
+`method="labelprop"` for comparison: on the 8 x 100k-variable random colouring
+instance it cuts 64 % of the factors in 58 s, the multilevel one 37 % in 4 s.
 """
+import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import List
 
@@ -18,17 +23,49 @@ import numpy as np
 
 from .graph import FlatGraph
 
+_PART_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libmxs_partition.so")
+_part_lib = None
+
+
+def _load_partition_lib():
+    global _part_lib
+    if _part_lib is None:
+        if not os.path.exists(_PART_LIB):
+            raise RuntimeError(f"{_PART_LIB} not found: build it with "
+                               "`python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(_PART_LIB)
+        lib.mxp_partition.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32,
+                                      C.c_double, C.c_uint64, C.c_void_p]
+        lib.mxp_partition.restype = C.c_int
+        lib.mxp_last_error.argtypes = []
+        lib.mxp_last_error.restype = C.c_char_p
+        _part_lib = lib
+    return _part_lib
+
 
 def _edge_factor(g: FlatGraph) -> np.ndarray:
     return np.repeat(np.arange(g.n_factors, dtype=np.int64), np.diff(g.factor_rowptr))
 
 
 def partition_variables(g: FlatGraph, k: int, rounds: int = 6, seed: int = 0,
-                        imbalance: float = 1.03) -> np.ndarray:
-    """part[v] in 0..k-1 for every variable."""
+                        imbalance: float = 1.03, method: str = "multilevel") -> np.ndarray:
+    """part[v] in 0..k-1 for every variable (deterministic for a given seed: every rank
+    of a sharded run computes the same partition on its own)."""
     nv, nf = g.n_vars, g.n_factors
     if k <= 1 or nv == 0:
         return np.zeros(nv, dtype=np.int32)
+    if method == "multilevel":
+        lib = _load_partition_lib()
+        rowptr = np.ascontiguousarray(g.factor_rowptr, dtype=np.int32)
+        ev32 = np.ascontiguousarray(g.edge_var, dtype=np.int32)
+        part = np.empty(nv, dtype=np.int32)
+        rc = lib.mxp_partition(nv, nf, rowptr.ctypes.data, ev32.ctypes.data, int(k), float(imbalance),
+                               int(seed), part.ctypes.data)
+        if rc != 0:
+            raise RuntimeError(f"mxp_partition failed ({rc}): {lib.mxp_last_error().decode()}")
+        return part
+    if method != "labelprop":
+        raise ValueError("method must be 'multilevel' or 'labelprop'")
     import scipy.sparse as sp
     from scipy.sparse.csgraph import breadth_first_order
 

@@ -27,6 +27,17 @@ def test_header_symbols_are_exported(hip_lib):
     assert hip_lib.mxs_version() >= 100
 
 
+def test_partition_header_symbols_are_exported(hip_lib):
+    """include/maxsum_partition.h <-> libmxs_partition.so (host code, built by build())."""
+    import ctypes
+    header = open(os.path.join(ROOT, "include", "maxsum_partition.h")).read()
+    declared = set(re.findall(r"\b(mxp_[a-z_]+)\s*\(", header))
+    assert declared == {"mxp_partition", "mxp_last_error"}
+    lib = ctypes.CDLL(os.path.join(ROOT, "pydcop_amd", "csrc", "libmxs_partition.so"))
+    for name in declared:
+        assert hasattr(lib, name)
+
+
 def test_no_cpu_fallback_without_gpu(hip_lib):
     from pydcop_amd import generators as G
     from pydcop_amd.engine import MaxSumEngine, MaxSumGpuError, device_count

@@ -52,6 +52,48 @@ def test_partition_is_balanced_and_local():
         assert cut_statistics(g2, p)["edge_imbalance"] < 1.2
 
 
+def test_multilevel_partitioner_quality_and_corner_cases():
+    """pydcop_amd/csrc/partition.cpp (include/maxsum_partition.h) against the first,
+    label-propagation version: fewer cut factors, balanced, deterministic."""
+    from pydcop_amd import generators as G
+    from pydcop_amd.graph import FlatGraph
+    g = G.random_coloring(20_000, avg_degree=4, seed=3, names=False)
+    for k in (2, 8):
+        a = partition_variables(g, k)
+        b = partition_variables(g, k)
+        np.testing.assert_array_equal(a, b)  # every rank computes it on its own
+        sa, sb = cut_statistics(g, a), cut_statistics(g, partition_variables(g, k, method="labelprop"))
+        assert set(np.unique(a)) == set(range(k))
+        assert sa["edge_imbalance"] < 1.06
+        assert sa["cut_factors"] < 0.85 * sb["cut_factors"]
+    assert cut_statistics(g, partition_variables(g, 2))["cut_fraction"] < 0.2
+    # a grid has a small separator
+    gi = G.ising_grid(64, 64, seed=0, names=False)
+    assert cut_statistics(gi, partition_variables(gi, 4))["cut_fraction"] < 0.06
+    # isolated variables, one hub in every factor (star), an arity-9 factor, more parts than variables
+    n = 400
+    rowptr = np.arange(0, 2 * (n - 1) + 1, 2, dtype=np.int32)
+    ev = np.stack([np.zeros(n - 1, dtype=np.int32), np.arange(1, n, dtype=np.int32)], axis=1).reshape(-1)
+    class Star:  # only what partition_variables reads
+        n_vars, n_factors, factor_rowptr, edge_var = n + 50, n - 1, rowptr, ev
+    p = partition_variables(Star, 4)
+    assert p.shape == (n + 50,) and p.min() == 0 and p.max() == 3
+    sizes = np.bincount(p, minlength=4)
+    assert sizes.min() > 60  # leaves and isolated variables are spread, the hub cannot be
+    class Wide:
+        n_vars, n_factors = 30, 3
+        factor_rowptr = np.array([0, 9, 18, 27], dtype=np.int32)
+        edge_var = np.arange(27, dtype=np.int32)
+    p = partition_variables(Wide, 3)
+    assert sorted(np.bincount(p, minlength=3).tolist()) == [10, 10, 10] or p.max() == 2
+    class Tiny:
+        n_vars, n_factors = 3, 1
+        factor_rowptr = np.array([0, 2], dtype=np.int32)
+        edge_var = np.array([0, 1], dtype=np.int32)
+    p = partition_variables(Tiny, 8)
+    assert p.shape == (3,) and p.min() >= 0 and p.max() < 8
+
+
 def test_shards_cover_the_graph():
     g, _ = make_case("mixed_max")
     k = 3
