@@ -229,20 +229,21 @@ template <typename T, int D>
 __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
     constexpr int H = Msg<T, D>::H;
     const int e = ci.edge_base + 2 * j;
-    const int64_t fo = ci.f2v_base + (int64_t)j * 2 * H;  // both messages of the factor
+    // the class's records are split by scope position: two dense streams
+    const int64_t fo0 = ci.f2v_base + (int64_t)j * H, fo1 = ci.f2v_base1 + (int64_t)j * H;
     // everything addressed by j: coalesced
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     const int v0 = a.edge_v2f[e], v1 = a.edge_v2f[e + 1];
     uint8_t cn0, cn1;
     T m0[D], p0[D], m1[D], p1[D], tab[D * D];
     if constexpr (CIM) {
-        cn0 = Msg<T, D>::load_c(a.f2v_old + fo, p0);      // F->V message last sent to variable 0
-        cn1 = Msg<T, D>::load_c(a.f2v_old + fo + H, p1);  // (+ its send counter)
+        cn0 = Msg<T, D>::load_c(a.f2v_old + fo0, p0);  // F->V message last sent to variable 0
+        cn1 = Msg<T, D>::load_c(a.f2v_old + fo1, p1);  // (+ its send counter)
     } else {
         cn0 = a.cF[e];
         cn1 = a.cF[e + 1];
-        Msg<T, D>::load(a.f2v_old + fo, p0);
-        Msg<T, D>::load(a.f2v_old + fo + H, p1);
+        Msg<T, D>::load(a.f2v_old + fo0, p0);
+        Msg<T, D>::load(a.f2v_old + fo1, p1);
     }
 #pragma unroll
     for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
@@ -276,17 +277,22 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         c1 = damp_and_filter<T, D>(o1, p1, cn1, a.damp_f != 0, a.damping, a.stability);
     }
     const int lw = (int)threadIdx.x & 63;
-    if ((j - lw + 63) < ci.count) {  // wave-uniform: a whole wave of factors
-        T full[2 * H];
+    if constexpr ((H * sizeof(T)) % 16 == 0) {
+        if ((j - lw + 63) < ci.count) {  // wave-uniform: a whole wave of factors
+            T full[H];
 #pragma unroll
-        for (int d = 0; d < H; ++d) {
-            full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
-            full[H + d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
+            for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
+            wave_store_linear<T, H>(a.f2v_new, fo0 - (int64_t)lw * H, full);
+#pragma unroll
+            for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
+            wave_store_linear<T, H>(a.f2v_new, fo1 - (int64_t)lw * H, full);
+        } else {
+            Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
+            Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
         }
-        wave_store_linear<T, 2 * H>(a.f2v_new, fo - (int64_t)lw * 2 * H, full);
     } else {
-        Msg<T, D>::store_c(a.f2v_new + fo, o0, CIM ? c0 : 0);
-        Msg<T, D>::store_c(a.f2v_new + fo + H, o1, CIM ? c1 : 0);
+        Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
+        Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
     }
     if constexpr (!CIM) {
         a.cF[e] = c0;

@@ -18,6 +18,9 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.no_specialise = (f & 4) != 0;   // bit2: generic kernels only
     o.sort_by_degree = !(f & 8);      // bit3: keep the caller's variable order
     o.nary = !(f & 16);               // bit4: no workgroup-per-factor kernel
+    o.sort_factors = MXS_SORT_FACTORS_DEFAULT != 0;
+    if (f & 128) o.sort_factors = true;   // bit7: factor order follows the variable order
+    if (f & 256) o.sort_factors = false;  // bit8: factors of a class keep the caller's order
     return o;
 }
 
@@ -109,6 +112,33 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     const double sign = L.is_max ? -1.0 : 1.0;  // max-sum == min-sum on negated costs
     const int nV = g.n_vars, nF = g.n_factors, nE = g.n_edges;
 
+    // ---- classify and order variables ---------------------------------------
+    std::vector<int> vsort(nV);
+    for (int v = 0; v < nV; ++v) {
+        const int deg = g.var_rowptr[v + 1] - g.var_rowptr[v];
+        const int D = g.dom_size[v];
+        const bool own = !g.var_owned || g.var_owned[v];
+        int kind, sub;
+        if (!own) { kind = 90; sub = 0; }                       // ghost: never swept
+        else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
+        else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
+            kind = K_V_PACK; sub = D;
+        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
+            kind = K_V_WIDE;  // wave per variable, messages staged in LDS; two LDS footprints
+            sub = ((int64_t)deg * D <= 128 && deg <= 32) ? 0 : 1;
+        } else { kind = K_V_GEN; sub = 0; }
+        // sort key: class, then degree (the packed class needs equal degrees side
+        // by side; bit3 of layout_flags keeps the caller's order elsewhere)
+        const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
+        vsort[v] = (kind * 1024 + sub) * 4096 + (by_deg ? std::min(deg, 4095) : 0);
+    }
+    L.var_i2e.resize(nV);
+    std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);
+    std::stable_sort(L.var_i2e.begin(), L.var_i2e.end(),
+                     [&](int a, int b) { return vsort[a] < vsort[b]; });
+    L.var_e2i.resize(nV);
+    for (int vi = 0; vi < nV; ++vi) L.var_e2i[L.var_i2e[vi]] = vi;
+
     // ---- classify factors ------------------------------------------------
     std::vector<FKey> fkey(nF);
     for (int f = 0; f < nF; ++f) {
@@ -146,8 +176,19 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     }
     L.factor_i2e.resize(nF);
     std::iota(L.factor_i2e.begin(), L.factor_i2e.end(), 0);
-    std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(),
-                     [&](int a, int b) { return fkey[a] < fkey[b]; });
+    // Inside a class the factors follow the internal order of their FIRST scope variable
+    // (sort_factors): the V->F records of that variable are then gathered by neighbouring
+    // lanes, and -- the F->V records of a binary class being split by scope position, see
+    // below -- the variable side reads the position-0 records as one dense stream.  One of
+    // the two gathers per edge end turns from a random 64-byte request into streaming.
+    // Any order gives the same arithmetic (every message is computed on its own).
+    std::vector<int32_t> floc(nF, 0);
+    if (L.opt.sort_factors)
+        for (int f = 0; f < nF; ++f)
+            if (g.factor_rowptr[f + 1] > g.factor_rowptr[f]) floc[f] = L.var_e2i[g.edge_var[g.factor_rowptr[f]]];
+    std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(), [&](int a, int b) {
+        return fkey[a] < fkey[b] || (fkey[a] == fkey[b] && floc[a] < floc[b]);
+    });
 
     L.factor_e2i.resize(nF);
     for (int fi = 0; fi < nF; ++fi) L.factor_e2i[L.factor_i2e[fi]] = fi;
@@ -169,21 +210,37 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         int ei = 0;
         int64_t off = 0;
         const int align = 32 / L.opt.word;  // every class starts on a 32-byte boundary
-        for (int fi = 0; fi < nF; ++fi) {
-            const int f = L.factor_i2e[fi];
-            L.frowptr[fi] = ei;
-            if (fi == 0 || !(fkey[f] == fkey[L.factor_i2e[fi - 1]])) off = (off + align - 1) / align * align;
-            for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e, ++ei) {
-                L.edge_i2e[ei] = e;
-                L.edge_e2i[e] = ei;
-                const int D = g.dom_size[g.edge_var[e]];
-                const int H = L.half(D);
-                L.edge_dom[ei] = D;
-                L.edge_half[ei] = H;
-                if (off > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
-                L.f2v_off[ei] = (int32_t)off;
-                off += H;
+        for (int fi = 0; fi < nF;) {
+            const FKey key = fkey[L.factor_i2e[fi]];
+            int fj = fi;
+            while (fj < nF && fkey[L.factor_i2e[fj]] == key) ++fj;
+            off = (off + align - 1) / align * align;
+            // A binary register class keeps its records split by scope position: record
+            // (j, 0) at base + j*H, record (j, 1) at base1 + j*H -- two dense streams for
+            // the factor side, and with sort_factors the first one is in variable order.
+            const bool split = key.kind == K_F_BIN;
+            const int Hc = split ? L.half(key.D) : 0;
+            const int64_t half_len = split ? ((int64_t)(fj - fi) * Hc + align - 1) / align * align : 0;
+            for (int f2 = fi; f2 < fj; ++f2) {
+                const int f = L.factor_i2e[f2];
+                L.frowptr[f2] = ei;
+                for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e, ++ei) {
+                    L.edge_i2e[ei] = e;
+                    L.edge_e2i[e] = ei;
+                    const int D = g.dom_size[g.edge_var[e]];
+                    const int H = L.half(D);
+                    L.edge_dom[ei] = D;
+                    L.edge_half[ei] = H;
+                    int64_t at = off;
+                    if (split) at = off + (int64_t)(e - g.factor_rowptr[f]) * half_len + (int64_t)(f2 - fi) * Hc;
+                    else off += H;
+                    if (at > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
+                    L.f2v_off[ei] = (int32_t)at;
+                }
             }
+            if (split) off += 2 * half_len;
+            if (off > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
+            fi = fj;
         }
         L.frowptr[nF] = ei;
         // an all-zero block nobody writes, gathered through the padding slots of the
@@ -193,33 +250,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         off += L.half(MAX_REG_D);
         L.f2v_elems = off;
     }
-
-    // ---- classify and order variables ---------------------------------------
-    std::vector<int> vsort(nV);
-    for (int v = 0; v < nV; ++v) {
-        const int deg = g.var_rowptr[v + 1] - g.var_rowptr[v];
-        const int D = g.dom_size[v];
-        const bool own = !g.var_owned || g.var_owned[v];
-        int kind, sub;
-        if (!own) { kind = 90; sub = 0; }                       // ghost: never swept
-        else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
-        else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
-            kind = K_V_PACK; sub = D;
-        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
-            kind = K_V_WIDE;  // wave per variable, messages staged in LDS; two LDS footprints
-            sub = ((int64_t)deg * D <= 128 && deg <= 32) ? 0 : 1;
-        } else { kind = K_V_GEN; sub = 0; }
-        // sort key: class, then degree (the packed class needs equal degrees side
-        // by side; bit3 of layout_flags keeps the caller's order elsewhere)
-        const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
-        vsort[v] = (kind * 1024 + sub) * 4096 + (by_deg ? std::min(deg, 4095) : 0);
-    }
-    L.var_i2e.resize(nV);
-    std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);
-    std::stable_sort(L.var_i2e.begin(), L.var_i2e.end(),
-                     [&](int a, int b) { return vsort[a] < vsort[b]; });
-    L.var_e2i.resize(nV);
-    for (int vi = 0; vi < nV; ++vi) L.var_e2i[L.var_i2e[vi]] = vi;
 
     L.vrowptr.assign(nV + 1, 0);
     L.vslot_edge.resize(nE);
@@ -295,6 +325,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         ci.count = n;
         ci.edge_base = L.frowptr[fi];
         ci.f2v_base = nE ? L.f2v_off[L.frowptr[fi]] : 0;
+        ci.f2v_base1 = key.kind == K_F_BIN ? L.f2v_off[L.frowptr[fi] + 1] : 0;  // record (0, 1)
         ci.tab_base = L.eval_tab_off[fi];
         const int cls = (int)L.classes.size();
         if (key.kind == K_F_UNARY || key.kind == K_F_BIN) {

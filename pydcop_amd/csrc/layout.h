@@ -26,6 +26,10 @@
 //            cF factor-major, cV in the variable classes' slot order -- each is
 //            private to the side that owns it, so neither is ever gathered.
 //   variables internal order = sorted by class then degree.
+//   factors  internal order = sorted by class, then (sort_factors) by the internal
+//            position of their first scope variable; the F2V records of a binary
+//            register class are split by scope position (all position-0 records, then
+//            all position-1 records).
 //
 // Factors and variables are grouped into classes; one 256-thread block works on
 // one class, and one launch sweeps all classes of both sides.
@@ -57,6 +61,9 @@ enum Kind : int32_t {
 #define MXS_BLOCK 256  // threads per workgroup of the sweep (other values: experiments only)
 #endif
 constexpr int BLOCK = MXS_BLOCK;
+#ifndef MXS_SORT_FACTORS_DEFAULT
+#define MXS_SORT_FACTORS_DEFAULT 1  // layout_flags bit7 forces it on, bit8 off
+#endif
 constexpr int MAX_REG_D = 4;
 constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
@@ -85,6 +92,8 @@ struct ClassInfo {       // one per class, read with one scalar load
     int64_t ell_base;    // K_V_PACK: first lane of the class in the per-lane tables
     int64_t cv_base;     // K_V_PACK: first send counter of the class in cV
     int64_t v2f_base;    // K_V_PACK: element offset of the class in V2F
+    int64_t f2v_base1;   // K_F_BIN: element offset of the class's position-1 records in F2V
+                         // (the records of a binary class are split by scope position)
 };
 
 struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block
@@ -124,6 +133,7 @@ struct LayoutOptions {
     bool no_specialise = false;  // force the generic kernels (testing)
     bool sort_by_degree = true;
     bool nary = true;            // use the workgroup-per-factor kernel (K_F_NARY)
+    bool sort_factors = false;   // inside a class, factors follow their first variable's order
 };
 
 struct Layout {

@@ -23,7 +23,8 @@ def emu_lib():
     return build()
 
 
-LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16}
+LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16,
+           "sorted_factors": 128, "unsorted_factors": 256, "sorted_keep_order": 128 + 8}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
@@ -36,9 +37,11 @@ def test_emu_bit_exact_vs_oracle(case, dtype, emu_lib, oracle_built):
 
 @pytest.mark.parametrize("layout", [k for k in LAYOUTS if k != "default"])
 def test_emu_layout_variants(layout, emu_lib, oracle_built):
-    for name, make, kw in parity_cases()[:3] + parity_cases()[6:8]:
-        compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], **kw), 0,
-                            lib_path=emu_lib, steps=[1, 6])
+    cases = parity_cases() if "sorted" in layout else parity_cases()[:3] + parity_cases()[6:8]
+    for name, make, kw in cases:
+        for dtype in (("f64", "f32") if "sorted" in layout else ("f64",)):
+            compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], dtype=dtype, **kw), 0,
+                                lib_path=emu_lib, steps=[1, 6])
 
 
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
