@@ -52,10 +52,10 @@ def measured_traffic(workload, dtype):
         return None
 
 
-def make_workload(name, n_gpus=1):
+def make_workload(name, n_gpus=1, per_gpu=100_000):
     from pydcop_amd import generators as G
     if name == "coloring_100k":     # the metric's configuration (north-star); x n_gpus when weak-scaled
-        return G.random_coloring(100_000 * n_gpus, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+        return G.random_coloring(per_gpu * n_gpus, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_10k":      # BASELINE.json configs[1]
         return G.random_coloring(10_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_100k_hard":
@@ -116,6 +116,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N > 1: weak = N x 100k-variable instance (default), strong = the fixed instance")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="N > 1: torch.distributed backend; gloo only for the CPU test of this script "
+                         "(tests/test_bench_cli.py, emulated engine)")
+    ap.add_argument("--vars-per-gpu", type=int, default=100_000,
+                    help="testing only: size of the coloring_100k workload (the metric is defined at 100000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +138,7 @@ def main():
     from pydcop_amd.graph import Params
 
     weak = args.scaling == "weak" and args.gpus > 1 and args.workload == "coloring_100k"
-    graph, mode = make_workload(args.workload, args.gpus if weak else 1)
+    graph, mode = make_workload(args.workload, args.gpus if weak else 1, args.vars_per_gpu)
     units = args.gpus if weak else 1  # 100k-variable instances' worth of work per iteration
     params = Params(mode=mode, dtype=args.dtype, layout_flags=args.layout_flags,
                     graph_chunk=args.graph_chunk)
@@ -143,21 +148,23 @@ def main():
     if world > 1:
         from pydcop_amd.sharded import ShardedMaxSum
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        # one node: RCCL bootstraps over loopback, no InfiniBand probing (the container's
-        # hostname may not resolve); respected only if the launcher did not set them
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-        os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        dist.init_process_group("nccl")
-        runner = ShardedMaxSum(graph, params, rank, world, device=local_rank)
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            # one node: RCCL bootstraps over loopback, no InfiniBand probing (the container's
+            # hostname may not resolve); respected only if the launcher did not set them
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
+        dist.init_process_group(args.backend)
+        runner = ShardedMaxSum(graph, params, rank, world,
+                               device=local_rank if args.backend == "nccl" else 0)
         barrier = dist.barrier
     else:
         runner = MaxSumEngine(graph, params, device=local_rank)
         barrier = lambda: None  # noqa: E731
 
     def sync():
-        runner.sync()  # hipStreamSynchronize on the engine's stream
-        if world > 1:
+        runner.sync()  # hipStreamSynchronize on the engine's streams
+        if world > 1 and args.backend == "nccl":
             torch.cuda.synchronize()
 
     runner.run(args.warmup)
@@ -174,7 +181,7 @@ def main():
     elapsed = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], device="cuda")
+        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

@@ -296,7 +296,8 @@ def test_nccl_world1_code_path(collective, tmp_path):
     rccl: the engine's own communicator (real librccl: ncclCommInitRank, grouped
     ncclSend / ncclRecv on the comm stream, cycle loop in the library); torch: external
     stream + torch-owned halo tensors bound to the engine."""
-    z = _run_ranks(1, None, "coloring_50k", [25], tmp_path, extra_env={"MAXSUM_COLLECTIVE": collective})
+    z = _run_ranks(1, None, "coloring_50k", [25], tmp_path, timeout=150,
+                   extra_env={"MAXSUM_COLLECTIVE": collective})
     assert str(z["collective"]) == collective
     g, kw = make_case("coloring_50k")
     one = MaxSumEngine(g, Params(**kw))

@@ -73,6 +73,21 @@ __global__ void __launch_bounds__(256) k_gather(const float4* __restrict__ rec, 
     out[(size_t)r * 4 + 1] = s1;
 }
 
+// one 32-B record (a padded D=3 f64 message) gathered per lane, 16 B written linearly:
+// the shape of a message gather of the sweep.  Index patterns: random, every record in
+// order (dense), every other record in order (half dense) -- calibrates what FETCH_SIZE
+// reports for near-sequential gathers.
+__global__ void __launch_bounds__(256) k_gather32(const float4* __restrict__ rec, float4* __restrict__ out,
+                                                  const uint32_t* __restrict__ idx, size_t n_lanes) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lanes) return;
+    const uint32_t r = idx[i];
+    const float4 a = rec[(size_t)r * 2 + 0], b = rec[(size_t)r * 2 + 1];
+    float4 s0;
+    s0.x = a.x + b.x; s0.y = a.y + b.y; s0.z = a.z + b.z; s0.w = a.w + b.w;
+    out[i] = s0;
+}
+
 __global__ void k_chase(const uint32_t* __restrict__ next, uint32_t start, int steps, uint32_t* out) {
     uint32_t p = start;
     for (int i = 0; i < steps; ++i) p = next[(size_t)p * 16];  // one 64-B line per hop
@@ -184,6 +199,44 @@ int main() {
         printf("{\"bench\": \"gather64_scatter32\", \"records\": %zu, \"mb\": %.1f, \"us_per_launch\": %.2f, "
                "\"useful_GBps\": %.1f}\n",
                n_rec, bytes / 1048576.0, 1e3 * ms / reps, (double)n_rec * (64 + 32 + 4) * reps / (ms * 1e-3) / 1e9);
+        CHECK(hipFree(rec));
+        CHECK(hipFree(out));
+        CHECK(hipFree(idx));
+    }
+
+    // 3b. 32-B record gathers: random / dense / half dense ----------------------------
+    {
+        const size_t n_lanes = 6000000, n_rec = 2 * n_lanes;  // 384 MB of records: beyond the cache
+        float4 *rec, *out;
+        uint32_t* idx;
+        CHECK(hipMalloc((void**)&rec, n_rec * 32));
+        CHECK(hipMalloc((void**)&out, n_lanes * 16));
+        CHECK(hipMalloc((void**)&idx, n_lanes * 4));
+        CHECK(hipMemsetAsync(rec, 0, n_rec * 32, st));
+        std::vector<uint32_t> h(n_lanes);
+        const char* names[3] = {"random", "dense", "half_dense"};
+        for (int pat = 0; pat < 3; ++pat) {
+            for (size_t i = 0; i < n_lanes; ++i) h[i] = pat == 1 ? (uint32_t)i : (uint32_t)(2 * i);
+            if (pat == 0) {
+                uint64_t s = 88172645463325252ull;
+                for (size_t i = n_lanes - 1; i > 0; --i) {
+                    s ^= s << 13; s ^= s >> 7; s ^= s << 17;
+                    std::swap(h[i], h[s % (i + 1)]);
+                }
+            }
+            CHECK(hipMemcpyAsync(idx, h.data(), n_lanes * 4, hipMemcpyHostToDevice, st));
+            CHECK(hipStreamSynchronize(st));
+            // the grid size tells the patterns apart in a counter trace: +0 / +1 / +2 blocks
+            const int blocks = (int)((n_lanes + 255) / 256) + pat, reps = 10;
+            for (int i = 0; i < 2; ++i) hipLaunchKernelGGL(k_gather32, dim3(blocks), dim3(256), 0, st, rec, out, idx, n_lanes);
+            CHECK(hipEventRecord(e0, st));
+            for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_gather32, dim3(blocks), dim3(256), 0, st, rec, out, idx, n_lanes);
+            CHECK(hipEventRecord(e1, st));
+            const float ms = time_ms(st, e0, e1);
+            printf("{\"bench\": \"gather32_%s\", \"lanes\": %zu, \"grid_blocks\": %d, \"us_per_launch\": %.2f, "
+                   "\"payload_GBps\": %.1f}\n",
+                   names[pat], n_lanes, blocks, 1e3 * ms / reps, (double)n_lanes * (32 + 16 + 4) * reps / (ms * 1e-3) / 1e9);
+        }
         CHECK(hipFree(rec));
         CHECK(hipFree(out));
         CHECK(hipFree(idx));
