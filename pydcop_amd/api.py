@@ -62,6 +62,37 @@ def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: s
             "cost_curve": curve}
 
 
+def solve_flat(graph: FlatGraph, objective: str = "min", cycles: int = 30, *, damping: float = 0.5,
+               damping_nodes: str = "both", stability: float = 0.1, start_messages: str = "leafs",
+               precision: str = "f64", infinity: float = 10000, device: int = 0, cost_every: int = 0,
+               lib_path: Optional[str] = None) -> Dict:
+    """`solve_dcop` for an already compiled instance (`FlatGraph`, e.g. loaded from the
+    .npz instance format): no pyDCOP import at all.  Cost and violations come from the
+    device (`mxs_eval_cost` = DCOP.solution_cost, pydcop/dcop/dcop.py:308-367); noise, if
+    wanted, is already folded into `graph.var_cost` by whoever compiled the instance."""
+    from .engine import MaxSumEngine
+    params = Params(mode=objective, damping=damping, damping_nodes=damping_nodes,
+                    stability=stability, start_messages=start_messages, dtype=precision)
+    curve: List[Tuple[int, float, int]] = []
+    with MaxSumEngine(graph, params, device=device, lib_path=lib_path) as eng:
+        done = 0
+        while done < cycles:
+            n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
+            eng.run(n)
+            done += n
+            if cost_every > 0:
+                c, v = eng.eval_cost(infinity=infinity)
+                curve.append((done, c, v))
+        idx, _ = eng.assignment()
+        cost, violation = eng.eval_cost(infinity=infinity)
+    if graph.var_names is not None and graph.domains is not None:
+        assignment = assignment_to_values(graph, idx)
+    else:
+        assignment = {f"v{i}": int(x) for i, x in enumerate(idx)}
+    return {"assignment": assignment, "cost": cost, "violation": violation, "cycle": cycles,
+            "cost_curve": curve}
+
+
 def solve_yaml(paths, cycles: int = 30, **kw) -> Dict:
     """`solve_dcop` on DCOP YAML file(s) (pydcop/dcop/yamldcop.py:96)."""
     from . import plugin
@@ -73,11 +104,14 @@ def solve_yaml(paths, cycles: int = 30, **kw) -> Dict:
 
 
 def main(argv=None):
-    """`python -m pydcop_amd.api [-c CYCLES] [-p name:value ...] dcop.yaml ...` -- solve
-    without agents and print a result in the schema of `pydcop solve`
-    (docs/tutorials/analysing_results.rst:31-48; no agent metrics: there are no agents)."""
+    """`python -m pydcop_amd.api [-c CYCLES] [-p name:value ...] dcop.yaml ... | instance.npz`
+    -- solve without agents and print a result in the schema of `pydcop solve`
+    (docs/tutorials/analysing_results.rst:31-48; no agent metrics: there are no agents).
+    `--export out.npz` compiles the YAML DCOP to the binary instance format instead
+    (`FlatGraph.save`); an .npz instance is solved without importing pyDCOP."""
     import argparse
     import json
+    import os
     import time
     ap = argparse.ArgumentParser(prog="python -m pydcop_amd.api")
     ap.add_argument("dcop_files", nargs="+")
@@ -86,6 +120,8 @@ def main(argv=None):
                     help="name:value, e.g. damping:0.7 noise:0 precision:f32 (maxsum.py:212-220)")
     ap.add_argument("--infinity", type=float, default=float("inf"))   # pydcop/commands/solve.py:316-324
     ap.add_argument("--cost_every", type=int, default=0)
+    ap.add_argument("--export", metavar="OUT.npz", default=None,
+                    help="compile the YAML DCOP (noise folded in) and write it as an instance file")
     args = ap.parse_args(argv)
     kinds = {"damping": float, "stability": float, "noise": float, "seed": int,
              "damping_nodes": str, "start_messages": str, "precision": str}
@@ -96,8 +132,25 @@ def main(argv=None):
             raise SystemExit(f"Error: unknown parameter {name!r} (one of {sorted(kinds)})")
         kw[name] = kinds[name](value)
     t0 = time.perf_counter()
-    res = solve_yaml(args.dcop_files, args.cycles, infinity=args.infinity,
-                     cost_every=args.cost_every, **kw)
+    if args.export:
+        from . import plugin
+        plugin.install()
+        from pydcop.dcop.yamldcop import load_dcop_from_file
+        dcop = load_dcop_from_file(list(args.dcop_files))
+        g = compile_dcop(dcop, noise=kw.get("noise", 0.01), seed=kw.get("seed", 0))
+        g.save(args.export, objective=dcop.objective, source=[os.path.basename(f) for f in args.dcop_files])
+        print(json.dumps({"exported": args.export, "n_vars": g.n_vars, "n_factors": g.n_factors,
+                          "n_edges": g.n_edges, "objective": dcop.objective}))
+        return
+    if len(args.dcop_files) == 1 and args.dcop_files[0].endswith(".npz"):
+        graph, header = FlatGraph.load(args.dcop_files[0])
+        for k in ("noise", "seed"):  # folded into the instance when it was compiled
+            kw.pop(k, None)
+        res = solve_flat(graph, header.get("objective", "min"), args.cycles, infinity=args.infinity,
+                         cost_every=args.cost_every, **kw)
+    else:
+        res = solve_yaml(args.dcop_files, args.cycles, infinity=args.infinity,
+                         cost_every=args.cost_every, **kw)
     out = {"assignment": res["assignment"], "cost": res["cost"], "violation": res["violation"],
            "cycle": res["cycle"], "status": "FINISHED", "time": time.perf_counter() - t0,
            "msg_count": 0, "msg_size": 0, "agt_metrics": {}}

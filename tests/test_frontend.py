@@ -135,6 +135,26 @@ def test_direct_api_reproduces_reference_results(pydcop_ready, name, expected, c
     assert abs(res["cost_curve"][-1][1] - res["cost"]) < 1e-9   # device cost == DCOP.solution_cost
 
 
+@pytest.mark.parametrize("name", ["graph_coloring1.yaml", "secp_simple1.yaml"])
+def test_yaml_export_to_instance_file(pydcop_ready, name, tmp_path, capsys):
+    """`python -m pydcop_amd.api --export`: YAML -> .npz instance, solved without pyDCOP
+    objects, equals the solve from the YAML."""
+    import json
+    from emu.build_emu import build
+    from pydcop_amd import api
+    from pydcop_amd.graph import FlatGraph
+    out = str(tmp_path / "inst.npz")
+    api.main(["--export", out, "-p", "noise:0", os.path.join(INST, name)])
+    info = json.loads(capsys.readouterr().out)
+    g, header = FlatGraph.load(out)
+    assert info["n_vars"] == g.n_vars and header["objective"] == info["objective"]
+    assert header["meta"]["source"] == [name]
+    a = api.solve_yaml(os.path.join(INST, name), cycles=15, noise=0, lib_path=build(), infinity=float("inf"))
+    b = api.solve_flat(g, header["objective"], 15, lib_path=build(), infinity=float("inf"))
+    assert a["assignment"] == b["assignment"] and a["violation"] == b["violation"]
+    assert abs(a["cost"] - b["cost"]) < 1e-9
+
+
 def test_plugin_uses_fast_graph_when_asked(pydcop_ready):
     from pydcop.algorithms import load_algorithm_module
     mod = load_algorithm_module("maxsum_gpu")

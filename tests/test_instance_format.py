@@ -1,0 +1,89 @@
+"""the compact binary instance format (.npz) beside YAML --
+`FlatGraph.save / load`, `pydcop_amd.api.solve_flat` and the CLI on an .npz instance
+(no pyDCOP import on that path).  Emulated engine: no GPU here."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from pydcop_amd import generators as G
+from pydcop_amd.graph import FlatGraph
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="session")
+def emu_lib():
+    from emu.build_emu import build
+    return build()
+
+
+def test_save_load_round_trip(tmp_path):
+    g = G.random_mixed(60, 90, seed=4)
+    g.init_idx = np.where(np.arange(g.n_vars) % 7 == 0, 0, -1).astype(np.int32)
+    path = str(tmp_path / "inst.npz")
+    g.save(path, objective="max", note="round trip")
+    h, header = FlatGraph.load(path)
+    assert header["objective"] == "max" and header["meta"] == {"note": "round trip"}
+    for k in FlatGraph._ARRAYS + ("init_idx",):
+        a, b = getattr(g, k), getattr(h, k)
+        assert a.dtype == b.dtype and np.array_equal(a, b), k
+    assert h.var_names == g.var_names and h.factor_names == g.factor_names
+    assert [list(d) for d in h.domains] == [list(d) for d in g.domains]
+    assert h.var_owned is None and h.factor_owned is None
+
+
+def test_load_rejects_foreign_files(tmp_path):
+    p = str(tmp_path / "x.npz")
+    np.savez(p, a=np.arange(3))
+    with pytest.raises(ValueError, match="not a maxsum_gpu instance"):
+        FlatGraph.load(p)
+    g = G.random_coloring(10, seed=0)
+    g.save(p)
+    z = dict(np.load(p))
+    z["edge_var"] = z["edge_var"][:-1]
+    np.savez(p, **z)
+    with pytest.raises(ValueError):
+        FlatGraph.load(p)
+
+
+def test_solve_flat_and_cli_on_npz(emu_lib, tmp_path):
+    from pydcop_amd.api import solve_flat
+    from pydcop_amd.engine import MaxSumEngine
+    from pydcop_amd.graph import Params
+    g = G.random_coloring(300, seed=2)
+    path = str(tmp_path / "col.npz")
+    g.save(path, objective="min")
+    res = solve_flat(FlatGraph.load(path)[0], "min", 25, lib_path=emu_lib, cost_every=10)
+    with MaxSumEngine(g, Params(), lib_path=emu_lib) as e:
+        e.run(25)
+        idx = e.assignment()[0]
+        cost, viol = e.eval_cost(infinity=10000)
+    assert res["cost"] == cost and res["violation"] == viol and res["cycle"] == 25
+    assert [c[0] for c in res["cost_curve"]] == [10, 20, 25]
+    assert res["assignment"] == {n: g.domains[i][int(idx[i])] for i, n in enumerate(g.var_names)}
+    # the CLI, in a process that never imports pyDCOP
+    code = ("import sys, runpy; sys.argv = ['api', '-c', '25', '-p', 'precision:f64', %r]; "
+            "runpy.run_module('pydcop_amd.api', run_name='__main__'); "
+            "assert 'pydcop' not in sys.modules" % path)
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, MAXSUM_HIP_LIB=emu_lib))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout)
+    assert out["status"] == "FINISHED" and out["cycle"] == 25 and out["violation"] == viol
+    assert abs(out["cost"] - g_cost(g, idx)) < 1e-9 * max(1.0, abs(cost))
+
+
+def g_cost(g, idx):
+    """numpy evaluation of the assignment: sum of table entries + variable costs."""
+    cost = float(g.var_cost[g.cost_off[:-1] + idx].sum())
+    for f in range(g.n_factors):
+        e0, e1 = g.factor_rowptr[f], g.factor_rowptr[f + 1]
+        lin = 0
+        for e in range(e0, e1):
+            lin = lin * g.dom_size[g.edge_var[e]] + idx[g.edge_var[e]]
+        cost += float(g.tables[g.table_off[f] + lin])
+    return cost
