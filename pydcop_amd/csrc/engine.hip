@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <climits>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -183,6 +184,10 @@ struct Engine : EngineBase {
     DevBuf<FactorGen> fgen;
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
+    DevBuf<ClassInfo> classes_f; // both lists as ONE grid (fused sharded launch), cut classes last
+    DevBuf<uint32_t> halo_flags; // [0] exchanges unpacked so far, [1] error bits, [2] unpack block counter
+    bool fused = false;          // sharded cycles use the fused launch
+    uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
     DevBuf<NaryDesc> ndesc;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
@@ -198,6 +203,7 @@ struct Engine : EngineBase {
     T* recv_buf = nullptr;  // halo_recv) or caller-owned memory (mxs_halo_bind)
     bool halo_ready = false;
     static constexpr int EVAL_BLOCKS = 1024;
+    static constexpr int FUSED_MAX_CUT_BLOCKS = 1024;  // half of the 2048 resident workgroup slots
 
     ~Engine() override {
         if (nccl_comm) {
@@ -246,6 +252,17 @@ struct Engine : EngineBase {
         a.start_mode = params.start_messages;
         a.null_f2v = (int32_t)L.null_f2v;
         a.timeline = timeline_on ? timeline.p : nullptr;
+        a.halo_flags = nullptr;
+        a.need_epoch = 0;
+        if (phase == 3) {  // fused sharded launch: phase-1 classes, then the cut factor classes
+            a.n_classes = (int32_t)L.fused_block_base.size();
+            for (int i = 0; i < MAX_CLASSES; ++i)
+                a.block_base[i] = i < a.n_classes ? L.fused_block_base[i] : INT32_MAX;
+            a.classes = classes_f.p;
+            a.halo_flags = halo_flags.p;
+            a.need_epoch = unpacks;  // every exchange enqueued so far has to be in place
+            return a;
+        }
         const std::vector<int32_t>& order = phase == 1 ? L.sweep_order : L.sweep_order2;
         a.n_classes = (int32_t)order.size();
         for (int i = 0; i < MAX_CLASSES; ++i)
@@ -304,6 +321,18 @@ struct Engine : EngineBase {
     // A single-GPU engine has no phase-2 work.
     int launch_phase(int from, bool start, int phase) {
         const SweepArgs<T> a = make_args(from, start, phase);
+        if (phase == 3) {  // everything of the cycle; the cut factor blocks wait inside the sweep
+            int rc = launch_sweep(a, L.n_blocks_fused);
+            if (rc) return rc;
+            for (int c : L.wide_classes) {
+                const ClassInfo& ci = L.classes[c];
+                const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
+                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
+                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
+                HIP_TRY(hipGetLastError());
+            }
+            return launch_nary(a, 0);
+        }
         if (phase == 1) {
             // isolated variables only act in cycle 0
             int rc = launch_sweep(a, (start || L.sweep_regular) ? L.n_blocks_sweep : 0);
@@ -352,7 +381,11 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipStreamCreateWithFlags(&comm, hipStreamNonBlocking));
+        {   // the comm stream's kernels (pack, RCCL, unpack) go first whenever a slot frees up
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            HIP_TRY(hipStreamCreateWithPriority(&comm, hipStreamNonBlocking, hi));
+        }
         HIP_TRY(hipEventCreateWithFlags(&ev_p1, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
 
@@ -393,7 +426,15 @@ struct Engine : EngineBase {
             order.clear();
             for (int c : L.sweep_order2) order.push_back(L.classes[c]);
             HIP_TRY(classes2.upload(order, stream));
+            order.clear();
+            if (L.n_blocks_fused > 0) {
+                for (int c : L.sweep_order) order.push_back(L.classes[c]);
+                for (int c : L.sweep_order2) order.push_back(L.classes[c]);
+                for (size_t i = 0; i < order.size(); ++i) order[i].block_base = L.fused_block_base[i];
+            }
+            HIP_TRY(classes_f.upload(order, stream));
         }
+        HIP_TRY(halo_flags.alloc(16));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
@@ -419,6 +460,9 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemsetAsync(cV.p, 0, std::max<size_t>(cV.n, 1), stream));
         HIP_TRY(hipMemsetAsync(sel.p, 0, std::max<size_t>(sel.n, 1) * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(belief.p, 0, std::max<size_t>(belief.n, 1) * sizeof(T), stream));
+        HIP_TRY(hipMemsetAsync(halo_flags.p, 0, 16 * sizeof(uint32_t), stream));
+        if (comm) HIP_TRY(hipStreamSynchronize(comm));  // no unpack of the previous run is still writing
+        unpacks = 0;
         cur = 0;
         cycles = 0;
         // cycle 0 == start() of every computation (computations.py:741-753)
@@ -497,6 +541,14 @@ struct Engine : EngineBase {
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
+        if (fused) {  // did a cut factor block give up waiting for its halo?
+            uint32_t h[2] = {0, 0};
+            HIP_TRY(hipMemcpyAsync(h, halo_flags.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(hipStreamSynchronize(stream));
+            if (h[1] != 0)
+                return fail(MXS_E_STATE, "sharded cycle: cut factors waited > 2 s for a halo exchange that "
+                                         "never arrived (an exchange / mxs_step_unpack per mxs_step_compute?)");
+        }
         return MXS_OK;
     }
 
@@ -698,6 +750,19 @@ struct Engine : EngineBase {
         send_buf = halo_send.p;
         recv_buf = halo_recv.p;
         halo_ready = true;
+        // Fused sharded launch: ONE sweep per cycle whose last blocks -- the cut factor
+        // classes -- wait for the halo exchange inside the kernel.  While they wait they
+        // hold workgroup slots, and the pack / RCCL / unpack kernels they wait for need
+        // slots too: only when the cut blocks are few (at most half of the 2048
+        // resident slots), and there is no cut work outside the sweep launch.
+        {
+            bool cut_nary = false;
+            for (const NaryLaunch& nl : L.nary_launches) cut_nary = cut_nary || nl.cut;
+            const char* env = getenv("MAXSUM_SHARD_FUSED");
+            fused = L.n_blocks_fused > 0 && L.n_blocks_sweep2 > 0 && L.n_blocks_sweep2 <= FUSED_MAX_CUT_BLOCKS &&
+                    !cut_nary && !(env && env[0] == '0');
+            if (fused) launches_per_cycle -= 1;  // the two sweep launches are one
+        }
         // the start messages of cycle 0 have to cross too: pack them now
         HIP_TRY(hipEventRecord(ev_p1, stream));
         return pack();
@@ -743,6 +808,17 @@ struct Engine : EngineBase {
     // Ping-pong buffers keep the two streams on disjoint data.
     int step_compute() override {
         HIP_TRY(hipSetDevice(device));
+        if (fused) {
+            // compute stream: one launch per cycle, nothing to wait for on the host side --
+            // the cut factor blocks (last of the grid) wait for halo_flags[0] themselves;
+            // comm stream: wait for the launch, pack, <collective>, unpack (publishes the epoch)
+            int rc = launch_phase(cur, false, 3);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_p1, stream));
+            cur ^= 1;
+            cycles += 1;
+            return pack();
+        }
         int rc = launch_phase(cur, false, 1);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev_p1, stream));
@@ -761,10 +837,12 @@ struct Engine : EngineBase {
 
     int step_unpack() override {
         HIP_TRY(hipSetDevice(device));
-        if (n_halo_recv > 0) {
-            const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
+        if (n_halo_recv > 0 || fused) {
+            const int nb = std::max(1, (int)((n_halo_recv + BLOCK - 1) / BLOCK));
+            ++unpacks;
             hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, comm, v2f[cur].p,
-                               (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv);
+                               (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv,
+                               fused ? halo_flags.p : (uint32_t*)nullptr, unpacks);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev_halo, comm));

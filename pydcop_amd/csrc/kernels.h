@@ -104,6 +104,11 @@ struct SweepArgs {
     int32_t null_f2v;    // offset of the all-zero F2V block (padding slots)
     int64_t* timeline;   // profiling only (mxs_debug_timeline): per block {start, end} in
                          // wall_clock64 ticks and its class kind; NULL in normal runs
+    // Fused sharded launch (engine.hip, step_compute): the blocks of a cut factor class
+    // (ClassInfo::wait_halo) wait until halo_flags[0] -- the number of halo exchanges
+    // unpacked so far -- reaches need_epoch.  NULL in every other launch.
+    uint32_t* halo_flags;  // [0] epoch, [1] error bits, [2] block counter of the unpack kernel
+    uint32_t need_epoch;
     int32_t n_classes;
     // First block of every class of the launch (in launch order; unused entries
     // hold INT32_MAX): a block finds its class with compares on kernel arguments,
@@ -561,6 +566,31 @@ __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& 
     else if (ci.kind == K_F_UNARY) factor_unary<T, D>(a, ci, j);
 }
 
+// A block of a cut factor class in the fused sharded launch: the ghost V->F messages it
+// gathers are delivered by the halo exchange of the previous cycle (comm stream), whose
+// unpack kernel publishes its number in halo_flags[0].  These blocks are the LAST of the
+// grid and the exchange had the whole launch to finish, so normally nothing waits; when
+// it does, lane 0 polls with a sleep.  A wait that exceeds ~2 s (100 MHz ticks) sets an
+// error bit the host reports at the next sync instead of hanging the GPU.
+constexpr unsigned long long HALO_WAIT_TICKS = 200000000ull;
+__device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need) {
+    if (threadIdx.x == 0) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need &&
+               __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // fail fast after a timeout
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > HALO_WAIT_TICKS) {
+                atomicOr(flags + 1, 1u);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    // the unpack kernel's stores (another XCD's L2, written back before it published the
+    // epoch) must not be served from a stale line of this XCD's L2
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+
 template <typename T, int DSEL>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0;
@@ -568,6 +598,7 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
     const ClassInfo ci = a.classes[c];
     const int item = ((int)blockIdx.x - ci.block_base) * ci.per_block;
+    if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch);
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;
         if (j >= ci.count) return ci.kind;
@@ -1175,11 +1206,24 @@ __global__ void __launch_bounds__(BLOCK) k_halo_pack(const T* rec, const int64_t
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) out[i] = rec[elem_off[i]];
 }
+// Scatters the received messages into the ghost slots; the last block to finish publishes
+// `epoch` (the number of this exchange) in flags[0] for the waiting cut-factor blocks of
+// the fused sharded launch (kernels.h, wait_for_halo).
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_halo_unpack(T* rec, const int64_t* elem_off, const T* in,
-                                                       int64_t n) {
+                                                       int64_t n, uint32_t* flags, uint32_t epoch) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) rec[elem_off[i]] = in[i];
+    if (flags == nullptr) return;
+    __threadfence();  // this thread's store is visible device-wide ...
+    __syncthreads();  // ... for every thread of the block
+    if (threadIdx.x == 0) {
+        const uint32_t done = atomicAdd(flags + 2, 1u);
+        if (done == gridDim.x - 1) {
+            flags[2] = 0;
+            __hip_atomic_store(flags, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 }  // namespace mxs

@@ -519,6 +519,13 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             nb += (ci.count + ci.per_block - 1) / ci.per_block;
         }
         L.n_blocks_sweep2 = nb;
+        for (int c : L.sweep_order2) L.classes[c].wait_halo = 1;
+        // the same classes as ONE grid: phase-1 classes, then the cut factor classes
+        if (!L.sweep_order2.empty() && L.sweep_order.size() + L.sweep_order2.size() <= (size_t)MAX_CLASSES) {
+            for (int c : L.sweep_order) L.fused_block_base.push_back(L.classes[c].block_base);
+            for (int c : L.sweep_order2) L.fused_block_base.push_back(L.n_blocks_sweep + L.classes[c].block_base);
+            L.n_blocks_fused = L.n_blocks_sweep + L.n_blocks_sweep2;
+        }
         for (int c : L.sweep_order)
             if (!L.classes[c].start_only) L.sweep_regular = true;
         // one compile-time D for every register / wave class -> leaner kernel

@@ -79,7 +79,8 @@ struct ClassInfo {       // one per class, read with one scalar load
     int32_t kind;
     int32_t D;           // uniform domain size (0 for generic classes)
     int32_t H;           // padded message length of the class (uniform classes)
-    int32_t maxdeg;      // unused
+    int32_t wait_halo;   // 1: a cut factor class of a shard -- in the fused sharded launch its
+                         // blocks first wait for the halo exchange of the previous cycle
     int32_t first;       // first internal factor / variable id of the class
     int32_t count;       // number of factors / variables (K_F_GEN: edges; K_V_PACK: lanes)
     int32_t edge_base;   // first internal edge id (factor classes)
@@ -154,6 +155,10 @@ struct Layout {
     std::vector<ClassInfo> classes;
     std::vector<int32_t> sweep_order;  // classes of the sweep launch in launch order
     std::vector<int32_t> sweep_order2; // classes of the second sweep launch: cut factors (sharded)
+    // fused sharded launch: sweep_order then sweep_order2 in ONE grid (cut classes last,
+    // wait_halo set); block bases of that grid, per class of the concatenated list
+    std::vector<int32_t> fused_block_base;
+    int32_t n_blocks_fused = 0;        // 0: no fused launch possible (too many classes)
     int32_t n_blocks_sweep2 = 0;
     int32_t n_blocks_sweep = 0;        // grid size of launch 0
     bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)

@@ -63,6 +63,8 @@ inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind
 inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
+inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }
 enum { hipEventDisableTiming = 2 };
@@ -219,7 +221,25 @@ inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
 
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::yield_barrier(); }  // let the other lanes catch up
-inline unsigned long long wall_clock64() { return 0; }
+// advances by 10 ms (100 MHz ticks) per reading: a kernel polling for something that never
+// comes runs into its time limit at once instead of hanging the test
+inline unsigned long long wall_clock64() {
+    static thread_local unsigned long long t = 0;
+    return t += 1000000ull;
+}
+#define __ATOMIC_RELAXED_HIPEMU 0
+#define __HIP_MEMORY_SCOPE_AGENT 4
+template <typename U>
+inline U __hip_atomic_load(const U* p, int, int) { return *p; }
+template <typename U>
+inline void __hip_atomic_store(U* p, U v, int, int) { *p = v; }
+inline void __builtin_amdgcn_s_sleep(int) {}
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+inline void __threadfence() {}
+template <typename U>
+inline U atomicOr(U* addr, U val) { const U old = *addr; *addr = old | val; return old; }
+template <typename U>
+inline U atomicAdd(U* addr, U val) { const U old = *addr; *addr = old + val; return old; }
 
 // ---- gfx950 builtins the kernels use -------------------------------------------
 inline int __builtin_amdgcn_readfirstlane(int x) { return x; }  // callers pass wave-uniform values

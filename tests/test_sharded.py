@@ -134,6 +134,25 @@ def test_local_shards_equal_single_engine_emu(case, k, emu_lib):
     _check_against_single(g, kw, k, emu_lib)
 
 
+def test_fused_sharded_launch_is_used_and_optional(emu_lib, monkeypatch):
+    """A shard sweeps a cycle in ONE launch whose last blocks (the cut factor classes) wait
+    for the halo inside the kernel; MAXSUM_SHARD_FUSED=0 keeps the two-launch schedule.
+    Same results either way."""
+    g, kw = make_case("coloring")
+    part = partition_variables(g, 3)
+    s = build_shard(g, part, 1, 3)
+    launches = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("MAXSUM_SHARD_FUSED", mode)
+        e = MaxSumEngine(s.graph, Params(**kw), lib_path=emu_lib)
+        before = e.cycle_bytes()[1]
+        e.halo_setup(s.send_edges, s.recv_edges)
+        launches[mode] = (before, e.cycle_bytes()[1])
+        e.close()
+        _check_against_single(g, kw, 3, emu_lib, steps=(1, 4, 11))
+    assert launches["1"] == (2, 1) and launches["0"] == (2, 2)
+
+
 def test_local_shards_parity_cases_emu(emu_lib):
     for name, make, kw in parity_cases()[:4] + parity_cases()[9:11]:
         _check_against_single(make(), kw, 3, emu_lib, steps=(1, 6))
