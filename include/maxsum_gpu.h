@@ -240,6 +240,17 @@ int mxs_comm_exchange(mxs_engine *e);
 /* n sharded cycles, each mxs_step_compute -> exchange -> mxs_step_unpack, enqueued
  * by the library; does not wait (mxs_sync does). */
 int mxs_run_sharded(mxs_engine *e, int32_t n_cycles);
+/* How this shard runs its cycles (decided by mxs_halo_setup / mxs_comm_init from the
+ * shape of the shard):
+ *   direct_exchange  1: the variable kernel writes the records of cut edges into the send
+ *                    buffer itself and RCCL receives straight into the ghost slots (laid out
+ *                    in receive order) -- no pack / unpack kernel; needs mxs_comm_init, every
+ *                    sent edge in a packed variable class and sent to one shard only.
+ *                    MAXSUM_SHARD_DIRECT=0 keeps the pack / unpack kernels.
+ *   fused_launch     1: one sweep launch per cycle whose last blocks (the cut factors) wait
+ *                    for the halo inside the kernel (opt-in: MAXSUM_SHARD_FUSED=1; measured
+ *                    slower than the two-launch schedule). */
+int mxs_shard_mode(const mxs_engine *e, int32_t *fused_launch, int32_t *direct_exchange);
 
 int mxs_destroy(mxs_engine *e);
 

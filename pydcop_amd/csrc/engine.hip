@@ -159,6 +159,7 @@ struct EngineBase {
                           const int64_t* sc, const int64_t* rc) = 0;
     virtual int comm_exchange() = 0;
     virtual int run_sharded(int n) = 0;
+    virtual void shard_mode(int32_t* f, int32_t* d) const = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
     Layout L;
@@ -254,6 +255,8 @@ struct Engine : EngineBase {
         a.timeline = timeline_on ? timeline.p : nullptr;
         a.halo_flags = nullptr;
         a.need_epoch = 0;
+        a.send_out = direct ? send2[from ^ 1].p : nullptr;  // the parity this cycle writes
+        a.send_slot = direct ? send_slot.p : nullptr;
         if (phase == 3) {  // fused sharded launch: phase-1 classes, then the cut factor classes
             a.n_classes = (int32_t)L.fused_block_base.size();
             for (int i = 0; i < MAX_CLASSES; ++i)
@@ -734,13 +737,20 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    std::vector<int32_t> send_ei, recv_ei;  // halo lists as internal edge ids, in the caller's order
+
     int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) override {
         HIP_TRY(hipSetDevice(device));
+        if (direct) return fail(MXS_E_STATE, "mxs_halo_setup: the direct exchange is already set up");
         std::vector<int64_t> so, ro;
         int rc = build_elem_offsets(se, ns, so);
         if (rc) return rc;
         rc = build_elem_offsets(re, nr, ro);
         if (rc) return rc;
+        send_ei.resize((size_t)ns);
+        recv_ei.resize((size_t)nr);
+        for (int64_t i = 0; i < ns; ++i) send_ei[i] = L.edge_e2i[se[i]];
+        for (int64_t i = 0; i < nr; ++i) recv_ei[i] = L.edge_e2i[re[i]];
         n_halo_send = (int64_t)so.size();
         n_halo_recv = (int64_t)ro.size();
         HIP_TRY(halo_send_off.upload(so, stream));
@@ -760,7 +770,7 @@ struct Engine : EngineBase {
             for (const NaryLaunch& nl : L.nary_launches) cut_nary = cut_nary || nl.cut;
             const char* env = getenv("MAXSUM_SHARD_FUSED");
             fused = L.n_blocks_fused > 0 && L.n_blocks_sweep2 > 0 && L.n_blocks_sweep2 <= FUSED_MAX_CUT_BLOCKS &&
-                    !cut_nary && !(env && env[0] == '0');
+                    !cut_nary && env && env[0] == '1';  // measured slower than two launches: opt-in
             if (fused) launches_per_cycle -= 1;  // the two sweep launches are one
         }
         // the start messages of cycle 0 have to cross too: pack them now
@@ -772,6 +782,15 @@ struct Engine : EngineBase {
     // V->F messages of the cut edges this shard owns into the send buffer
     int pack() {
         HIP_TRY(hipStreamWaitEvent(comm, ev_p1, 0));
+        if (direct) {  // padded records into the send buffer of the current parity
+            if (n_send_pad > 0) {
+                const int nb = (int)((n_send_pad + BLOCK - 1) / BLOCK);
+                hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, comm, (const T*)v2f[cur].p,
+                                   (const int64_t*)halo_send_off.p, send2[cur].p, n_send_pad);
+                HIP_TRY(hipGetLastError());
+            }
+            return MXS_OK;
+        }
         if (n_halo_send > 0) {
             const int nb = (int)((n_halo_send + BLOCK - 1) / BLOCK);
             hipLaunchKernelGGL((k_halo_pack<T>), dim3(nb), dim3(BLOCK), 0, comm,
@@ -827,6 +846,7 @@ struct Engine : EngineBase {
         if (rc) return rc;
         cur ^= 1;
         cycles += 1;
+        if (direct) return MXS_OK;  // the variable kernel has written the send buffer itself
         return pack();  // comm stream, behind ev_p1: one host call per cycle before the collective
     }
 
@@ -837,12 +857,20 @@ struct Engine : EngineBase {
 
     int step_unpack() override {
         HIP_TRY(hipSetDevice(device));
-        if (n_halo_recv > 0 || fused) {
-            const int nb = std::max(1, (int)((n_halo_recv + BLOCK - 1) / BLOCK));
-            ++unpacks;
+        if (direct) {  // RCCL has received straight into the ghost slots
+            HIP_TRY(hipEventRecord(ev_halo, comm));
+            halo_pending = true;
+            return MXS_OK;
+        }
+        if (n_halo_recv > 0) {
+            const int nb = (int)((n_halo_recv + BLOCK - 1) / BLOCK);
             hipLaunchKernelGGL((k_halo_unpack<T>), dim3(nb), dim3(BLOCK), 0, comm, v2f[cur].p,
-                               (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv,
-                               fused ? halo_flags.p : (uint32_t*)nullptr, unpacks);
+                               (const int64_t*)halo_recv_off.p, (const T*)recv_buf, n_halo_recv);
+            HIP_TRY(hipGetLastError());
+        }
+        if (fused) {
+            ++unpacks;
+            hipLaunchKernelGGL(k_halo_publish, dim3(1), dim3(1), 0, comm, halo_flags.p, unpacks);
             HIP_TRY(hipGetLastError());
         }
         HIP_TRY(hipEventRecord(ev_halo, comm));
@@ -854,6 +882,16 @@ struct Engine : EngineBase {
     // One exchange = one group of ncclSend / ncclRecv per peer with the fixed counts of the
     // partition (an all-to-all with unequal splits) on the comm stream, between the pack and
     // the unpack of the cycle.  The cycle loop of a sharded run then stays in this library.
+    // Direct exchange (set up by comm_init when the shard allows it): the variable kernel
+    // writes the records of cut edges straight into a send buffer (no pack kernel), RCCL
+    // receives straight into the ghost slots of the V2F buffer, laid out in receive order
+    // (no unpack kernel).  What stays on the comm stream per cycle is the collective alone.
+    bool direct = false;
+    DevBuf<T> send2[2];             // padded records (H elements), one buffer per cycle parity
+    DevBuf<int32_t> send_slot;      // per lane of the packed variable classes: record index / -1
+    int64_t ghost_base = 0;         // element offset of the ghost region in a V2F buffer
+    int64_t n_send_pad = 0;         // elements of a padded send buffer
+    std::vector<int64_t> psend_cnt, precv_cnt, psend_at, precv_at;  // padded elements, per peer
     const Rccl* rccl = nullptr;
     void* nccl_comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -894,13 +932,134 @@ struct Engine : EngineBase {
             send_at[q] = send_at[q - 1] + send_cnt[q - 1];
             recv_at[q] = recv_at[q - 1] + recv_cnt[q - 1];
         }
-        return MXS_OK;
+        return setup_direct();
+    }
+
+    // Try to switch the shard to the direct exchange.  Not an error when the shard does not
+    // qualify (pack / unpack kernels and the compact staging buffers stay in use then).
+    int setup_direct() {
+        const char* env = getenv("MAXSUM_SHARD_DIRECT");
+        if ((env && env[0] == '0') || fused || send_buf != halo_send.p) return MXS_OK;
+        const int nE = L.n_edges;
+        // (1) every sent edge is a lane of a packed variable class, and is sent once
+        std::vector<int32_t> slot(L.vell.size(), -1);
+        std::vector<const ClassInfo*> packed;
+        for (const ClassInfo& ci : L.classes)
+            if (ci.kind == K_V_PACK) packed.push_back(&ci);
+        for (size_t i = 0; i < send_ei.size(); ++i) {
+            const int64_t off = L.v2f_off[send_ei[i]];
+            const ClassInfo* home = nullptr;
+            for (const ClassInfo* ci : packed)
+                if (off >= ci->v2f_base && off < ci->v2f_base + (int64_t)ci->count * ci->H) home = ci;
+            if (!home) return MXS_OK;
+            const int64_t pos = home->ell_base + (off - home->v2f_base) / home->H;
+            if (slot[pos] >= 0) return MXS_OK;  // an edge of an n-ary cut factor going to two shards
+            slot[pos] = (int32_t)i;
+        }
+        // (2) the received edges are exactly the edges of the ghost variables, each once
+        std::vector<uint8_t> is_ghost_edge(nE, 0), seen(nE, 0);
+        int64_t n_ghost = 0, g0 = INT64_MAX, ghost_len = 0;
+        for (int ei = 0; ei < nE; ++ei)
+            if (!L.owned[L.edge_var_int[ei]]) {
+                is_ghost_edge[ei] = 1;
+                ++n_ghost;
+                g0 = std::min<int64_t>(g0, L.v2f_off[ei]);
+                ghost_len += L.edge_half[ei];
+            }
+        if ((int64_t)recv_ei.size() != n_ghost) return MXS_OK;
+        for (int32_t ei : recv_ei) {
+            if (!is_ghost_edge[ei] || seen[ei]) return MXS_OK;
+            seen[ei] = 1;
+        }
+        if (n_ghost && g0 + ghost_len > L.v2f_elems) return MXS_OK;  // the ghost slots are not one block
+        // (3) per-peer edge ranges from the per-peer element counts
+        auto split = [&](const std::vector<int32_t>& edges, const std::vector<int64_t>& cnt,
+                         std::vector<int64_t>& pcnt, std::vector<int64_t>& pat) -> bool {
+            pcnt.assign(comm_world, 0);
+            pat.assign(comm_world, 0);
+            size_t i = 0;
+            int64_t at = 0;
+            for (int q = 0; q < comm_world; ++q) {
+                pat[q] = at;
+                int64_t left = cnt[q];
+                while (left > 0 && i < edges.size()) {
+                    left -= L.edge_dom[edges[i]];
+                    pcnt[q] += L.edge_half[edges[i]];
+                    ++i;
+                }
+                if (left != 0) return false;
+                at += pcnt[q];
+            }
+            return i == edges.size();
+        };
+        if (!split(send_ei, send_cnt, psend_cnt, psend_at) || !split(recv_ei, recv_cnt, precv_cnt, precv_at))
+            return MXS_OK;
+        // uniform record length on the send side (the lane writes send_out + slot * H)
+        int Hs = 0;
+        for (int32_t ei : send_ei) {
+            if (Hs == 0) Hs = L.edge_half[ei];
+            if (L.edge_half[ei] != Hs) return MXS_OK;
+        }
+        n_send_pad = (int64_t)send_ei.size() * Hs;
+        { int rc = sync(); if (rc) return rc; }
+        // (4) ghost slots in receive order
+        ghost_base = n_ghost ? g0 : 0;
+        int64_t at = ghost_base;
+        for (int32_t ei : recv_ei) {
+            L.v2f_off[ei] = (int32_t)at;
+            at += L.edge_half[ei];
+        }
+        for (int k = 0; k < nE; ++k) L.vslot_v2f[k] = L.v2f_off[L.vslot_edge[k]];
+        for (NaryDesc& d : L.ndesc)
+            for (int i = 0; i < d.arity; ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
+        HIP_TRY(hipMemcpyAsync(edge_v2f.p, L.v2f_off.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(vslot_v2f.p, L.vslot_v2f.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
+        if (!L.ndesc.empty())
+            HIP_TRY(hipMemcpyAsync(ndesc.p, L.ndesc.data(), sizeof(NaryDesc) * L.ndesc.size(), hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        // (5) padded send buffers + the lanes' slots; pack offsets in the padded format
+        for (int b = 0; b < 2; ++b) {
+            HIP_TRY(send2[b].alloc((size_t)std::max<int64_t>(n_send_pad, 1)));
+            HIP_TRY(hipMemsetAsync(send2[b].p, 0, sizeof(T) * (size_t)std::max<int64_t>(n_send_pad, 1), stream));
+        }
+        HIP_TRY(send_slot.upload(slot, stream));
+        std::vector<int64_t> so;
+        for (int32_t ei : send_ei)
+            for (int d = 0; d < L.edge_half[ei]; ++d) so.push_back((int64_t)L.v2f_off[ei] + d);
+        if (halo_send_off.p) (void)hipFree(halo_send_off.p);
+        halo_send_off.p = nullptr;
+        HIP_TRY(halo_send_off.upload(so, stream));
+        direct = true;
+        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
+                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
+        // the messages of the current cycle (the start messages right after mxs_create): packed
+        // by the generic kernel this once, later cycles write the send buffer themselves
+        return pack();
     }
 
     int comm_exchange() override {
         if (!nccl_comm) return fail(MXS_E_STATE, "no communicator: call mxs_comm_init first");
         HIP_TRY(hipSetDevice(device));
         const int dt = sizeof(T) == 8 ? NCCL_F64 : NCCL_F32;
+        if (direct) {
+            // send buffer of the cycle just enqueued (written by its variable kernel: wait for
+            // it), ghost slots of the V2F buffer that cycle wrote
+            HIP_TRY(hipStreamWaitEvent(comm, ev_p1, 0));
+            NCCL_TRY(rccl->GroupStart());
+            if (comm_world == 1 && psend_cnt[0] == 0) {
+                NCCL_TRY(rccl->Send(self_pad.p, 1, dt, 0, nccl_comm, comm));
+                NCCL_TRY(rccl->Recv(self_pad.p + 32, 1, dt, 0, nccl_comm, comm));
+            }
+            for (int q = 0; q < comm_world; ++q) {
+                if (psend_cnt[q])
+                    NCCL_TRY(rccl->Send(send2[cur].p + psend_at[q], (size_t)psend_cnt[q], dt, q, nccl_comm, comm));
+                if (precv_cnt[q])
+                    NCCL_TRY(rccl->Recv(v2f[cur].p + ghost_base + precv_at[q], (size_t)precv_cnt[q], dt, q,
+                                        nccl_comm, comm));
+            }
+            NCCL_TRY(rccl->GroupEnd());
+            return MXS_OK;
+        }
         NCCL_TRY(rccl->GroupStart());
         if (comm_world == 1 && send_cnt[0] == 0) {
             // nothing crosses; one padding element to ourselves keeps the very call sequence
@@ -916,6 +1075,11 @@ struct Engine : EngineBase {
         }
         NCCL_TRY(rccl->GroupEnd());
         return MXS_OK;
+    }
+
+    void shard_mode(int32_t* f, int32_t* d) const override {
+        if (f) *f = fused ? 1 : 0;
+        if (d) *d = direct ? 1 : 0;
     }
 
     int run_sharded(int n) override {
@@ -1056,6 +1220,12 @@ int mxs_comm_init(mxs_engine* e, const char* rccl_path, int32_t rank, int32_t wo
 
 int mxs_comm_exchange(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->comm_exchange(); }
 int mxs_run_sharded(mxs_engine* e, int32_t n) { CHECK_HANDLE(e); return e->impl->run_sharded(n); }
+
+int mxs_shard_mode(const mxs_engine* e, int32_t* fused_launch, int32_t* direct_exchange) {
+    CHECK_HANDLE(e);
+    e->impl->shard_mode(fused_launch, direct_exchange);
+    return MXS_OK;
+}
 
 int mxs_stream(mxs_engine* e, void** stream) {
     CHECK_HANDLE(e);

@@ -25,7 +25,7 @@ ABI_SYMBOLS = (
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
-    "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded",
+    "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded", "mxs_shard_mode",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
 
@@ -111,6 +111,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_comm_init": ([vp, C.c_char_p, i32, i32, vp, vp, vp], C.c_int),
         "mxs_comm_exchange": ([vp], C.c_int),
         "mxs_run_sharded": ([vp, i32], C.c_int),
+        "mxs_shard_mode": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
         "mxs_debug_timeline": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
         "mxs_update_factor_table": ([vp, i32, vp, i64], C.c_int),
         "mxs_destroy": ([vp], C.c_int),
@@ -311,6 +312,12 @@ class MaxSumEngine:
     def run_sharded(self, n_cycles: int):
         """n sharded cycles (compute, RCCL exchange, unpack) enqueued by the library."""
         self._check(self._lib.mxs_run_sharded(self._h, int(n_cycles)))
+
+    def shard_mode(self) -> dict:
+        """{"fused_launch": bool, "direct_exchange": bool} -- how this shard runs its cycles."""
+        f, d = C.c_int32(0), C.c_int32(0)
+        self._check(self._lib.mxs_shard_mode(self._h, C.byref(f), C.byref(d)))
+        return {"fused_launch": bool(f.value), "direct_exchange": bool(d.value)}
 
     def stream(self) -> int:
         s = C.c_void_p()

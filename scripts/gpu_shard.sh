@@ -7,11 +7,11 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; expo
 T0=$(date +%s); lap() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
 lap "pytest -m gpu (sharded)"
 timeout 300 python -m pytest tests/test_sharded.py -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_sharded.txt
-lap "shard cost, fused launch"
-(timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1; timeout 120 python tools/shard_cost.py 2 f64 2>&1 | tail -1) | tee $OUT/shard_cost_fused.jsonl
-lap "shard cost, two launches + events"
-(MAXSUM_SHARD_FUSED=0 timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1) | tee $OUT/shard_cost_two_launches.jsonl
-lap "kernel trace of the fused shard cycle (8-way shard 0)"
+lap "shard cost: direct exchange (default for the native path)"
+(timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1; timeout 120 python tools/shard_cost.py 2 f64 2>&1 | tail -1) | tee $OUT/shard_cost_direct.jsonl
+lap "shard cost: pack / unpack kernels (MAXSUM_SHARD_DIRECT=0)"
+(MAXSUM_SHARD_DIRECT=0 timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1) | tee $OUT/shard_cost_staged.jsonl
+lap "kernel trace of the shard cycle (8-way shard 0)"
 ( cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/tools/shard_cost.py 8 f64 > $OUT/prof.log 2>&1 )
 find $OUT/prof -name "*kernel_stats*.csv" | head -1 | while read f; do head -12 "$f" | cut -c1-200; cp "$f" $OUT/kernel_stats_shard.csv; done
 rm -rf $OUT/prof

@@ -142,12 +142,13 @@ def test_fused_sharded_launch_is_used_and_optional(emu_lib, monkeypatch):
     part = partition_variables(g, 3)
     s = build_shard(g, part, 1, 3)
     launches = {}
-    for mode in ("1", "0"):
+    for mode in ("1", "0"):  # opt-in: measured slower than two launches on the GPU
         monkeypatch.setenv("MAXSUM_SHARD_FUSED", mode)
         e = MaxSumEngine(s.graph, Params(**kw), lib_path=emu_lib)
         before = e.cycle_bytes()[1]
         e.halo_setup(s.send_edges, s.recv_edges)
         launches[mode] = (before, e.cycle_bytes()[1])
+        assert e.shard_mode() == {"fused_launch": mode == "1", "direct_exchange": False}
         e.close()
         _check_against_single(g, kw, 3, emu_lib, steps=(1, 4, 11))
     assert launches["1"] == (2, 1) and launches["0"] == (2, 2)
@@ -207,13 +208,16 @@ def fake_rccl():
     return build_fake_rccl()
 
 
-@pytest.mark.parametrize("case,k", [("coloring", 3), ("mixed_max", 2), ("ising", 4)])
-def test_native_exchange_thread_ranks_emu(case, k, emu_lib, fake_rccl, tmp_path, monkeypatch):
+@pytest.mark.parametrize("case,k,direct", [("coloring", 3, True), ("mixed_max", 2, False), ("ising", 4, True),
+                                           ("coloring", 4, False), ("coloring_deg9", 2, True)])
+def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, tmp_path, monkeypatch):
     """mxs_comm_init / mxs_run_sharded: k ranks as k threads of this process, every one
     stepping its own engine through the library's cycle loop."""
     import threading
     from pydcop_amd.engine import comm_unique_id
     monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    if case == "coloring" and not direct:
+        monkeypatch.setenv("MAXSUM_SHARD_DIRECT", "0")  # pack / unpack kernels, compact buffers
     g, kw = make_case(case)
     p = Params(**kw)
     part = partition_variables(g, k)
@@ -221,6 +225,7 @@ def test_native_exchange_thread_ranks_emu(case, k, emu_lib, fake_rccl, tmp_path,
     uid = comm_unique_id(emu_lib, fake_rccl)
     steps = (1, 2, 9)
     results, errors = [None] * k, []
+    modes = [None] * k
 
     def rank_main(r):
         try:
@@ -228,6 +233,7 @@ def test_native_exchange_thread_ranks_emu(case, k, emu_lib, fake_rccl, tmp_path,
             e = MaxSumEngine(s.graph, p, lib_path=emu_lib)
             e.halo_setup(s.send_edges, s.recv_edges)
             e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=fake_rccl)
+            modes[r] = e.shard_mode()["direct_exchange"]
             e.comm_exchange()
             e.step_unpack()
             out = []
@@ -247,6 +253,9 @@ def test_native_exchange_thread_ranks_emu(case, k, emu_lib, fake_rccl, tmp_path,
     for t in threads:
         t.join(300)
     assert not errors, errors
+    # direct exchange (no pack / unpack kernel) wherever the shard qualifies: uniform packed
+    # variable classes on the sending side; mixed domains fall back to the staging kernels
+    assert modes == [direct] * k, modes
     one = MaxSumEngine(g, p, lib_path=emu_lib)
     for i, n in enumerate(steps):
         one.run(n)

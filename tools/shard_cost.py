@@ -59,6 +59,7 @@ if n_send == n_recv:
     e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
     e.halo_setup(sh.send_edges, sh.recv_edges)
     e.comm_init(0, 1, comm_unique_id(), [n_send], [n_recv])
+    out["shard_mode"] = e.shard_mode()
     out["shard_cycle_us_native_rccl_loopback"] = timed(e.run_sharded, e.sync)
     e.close()
 
