@@ -836,7 +836,7 @@ struct Engine : EngineBase {
             HIP_TRY(hipEventRecord(ev_p1, stream));
             cur ^= 1;
             cycles += 1;
-            return pack();
+            return direct ? MXS_OK : pack();
         }
         int rc = launch_phase(cur, false, 1);
         if (rc) return rc;
@@ -858,6 +858,11 @@ struct Engine : EngineBase {
     int step_unpack() override {
         HIP_TRY(hipSetDevice(device));
         if (direct) {  // RCCL has received straight into the ghost slots
+            if (fused) {
+                ++unpacks;
+                hipLaunchKernelGGL(k_halo_publish, dim3(1), dim3(1), 0, comm, halo_flags.p, unpacks);
+                HIP_TRY(hipGetLastError());
+            }
             HIP_TRY(hipEventRecord(ev_halo, comm));
             halo_pending = true;
             return MXS_OK;
@@ -939,7 +944,7 @@ struct Engine : EngineBase {
     // qualify (pack / unpack kernels and the compact staging buffers stay in use then).
     int setup_direct() {
         const char* env = getenv("MAXSUM_SHARD_DIRECT");
-        if ((env && env[0] == '0') || fused || send_buf != halo_send.p) return MXS_OK;
+        if ((env && env[0] == '0') || send_buf != halo_send.p) return MXS_OK;
         const int nE = L.n_edges;
         // (1) every sent edge is a lane of a packed variable class, and is sent once
         std::vector<int32_t> slot(L.vell.size(), -1);
@@ -1030,8 +1035,6 @@ struct Engine : EngineBase {
         halo_send_off.p = nullptr;
         HIP_TRY(halo_send_off.upload(so, stream));
         direct = true;
-        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
-                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
         // the messages of the current cycle (the start messages right after mxs_create): packed
         // by the generic kernel this once, later cycles write the send buffer themselves
         return pack();

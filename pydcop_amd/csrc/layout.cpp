@@ -21,6 +21,9 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.sort_factors = MXS_SORT_FACTORS_DEFAULT != 0;
     if (f & 128) o.sort_factors = true;   // bit7: factor order follows the variable order
     if (f & 256) o.sort_factors = false;  // bit8: factors of a class keep the caller's order
+    o.factors_second = MXS_FACTORS_SECOND_DEFAULT != 0;
+    if (f & 512) o.factors_second = true;    // bit9: shard: every factor class in the second launch
+    if (f & 1024) o.factors_second = false;  // bit10: shard: only the cut factor classes
     return o;
 }
 
@@ -308,6 +311,11 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         std::copy(g.tables + g.table_off[f], g.tables + g.table_off[f + 1],
                   L.eval_tables.begin() + L.eval_tab_off[fi]);
     }
+    // A shard sweeps a cycle in two launches: the second one waits for the halo exchange.  The
+    // cut factor classes have to be in it; with factors_second the interior factor classes
+    // join them, so that the first launch (the variables) fits the 2048 resident workgroup
+    // slots in one generation and both launches are of similar size.
+    const bool second = g.var_owned != nullptr && L.opt.factors_second;
     auto sweep_class = [&](int cls, int per_block, int cut = 0) {  // blocks are derived from blockIdx
         L.classes[cls].per_block = per_block;
         (cut ? L.sweep_order2 : L.sweep_order).push_back(cls);
@@ -341,7 +349,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (ci.H > ci.D)  // counters ride in the records' padding (kernels.h, Msg::CNT_IN_MSG)
                 for (int e = L.frowptr[fi]; e < L.frowptr[fj]; ++e) L.edge_fcim[e] = 1;
             L.classes.push_back(ci);
-            sweep_class(cls, BLOCK, key.cut);
+            sweep_class(cls, BLOCK, key.cut || second);
         } else {
             const int gen_base = (int)L.fgen.size();
             for (int j = 0; j < n; ++j) {
@@ -358,7 +366,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (key.kind == K_F_GEN) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
                 L.classes.push_back(ci);
-                sweep_class(cls, BLOCK, key.cut);
+                sweep_class(cls, BLOCK, key.cut || second);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
                 NaryLaunch nl{key.D / 256, (key.D / 16) % 16, (key.D % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut};
                 for (int j = 0; j < n; ++j) {

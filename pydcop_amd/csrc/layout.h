@@ -61,6 +61,9 @@ enum Kind : int32_t {
 #define MXS_BLOCK 256  // threads per workgroup of the sweep (other values: experiments only)
 #endif
 constexpr int BLOCK = MXS_BLOCK;
+#ifndef MXS_FACTORS_SECOND_DEFAULT
+#define MXS_FACTORS_SECOND_DEFAULT 0  // layout_flags bit9 forces it on, bit10 off
+#endif
 #ifndef MXS_SORT_FACTORS_DEFAULT
 #define MXS_SORT_FACTORS_DEFAULT 1  // layout_flags bit7 forces it on, bit8 off
 #endif
@@ -135,6 +138,7 @@ struct LayoutOptions {
     bool sort_by_degree = true;
     bool nary = true;            // use the workgroup-per-factor kernel (K_F_NARY)
     bool sort_factors = false;   // inside a class, factors follow their first variable's order
+    bool factors_second = false; // shard: all register factor classes go to the second launch
 };
 
 struct Layout {

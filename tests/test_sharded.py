@@ -154,6 +154,15 @@ def test_fused_sharded_launch_is_used_and_optional(emu_lib, monkeypatch):
     assert launches["1"] == (2, 1) and launches["0"] == (2, 2)
 
 
+@pytest.mark.parametrize("flags", [512, 1024])
+def test_shard_launch_split_variants_emu(flags, emu_lib):
+    """layout_flags 512 / 1024: every factor class / only the cut factor classes in the
+    second launch of a sharded cycle -- a scheduling choice, same results."""
+    for case in ("coloring", "mixed_max"):
+        g, kw = make_case(case)
+        _check_against_single(g, dict(kw, layout_flags=flags), 3, emu_lib, steps=(1, 5))
+
+
 def test_local_shards_parity_cases_emu(emu_lib):
     for name, make, kw in parity_cases()[:4] + parity_cases()[9:11]:
         _check_against_single(make(), kw, 3, emu_lib, steps=(1, 6))
@@ -218,6 +227,8 @@ def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, t
     monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
     if case == "coloring" and not direct:
         monkeypatch.setenv("MAXSUM_SHARD_DIRECT", "0")  # pack / unpack kernels, compact buffers
+    if case == "coloring_deg9":
+        monkeypatch.setenv("MAXSUM_SHARD_FUSED", "1")   # direct exchange + fused launch
     g, kw = make_case(case)
     p = Params(**kw)
     part = partition_variables(g, k)

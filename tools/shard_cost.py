@@ -20,6 +20,7 @@ from pydcop_amd.engine import MaxSumEngine, comm_unique_id
 from pydcop_amd.graph import Params
 from pydcop_amd.partition import build_shard, cut_statistics, partition_variables
 
+FLAGS = int(os.environ.get("MAXSUM_LAYOUT_FLAGS", "0"))  # experiments, e.g. 512 = all factors in launch 2
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 dt = sys.argv[2] if len(sys.argv) > 2 else "f64"
 STEPS = 2000
@@ -46,7 +47,7 @@ def timed(fn, sync):
 
 
 # (a) no collective
-e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
+e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
 e.halo_setup(sh.send_edges, sh.recv_edges)
 def cycles_a(n):
     for _ in range(n):
@@ -56,7 +57,7 @@ e.close()
 
 # (b) library loop + real RCCL, halo looped back (needs n_send == n_recv)
 if n_send == n_recv:
-    e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
+    e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
     e.halo_setup(sh.send_edges, sh.recv_edges)
     e.comm_init(0, 1, comm_unique_id(), [n_send], [n_recv])
     out["shard_mode"] = e.shard_mode()
@@ -68,7 +69,7 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo"); os.environ.setdefault("NCCL_IB_DISABLE", "1")
 torch.cuda.set_device(0)
 dist.init_process_group("nccl", rank=0, world_size=1)
-e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt))
+e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
 e.halo_setup(sh.send_edges, sh.recv_edges)
 tdt = torch.float64 if dt == "f64" else torch.float32
 send = torch.zeros(max(n_send, 1), dtype=tdt, device="cuda")
