@@ -381,7 +381,22 @@ struct Engine : EngineBase {
             return fail(MXS_E_NODEVICE, std::string("device is ") + prop.gcnArchName +
                                             ", this library is built for gfx950 (MI355X) only");
         HIP_TRY(hipSetDevice(dev));
-        HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        // A shard can keep a few CUs free of sweep blocks ($MAXSUM_COMM_CUS, default 0): the
+        // kernels of the comm stream (RCCL's workgroups are large) otherwise find no CU with
+        // enough free resources while a sweep grid still has blocks to dispatch.
+        int reserve = 0;
+        if (g.var_owned) {
+            const char* env = getenv("MAXSUM_COMM_CUS");
+            if (env) reserve = std::max(0, std::min(atoi(env), prop.multiProcessorCount / 2));
+        }
+        if (reserve > 0) {
+            const int n_cu = prop.multiProcessorCount, keep = n_cu - reserve;
+            std::vector<uint32_t> mask((size_t)(n_cu + 31) / 32, 0u);
+            for (int c = 0; c < keep; ++c) mask[c / 32] |= 1u << (c % 32);
+            HIP_TRY(hipExtStreamCreateWithCUMask(&stream, (uint32_t)mask.size(), mask.data()));
+        } else {
+            HIP_TRY(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        }
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         {   // the comm stream's kernels (pack, RCCL, unpack) go first whenever a slot frees up

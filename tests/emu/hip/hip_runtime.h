@@ -44,6 +44,7 @@ enum hipMemcpyKind { hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDevi
 enum { hipStreamNonBlocking = 1, hipStreamCaptureModeThreadLocal = 1 };
 struct hipDeviceProp_t {
     char gcnArchName[64];
+    int multiProcessorCount = 256;
 };
 
 inline const char* hipGetErrorString(hipError_t) { return "emulated HIP error"; }
@@ -64,6 +65,7 @@ inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { std::m
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = -1; return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s, uint32_t, const uint32_t*) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = (void*)1; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = (void*)1; return hipSuccess; }

@@ -23,8 +23,9 @@ def emu_lib():
     return build()
 
 
+# 0 = production (factors of a class follow their first variable: bit 7 is the default)
 LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16,
-           "sorted_factors": 128, "unsorted_factors": 256, "sorted_keep_order": 128 + 8}
+           "unsorted_factors": 256, "sorted_keep_order": 128 + 8}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
@@ -37,9 +38,9 @@ def test_emu_bit_exact_vs_oracle(case, dtype, emu_lib, oracle_built):
 
 @pytest.mark.parametrize("layout", [k for k in LAYOUTS if k != "default"])
 def test_emu_layout_variants(layout, emu_lib, oracle_built):
-    cases = parity_cases() if "sorted" in layout else parity_cases()[:3] + parity_cases()[6:8]
+    cases = parity_cases() if layout == "unsorted_factors" else parity_cases()[:3] + parity_cases()[6:8]
     for name, make, kw in cases:
-        for dtype in (("f64", "f32") if "sorted" in layout else ("f64",)):
+        for dtype in (("f64", "f32") if layout == "unsorted_factors" else ("f64",)):
             compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], dtype=dtype, **kw), 0,
                                 lib_path=emu_lib, steps=[1, 6])
 

@@ -46,17 +46,24 @@ def timed(fn, sync):
     return 1e6 * (time.perf_counter() - t) / STEPS
 
 
+ONLY = os.environ.get("MAXSUM_COST_ONLY", "abc")  # which of the three loops to time
+for k in ("MAXSUM_COMM_CUS", "MAXSUM_SHARD_FUSED", "MAXSUM_SHARD_DIRECT", "MAXSUM_LAYOUT_FLAGS"):
+    if os.environ.get(k):
+        out[k] = os.environ[k]
+if "a" not in ONLY:
+    pass
 # (a) no collective
 e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
 e.halo_setup(sh.send_edges, sh.recv_edges)
 def cycles_a(n):
     for _ in range(n):
         e.step_compute(); e.step_unpack()
-out["shard_cycle_us_without_collective"] = timed(cycles_a, e.sync)
+if "a" in ONLY:
+    out["shard_cycle_us_without_collective"] = timed(cycles_a, e.sync)
 e.close()
 
 # (b) library loop + real RCCL, halo looped back (needs n_send == n_recv)
-if n_send == n_recv:
+if n_send == n_recv and "b" in ONLY:
     e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
     e.halo_setup(sh.send_edges, sh.recv_edges)
     e.comm_init(0, 1, comm_unique_id(), [n_send], [n_recv])
@@ -65,6 +72,9 @@ if n_send == n_recv:
     e.close()
 
 # (c) torch.distributed on the comm stream, same volume
+if "c" not in ONLY:
+    print(json.dumps(out))
+    sys.exit(0)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
 os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo"); os.environ.setdefault("NCCL_IB_DISABLE", "1")
 torch.cuda.set_device(0)
