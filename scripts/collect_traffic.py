@@ -10,9 +10,15 @@ traffic, profiles/r01_pmc_calibration_v4.txt, r01_pmc_requests_calibration_v4.tx
     8.39 M requests) and is therefore reported at exactly 1/2; a random sub-line
     gather issues one 64-B request per gather (k_gather: 6.0 M gathers + index
     stream -> 6.19 M requests) and is reported in full.
-  * Hence for a sweep with G random gathers per launch (two per edge on a graph
-    without locality):  read bytes = 2 * FETCH - 64 * G ;  with locality the
-    gathers merge into line requests and 2 * FETCH is an upper bound.
+  * Near-sequential gathers of 32-B records -- every record in order, or every other one --
+    merge into 128-B line requests like a stream (k_gather32 dense / half_dense in
+    tools/microbench: 6 M lanes -> FETCH_SIZE = 1/2 x the bytes of the lines touched,
+    profiles/r01_pmc_calibration_v8.txt).
+  * Hence for a sweep with G RANDOM gathers per launch:  read bytes = 2 * FETCH - 64 * G.
+    G = 2 per edge with the caller's factor order (layout flag 256); with the factors of a
+    class sorted by their first variable (the default since v7) one of the two gathers per
+    edge end is near-sequential, G = 1 per edge; on a graph with locality (Ising grid) the
+    gathers merge into line requests, G = 0 and 2 * FETCH is an upper bound.
 usage: python scripts/collect_traffic.py TAG workload/dtype=file.txt:n_gather ...
 """
 import json
@@ -26,7 +32,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def read_counters(path):
     out = {}
     for line in open(path):
-        m = re.match(r"(\S+)\s+.*k_sweep.*mean(?:_KiB)?\s+([0-9.]+)", line)
+        m = re.search(r"\b([A-Z][A-Z0-9_]+_SIZE)\s+.*k_sweep.*mean(?:_KiB)?\s+([0-9.]+)", line)
         if m:
             out[m.group(1)] = float(m.group(2))
     return out
