@@ -240,9 +240,47 @@ int mxs_comm_exchange(mxs_engine *e);
 /* n sharded cycles, each mxs_step_compute -> exchange -> mxs_step_unpack, enqueued
  * by the library; does not wait (mxs_sync does). */
 int mxs_run_sharded(mxs_engine *e, int32_t n_cycles);
+/* ---- peer-store exchange: no collective ------------------------------------
+ * The ranks of one node (2..8) map each other's ghost buffers and flag words through
+ * hipIpc; from then on the variable kernel stores the records of cut edges straight
+ * into the ghost region of the shard that holds the factor's replica (xGMI peer
+ * stores), a tiny kernel behind every launch publishes the launch number in the
+ * peers' flag words, and a cycle is ONE launch whose cut factor blocks poll those
+ * words (time-limited; a wait that expires is reported by mxs_sync).  What the
+ * agents' transport (pydcop/infrastructure/communication.py:588-698) does with one
+ * message per edge and cycle is then a 32-byte store.
+ *   mxs_peer_export   after mxs_halo_setup, instead of mxs_comm_init: allocates the
+ *                     ghost regions and describes them.  out->qualifies == 0: this
+ *                     shard cannot run in this mode (cut factors that are not binary
+ *                     register classes, sent edges outside the packed variable
+ *                     classes or bound for two shards, too many cut blocks, or
+ *                     MAXSUM_SHARD_P2P=0) -- use mxs_comm_init then.
+ *   mxs_peer_connect  once every rank holds every rank's mxs_peer_info -- the launcher
+ *                     gathers them -- and ALL qualify: maps the peers' buffers, pushes
+ *                     the current messages.  mxs_run_sharded / mxs_step_compute then
+ *                     run fused launches; mxs_comm_exchange / mxs_step_unpack are no-ops.
+ *                     mxs_reset needs a barrier over the ranks before it (no peer may
+ *                     still be running cycles of the previous run). */
+#define MXS_MAX_PEERS 8
+#define MXS_IPC_HANDLE_BYTES 64
+typedef struct mxs_peer_info {
+    int32_t qualifies;
+    int32_t rank;
+    int64_t ghost_len;                    /* elements of one ghost region          */
+    int64_t recv_at[MXS_MAX_PEERS];       /* where rank q's block starts in it ... */
+    int64_t recv_len[MXS_MAX_PEERS];      /* ... and its length (elements)         */
+    uint8_t ghost_handle[MXS_IPC_HANDLE_BYTES];
+    uint8_t flag_handle[MXS_IPC_HANDLE_BYTES];
+    int64_t pid;                          /* ranks of ONE process (k shards on one GPU,  */
+    uint64_t ghost_ptr, flag_ptr;         /* tests, tools) use the pointers themselves   */
+} mxs_peer_info;
+int mxs_peer_export(mxs_engine *e, int32_t rank, int32_t world, const int64_t *send_counts,
+                    const int64_t *recv_counts, mxs_peer_info *out);
+int mxs_peer_connect(mxs_engine *e, const mxs_peer_info *all /* [world] */);
+
 /* How this shard runs its cycles (decided by mxs_halo_setup / mxs_comm_init from the
  * shape of the shard):
- *   direct_exchange  1: the variable kernel writes the records of cut edges into the send
+ *   direct_exchange  2: peer stores (above).  1: the variable kernel writes the records of cut edges into the send
  *                    buffer itself and RCCL receives straight into the ghost slots (laid out
  *                    in receive order) -- no pack / unpack kernel; needs mxs_comm_init, every
  *                    sent edge in a packed variable class and sent to one shard only.

@@ -10,6 +10,7 @@
 // There is no host fallback: every cycle runs on the device.
 #include <hip/hip_runtime.h>
 #include <dlfcn.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <climits>
@@ -122,6 +123,8 @@ struct DevBuf {
     U* p = nullptr;
     size_t n = 0;
     hipError_t alloc(size_t count) {
+        if (p) (void)hipFree(p);  // re-allocation (e.g. a second attempt at setting an exchange up)
+        p = nullptr;
         n = count;
         return hipMalloc((void**)&p, std::max<size_t>(count, 1) * sizeof(U));
     }
@@ -160,6 +163,9 @@ struct EngineBase {
     virtual int comm_exchange() = 0;
     virtual int run_sharded(int n) = 0;
     virtual void shard_mode(int32_t* f, int32_t* d) const = 0;
+    virtual int peer_export(int rank, int world, const int64_t* sc, const int64_t* rc, mxs_peer_info* out) = 0;
+    virtual int peer_connect(const mxs_peer_info* all) = 0;
+    virtual bool peer_mode() const = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
     Layout L;
@@ -207,6 +213,11 @@ struct Engine : EngineBase {
     static constexpr int FUSED_MAX_CUT_BLOCKS = 1024;  // half of the 2048 resident workgroup slots
 
     ~Engine() override {
+        for (int q = 0; q < MXS_MAX_PEERS; ++q) {
+            if (peer_local[q]) continue;
+            if (peer_ghost[q]) (void)hipIpcCloseMemHandle(peer_ghost[q]);
+            if (peer_flag[q]) (void)hipIpcCloseMemHandle(peer_flag[q]);
+        }
         if (nccl_comm) {
             if (comm) (void)hipStreamSynchronize(comm);
             (void)rccl->CommDestroy(nccl_comm);
@@ -257,13 +268,35 @@ struct Engine : EngineBase {
         a.need_epoch = 0;
         a.send_out = direct ? send2[from ^ 1].p : nullptr;  // the parity this cycle writes
         a.send_slot = direct ? send_slot.p : nullptr;
+        a.n_peers = 0;
+        a.me = comm_rank;
+        a.ghost_lo = INT32_MAX;
+        a.ghost_old = nullptr;
+        for (int q = 0; q < MXS_MAX_PEERS; ++q) {
+            a.peer_first[q] = INT32_MAX;
+            a.peer_dst[q] = nullptr;
+        }
+        if (p2p) {
+            // this launch becomes publish number gen + 1: it reads the records of publish `gen`
+            // (ghost region gen % 3; all zeros in the start cycle, like every other message) and
+            // stores its own into region (gen + 1) % 3 of the peers
+            a.n_peers = comm_world;
+            a.ghost_lo = (int32_t)L.v2f_elems;
+            a.ghost_old = start ? ghost3.p + 3 * ghost_len : ghost3.p + (int64_t)(gen % 3) * ghost_len;
+            a.send_slot = send_slot.p;
+            a.send_out = nullptr;
+            for (int q = 0; q < comm_world; ++q) {
+                a.peer_first[q] = peer_first[q];
+                a.peer_dst[q] = peer_ghost[q] ? peer_ghost[q] + (int64_t)((gen + 1) % 3) * peer_len[q] + peer_at[q] : nullptr;
+            }
+        }
         if (phase == 3) {  // fused sharded launch: phase-1 classes, then the cut factor classes
             a.n_classes = (int32_t)L.fused_block_base.size();
             for (int i = 0; i < MAX_CLASSES; ++i)
                 a.block_base[i] = i < a.n_classes ? L.fused_block_base[i] : INT32_MAX;
             a.classes = classes_f.p;
             a.halo_flags = halo_flags.p;
-            a.need_epoch = unpacks;  // every exchange enqueued so far has to be in place
+            a.need_epoch = p2p ? gen : unpacks;  // every exchange enqueued so far has to be in place
             return a;
         }
         const std::vector<int32_t>& order = phase == 1 ? L.sweep_order : L.sweep_order2;
@@ -277,7 +310,14 @@ struct Engine : EngineBase {
     int launch_sweep(const SweepArgs<T>& a, int nb) {
         if (nb <= 0) return MXS_OK;
         const dim3 grid(nb), block(BLOCK);
-        if (a.timeline != nullptr) {  // profiling twin
+        if (p2p) {  // peer-store twin
+            switch (L.dsel) {
+                case 2: hipLaunchKernelGGL((k_sweep_p2p<T, 2>), grid, block, 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((k_sweep_p2p<T, 3>), grid, block, 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((k_sweep_p2p<T, 4>), grid, block, 0, stream, a); break;
+                default: hipLaunchKernelGGL((k_sweep_p2p<T, 0>), grid, block, 0, stream, a); break;
+            }
+        } else if (a.timeline != nullptr) {  // profiling twin
             switch (L.dsel) {
                 case 2: hipLaunchKernelGGL((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
                 case 3: hipLaunchKernelGGL((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
@@ -452,7 +492,7 @@ struct Engine : EngineBase {
             }
             HIP_TRY(classes_f.upload(order, stream));
         }
-        HIP_TRY(halo_flags.alloc(16));
+        HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
@@ -478,16 +518,24 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemsetAsync(cV.p, 0, std::max<size_t>(cV.n, 1), stream));
         HIP_TRY(hipMemsetAsync(sel.p, 0, std::max<size_t>(sel.n, 1) * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(belief.p, 0, std::max<size_t>(belief.n, 1) * sizeof(T), stream));
-        HIP_TRY(hipMemsetAsync(halo_flags.p, 0, 16 * sizeof(uint32_t), stream));
+        if (!p2p) HIP_TRY(hipMemsetAsync(halo_flags.p, 0, 64 * sizeof(uint32_t), stream));  // (peers write a p2p shard's)
         if (comm) HIP_TRY(hipStreamSynchronize(comm));  // no unpack of the previous run is still writing
         unpacks = 0;
         cur = 0;
         cycles = 0;
         // cycle 0 == start() of every computation (computations.py:741-753)
-        int rc = launch_cycle(cur, true);
+        // (peer-store mode: the caller has made sure every rank is here -- no peer is still
+        // running cycles of the previous run; the start cycle reads zeros for the ghosts and its
+        // records are pushed afterwards, see p2p_push)
+        int rc = p2p ? launch_phase(cur, true, 3) : launch_cycle(cur, true);
         if (rc) return rc;
         cur ^= 1;
         halo_pending = false;
+        if (p2p) {  // the start launch has stored its records at the peers itself
+            rc = p2p_publish();
+            if (rc) return rc;
+            return sync();
+        }
         HIP_TRY(hipEventRecord(ev_p1, stream));
         if (halo_ready) {  // the start messages have to cross too
             rc = pack();
@@ -559,11 +607,11 @@ struct Engine : EngineBase {
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
-        if (fused) {  // did a cut factor block give up waiting for its halo?
-            uint32_t h[2] = {0, 0};
-            HIP_TRY(hipMemcpyAsync(h, halo_flags.p, sizeof(h), hipMemcpyDeviceToHost, stream));
+        if (fused || p2p) {  // did a cut factor block give up waiting for its halo?
+            uint32_t h[1] = {0};
+            HIP_TRY(hipMemcpyAsync(h, halo_flags.p + HALO_ERR_WORD, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
-            if (h[1] != 0)
+            if (h[0] != 0)
                 return fail(MXS_E_STATE, "sharded cycle: cut factors waited > 2 s for a halo exchange that "
                                          "never arrived (an exchange / mxs_step_unpack per mxs_step_compute?)");
         }
@@ -609,10 +657,14 @@ struct Engine : EngineBase {
         HIP_TRY(hipSetDevice(device));
         { int rc = sync(); if (rc) return rc; }
         const int nE = L.n_edges;
-        std::vector<T> hv((size_t)L.v2f_elems), hf((size_t)L.f2v_elems);
+        // (peer-store mode: the ghost records live behind the V2F buffer, offsets >= v2f_elems)
+        std::vector<T> hv((size_t)(L.v2f_elems + (p2p ? ghost_len : 0))), hf((size_t)L.f2v_elems);
         std::vector<uint8_t> hcF(nE), hcV((size_t)L.n_cv);
         if (L.v2f_elems)
-            HIP_TRY(copy_sync(hv.data(), v2f[cur].p, sizeof(T) * hv.size(), hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hv.data(), v2f[cur].p, sizeof(T) * (size_t)L.v2f_elems, hipMemcpyDeviceToHost, stream));
+        if (p2p && ghost_len)
+            HIP_TRY(copy_sync(hv.data() + L.v2f_elems, ghost3.p + (int64_t)(gen % 3) * ghost_len,
+                              sizeof(T) * (size_t)ghost_len, hipMemcpyDeviceToHost, stream));
         if (L.f2v_elems)
             HIP_TRY(copy_sync(hf.data(), f2v[cur].p, sizeof(T) * hf.size(), hipMemcpyDeviceToHost, stream));
         if (nE) {
@@ -842,6 +894,13 @@ struct Engine : EngineBase {
     // Ping-pong buffers keep the two streams on disjoint data.
     int step_compute() override {
         HIP_TRY(hipSetDevice(device));
+        if (p2p) {  // one launch (it stores the cut-edge records at the peers) + the publish
+            int rc = launch_phase(cur, false, 3);
+            if (rc) return rc;
+            cur ^= 1;
+            cycles += 1;
+            return p2p_publish();
+        }
         if (fused) {
             // compute stream: one launch per cycle, nothing to wait for on the host side --
             // the cut factor blocks (last of the grid) wait for halo_flags[0] themselves;
@@ -872,6 +931,7 @@ struct Engine : EngineBase {
 
     int step_unpack() override {
         HIP_TRY(hipSetDevice(device));
+        if (p2p) return MXS_OK;  // nothing to unpack: the peers store into the ghost regions
         if (direct) {  // RCCL has received straight into the ghost slots
             if (fused) {
                 ++unpacks;
@@ -912,6 +972,23 @@ struct Engine : EngineBase {
     int64_t ghost_base = 0;         // element offset of the ghost region in a V2F buffer
     int64_t n_send_pad = 0;         // elements of a padded send buffer
     std::vector<int64_t> psend_cnt, precv_cnt, psend_at, precv_at;  // padded elements, per peer
+    // Peer-store exchange: no collective and no comm stream.  Every rank maps the ghost buffer
+    // and the flag words of every other rank (hipIpc); the variable kernel stores cut-edge
+    // records straight into the peer's ghost region, a tiny kernel behind each launch publishes
+    // the launch number in the peers' flag words, and a cycle is ONE fused launch whose cut
+    // factor blocks poll those words.  Ghost regions are three deep: a peer may run one launch
+    // ahead of this rank, never two (its next launch cannot finish before it has seen this one).
+    bool p2p = false;
+    uint32_t gen = 0;                 // publishes done by this rank (the same on every rank)
+    DevBuf<T> ghost3;                 // 3 ghost regions + 1 region of zeros (start cycle), ghost_len each
+    int64_t ghost_len = 0;            // elements per region (padded records, receive order)
+    T* peer_ghost[MXS_MAX_PEERS] = {};      // peer q's ghost3 (mapped), nullptr for this rank
+    uint32_t* peer_flag[MXS_MAX_PEERS] = {};
+    bool peer_local[MXS_MAX_PEERS] = {};    // mapped without IPC (a shard of this process)
+    int64_t peer_len[MXS_MAX_PEERS] = {};   // peer q's ghost_len
+    int64_t peer_at[MXS_MAX_PEERS] = {};    // where my block starts inside a region of peer q
+    int32_t peer_first[MXS_MAX_PEERS] = {}; // my send slots [peer_first[q], ...) go to peer q
+    std::vector<int64_t> pexp_send, pexp_recv;  // counts given to peer_export
     const Rccl* rccl = nullptr;
     void* nccl_comm = nullptr;
     int comm_rank = 0, comm_world = 0;
@@ -1046,8 +1123,6 @@ struct Engine : EngineBase {
         std::vector<int64_t> so;
         for (int32_t ei : send_ei)
             for (int d = 0; d < L.edge_half[ei]; ++d) so.push_back((int64_t)L.v2f_off[ei] + d);
-        if (halo_send_off.p) (void)hipFree(halo_send_off.p);
-        halo_send_off.p = nullptr;
         HIP_TRY(halo_send_off.upload(so, stream));
         direct = true;
         // the messages of the current cycle (the start messages right after mxs_create): packed
@@ -1056,6 +1131,7 @@ struct Engine : EngineBase {
     }
 
     int comm_exchange() override {
+        if (p2p) return MXS_OK;  // the launches exchange by themselves
         if (!nccl_comm) return fail(MXS_E_STATE, "no communicator: call mxs_comm_init first");
         HIP_TRY(hipSetDevice(device));
         const int dt = sizeof(T) == 8 ? NCCL_F64 : NCCL_F32;
@@ -1095,9 +1171,211 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    bool peer_mode() const override { return p2p; }
+
+    // Split the halo lists by peer and lay the ghost records out in receive order (shared with
+    // the direct RCCL exchange).  false: the shard does not qualify.
+    bool plan_direct(int world, const int64_t* sc, const int64_t* rc, std::vector<int32_t>& slot,
+                     int64_t& g_len, int& Hs) {
+        const int nE = L.n_edges;
+        comm_world = world;
+        send_cnt.assign(sc, sc + world);
+        recv_cnt.assign(rc, rc + world);
+        slot.assign(L.vell.size(), -1);
+        std::vector<const ClassInfo*> packed;
+        for (const ClassInfo& ci : L.classes)
+            if (ci.kind == K_V_PACK) packed.push_back(&ci);
+        for (size_t i = 0; i < send_ei.size(); ++i) {
+            const int64_t off = L.v2f_off[send_ei[i]];
+            const ClassInfo* home = nullptr;
+            for (const ClassInfo* ci : packed)
+                if (off >= ci->v2f_base && off < ci->v2f_base + (int64_t)ci->count * ci->H) home = ci;
+            if (!home) return false;
+            const int64_t pos = home->ell_base + (off - home->v2f_base) / home->H;
+            if (slot[pos] >= 0) return false;
+            slot[pos] = (int32_t)i;
+        }
+        std::vector<uint8_t> seen(nE, 0);
+        int64_t n_ghost = 0;
+        g_len = 0;
+        for (int ei = 0; ei < nE; ++ei)
+            if (!L.owned[L.edge_var_int[ei]]) ++n_ghost;
+        if ((int64_t)recv_ei.size() != n_ghost) return false;
+        for (int32_t ei : recv_ei) {
+            if (L.owned[L.edge_var_int[ei]] || seen[ei]) return false;
+            seen[ei] = 1;
+            g_len += L.edge_half[ei];
+        }
+        auto split = [&](const std::vector<int32_t>& edges, const std::vector<int64_t>& cnt,
+                         std::vector<int64_t>& pcnt, std::vector<int64_t>& pat) -> bool {
+            pcnt.assign(world, 0);
+            pat.assign(world, 0);
+            size_t i = 0;
+            int64_t at = 0;
+            for (int q = 0; q < world; ++q) {
+                pat[q] = at;
+                int64_t left = cnt[q];
+                while (left > 0 && i < edges.size()) {
+                    left -= L.edge_dom[edges[i]];
+                    pcnt[q] += L.edge_half[edges[i]];
+                    ++i;
+                }
+                if (left != 0) return false;
+                at += pcnt[q];
+            }
+            return i == edges.size();
+        };
+        if (!split(send_ei, send_cnt, psend_cnt, psend_at) || !split(recv_ei, recv_cnt, precv_cnt, precv_at))
+            return false;
+        Hs = 0;
+        for (int32_t ei : send_ei) {
+            if (Hs == 0) Hs = L.edge_half[ei];
+            if (L.edge_half[ei] != Hs) return false;
+        }
+        return true;
+    }
+
+    // Peer-store exchange, step 1: decide whether this shard qualifies, allocate the ghost
+    // regions and the flag words, and describe them for the other ranks.
+    int peer_export(int rank, int world, const int64_t* sc, const int64_t* rc, mxs_peer_info* out) override {
+        if (!out) return fail(MXS_E_INVALID, "null argument");
+        std::memset(out, 0, sizeof(*out));
+        if (!halo_ready) return fail(MXS_E_STATE, "mxs_peer_export needs mxs_halo_setup first");
+        if (p2p || direct || nccl_comm) return fail(MXS_E_STATE, "the exchange of this shard is already set up");
+        if (world < 2 || world > MXS_MAX_PEERS || rank < 0 || rank >= world || !sc || !rc)
+            return fail(MXS_E_INVALID, "mxs_peer_export: 2..8 ranks of one node");
+        HIP_TRY(hipSetDevice(device));
+        comm_rank = rank;
+        // the fused launch has to be possible (cut factor work inside the sweep launch, few
+        // enough cut blocks) and the cut factors must be binary register classes (they are the
+        // ones that address the ghost region)
+        bool ok = L.n_blocks_fused > 0 && L.n_blocks_sweep2 > 0 && L.n_blocks_sweep2 <= FUSED_MAX_CUT_BLOCKS &&
+                  send_buf == halo_send.p;
+        for (const NaryLaunch& nl : L.nary_launches) ok = ok && !nl.cut;
+        for (int c : L.sweep_order2) ok = ok && L.classes[c].kind == K_F_BIN;
+        std::vector<int32_t> slot;
+        int Hs = 0;
+        ok = ok && plan_direct(world, sc, rc, slot, ghost_len, Hs);
+        ok = ok && L.v2f_elems + ghost_len < ((int64_t)1 << 31) - 8192;
+        const char* env = getenv("MAXSUM_SHARD_P2P");
+        if (env && env[0] == '0') ok = false;
+        if (!ok) return MXS_OK;  // out->qualifies stays 0: the caller falls back to RCCL
+        ghost_len = (ghost_len + 63) / 64 * 64;
+        HIP_TRY(ghost3.alloc((size_t)(4 * std::max<int64_t>(ghost_len, 64))));
+        HIP_TRY(hipMemsetAsync(ghost3.p, 0, sizeof(T) * ghost3.n, stream));
+        HIP_TRY(hipMemsetAsync(halo_flags.p, 0, 64 * sizeof(uint32_t), stream));
+        HIP_TRY(send_slot.upload(slot, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        hipIpcMemHandle_t hg, hf;
+        HIP_TRY(hipIpcGetMemHandle(&hg, ghost3.p));
+        HIP_TRY(hipIpcGetMemHandle(&hf, halo_flags.p));
+        static_assert(sizeof(hg) == MXS_IPC_HANDLE_BYTES, "hipIpcMemHandle_t is 64 bytes");
+        std::memcpy(out->ghost_handle, &hg, MXS_IPC_HANDLE_BYTES);
+        std::memcpy(out->flag_handle, &hf, MXS_IPC_HANDLE_BYTES);
+        out->pid = (int64_t)getpid();
+        out->ghost_ptr = (uint64_t)(uintptr_t)ghost3.p;
+        out->flag_ptr = (uint64_t)(uintptr_t)halo_flags.p;
+        out->qualifies = 1;
+        out->rank = rank;
+        out->ghost_len = ghost_len;
+        for (int q = 0; q < world; ++q) {
+            out->recv_at[q] = precv_at[q];     // where rank q's block starts inside my regions
+            out->recv_len[q] = precv_cnt[q];   // ... and how long it is (checked against q's sends)
+        }
+        pexp_send.assign(sc, sc + world);
+        pexp_recv.assign(rc, rc + world);
+        return MXS_OK;
+    }
+
+    // Step 2 (every rank holds every rank's mxs_peer_info, all of them qualifying): map the
+    // peers' buffers, point the ghost edges at the ghost region, push the current records.
+    int peer_connect(const mxs_peer_info* all) override {
+        if (!all) return fail(MXS_E_INVALID, "null argument");
+        if (pexp_send.empty() || p2p) return fail(MXS_E_STATE, "mxs_peer_connect needs mxs_peer_export first");
+        HIP_TRY(hipSetDevice(device));
+        const int world = comm_world, me = comm_rank;
+        for (int q = 0; q < world; ++q) {
+            if (!all[q].qualifies || all[q].rank != q) return fail(MXS_E_INVALID, "mxs_peer_connect: a rank does not qualify");
+            if (q != me && all[q].recv_len[me] != psend_cnt[q])
+                return fail(MXS_E_INVALID, "mxs_peer_connect: what a peer expects from this rank is not what it sends");
+        }
+        for (int q = 0; q < world; ++q) {
+            peer_first[q] = (int32_t)(psend_at[q] / std::max<int64_t>(1, send_ei.empty() ? 1 : L.edge_half[send_ei[0]]));
+            peer_len[q] = all[q].ghost_len;
+            peer_at[q] = all[q].recv_at[me];
+            if (q == me) continue;
+            if (all[q].pid == (int64_t)getpid()) {  // a shard of this very process: no IPC needed
+                peer_ghost[q] = (T*)(uintptr_t)all[q].ghost_ptr;
+                peer_flag[q] = (uint32_t*)(uintptr_t)all[q].flag_ptr;
+                peer_local[q] = true;
+                continue;
+            }
+            hipIpcMemHandle_t hg, hf;
+            std::memcpy(&hg, all[q].ghost_handle, MXS_IPC_HANDLE_BYTES);
+            std::memcpy(&hf, all[q].flag_handle, MXS_IPC_HANDLE_BYTES);
+            void *pg = nullptr, *pf = nullptr;
+            HIP_TRY(hipIpcOpenMemHandle(&pg, hg, hipIpcMemLazyEnablePeerAccess));
+            HIP_TRY(hipIpcOpenMemHandle(&pf, hf, hipIpcMemLazyEnablePeerAccess));
+            peer_ghost[q] = (T*)pg;
+            peer_flag[q] = (uint32_t*)pf;
+        }
+        { int rc = sync(); if (rc) return rc; }
+        // ghost edges address the ghost region: V2F offsets >= v2f_elems, in receive order
+        const int nE = L.n_edges;
+        int64_t at = L.v2f_elems;
+        for (int32_t ei : recv_ei) {
+            L.v2f_off[ei] = (int32_t)at;
+            at += L.edge_half[ei];
+        }
+        for (int k = 0; k < nE; ++k) L.vslot_v2f[k] = L.v2f_off[L.vslot_edge[k]];
+        HIP_TRY(hipMemcpyAsync(edge_v2f.p, L.v2f_off.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
+        HIP_TRY(hipMemcpyAsync(vslot_v2f.p, L.vslot_v2f.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
+        // offsets of the padded records of the send order (k_p2p_push)
+        std::vector<int64_t> so;
+        for (int32_t ei : send_ei)
+            for (int d = 0; d < L.edge_half[ei]; ++d) so.push_back((int64_t)L.v2f_off[ei] + d);
+        n_send_pad = (int64_t)so.size();
+        HIP_TRY(halo_send_off.upload(so, stream));
+        HIP_TRY(hipStreamSynchronize(stream));
+        p2p = true;
+        fused = true;
+        launches_per_cycle = 1 + (int)L.wide_classes.size() + (int)L.nary_launches.size();
+        gen = 0;
+        return p2p_push();
+    }
+
+    // Store the CURRENT records of the cut edges into the peers' next ghost region and publish:
+    // the state right after mxs_create / mxs_reset, whose start cycle ran before any peer was
+    // listening (reset) or mapped (create).  Counts as one publish on every rank.
+    int p2p_push() {
+        if (n_send_pad > 0) {
+            PeerDst<T> dst{};
+            for (int q = 0; q < MXS_MAX_PEERS; ++q) {
+                dst.first[q] = q < comm_world ? peer_first[q] : INT32_MAX;
+                dst.p[q] = (q < comm_world && peer_ghost[q])
+                               ? peer_ghost[q] + (int64_t)((gen + 1) % 3) * peer_len[q] + peer_at[q] : nullptr;
+            }
+            const int Hs = L.edge_half[send_ei[0]];
+            const int nb = (int)((n_send_pad + BLOCK - 1) / BLOCK);
+            hipLaunchKernelGGL((k_p2p_push<T>), dim3(nb), dim3(BLOCK), 0, stream, (const T*)v2f[cur].p,
+                               (const int64_t*)halo_send_off.p, dst, Hs, n_send_pad);
+            HIP_TRY(hipGetLastError());
+        }
+        return p2p_publish();
+    }
+
+    int p2p_publish() {
+        ++gen;
+        PeerFlags pf{};
+        for (int q = 0; q < MXS_MAX_PEERS; ++q) pf.p[q] = q < comm_world ? peer_flag[q] : nullptr;
+        hipLaunchKernelGGL(k_p2p_publish, dim3(1), dim3(64), 0, stream, pf, comm_rank, comm_world, gen);
+        HIP_TRY(hipGetLastError());
+        return MXS_OK;
+    }
+
     void shard_mode(int32_t* f, int32_t* d) const override {
         if (f) *f = fused ? 1 : 0;
-        if (d) *d = direct ? 1 : 0;
+        if (d) *d = p2p ? 2 : direct ? 1 : 0;
     }
 
     int run_sharded(int n) override {
@@ -1238,6 +1516,17 @@ int mxs_comm_init(mxs_engine* e, const char* rccl_path, int32_t rank, int32_t wo
 
 int mxs_comm_exchange(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->comm_exchange(); }
 int mxs_run_sharded(mxs_engine* e, int32_t n) { CHECK_HANDLE(e); return e->impl->run_sharded(n); }
+
+int mxs_peer_export(mxs_engine* e, int32_t rank, int32_t world, const int64_t* send_counts,
+                    const int64_t* recv_counts, mxs_peer_info* out) {
+    CHECK_HANDLE(e);
+    return e->impl->peer_export(rank, world, send_counts, recv_counts, out);
+}
+
+int mxs_peer_connect(mxs_engine* e, const mxs_peer_info* all) {
+    CHECK_HANDLE(e);
+    return e->impl->peer_connect(all);
+}
 
 int mxs_shard_mode(const mxs_engine* e, int32_t* fused_launch, int32_t* direct_exchange) {
     CHECK_HANDLE(e);

@@ -107,13 +107,25 @@ struct SweepArgs {
     // Fused sharded launch (engine.hip, step_compute): the blocks of a cut factor class
     // (ClassInfo::wait_halo) wait until halo_flags[0] -- the number of halo exchanges
     // unpacked so far -- reaches need_epoch.  NULL in every other launch.
-    uint32_t* halo_flags;  // [0] epoch, [1] error bits
+    uint32_t* halo_flags;  // epoch word(s), error bits at [HALO_ERR_WORD]
     uint32_t need_epoch;
     // Sharded operation, direct exchange: the lane of a boundary edge also writes its record
     // into the send buffer the engine hands to RCCL (no pack kernel).  send_slot[pos] = record
     // index in send_out or -1, per lane of the packed variable classes; NULL otherwise.
     T* send_out;
     const int32_t* send_slot;
+    // Peer-store exchange (engine.hip, "p2p"): no collective at all.  The lane of a cut edge
+    // stores its record straight into the ghost region of the shard that holds the factor's
+    // replica (peer memory mapped through hipIpc, xGMI): slots [peer_first[q], peer_first[q+1])
+    // of the send order belong to peer q, whose copy of my block starts at peer_dst[q].  The
+    // cut factors of a launch read the ghost region ghost_old (V2F offsets >= ghost_lo address
+    // it) once every peer has published the epoch need_epoch in halo_flags[q].
+    int32_t n_peers;                        // 0: not in peer-store mode
+    int32_t me;                             // this shard's rank
+    int32_t ghost_lo;                       // INT32_MAX when unused
+    const T* ghost_old;
+    int32_t peer_first[MXS_MAX_PEERS];      // unused entries: INT32_MAX
+    T* peer_dst[MXS_MAX_PEERS];
     int32_t n_classes;
     // First block of every class of the launch (in launch order; unused entries
     // hold INT32_MAX): a block finds its class with compares on kernel arguments,
@@ -235,7 +247,7 @@ __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassI
     }
 }
 
-template <typename T, int D>
+template <typename T, int D, bool P2P = false>
 __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
     constexpr int H = Msg<T, D>::H;
     const int e = ci.edge_base + 2 * j;
@@ -258,8 +270,14 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
 #pragma unroll
     for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
     // the two gathers
-    Msg<T, D>::load(a.v2f_old + v0, m0);      // V->F message of scope variable 0
-    Msg<T, D>::load(a.v2f_old + v1, m1);
+    // (peer-store mode: the message of a ghost variable lives in the ghost region)
+    const T *s0 = a.v2f_old + v0, *s1 = a.v2f_old + v1;
+    if constexpr (P2P) {
+        s0 = v0 >= a.ghost_lo ? a.ghost_old + (v0 - a.ghost_lo) : s0;
+        s1 = v1 >= a.ghost_lo ? a.ghost_old + (v1 - a.ghost_lo) : s1;
+    }
+    Msg<T, D>::load(s0, m0);      // V->F message of scope variable 0
+    Msg<T, D>::load(s1, m1);
     T o0[D], o1[D];
 #pragma unroll
     for (int x = 0; x < D; ++x) {
@@ -392,7 +410,7 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
 //   select_value      maxsum.py:584-620
 //   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
 // ---------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool P2P = false>
 __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     constexpr int H = Msg<T, D>::H;
     const int lane_id = item + (int)threadIdx.x;
@@ -474,8 +492,21 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
 #pragma unroll
         for (int d = 0; d < D; ++d) m[d] = (T)0;
     }
-    if (send_at >= 0)  // a cut edge: the record crosses to the shard that holds its factor's replica
-        Msg<T, D>::store_c(a.send_out + (int64_t)send_at * H, m, CIM ? co : 0);
+    if (send_at >= 0) {  // a cut edge: the record crosses to the shard that holds its factor's replica
+        T* dst = a.send_out + (int64_t)send_at * H;
+        if constexpr (P2P) {  // peer-store mode: straight into that shard's ghost region
+            T* base = a.peer_dst[0];
+            int first = a.peer_first[0];
+#pragma unroll
+            for (int q = 1; q < MXS_MAX_PEERS; ++q) {
+                const bool ge = send_at >= a.peer_first[q];
+                base = ge ? a.peer_dst[q] : base;
+                first = ge ? a.peer_first[q] : first;
+            }
+            dst = base + (int64_t)(send_at - first) * H;
+        }
+        Msg<T, D>::store_c(dst, m, CIM ? co : 0);
+    }
     if constexpr ((H * sizeof(T)) % 16 == 0) {  // the whole wave is here (count is a multiple of 64)
         T full[H];
 #pragma unroll
@@ -562,15 +593,15 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // size only (the engine picks it when the graph has a single D), which keeps the
 // kernel's register allocation -- the maximum over all paths -- small.
 // ---------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, bool P2P = false>
 __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     if (ci.kind == K_V_PACK) {  // one lane per edge
-        variable_pack<T, D>(a, ci, item);
+        variable_pack<T, D, P2P>(a, ci, item);
         return;
     }
     const int j = item + (int)threadIdx.x;
     if (j >= ci.count) return;
-    if (ci.kind == K_F_BIN) factor_binary<T, D>(a, ci, j);
+    if (ci.kind == K_F_BIN) factor_binary<T, D, P2P>(a, ci, j);
     else if (ci.kind == K_F_UNARY) factor_unary<T, D>(a, ci, j);
 }
 
@@ -581,32 +612,39 @@ __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& 
 // it does, lane 0 polls with a sleep.  A wait that exceeds ~2 s (100 MHz ticks) sets an
 // error bit the host reports at the next sync instead of hanging the GPU.
 constexpr unsigned long long HALO_WAIT_TICKS = 200000000ull;
-__device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need) {
+constexpr int HALO_ERR_WORD = 32;  // halo_flags[32]: error bits (flags[0..] are epochs)
+// n_peers == 0: one epoch word, written by this GPU's publish kernel (fused launch);
+// n_peers  > 0: one word per rank, written by that rank's publish kernel over xGMI.
+__device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, int n_peers, int me) {
     if (threadIdx.x == 0) {
         const unsigned long long t0 = wall_clock64();
-        while (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < need &&
-               __hip_atomic_load(flags + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {  // fail fast after a timeout
-            __builtin_amdgcn_s_sleep(64);
-            if (wall_clock64() - t0 > HALO_WAIT_TICKS) {
-                atomicOr(flags + 1, 1u);
-                break;
+        const int n = n_peers > 0 ? n_peers : 1;
+        for (int q = 0; q < n; ++q) {
+            if (n_peers > 0 && q == me) continue;
+            while (__hip_atomic_load(flags + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < need &&
+                   __hip_atomic_load(flags + HALO_ERR_WORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                __builtin_amdgcn_s_sleep(64);
+                if (wall_clock64() - t0 > HALO_WAIT_TICKS) {
+                    atomicOr(flags + HALO_ERR_WORD, 1u);  // the others fail fast
+                    break;
+                }
             }
         }
     }
     __syncthreads();
-    // the unpack kernel's stores (another XCD's L2, written back before it published the
-    // epoch) must not be served from a stale line of this XCD's L2
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    // the ghost messages were written by another kernel (another XCD's L2, or another GPU):
+    // they must not be served from a stale line of this XCD's L2
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
 }
 
-template <typename T, int DSEL>
+template <typename T, int DSEL, bool P2P = false>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0;
 #pragma unroll
     for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
     const ClassInfo ci = a.classes[c];
     const int item = ((int)blockIdx.x - ci.block_base) * ci.per_block;
-    if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch);
+    if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;
         if (j >= ci.count) return ci.kind;
@@ -615,12 +653,12 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
         return ci.kind;
     }
     if (DSEL != 0) {
-        sweep_d<T, (DSEL != 0 ? DSEL : 2)>(a, ci, item);
+        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P>(a, ci, item);
     } else {
         switch (ci.D) {
-            case 2: sweep_d<T, 2>(a, ci, item); break;
-            case 3: sweep_d<T, 3>(a, ci, item); break;
-            case 4: sweep_d<T, 4>(a, ci, item); break;
+            case 2: sweep_d<T, 2, P2P>(a, ci, item); break;
+            case 3: sweep_d<T, 3, P2P>(a, ci, item); break;
+            case 4: sweep_d<T, 4, P2P>(a, ci, item); break;
             default: break;
         }
     }
@@ -634,6 +672,14 @@ template <typename T, int DSEL>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep(SweepArgs<T> a) {
     sweep_block<T, DSEL>(a);
+}
+
+// The sweep of a shard in peer-store mode (engine.hip, p2p): same blocks, plus the stores of
+// cut-edge records into the peers' ghost regions and the ghost addressing of the cut factors.
+// A kernel of its own so that these cost the plain sweep no register.
+template <typename T, int DSEL>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_p2p(SweepArgs<T> a) {
+    sweep_block<T, DSEL, true>(a);
 }
 
 // Profiling twin (mxs_debug_timeline): when did each block start, when were its stores done.
@@ -1227,6 +1273,39 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(T* rec, const int64_t* el
 // (measured: 249 us instead of 3).
 __global__ void k_halo_publish(uint32_t* flags, uint32_t epoch) {
     __hip_atomic_store(flags, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// Peer-store mode: tell every other rank that the records of launch `epoch` are in its ghost
+// region (the launch that stored them is complete: this kernel runs behind it in the stream).
+struct PeerFlags {
+    uint32_t* p[MXS_MAX_PEERS];
+};
+__global__ void k_p2p_publish(PeerFlags peers, int me, int world, uint32_t epoch) {
+    const int q = (int)threadIdx.x;
+    if (q < world && q != me)
+        __hip_atomic_store(peers.p[q] + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// Peer-store mode, outside the sweep (after mxs_peer_connect / mxs_reset): copy the current
+// records of the cut edges to the peers.  slot i of the send order -> peer's ghost region.
+template <typename T>
+struct PeerDst {
+    T* p[MXS_MAX_PEERS];
+    int32_t first[MXS_MAX_PEERS];
+};
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_p2p_push(const T* rec, const int64_t* elem_off, PeerDst<T> dst,
+                                                    int H, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int slot = (int)(i / H);
+    T* base = dst.p[0];
+    int first = dst.first[0];
+#pragma unroll
+    for (int q = 1; q < MXS_MAX_PEERS; ++q) {
+        const bool ge = slot >= dst.first[q];
+        base = ge ? dst.p[q] : base;
+        first = ge ? dst.first[q] : first;
+    }
+    base[(int64_t)(slot - first) * H + (i - (int64_t)slot * H)] = rec[elem_off[i]];
 }
 
 }  // namespace mxs

@@ -26,8 +26,21 @@ ABI_SYMBOLS = (
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
     "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded", "mxs_shard_mode",
+    "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
 )
+
+
+MAX_PEERS = 8
+
+
+class PeerInfo(C.Structure):
+    """struct mxs_peer_info (include/maxsum_gpu.h): what a rank tells the others for the
+    peer-store exchange.  Plain bytes: pickles through torch.distributed."""
+    _fields_ = [("qualifies", C.c_int32), ("rank", C.c_int32), ("ghost_len", C.c_int64),
+                ("recv_at", C.c_int64 * MAX_PEERS), ("recv_len", C.c_int64 * MAX_PEERS),
+                ("ghost_handle", C.c_uint8 * 64), ("flag_handle", C.c_uint8 * 64),
+                ("pid", C.c_int64), ("ghost_ptr", C.c_uint64), ("flag_ptr", C.c_uint64)]
 
 
 class MaxSumGpuError(RuntimeError):
@@ -112,6 +125,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_comm_exchange": ([vp], C.c_int),
         "mxs_run_sharded": ([vp, i32], C.c_int),
         "mxs_shard_mode": ([vp, C.POINTER(i32), C.POINTER(i32)], C.c_int),
+        "mxs_peer_export": ([vp, i32, i32, vp, vp, C.POINTER(PeerInfo)], C.c_int),
+        "mxs_peer_connect": ([vp, C.POINTER(PeerInfo)], C.c_int),
         "mxs_debug_timeline": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
         "mxs_update_factor_table": ([vp, i32, vp, i64], C.c_int),
         "mxs_destroy": ([vp], C.c_int),
@@ -157,6 +172,10 @@ def comm_unique_id(lib_path: Optional[str] = None, rccl: Optional[str] = None) -
     if rc != 0:
         raise MaxSumGpuError(f"maxsum_gpu error {rc}: {lib.mxs_last_error().decode()}")
     return buf.raw
+
+
+def peer_qualifies(info: bytes) -> bool:
+    return bool(PeerInfo.from_buffer_copy(info).qualifies)
 
 
 def device_count(lib_path: Optional[str] = None) -> int:
@@ -314,10 +333,29 @@ class MaxSumEngine:
         self._check(self._lib.mxs_run_sharded(self._h, int(n_cycles)))
 
     def shard_mode(self) -> dict:
-        """{"fused_launch": bool, "direct_exchange": bool} -- how this shard runs its cycles."""
+        """{"fused_launch", "direct_exchange", "peer_stores"} -- how this shard runs its cycles."""
         f, d = C.c_int32(0), C.c_int32(0)
         self._check(self._lib.mxs_shard_mode(self._h, C.byref(f), C.byref(d)))
-        return {"fused_launch": bool(f.value), "direct_exchange": bool(d.value)}
+        return {"fused_launch": bool(f.value), "direct_exchange": d.value == 1, "peer_stores": d.value == 2}
+
+    def peer_export(self, rank: int, world: int, send_counts, recv_counts) -> bytes:
+        """Peer-store exchange, step 1 (after halo_setup): this rank's `mxs_peer_info` as bytes;
+        `peer_qualifies(info)` tells whether the shard can run in that mode."""
+        sc = np.ascontiguousarray(send_counts, dtype=np.int64)
+        rc = np.ascontiguousarray(recv_counts, dtype=np.int64)
+        if sc.shape != (world,) or rc.shape != (world,):
+            raise ValueError("one count per rank")
+        info = PeerInfo()
+        self._check(self._lib.mxs_peer_export(self._h, int(rank), int(world), sc.ctypes.data, rc.ctypes.data,
+                                              C.byref(info)))
+        return bytes(info)
+
+    def peer_connect(self, infos):
+        """Step 2: `infos[q]` = the bytes rank q got from `peer_export` (all qualifying)."""
+        arr = (PeerInfo * len(infos))()
+        for i, b in enumerate(infos):
+            C.memmove(C.byref(arr[i]), bytes(b), C.sizeof(PeerInfo))
+        self._check(self._lib.mxs_peer_connect(self._h, arr))
 
     def stream(self) -> int:
         s = C.c_void_p()

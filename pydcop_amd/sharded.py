@@ -31,7 +31,7 @@ from typing import Optional, Tuple
 
 import numpy as np
 
-from .engine import MaxSumEngine, MaxSumGpuError, comm_unique_id
+from .engine import MaxSumEngine, MaxSumGpuError, comm_unique_id, peer_qualifies
 from .graph import FlatGraph, Params
 from .partition import Shard, build_shard, partition_variables
 
@@ -63,8 +63,16 @@ class ShardedMaxSum:
         collective = os.environ.get("MAXSUM_COLLECTIVE") or collective
         if collective == "auto":
             collective = "rccl" if self._on_gpu else "torch"
-        if collective not in ("rccl", "torch"):
-            raise ValueError("collective must be 'auto', 'rccl' or 'torch'")
+        if collective not in ("p2p", "rccl", "torch"):
+            raise ValueError("collective must be 'auto', 'p2p', 'rccl' or 'torch'")
+        self._p2p = collective == "p2p" and self._init_p2p()
+        if self._p2p:
+            self._native = True  # the cycle loop is in the library here too
+            self.collective = "p2p"
+            self.engine.sync()
+            return
+        if collective == "p2p":
+            collective = "rccl" if self._on_gpu else "torch"
         self._native = collective == "rccl" and self._init_native(lib_path, rccl)
         self.collective = "rccl" if self._native else "torch"
         if self._native:
@@ -93,6 +101,25 @@ class ShardedMaxSum:
         self._exchange()          # the start messages of cycle 0
         self.engine.step_unpack()
         self.engine.sync()
+
+    def _init_p2p(self) -> bool:
+        """Peer-store exchange (no collective): every rank describes its ghost buffers, and only
+        if ALL shards qualify do they map each other's memory (hipIpc over xGMI)."""
+        dist = self._dist
+        if self.world < 2 or self._backend == "none":
+            return False
+        try:
+            info = self.engine.peer_export(self.rank, self.world, self.shard.send_counts, self.shard.recv_counts)
+        except MaxSumGpuError as e:
+            warnings.warn(f"peer-store exchange unavailable: {e}")
+            info = None
+        infos = [None] * self.world
+        dist.all_gather_object(infos, info, group=self.group)
+        if any(i is None or not peer_qualifies(i) for i in infos):
+            return False
+        self.engine.peer_connect(infos)
+        dist.barrier(group=self.group)  # every rank has pushed its current records
+        return True
 
     def _init_native(self, lib_path, rccl) -> bool:
         """Create the engine's own RCCL communicator.  Every rank first checks that it can
@@ -176,6 +203,10 @@ class ShardedMaxSum:
         self.sync()
 
     def reset(self):
+        if self._p2p:
+            self._dist.barrier(group=self.group)  # no peer still runs cycles of the previous run
+            self.engine.reset()
+            return
         self.engine.reset()
         self._exchange()
         self.engine.step_unpack()

@@ -231,6 +231,21 @@ inline unsigned long long wall_clock64() {
 }
 #define __ATOMIC_RELAXED_HIPEMU 0
 #define __HIP_MEMORY_SCOPE_AGENT 4
+#define __HIP_MEMORY_SCOPE_SYSTEM 5
+// "IPC" between the rank threads of one test process: the handle is the pointer itself
+#define HIP_IPC_HANDLE_SIZE 64
+#define hipIpcMemLazyEnablePeerAccess 1
+struct hipIpcMemHandle_t { char reserved[HIP_IPC_HANDLE_SIZE]; };
+inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
+    std::memset(h, 0, sizeof(*h));
+    std::memcpy(h->reserved, &p, sizeof(p));
+    return hipSuccess;
+}
+inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    std::memcpy(p, h.reserved, sizeof(*p));
+    return hipSuccess;
+}
+inline hipError_t hipIpcCloseMemHandle(void*) { return hipSuccess; }
 template <typename U>
 inline U __hip_atomic_load(const U* p, int, int) { return *p; }
 template <typename U>

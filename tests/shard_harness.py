@@ -108,7 +108,9 @@ def rank_main(argv):
     import torch
     import torch.distributed as dist
     from pydcop_amd.sharded import ShardedMaxSum
-    backend = "gloo" if lib else "nccl"
+    # MAXSUM_TEST_BACKEND=gloo: two ranks on ONE GPU (RCCL refuses that; the peer-store
+    # exchange does not need a collective, only a bootstrap)
+    backend = os.environ.get("MAXSUM_TEST_BACKEND") or ("gloo" if lib else "nccl")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     if backend == "nccl":

@@ -148,7 +148,7 @@ def test_fused_sharded_launch_is_used_and_optional(emu_lib, monkeypatch):
         before = e.cycle_bytes()[1]
         e.halo_setup(s.send_edges, s.recv_edges)
         launches[mode] = (before, e.cycle_bytes()[1])
-        assert e.shard_mode() == {"fused_launch": mode == "1", "direct_exchange": False}
+        assert e.shard_mode() == {"fused_launch": mode == "1", "direct_exchange": False, "peer_stores": False}
         e.close()
         _check_against_single(g, kw, 3, emu_lib, steps=(1, 4, 11))
     assert launches["1"] == (2, 1) and launches["0"] == (2, 2)
@@ -245,6 +245,7 @@ def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, t
             e.halo_setup(s.send_edges, s.recv_edges)
             e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=fake_rccl)
             modes[r] = e.shard_mode()["direct_exchange"]
+            assert not e.shard_mode()["peer_stores"]
             e.comm_exchange()
             e.step_unpack()
             out = []
@@ -275,6 +276,93 @@ def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, t
             np.testing.assert_array_equal(results[r][i][0][:s.n_owned], i1[s.local_vars[:s.n_owned]])
             np.testing.assert_array_equal(results[r][i][1][:s.n_owned], b1[s.local_vars[:s.n_owned]])
     one.close()
+
+
+@pytest.mark.parametrize("case,k", [("coloring", 3), ("ising", 4), ("coloring_deg9", 2)])
+def test_peer_store_exchange_thread_ranks_emu(case, k, emu_lib):
+    """mxs_peer_export / mxs_peer_connect: no collective -- the variable kernel of a rank stores
+    cut-edge records straight into the ghost regions of the others ("IPC" between the rank
+    threads of this process), a cycle is one fused launch.  The emulated kernels run one at a
+    time, so the ranks move in lockstep here (a barrier per cycle) and never have to poll."""
+    import threading
+    from pydcop_amd.engine import peer_qualifies
+    g, kw = make_case(case)
+    p = Params(**kw)
+    part = partition_variables(g, k)
+    shards = [build_shard(g, part, r, k) for r in range(k)]
+    steps = (1, 2, 9)
+    results, errors, infos, modes = [None] * k, [], [None] * k, [None] * k
+    barrier = threading.Barrier(k)
+
+    def rank_main(r):
+        try:
+            s = shards[r]
+            e = MaxSumEngine(s.graph, p, lib_path=emu_lib)
+            e.halo_setup(s.send_edges, s.recv_edges)
+            infos[r] = e.peer_export(r, k, s.send_counts, s.recv_counts)
+            barrier.wait()
+            assert all(peer_qualifies(i) for i in infos)
+            e.peer_connect(infos)
+            modes[r] = e.shard_mode()
+            barrier.wait()
+            out = []
+            for n in steps:
+                for _ in range(n):
+                    e.run_sharded(1)
+                    e.sync()
+                    barrier.wait()
+                out.append(e.assignment())
+            # a reset in the middle of the epochs, then the same cycles again
+            barrier.wait()
+            e.reset()
+            barrier.wait()
+            for _ in range(steps[0]):
+                e.run_sharded(1)
+                e.sync()
+                barrier.wait()
+            out.append(e.assignment())
+            v2f = e.messages()[0]
+            assert np.isfinite(v2f).all()
+            results[r] = out
+            e.close()
+        except Exception as ex:
+            errors.append((r, repr(ex)))
+            barrier.abort()
+
+    threads = [threading.Thread(target=rank_main, args=(r,)) for r in range(k)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(300)
+    assert not errors, errors
+    assert all(m == {"fused_launch": True, "direct_exchange": False, "peer_stores": True} for m in modes), modes
+    one = MaxSumEngine(g, p, lib_path=emu_lib)
+    firsts = None
+    for i, n in enumerate(steps):
+        one.run(n)
+        i1, b1 = one.assignment()
+        if i == 0:
+            firsts = (i1.copy(), b1.copy())
+        for r, s in enumerate(shards):
+            np.testing.assert_array_equal(results[r][i][0][:s.n_owned], i1[s.local_vars[:s.n_owned]])
+            np.testing.assert_array_equal(results[r][i][1][:s.n_owned], b1[s.local_vars[:s.n_owned]])
+    for r, s in enumerate(shards):  # after the reset
+        np.testing.assert_array_equal(results[r][-1][0][:s.n_owned], firsts[0][s.local_vars[:s.n_owned]])
+        np.testing.assert_array_equal(results[r][-1][1][:s.n_owned], firsts[1][s.local_vars[:s.n_owned]])
+    one.close()
+
+
+def test_peer_store_needs_binary_cut_factors(emu_lib):
+    """Shards with mixed domains / n-ary cut factors do not qualify: the caller falls back."""
+    from pydcop_amd.engine import peer_qualifies
+    g, kw = make_case("mixed_max")
+    part = partition_variables(g, 2)
+    s = build_shard(g, part, 0, 2)
+    e = MaxSumEngine(s.graph, Params(**kw), lib_path=emu_lib)
+    e.halo_setup(s.send_edges, s.recv_edges)
+    assert not peer_qualifies(e.peer_export(0, 2, s.send_counts, s.recv_counts))
+    assert e.shard_mode()["peer_stores"] is False
+    e.close()
 
 
 def test_native_exchange_rejects_bad_counts(emu_lib, fake_rccl, tmp_path, monkeypatch):
@@ -326,6 +414,27 @@ def test_local_shards_equal_single_engine_gpu(k, dtype):
         _check_against_single(g, kw, k, None, device="cuda", dtype=dtype)
     g, kw = make_case("coloring_50k")
     _check_against_single(g, kw, k, None, device="cuda", steps=(30,), dtype=dtype)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["coloring", "coloring_50k"])
+def test_peer_stores_two_processes_one_gpu(case, tmp_path):
+    """ShardedMaxSum(collective="p2p") in two processes that share the one GPU of the test
+    box: real hipIpc handles, stores into the other process's ghost regions, flag words
+    polled by the fused launch -- everything of the peer-store exchange except the xGMI hop."""
+    steps = [3, 8]
+    z = _run_ranks(2, None, case, steps, tmp_path, timeout=200,
+                   extra_env={"MAXSUM_COLLECTIVE": "p2p", "MAXSUM_TEST_BACKEND": "gloo"})
+    assert str(z["collective"]) == "p2p"
+    g, kw = make_case(case)
+    one = MaxSumEngine(g, Params(**kw))
+    done = 0
+    for n in steps:
+        one.run(n)
+        done += n
+        i1, b1 = one.assignment()
+        np.testing.assert_array_equal(z[f"idx_{done}"], i1)
+        np.testing.assert_array_equal(z[f"bel_{done}"], b1)
 
 
 @pytest.mark.gpu

@@ -46,7 +46,7 @@ def timed(fn, sync):
     return 1e6 * (time.perf_counter() - t) / STEPS
 
 
-ONLY = os.environ.get("MAXSUM_COST_ONLY", "abc")  # which of the three loops to time
+ONLY = os.environ.get("MAXSUM_COST_ONLY", "abcd")  # which of the three loops to time
 for k in ("MAXSUM_COMM_CUS", "MAXSUM_SHARD_FUSED", "MAXSUM_SHARD_DIRECT", "MAXSUM_LAYOUT_FLAGS"):
     if os.environ.get(k):
         out[k] = os.environ[k]
@@ -69,6 +69,31 @@ if n_send == n_recv and "b" in ONLY:
     e.comm_init(0, 1, comm_unique_id(), [n_send], [n_recv])
     out["shard_mode"] = e.shard_mode()
     out["shard_cycle_us_native_rccl_loopback"] = timed(e.run_sharded, e.sync)
+    e.close()
+
+# (d) peer-store exchange, looped back: the engine is every one of its own peers -- its
+# "remote" stores land in its own ghost regions (where peer q's block would be) and its publish
+# kernel sets the flag word of every peer.  One fused launch + the publish per cycle, the real
+# in-kernel wait on the previous launch's flags; what is missing is the xGMI hop.
+if "d" in ONLY and N <= 8:
+    from pydcop_amd.engine import PeerInfo, peer_qualifies
+    import ctypes as C
+    e = MaxSumEngine(sh.graph, Params(mode=mode, dtype=dt, layout_flags=FLAGS))
+    e.halo_setup(sh.send_edges, sh.recv_edges)
+    mine = e.peer_export(0, N, sh.send_counts, sh.recv_counts)
+    out["peer_store_qualifies"] = peer_qualifies(mine)
+    if peer_qualifies(mine) and np.array_equal(sh.send_counts, sh.recv_counts):
+        me = PeerInfo.from_buffer_copy(mine)
+        infos = [mine]
+        for q in range(1, N):
+            fake = PeerInfo.from_buffer_copy(mine)
+            fake.rank = q
+            fake.recv_at[0], fake.recv_len[0] = me.recv_at[q], me.recv_len[q]
+            fake.flag_ptr = me.flag_ptr + 4 * q   # its word [0] (= me) is my word [q]
+            infos.append(bytes(fake))
+        e.peer_connect(infos)
+        out["shard_mode_peer_stores"] = e.shard_mode()
+        out["shard_cycle_us_peer_stores_loopback"] = timed(e.run_sharded, e.sync)
     e.close()
 
 # (c) torch.distributed on the comm stream, same volume
