@@ -193,6 +193,13 @@ struct Msg {
 #pragma unroll
         for (int d = 0; d < H; ++d) q[d] = d < D ? m[d < D ? d : 0] : (T)0;
     }
+    // Element-wise loads that are coherent with stores of OTHER GPUs / other kernels in flight
+    // (system scope: not served from a stale line of this XCD's L2): the ghost records of the
+    // peer-store exchange.
+    static __device__ __forceinline__ void load_sys(const T* p, T (&m)[D]) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = __hip_atomic_load(p + d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
     // A record with padding (H > D, e.g. D = 3) keeps the SEND COUNTER of its message in the
     // first padding element (a small integer, exact in T): the owner of the record reads
     // and writes it with the message itself -- no separate one-byte load and store per
@@ -271,13 +278,16 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
     for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
     // the two gathers
     // (peer-store mode: the message of a ghost variable lives in the ghost region)
-    const T *s0 = a.v2f_old + v0, *s1 = a.v2f_old + v1;
     if constexpr (P2P) {
-        s0 = v0 >= a.ghost_lo ? a.ghost_old + (v0 - a.ghost_lo) : s0;
-        s1 = v1 >= a.ghost_lo ? a.ghost_old + (v1 - a.ghost_lo) : s1;
+        // a ghost record was stored by another GPU while this launch was already running
+        if (v0 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v0 - a.ghost_lo), m0);
+        else Msg<T, D>::load(a.v2f_old + v0, m0);
+        if (v1 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v1 - a.ghost_lo), m1);
+        else Msg<T, D>::load(a.v2f_old + v1, m1);
+    } else {
+        Msg<T, D>::load(a.v2f_old + v0, m0);      // V->F message of scope variable 0
+        Msg<T, D>::load(a.v2f_old + v1, m1);
     }
-    Msg<T, D>::load(s0, m0);      // V->F message of scope variable 0
-    Msg<T, D>::load(s1, m1);
     T o0[D], o1[D];
 #pragma unroll
     for (int x = 0; x < D; ++x) {
@@ -632,9 +642,17 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
         }
     }
     __syncthreads();
-    // the ghost messages were written by another kernel (another XCD's L2, or another GPU):
-    // they must not be served from a stale line of this XCD's L2
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    if (n_peers > 0) {
+        // peer-store mode: the ghost records are read with system-scope loads (Msg::load_sys),
+        // which no cache of this GPU serves stale; only the order "flag, then records" matters.
+        // (An acquire fence here would invalidate the L2 once per cut block and wave -- measured:
+        // 37.5 instead of 2x us per launch with 535 cut blocks.)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    } else {
+        // fused launch over RCCL: the unpack kernel wrote the ghost slots through another XCD's
+        // L2; they must not be served from a stale line of this one
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
 }
 
 template <typename T, int DSEL, bool P2P = false>
