@@ -155,9 +155,24 @@ def main():
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group(args.backend)
-        runner = ShardedMaxSum(graph, params, rank, world,
-                               device=local_rank if args.backend == "nccl" else 0)
+        dev = local_rank if args.backend == "nccl" else 0
+        runner = ShardedMaxSum(graph, params, rank, world, device=dev)
         barrier = dist.barrier
+        if runner.collective == "p2p":
+            # the peer-store exchange has in-kernel waits with a time limit; if they expire on
+            # this node (reported by the engine at sync), every rank falls back to RCCL together
+            from pydcop_amd.engine import MaxSumGpuError
+            ok = 1
+            try:
+                runner.run(min(args.warmup, 20) or 1)
+            except MaxSumGpuError as e:
+                ok = 0
+                print(f"[rank {rank}] peer-store exchange failed ({e}); falling back to RCCL", file=sys.stderr)
+            flag = torch.tensor([ok], device="cuda" if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                runner.close()
+                runner = ShardedMaxSum(graph, params, rank, world, device=dev, collective="rccl")
     else:
         runner = MaxSumEngine(graph, params, device=local_rank)
         barrier = lambda: None  # noqa: E731

@@ -11,8 +11,13 @@ leave a GPU are those of cut factors' remote variables:
                comm stream      pack (after the variables of cycle t) -> all-to-all
                                 (RCCL over xGMI) -> unpack into the ghost slots
 
-The all-to-all is one group of ncclSend / ncclRecv per peer with the fixed counts of
-the partition.  On GPUs the engine calls RCCL itself (`collective="rccl"`: the whole
+Three exchanges, fastest first (`collective=`, default "auto" = the first that applies):
+"p2p" -- no collective at all: the ranks of one node map each other's ghost buffers through
+hipIpc, the variable kernel stores cut-edge records straight into the peer's ghost region
+(xGMI peer stores), and a cycle is ONE launch whose cut factor blocks poll flag words the
+peers publish (mxs_peer_export / mxs_peer_connect; shards with binary cut factors only);
+"rccl" and "torch" -- an all-to-all, one group of ncclSend / ncclRecv per peer with the fixed
+counts of the partition, between the two launches of a cycle as drawn above.  On GPUs the engine calls RCCL itself (`collective="rccl"`: the whole
 cycle loop stays inside libmaxsum_hip.so, mxs_run_sharded -- no interpreter between
 two 50-microsecond cycles; torch.distributed only bootstraps the communicator and
 gathers results); `collective="torch"` runs the same exchange as
@@ -62,7 +67,9 @@ class ShardedMaxSum:
         self._on_gpu = backend == "nccl"
         collective = os.environ.get("MAXSUM_COLLECTIVE") or collective
         if collective == "auto":
-            collective = "rccl" if self._on_gpu else "torch"
+            # GPUs of one node: peer stores (no collective) when every shard qualifies, else the
+            # engine's own RCCL exchange; host-memory engines (tests): torch's all_to_all
+            collective = ("p2p" if 2 <= world <= 8 else "rccl") if self._on_gpu else "torch"
         if collective not in ("p2p", "rccl", "torch"):
             raise ValueError("collective must be 'auto', 'p2p', 'rccl' or 'torch'")
         self._p2p = collective == "p2p" and self._init_p2p()
