@@ -60,6 +60,7 @@ class ShardedMaxSum:
         self.params = params or Params()
         self.part = partition_variables(graph, world) if part is None else np.asarray(part, dtype=np.int32)
         self.shard: Shard = build_shard(graph, self.part, rank, world)
+        self._device, self._lib_path = device, lib_path
         self.engine = MaxSumEngine(self.shard.graph, self.params, device=device, lib_path=lib_path)
         self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
         backend = dist.get_backend(group) if dist.is_initialized() else "none"
@@ -124,8 +125,20 @@ class ShardedMaxSum:
         dist.all_gather_object(infos, info, group=self.group)
         if any(i is None or not peer_qualifies(i) for i in infos):
             return False
-        self.engine.peer_connect(infos)
-        dist.barrier(group=self.group)  # every rank has pushed its current records
+        err = None
+        try:
+            self.engine.peer_connect(infos)
+        except MaxSumGpuError as e:  # e.g. hipIpcOpenMemHandle refused
+            err = str(e)
+        oks = [None] * self.world
+        dist.all_gather_object(oks, err is None, group=self.group)  # also: every rank has pushed
+        if not all(oks):
+            # a connected engine cannot go back: start over with a fresh one for the collective
+            warnings.warn(f"peer-store exchange unavailable ({err or 'another rank failed'}); using RCCL")
+            self.engine.close()
+            self.engine = MaxSumEngine(self.shard.graph, self.params, device=self._device, lib_path=self._lib_path)
+            self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
+            return False
         return True
 
     def _init_native(self, lib_path, rccl) -> bool:
