@@ -14,10 +14,11 @@ engine creation).
 N > 1 is launched by the driver through torch.distributed.run (one rank per GPU):
 WEAK scaling -- ONE random 3-colouring instance of N x 100k variables (same degree,
 same cost convention) is partitioned across the ranks, 100k variables per GPU, and
-boundary V->F messages are exchanged once per cycle with an RCCL all-to-all
-(grouped ncclSend/ncclRecv issued by the engine itself, the cycle loop stays in the
-library: pydcop_amd/sharded.py; MAXSUM_COLLECTIVE=torch selects
-torch.distributed.all_to_all_single instead).  `value` is then N x iterations/s: the whole job's
+boundary V->F messages cross once per cycle -- as xGMI peer stores from the variable
+kernel into hipIpc-mapped ghost buffers (one fused launch per cycle, no collective), or,
+if a shard does not qualify or the in-kernel waits expire in the warm-up, as an RCCL
+all-to-all issued by the engine itself; the cycle loop stays in the library either way
+(pydcop_amd/sharded.py; MAXSUM_COLLECTIVE=p2p|rccl|torch forces one).  `value` is then N x iterations/s: the whole job's
 throughput in iterations of a 100k-variable instance (= directed edge-messages/s
 divided by the 800k messages of one such iteration), so N = 1 is the plain metric.
 `--scaling strong` keeps the fixed 100k instance and splits it instead.
@@ -233,7 +234,10 @@ def main():
             per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
             out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS,
                                "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None,
-                               "kernel": "k_sweep x2 + halo pack/unpack + RCCL all-to-all (one sharded cycle)",
+                               "kernel": {"p2p": "k_sweep_p2p (one fused launch, peer stores over xGMI) + k_p2p_publish",
+                                          "rccl": "k_sweep x2 + RCCL all-to-all issued by the engine (one sharded cycle)",
+                                          "torch": "k_sweep x2 + halo pack/unpack + torch all_to_all_single"
+                                          }.get(runner.collective, "one sharded cycle"),
                                "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
                                "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True}
         if args.gpus == 1 and not args.no_cpu_baseline:
