@@ -32,6 +32,8 @@ def make_case(name):
         return G.ising_grid(16, 12, seed=2, names=False), {"start_messages": "leafs_vars"}
     if name == "coloring_deg9":
         return G.random_coloring(300, avg_degree=9, seed=8, names=False), {"damping_nodes": "vars"}
+    if name == "coloring_2k":
+        return G.random_coloring(2000, avg_degree=4, seed=11, names=False), {}
     if name == "coloring_50k":
         return G.random_coloring(50_000, avg_degree=4, seed=1, names=False), {}
     raise ValueError(name)

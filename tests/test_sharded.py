@@ -218,7 +218,8 @@ def fake_rccl():
 
 
 @pytest.mark.parametrize("case,k,direct", [("coloring", 3, True), ("mixed_max", 2, False), ("ising", 4, True),
-                                           ("coloring", 4, False), ("coloring_deg9", 2, True)])
+                                           ("coloring", 4, False), ("coloring_deg9", 2, True),
+                                           ("coloring_2k", 8, True)])
 def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, tmp_path, monkeypatch):
     """mxs_comm_init / mxs_run_sharded: k ranks as k threads of this process, every one
     stepping its own engine through the library's cycle loop."""
@@ -278,8 +279,9 @@ def test_native_exchange_thread_ranks_emu(case, k, direct, emu_lib, fake_rccl, t
     one.close()
 
 
-@pytest.mark.parametrize("case,k", [("coloring", 3), ("ising", 4), ("coloring_deg9", 2)])
-def test_peer_store_exchange_thread_ranks_emu(case, k, emu_lib):
+@pytest.mark.parametrize("case,k,dtype", [("coloring", 3, "f64"), ("ising", 4, "f64"), ("coloring_deg9", 2, "f64"),
+                                          ("coloring", 8, "f32"), ("coloring_2k", 8, "f64")])
+def test_peer_store_exchange_thread_ranks_emu(case, k, dtype, emu_lib):
     """mxs_peer_export / mxs_peer_connect: no collective -- the variable kernel of a rank stores
     cut-edge records straight into the ghost regions of the others ("IPC" between the rank
     threads of this process), a cycle is one fused launch.  The emulated kernels run one at a
@@ -287,7 +289,7 @@ def test_peer_store_exchange_thread_ranks_emu(case, k, emu_lib):
     import threading
     from pydcop_amd.engine import peer_qualifies
     g, kw = make_case(case)
-    p = Params(**kw)
+    p = Params(dtype=dtype, **kw)
     part = partition_variables(g, k)
     shards = [build_shard(g, part, r, k) for r in range(k)]
     steps = (1, 2, 9)
