@@ -124,6 +124,8 @@ class ShardedMaxSum:
         infos = [None] * self.world
         dist.all_gather_object(infos, info, group=self.group)
         if any(i is None or not peer_qualifies(i) for i in infos):
+            if info is not None and peer_qualifies(info):
+                self._fresh_engine()  # drop what peer_export has set up on this rank
             return False
         err = None
         try:
@@ -135,11 +137,14 @@ class ShardedMaxSum:
         if not all(oks):
             # a connected engine cannot go back: start over with a fresh one for the collective
             warnings.warn(f"peer-store exchange unavailable ({err or 'another rank failed'}); using RCCL")
-            self.engine.close()
-            self.engine = MaxSumEngine(self.shard.graph, self.params, device=self._device, lib_path=self._lib_path)
-            self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
+            self._fresh_engine()
             return False
         return True
+
+    def _fresh_engine(self):
+        self.engine.close()
+        self.engine = MaxSumEngine(self.shard.graph, self.params, device=self._device, lib_path=self._lib_path)
+        self.engine.halo_setup(self.shard.send_edges, self.shard.recv_edges)
 
     def _init_native(self, lib_path, rccl) -> bool:
         """Create the engine's own RCCL communicator.  Every rank first checks that it can

@@ -11,6 +11,7 @@
 // fails without a GPU) and is not a fallback: see tests/test_emu_engine.py.
 #pragma once
 #include <ucontext.h>
+#include <unistd.h>
 
 #include <cmath>
 #include <cstdint>
@@ -238,10 +239,15 @@ inline unsigned long long wall_clock64() {
 struct hipIpcMemHandle_t { char reserved[HIP_IPC_HANDLE_SIZE]; };
 inline hipError_t hipIpcGetMemHandle(hipIpcMemHandle_t* h, void* p) {
     std::memset(h, 0, sizeof(*h));
+    const long long pid = (long long)getpid();
     std::memcpy(h->reserved, &p, sizeof(p));
+    std::memcpy(h->reserved + 16, &pid, sizeof(pid));
     return hipSuccess;
 }
 inline hipError_t hipIpcOpenMemHandle(void** p, hipIpcMemHandle_t h, unsigned) {
+    long long pid = 0;
+    std::memcpy(&pid, h.reserved + 16, sizeof(pid));
+    if (pid != (long long)getpid()) return hipErrorNotSupported;  // host memory of another process
     std::memcpy(p, h.reserved, sizeof(*p));
     return hipSuccess;
 }

@@ -405,6 +405,23 @@ def test_gloo_two_ranks_native_exchange(emu_lib, fake_rccl, tmp_path):
         np.testing.assert_array_equal(z[f"bel_{done}"], b1)
 
 
+def test_gloo_two_ranks_peer_stores_fall_back_together(emu_lib, tmp_path):
+    """collective="p2p" where the peers cannot be mapped (two processes of emulated engines:
+    host memory): every rank sees the failed connect, all start over with a fresh engine and the
+    collective, and the results are the single engine's."""
+    steps = [2, 6]
+    z = _run_ranks(2, emu_lib, "coloring", steps, tmp_path, extra_env={"MAXSUM_COLLECTIVE": "p2p"})
+    assert str(z["collective"]) == "torch"
+    g, kw = make_case("coloring")
+    one = MaxSumEngine(g, Params(**kw), lib_path=emu_lib)
+    done = 0
+    for n in steps:
+        one.run(n)
+        done += n
+        np.testing.assert_array_equal(z[f"idx_{done}"], one.assignment()[0])
+        np.testing.assert_array_equal(z[f"bel_{done}"], one.assignment()[1])
+
+
 # ---- on a real MI355X -----------------------------------------------------------
 
 @pytest.mark.gpu
