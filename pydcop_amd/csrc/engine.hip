@@ -612,7 +612,7 @@ struct Engine : EngineBase {
             HIP_TRY(hipMemcpyAsync(h, halo_flags.p + HALO_ERR_WORD, sizeof(h), hipMemcpyDeviceToHost, stream));
             HIP_TRY(hipStreamSynchronize(stream));
             if (h[0] != 0)
-                return fail(MXS_E_STATE, "sharded cycle: cut factors waited > 2 s for a halo exchange that "
+                return fail(MXS_E_STATE, "sharded cycle: cut factors waited > 5 s for a halo exchange that "
                                          "never arrived (an exchange / mxs_step_unpack per mxs_step_compute?)");
         }
         return MXS_OK;

@@ -619,9 +619,9 @@ __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& 
 // gathers are delivered by the halo exchange of the previous cycle (comm stream), whose
 // unpack kernel publishes its number in halo_flags[0].  These blocks are the LAST of the
 // grid and the exchange had the whole launch to finish, so normally nothing waits; when
-// it does, lane 0 polls with a sleep.  A wait that exceeds ~2 s (100 MHz ticks) sets an
+// it does, lane 0 polls with a sleep.  A wait that exceeds ~5 s (100 MHz ticks) sets an
 // error bit the host reports at the next sync instead of hanging the GPU.
-constexpr unsigned long long HALO_WAIT_TICKS = 200000000ull;
+constexpr unsigned long long HALO_WAIT_TICKS = 500000000ull;
 constexpr int HALO_ERR_WORD = 32;  // halo_flags[32]: error bits (flags[0..] are epochs)
 // n_peers == 0: one epoch word, written by this GPU's publish kernel (fused launch);
 // n_peers  > 0: one word per rank, written by that rank's publish kernel over xGMI.
