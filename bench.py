@@ -132,6 +132,9 @@ def main():
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
 
     if world > 1:
+        # dmabuf IPC (hipIpc handles of the peer-store exchange, RCCL's own buffers): has to be
+        # in the environment before the ROCm runtime starts; normally exported already
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # one HIP runtime per process: torch first, so that the engine binds to the
         # runtime torch bundles and can share its stream / buffers with RCCL
         import torch
