@@ -204,6 +204,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    check = None
+    if world > 1:
+        # outside the timed region: the sharded run must select what ONE engine sweeping the whole
+        # instance selects after the same number of cycles (bit-identical beliefs too)
+        idx_sh, bel_sh = runner.assignment()
+        n_cycles = runner.cycle_count
+        if rank == 0:
+            import numpy as np
+            with MaxSumEngine(graph, params, device=dev) as whole:
+                whole.run(n_cycles)
+                idx_1, bel_1 = whole.assignment()
+            diff = int((idx_sh != idx_1).sum()) + int((bel_sh != bel_1).sum())
+            check = {"cycles": int(n_cycles), "identical_to_single_engine": diff == 0, "differences": diff}
+            if diff:
+                print(f"[bench] sharded run differs from the single engine in {diff} places", file=sys.stderr)
+
     if rank == 0:
         its = units * args.steps / elapsed
         bytes_cycle = graph.cycle_bytes(word)
@@ -243,6 +259,8 @@ def main():
                                           }.get(runner.collective, "one sharded cycle"),
                                "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
                                "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True}
+        if check is not None:
+            out["config"]["check"] = check
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)
         print(json.dumps(out), flush=True)

@@ -44,6 +44,8 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
     assert out["config"]["n_vars"] == 3000 and f"exchange: {collective}" in out["config"]["parallelism"]
     assert out["value"] > 0 and abs(out["value"] - 2 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["value"]
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
+    assert out["config"]["check"] == {"cycles": 8 if collective != "p2p" else out["config"]["check"]["cycles"],
+                                      "identical_to_single_engine": True, "differences": 0}
 
 
 def test_bench_rejects_mismatched_world():
