@@ -227,9 +227,21 @@ def build_shard(g: FlatGraph, part: np.ndarray, rank: int, world: int) -> Shard:
 
     # ---- halo lists -----------------------------------------------------------------
     # The V->F message of global edge e=(f, u) goes from owner(u) to every other
-    # rank on which f is local.  Both ends enumerate (src, dst) pairs' edges in
-    # ascending global edge id, which fixes the packing order without any handshake.
+    # rank on which f is local.  Both ends enumerate the edges of a (src, dst) pair in the
+    # same order, computed from the global graph alone (no handshake): by (domain size,
+    # degree, variable, position in the variable's links) of the SENDING variable -- the
+    # order of the sender's lanes in the packed variable classes of the engine
+    # (csrc/layout.cpp), so that the lanes of a wave that hold cut edges write neighbouring
+    # records of the send buffer / of the peer's ghost region.
     D_e = g.dom_size[ev]
+    deg_all = np.diff(g.var_rowptr).astype(np.int64)
+    kpos = np.empty(g.n_edges, dtype=np.int64)
+    kpos[g.var_edges] = np.arange(g.n_edges) - np.repeat(g.var_rowptr[:-1].astype(np.int64), deg_all)
+
+    def lane_order(edges):
+        v = ev[edges]
+        return edges[np.lexsort((kpos[edges], v, deg_all[v], g.dom_size[v]))]
+
     send_edges, recv_edges = [], []
     send_counts = np.zeros(world, dtype=np.int64)
     recv_counts = np.zeros(world, dtype=np.int64)
@@ -246,8 +258,8 @@ def build_shard(g: FlatGraph, part: np.ndarray, rank: int, world: int) -> Shard:
             f_has_q = np.zeros(nf, dtype=bool)
             f_has_q[ef[fe][edge_part[fe] == q]] = True     # local factors touching rank q
             shared = fe[f_has_q[ef[fe]]]                    # their edges (ascending)
-            out = shared[edge_part[shared] == rank]         # my variables' messages -> q
-            inc = shared[edge_part[shared] == q]            # q's variables' messages -> me
+            out = lane_order(shared[edge_part[shared] == rank])  # my variables' messages -> q
+            inc = lane_order(shared[edge_part[shared] == q])     # q's variables' messages -> me
             send_edges.append(e_g2l[out])
             recv_edges.append(e_g2l[inc])
             send_counts[q] = int(D_e[out].sum())
