@@ -414,3 +414,15 @@ void mso_destroy(mso_state *s) {
 }
 
 int mso_real_bytes(void) { return (int)sizeof(real); }
+
+/* Test hook: approx_match on its own (the reference's unit tests pin it directly,
+ * tests/unit/test_algorithms_amaxsum.py:160-203). */
+int mso_approx_match(const double *costs, const double *prev, int32_t D, double stability) {
+    real c[64], p[64];
+    if (D > 64) return -1;
+    for (int d = 0; d < D; ++d) {
+        c[d] = (real)costs[d];
+        p[d] = (real)prev[d];
+    }
+    return approx_match(c, p, D, (real)stability);
+}
