@@ -1,27 +1,33 @@
 #!/usr/bin/env python
-"""bench.py -- Max-Sum iterations/s on the north-star instance (BASELINE.json):
-random 3-colouring, 100k variables, average degree 4, binary factors, synchronous
-Max-Sum, reference arithmetic (f64).
+"""bench.py -- Max-Sum iterations/s (BASELINE.json's metric).
 
-A "step" is one synchronous Max-Sum cycle over the whole factor graph (every
-F->V and V->F message recomputed once + value selection) = one k_sweep launch.
-Inputs are resident in HBM before the timed region (the graph is uploaded at
-engine creation).
+A "step" is one synchronous Max-Sum cycle over the whole factor graph (every F->V and V->F
+message recomputed once + value selection).  Inputs are resident in HBM before the timed
+region (the graph is uploaded at engine creation).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME]
-                    [--dtype f64|f32] [--no-cpu-baseline]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload NAME] [--dtype f64|f32]
+                    [--configs all|main] [--no-cpu-baseline]
 
-N > 1 is launched by the driver through torch.distributed.run (one rank per GPU):
-WEAK scaling -- ONE random 3-colouring instance of N x 100k variables (same degree,
-same cost convention) is partitioned across the ranks, 100k variables per GPU, and
-boundary V->F messages cross once per cycle -- as xGMI peer stores from the variable
-kernel into hipIpc-mapped ghost buffers (one fused launch per cycle, no collective), or,
-if a shard does not qualify or the in-kernel waits expire in the warm-up, as an RCCL
-all-to-all issued by the engine itself; the cycle loop stays in the library either way
-(pydcop_amd/sharded.py; MAXSUM_COLLECTIVE=p2p|rccl|torch forces one).  `value` is then N x iterations/s: the whole job's
-throughput in iterations of a 100k-variable instance (= directed edge-messages/s
-divided by the 800k messages of one such iteration), so N = 1 is the plain metric.
-`--scaling strong` keeps the fixed 100k instance and splits it instead.
+N = 1 (default): the top-level `value` / `config` / `roofline` are the configuration the metric
+is quoted on -- random 3-colouring, 100k variables, average degree 4, reference arithmetic
+(f64), one `k_sweep` launch per cycle.  The same JSON line carries, under "configs", every
+other BASELINE.json configuration that runs on one GPU (coloring_10k, ising_1024,
+coloring_1m_deg6, meeting_50k; f64 and f32) with its own cycle time, roofline fraction and the
+id of the `-m gpu` test that compares it bit for bit with the oracle at that size, and under
+"cpu_baseline" the C port of the reference algorithm timed on this box's host cores plus the
+recorded timing of the reference's own thread-agent runtime (profiles/, build container --
+the reference cannot travel to the GPU box).
+
+N > 1 (the driver launches one rank per GPU through torch.distributed.run): STRONG scaling of
+ONE instance -- by default BASELINE.json configs[3], the 1M-variable degree-6 colouring that
+north_star names for 8 GPUs -- partitioned across the ranks; boundary V->F messages cross once
+per cycle (RCCL all-to-all issued by the engine itself by default; MAXSUM_COLLECTIVE=p2p|torch
+selects the peer-store / torch exchanges).  `value` = iterations/s of THAT instance; the same
+line reports what ONE GPU does on the same instance (`config.one_gpu_iterations_per_s`, measured
+on rank 0 after the timed region), the strong-scaled 100k instance and the weak-scaled
+N x 100k instance as labelled extras -- never multiplied into `value`.  After the timed region
+rank 0 re-runs the instance on a single engine: the sharded selection and beliefs must be
+bit-identical, otherwise the run exits with a non-zero status.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -38,25 +44,42 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # the launch(es) one cycle is made of, per workload (roofline.avg_launch_us covers them all)
 KERNEL_OF = {"meeting_50k": "k_factor_nary + k_variable_wide (one cycle)"}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
+REFERENCE_BASELINE_FILE = os.path.join(ROOT, "profiles", "reference_thread_agents.json")
+METRIC = "MaxSum iterations/sec on 100k-var random graph-coloring DCOP"
+
+# BASELINE.json configs beside the metric's own: (workload, dtypes, -m gpu test that checks the
+# HIP path against the oracle bit for bit AT THIS SIZE)
+EXTRA_CONFIGS = [
+    ("coloring_100k", ("f32",), "tests/test_gpu_parity.py::test_north_star_100k_coloring"),
+    ("coloring_10k", ("f64", "f32"), "tests/test_gpu_parity.py::test_config2_10k_coloring"),
+    ("ising_1024", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[ising_1024-{dtype}]"),
+    ("coloring_1m_deg6", ("f64", "f32"),
+     "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[coloring_1m_deg6-{dtype}]"),
+    ("meeting_50k", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[meeting_50k-{dtype}]"),
+]
+MAIN_PARITY_TEST = "tests/test_gpu_parity.py::test_north_star_100k_coloring"
 
 
 def measured_traffic(workload, dtype):
-    """HBM-side bytes per launch of the dominant kernel from the rocprofv3 PMC
-    passes (FETCH_SIZE + WRITE_SIZE, separate runs; scripts/collect_traffic.py
-    turns the committed profiles/*.csv into profiles/traffic.json).  None when
-    this workload/dtype was not profiled."""
+    """HBM-side bytes per cycle from the rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, separate
+    runs; scripts/collect_traffic.py turns the committed profiles/*.txt into
+    profiles/traffic.json).  STATIC: read from the committed file, not measured in this run.
+    -> (bytes or None, source string or None)."""
     try:
         with open(TRAFFIC_FILE) as f:
             t = json.load(f)
-        return t.get(f"{workload}/{dtype}", {}).get("bytes_per_launch")
+        rec = t.get(f"{workload}/{dtype}")
+        if not rec:
+            return None, None
+        return rec.get("bytes_per_launch"), f"profiles/traffic.json (static, {rec.get('source')}: {rec.get('file')})"
     except (OSError, ValueError):
-        return None
+        return None, None
 
 
-def make_workload(name, n_gpus=1, per_gpu=100_000):
+def make_workload(name, scale=1, per_gpu=100_000):
     from pydcop_amd import generators as G
-    if name == "coloring_100k":     # the metric's configuration (north-star); x n_gpus when weak-scaled
-        return G.random_coloring(per_gpu * n_gpus, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+    if name == "coloring_100k":     # the metric's configuration (north-star); x scale when weak-scaled
+        return G.random_coloring(per_gpu * scale, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_10k":      # BASELINE.json configs[1]
         return G.random_coloring(10_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_100k_hard":
@@ -64,17 +87,16 @@ def make_workload(name, n_gpus=1, per_gpu=100_000):
     if name == "ising_1024":        # configs[2]
         return G.ising_grid(1024, 1024, seed=0, names=False), "min"
     if name == "coloring_1m_deg6":  # configs[3]
-        return G.random_coloring(1_000_000, avg_degree=6, n_colors=3, seed=0, names=False), "min"
+        return G.random_coloring(per_gpu * 10, avg_degree=6, n_colors=3, seed=0, names=False), "min"
     if name == "meeting_50k":       # configs[4]
         return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max"
     raise SystemExit(f"unknown workload {name}")
 
 
 def cpu_baseline(graph, mode, dtype, budget_s=12.0):
-    """The oracle (plain-C port of the reference algorithm) timed on the host
-    cores on a bounded number of cycles of the same workload.  The thread count
-    is the fastest of a few candidates (a 100k-variable cycle is too short to
-    feed every core of a big host)."""
+    """The oracle (plain-C port of the reference algorithm) timed on the host cores on a
+    bounded number of cycles of the same workload.  The thread count is the fastest of a few
+    candidates (a 100k-variable cycle is too short to feed every core of a big host)."""
     from oracle.maxsum_oracle import OracleMaxSum, build
     from pydcop_amd.graph import Params
     build()
@@ -100,9 +122,146 @@ def cpu_baseline(graph, mode, dtype, budget_s=12.0):
     ora.run(n)
     dt = time.perf_counter() - t0
     ora.close()
-    return {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
-            "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c (OpenMP, best of "
-                      f"1..{avail} threads = {cores}; host has {os.cpu_count()} logical cpus)"}
+    out = {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+           "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c (OpenMP, best of "
+                     f"1..{avail} threads = {cores}; host has {os.cpu_count()} logical cpus)"}
+    # The reference's OWN runtime (pydcop.infrastructure.run.run_local_thread_dcop, thread
+    # agents) cannot run on the GPU box (/root/reference does not travel): its timing is a
+    # recorded profile made in the build container by tools/reference_cpu_baseline.py.
+    try:
+        with open(REFERENCE_BASELINE_FILE) as f:
+            out["reference"] = json.load(f)
+    except (OSError, ValueError):
+        pass
+    return out
+
+
+def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None):
+    kernel_s = max(kernel_s, 1e-12)  # (the emulated engine of the CPU tests has no event clock)
+    achieved = bytes_cycle / kernel_s / 1e9
+    traffic, source = measured_traffic(workload, dtype)
+    r = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": source,
+         "kernel": KERNEL_OF.get(workload, "k_sweep"),
+         "algorithmic_bytes_per_launch": bytes_cycle, "avg_launch_us": kernel_s * 1e6}
+    if launches is not None:
+        r["launches_per_cycle"] = launches
+    return r
+
+
+def time_config(workload, dtype, graph, mode, budget_s=1.5):
+    """One extra single-GPU configuration: wall + HIP-event time of a bounded run."""
+    from pydcop_amd.engine import MaxSumEngine
+    from pydcop_amd.graph import Params
+    word = 8 if dtype == "f64" else 4
+    with MaxSumEngine(graph, Params(mode=mode, dtype=dtype)) as eng:
+        eng.run(5)
+        eng.sync()
+        t0 = time.perf_counter()
+        eng.run(10)
+        eng.sync()
+        est = (time.perf_counter() - t0) / 10
+        steps = int(max(20, min(4000, budget_s / max(est, 1e-7))))
+        eng.run(max(5, steps // 10))
+        eng.sync()
+        t0 = time.perf_counter()
+        event_ms = eng.run_timed(steps)
+        eng.sync()
+        wall = time.perf_counter() - t0
+        _, launches = eng.cycle_bytes()
+    bytes_cycle = graph.cycle_bytes(word)
+    return {"workload": workload, "dtype": dtype, "n_vars": graph.n_vars, "n_factors": graph.n_factors,
+            "n_edges": graph.n_edges, "steps": steps, "ms_per_step": 1e3 * wall / steps,
+            "iterations_per_s": steps / wall, "edge_messages_per_s": steps / wall * 2 * graph.n_edges,
+            "roofline": roofline_of(workload, dtype, bytes_cycle, event_ms * 1e-3 / steps, launches)}
+
+
+def extra_configs(skip=()):
+    out = []
+    for workload, dtypes, test in EXTRA_CONFIGS:
+        graph, mode = make_workload(workload)
+        for dtype in dtypes:
+            if (workload, dtype) in skip:
+                continue
+            rec = time_config(workload, dtype, graph, mode)
+            rec["parity_checked"] = True
+            rec["parity_test"] = test.format(dtype=dtype)
+            out.append(rec)
+        del graph
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# N > 1
+# ---------------------------------------------------------------------------------------------
+def sharded_run(graph, params, rank, world, dev, backend, warmup, steps, torch, dist):
+    """Partition `graph` over the ranks, time `steps` cycles (barrier + sync on both sides, max
+    over ranks), then check the result against ONE engine sweeping the whole instance on rank 0.
+    -> dict on rank 0 (None elsewhere)."""
+    from pydcop_amd.engine import MaxSumEngine, MaxSumGpuError
+    from pydcop_amd.sharded import ShardedMaxSum
+    runner = ShardedMaxSum(graph, params, rank, world, device=dev)
+    tdev = "cuda" if backend == "nccl" else "cpu"
+    if runner.collective == "p2p":
+        # the peer-store exchange has in-kernel waits with a time limit; if they expire on
+        # this node (reported by the engine at sync), every rank falls back to RCCL together
+        ok = 1
+        try:
+            runner.run(min(warmup, 20) or 1)
+        except MaxSumGpuError as e:
+            ok = 0
+            print(f"[rank {rank}] peer-store exchange failed ({e}); falling back to RCCL", file=sys.stderr)
+        flag = torch.tensor([ok], device=tdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            runner.close()
+            runner = ShardedMaxSum(graph, params, rank, world, device=dev, collective="rccl")
+
+    def sync():
+        runner.sync()  # hipStreamSynchronize on the engine's streams
+        if backend == "nccl":
+            torch.cuda.synchronize()
+
+    runner.run(warmup)
+    sync()
+    dist.barrier()
+    t0 = time.perf_counter()
+    runner.run(steps)
+    sync()
+    dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], device=tdev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+
+    # outside the timed region: the sharded run must select what ONE engine sweeping the whole
+    # instance selects after the same number of cycles (bit-identical beliefs too)
+    idx_sh, bel_sh = runner.assignment()
+    n_cycles = runner.cycle_count
+    collective = runner.collective
+    sh = runner.shard
+    shard_info = {"owned_vars": int(sh.n_owned), "ghost_vars": int(sh.local_vars.shape[0] - sh.n_owned),
+                  "factors": int(sh.graph.n_factors), "halo_send_elements": int(sh.send_counts.sum())}
+    runner.close()
+    out = None
+    if rank == 0:
+        with MaxSumEngine(graph, params, device=dev) as whole:
+            whole.run(n_cycles)
+            idx_1, bel_1 = whole.assignment()
+            one_steps = max(10, min(steps, 500))
+            whole.sync()
+            t0 = time.perf_counter()
+            whole.run(one_steps)
+            whole.sync()
+            one_gpu = one_steps / (time.perf_counter() - t0)
+        diff = int((idx_sh != idx_1).sum()) + int((bel_sh != bel_1).sum())
+        if diff:
+            print(f"[bench] sharded run differs from the single engine in {diff} places", file=sys.stderr)
+        out = {"elapsed": elapsed, "collective": collective, "one_gpu_iterations_per_s": one_gpu,
+               "check": {"cycles": int(n_cycles), "identical_to_single_engine": diff == 0, "differences": diff}}
+        out["shard_rank0"] = shard_info
+    dist.barrier()
+    return out
 
 
 def main():
@@ -110,18 +269,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=200)
-    ap.add_argument("--workload", default="coloring_100k")
+    ap.add_argument("--workload", default=None,
+                    help="default: coloring_100k at N = 1, coloring_1m_deg6 (BASELINE configs[3]) at N > 1")
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--layout-flags", type=int, default=0)
     ap.add_argument("--graph-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N > 1: weak = N x 100k-variable instance (default), strong = the fixed instance")
+    ap.add_argument("--configs", default="all", choices=["all", "main"],
+                    help="N = 1: all = also time the other BASELINE.json configurations (default); "
+                         "N > 1: all = also run the 100k instance strong- and weak-scaled")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: torch.distributed backend; gloo only for the CPU test of this script "
                          "(tests/test_bench_cli.py, emulated engine)")
     ap.add_argument("--vars-per-gpu", type=int, default=100_000,
-                    help="testing only: size of the coloring_100k workload (the metric is defined at 100000)")
+                    help="testing only: scales the colouring workloads (the metric is defined at 100000)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,6 +291,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    workload = args.workload or ("coloring_100k" if args.gpus == 1 else "coloring_1m_deg6")
 
     if world > 1:
         # dmabuf IPC (hipIpc handles of the peer-store exchange, RCCL's own buffers): has to be
@@ -141,132 +303,107 @@ def main():
     from pydcop_amd.engine import MaxSumEngine
     from pydcop_amd.graph import Params
 
-    weak = args.scaling == "weak" and args.gpus > 1 and args.workload == "coloring_100k"
-    graph, mode = make_workload(args.workload, args.gpus if weak else 1, args.vars_per_gpu)
-    units = args.gpus if weak else 1  # 100k-variable instances' worth of work per iteration
+    graph, mode = make_workload(workload, 1, args.vars_per_gpu)
     params = Params(mode=mode, dtype=args.dtype, layout_flags=args.layout_flags,
                     graph_chunk=args.graph_chunk)
     word = 8 if args.dtype == "f64" else 4
-    n_edges_total = graph.n_edges
+    bytes_cycle = graph.cycle_bytes(word)
+    out = {"metric": METRIC, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps,
+           "warmup": args.warmup, "higher_is_better": True, "vs_baseline": None,
+           "dtype": args.dtype, "data": "synthetic"}
+    failed = False
 
-    if world > 1:
-        from pydcop_amd.sharded import ShardedMaxSum
-        import torch.distributed as dist
-        if args.backend == "nccl":
-            torch.cuda.set_device(local_rank)
-            # one node: RCCL bootstraps over loopback, no InfiniBand probing (the container's
-            # hostname may not resolve); respected only if the launcher did not set them
-            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
-            os.environ.setdefault("NCCL_IB_DISABLE", "1")
-        dist.init_process_group(args.backend)
-        dev = local_rank if args.backend == "nccl" else 0
-        runner = ShardedMaxSum(graph, params, rank, world, device=dev)
-        barrier = dist.barrier
-        if runner.collective == "p2p":
-            # the peer-store exchange has in-kernel waits with a time limit; if they expire on
-            # this node (reported by the engine at sync), every rank falls back to RCCL together
-            from pydcop_amd.engine import MaxSumGpuError
-            ok = 1
-            try:
-                runner.run(min(args.warmup, 20) or 1)
-            except MaxSumGpuError as e:
-                ok = 0
-                print(f"[rank {rank}] peer-store exchange failed ({e}); falling back to RCCL", file=sys.stderr)
-            flag = torch.tensor([ok], device="cuda" if args.backend == "nccl" else "cpu")
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if int(flag.item()) == 0:
-                runner.close()
-                runner = ShardedMaxSum(graph, params, rank, world, device=dev, collective="rccl")
-    else:
+    if world == 1:
         runner = MaxSumEngine(graph, params, device=local_rank)
-        barrier = lambda: None  # noqa: E731
-
-    def sync():
-        runner.sync()  # hipStreamSynchronize on the engine's streams
-        if world > 1 and args.backend == "nccl":
-            torch.cuda.synchronize()
-
-    runner.run(args.warmup)
-    sync()
-    barrier()
-    t0 = time.perf_counter()
-    if world > 1:
-        runner.run(args.steps)
-        event_ms = None
-    else:
+        runner.run(args.warmup)
+        runner.sync()
+        t0 = time.perf_counter()
         event_ms = runner.run_timed(args.steps)  # HIP events on the engine's stream
-    sync()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device="cuda" if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    check = None
-    if world > 1:
-        # outside the timed region: the sharded run must select what ONE engine sweeping the whole
-        # instance selects after the same number of cycles (bit-identical beliefs too)
-        idx_sh, bel_sh = runner.assignment()
-        n_cycles = runner.cycle_count
-        if rank == 0:
-            import numpy as np
-            with MaxSumEngine(graph, params, device=dev) as whole:
-                whole.run(n_cycles)
-                idx_1, bel_1 = whole.assignment()
-            diff = int((idx_sh != idx_1).sum()) + int((bel_sh != bel_1).sum())
-            check = {"cycles": int(n_cycles), "identical_to_single_engine": diff == 0, "differences": diff}
-            if diff:
-                print(f"[bench] sharded run differs from the single engine in {diff} places", file=sys.stderr)
-
-    if rank == 0:
-        its = units * args.steps / elapsed
-        bytes_cycle = graph.cycle_bytes(word)
-        out = {
-            "metric": "MaxSum iterations/sec on 100k-var random graph-coloring DCOP",
-            "value": its, "unit": "iterations/s", "n_gpus": args.gpus, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-            "higher_is_better": True, "scaling": "weak" if (weak or args.gpus == 1) else "strong",
-            "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": args.workload + (f" x{args.gpus} (one {graph.n_vars}-variable instance, "
-                                                    f"100k variables per GPU)" if weak else ""),
-                       "n_vars": graph.n_vars,
-                       "n_factors": graph.n_factors, "n_edges": graph.n_edges,
-                       "domain": int(graph.dom_size.max()),
-                       "edge_messages_per_s": args.steps / elapsed * 2 * n_edges_total,
+        runner.sync()
+        elapsed = time.perf_counter() - t0
+        _, launches = runner.cycle_bytes()
+        runner.close()
+        out.update({
+            "value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak",
+            "config": {"workload": workload, "n_vars": graph.n_vars, "n_factors": graph.n_factors,
+                       "n_edges": graph.n_edges, "domain": int(graph.dom_size.max()),
+                       "edge_messages_per_s": args.steps / elapsed * 2 * graph.n_edges,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
-                       "parallelism": f"graph-partition x{args.gpus}"
-                                      + (f", exchange: {runner.collective}" if world > 1 else "")},
-        }
-        if event_ms is not None:
-            kernel_s = event_ms * 1e-3 / args.steps
-            achieved = bytes_cycle / kernel_s / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                               "traffic": measured_traffic(args.workload, args.dtype),
-                               "kernel": KERNEL_OF.get(args.workload, "k_sweep"),
-                               "algorithmic_bytes_per_launch": bytes_cycle,
-                               "avg_launch_us": kernel_s * 1e6}
-        else:  # N > 1: per-GPU figure from the wall clock of the whole sharded cycle
-            per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
-            out["roofline"] = {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS,
-                               "unit": "GB/s", "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None,
-                               "kernel": {"p2p": "k_sweep_p2p (one fused launch, peer stores over xGMI) + k_p2p_publish",
-                                          "rccl": "k_sweep x2 + RCCL all-to-all issued by the engine (one sharded cycle)",
-                                          "torch": "k_sweep x2 + halo pack/unpack + torch all_to_all_single"
-                                          }.get(runner.collective, "one sharded cycle"),
-                               "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
-                               "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True}
-        if check is not None:
-            out["config"]["check"] = check
-        if args.gpus == 1 and not args.no_cpu_baseline:
+                       "parallelism": "one GPU, one k_sweep launch per cycle",
+                       "parity_checked": True, "parity_test": MAIN_PARITY_TEST},
+            "roofline": roofline_of(workload, args.dtype, bytes_cycle, event_ms * 1e-3 / args.steps, launches),
+        })
+        if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)
+        if args.configs == "all" and args.workload is None:
+            del graph
+            out["configs"] = extra_configs(skip={(workload, args.dtype)})
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
-        dist.destroy_process_group()
+        return
+
+    import torch.distributed as dist
+    if args.backend == "nccl":
+        torch.cuda.set_device(local_rank)
+        # one node: RCCL bootstraps over loopback, no InfiniBand probing (the container's
+        # hostname may not resolve); respected only if the launcher did not set them
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+        os.environ.setdefault("NCCL_IB_DISABLE", "1")
+    dist.init_process_group(args.backend)
+    dev = local_rank if args.backend == "nccl" else 0
+    res = sharded_run(graph, params, rank, world, dev, args.backend, args.warmup, args.steps, torch, dist)
+    if rank == 0:
+        elapsed = res["elapsed"]
+        per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
+        failed = failed or not res["check"]["identical_to_single_engine"]
+        out.update({
+            "value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "strong",
+            "config": {"workload": f"{workload} (strong scaling: ONE {graph.n_vars}-variable instance "
+                                   f"partitioned over {args.gpus} GPUs; value = iterations/s of that instance)",
+                       "n_vars": graph.n_vars, "n_factors": graph.n_factors, "n_edges": graph.n_edges,
+                       "domain": int(graph.dom_size.max()),
+                       "edge_messages_per_s": args.steps / elapsed * 2 * graph.n_edges,
+                       "params": "damping 0.5/both, stability 0.1, start leafs",
+                       "parallelism": f"graph-partition x{args.gpus}, exchange: {res['collective']}",
+                       "one_gpu_iterations_per_s": res["one_gpu_iterations_per_s"],
+                       "shard_rank0": res["shard_rank0"], "check": res["check"]},
+            "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                         "kernel": {"p2p": "k_sweep_p2p (one fused launch, peer stores over xGMI) + k_p2p_publish",
+                                    "rccl": "k_sweep x2 + RCCL all-to-all issued by the engine (one sharded cycle)",
+                                    "torch": "k_sweep x2 + halo pack/unpack + torch all_to_all_single"
+                                    }.get(res["collective"], "one sharded cycle"),
+                         "algorithmic_bytes_per_launch": bytes_cycle // args.gpus,
+                         "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True},
+        })
+    if args.configs == "all" and args.workload is None:
+        # labelled extras: the metric's own 100k instance split N ways (strong), and ONE
+        # N x 100k-variable instance with 100k variables per GPU (weak)
+        extras = []
+        for label, scale in (("strong", 1), ("weak", args.gpus)):
+            g2, m2 = make_workload("coloring_100k", scale, args.vars_per_gpu)
+            steps2 = min(args.steps, 1000)
+            r2 = sharded_run(g2, Params(mode=m2, dtype=args.dtype), rank, world, dev, args.backend,
+                             min(args.warmup, 100), steps2, torch, dist)
+            if rank == 0:
+                failed = failed or not r2["check"]["identical_to_single_engine"]
+                its = steps2 / r2["elapsed"]
+                extras.append({"workload": "coloring_100k" + (f" x{args.gpus} (one {g2.n_vars}-variable instance, "
+                                                                f"{args.vars_per_gpu} variables per GPU)" if scale > 1 else ""),
+                               "scaling": label, "n_vars": g2.n_vars, "steps": steps2,
+                               "iterations_per_s_of_this_instance": its, "ms_per_step": 1e3 * r2["elapsed"] / steps2,
+                               "edge_messages_per_s": its * 2 * g2.n_edges,
+                               "one_gpu_iterations_per_s": r2["one_gpu_iterations_per_s"],
+                               "exchange": r2["collective"], "check": r2["check"]})
+            del g2
+        if rank == 0:
+            out["extras"] = extras
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    flag = torch.tensor([1 if failed else 0], device="cuda" if args.backend == "nccl" else "cpu")
+    dist.broadcast(flag, src=0)
+    dist.destroy_process_group()
+    if int(flag.item()):
+        raise SystemExit(3)  # the sharded result differs from the single engine: not a valid run
 
 
 if __name__ == "__main__":

@@ -134,7 +134,7 @@ def meeting_like(n_vars, n_factors=None, dom=24, arity=3, seed=0, penalty=100.0,
     tables = rng.integers(-10, 10, size=(n_factors, size)).astype(np.float64)
     grid = np.indices((dom,) * arity).reshape(arity, -1)
     same = (grid == grid[0]).all(axis=0)
-    tables[:, ~same] -= penalty
+    tables -= np.where(same, 0.0, penalty)[None, :]  # one broadcast pass (x - 0.0 == x exactly)
     factor_rowptr = np.arange(0, arity * n_factors + 1, arity, dtype=np.int32)
     table_off = np.arange(0, (n_factors + 1) * size, size, dtype=np.int64)
     return _finish(dom_size, var_cost, factor_rowptr, scope.reshape(-1).astype(np.int32),

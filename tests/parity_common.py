@@ -8,11 +8,11 @@ from pydcop_amd.graph import Params
 
 
 def compare_with_oracle(oracle_mod, graph, params: Params, T, lib_path=None, exact=True,
-                        steps=None):
+                        steps=None, threads=1):
     """Run engine and oracle side by side; compare messages, counters, selection,
     beliefs and solution cost after every chunk of `steps` cycles."""
     eng = MaxSumEngine(graph, params, lib_path=lib_path)
-    ora = oracle_mod.OracleMaxSum(graph, params)
+    ora = oracle_mod.OracleMaxSum(graph, params, threads=threads)
     done = 0
     for n in (steps or [T]):
         eng.run(n)

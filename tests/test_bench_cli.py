@@ -30,22 +30,67 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--backend", "gloo", "--vars-per-gpu", "1500"]
-    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=600)
+           "--backend", "gloo", "--vars-per-gpu", "300"]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout  # rank 0 only, one line
     out = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
-                "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+                "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "extras"):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
-    assert out["scaling"] == "weak" and out["unit"] == "iterations/s" and out["dtype"] == "f64"
-    assert out["config"]["n_vars"] == 3000 and f"exchange: {collective}" in out["config"]["parallelism"]
-    assert out["value"] > 0 and abs(out["value"] - 2 * 6 / (out["ms_per_step"] * 6e-3)) < 1e-6 * out["value"]
+    # N > 1 = STRONG scaling of BASELINE configs[3] (here scaled down 1 : 333): value is the
+    # iterations/s of that one instance, nothing multiplied in
+    assert out["scaling"] == "strong" and out["unit"] == "iterations/s" and out["dtype"] == "f64"
+    cfg = out["config"]
+    assert cfg["workload"].startswith("coloring_1m_deg6 (strong scaling")
+    assert cfg["n_vars"] == 3000 and cfg["n_factors"] == 9000
+    assert f"exchange: {collective}" in cfg["parallelism"]
+    assert out["value"] > 0 and abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
+    assert cfg["one_gpu_iterations_per_s"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
-    assert out["config"]["check"] == {"cycles": 8 if collective != "p2p" else out["config"]["check"]["cycles"],
-                                      "identical_to_single_engine": True, "differences": 0}
+    assert cfg["check"] == {"cycles": 8, "identical_to_single_engine": True, "differences": 0}
+    # labelled extras: the metric's 100k instance strong- and weak-scaled
+    strong, weak = out["extras"]
+    assert strong["scaling"] == "strong" and strong["n_vars"] == 300 and strong["workload"] == "coloring_100k"
+    assert weak["scaling"] == "weak" and weak["n_vars"] == 600 and weak["workload"].startswith("coloring_100k x2")
+    for e in (strong, weak):
+        assert e["check"]["identical_to_single_engine"] and e["iterations_per_s_of_this_instance"] > 0
+
+
+def test_bench_single_gpu_line_carries_every_config(tmp_path):
+    """N = 1 on the emulated engine, sizes scaled down by a patched workload table: the one JSON
+    line has the top-level metric, the cpu_baseline object and one record per extra configuration
+    with roofline + traffic source + the parity test id."""
+    from emu.build_emu import build
+    code = (
+        "import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400']\n"
+        "import pydcop_amd.generators as G\n"
+        "_ising, _meet, _col = G.ising_grid, G.meeting_like, G.random_coloring\n"
+        "G.ising_grid = lambda r, c, **k: _ising(12, 12, **k)\n"
+        "G.meeting_like = lambda n, **k: _meet(40, **{**k, 'dom': 6})\n"
+        "G.random_coloring = lambda n, **k: _col(min(n, 600), **k)\n"
+        f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
+    env = dict(os.environ, MAXSUM_HIP_LIB=build(), OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 1 and out["config"]["workload"] == "coloring_100k" and out["dtype"] == "f64"
+    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    assert out["roofline"]["traffic_source"] is None or "static" in out["roofline"]["traffic_source"]
+    got = {(c["workload"], c["dtype"]) for c in out["configs"]}
+    assert got == {("coloring_100k", "f32"), ("coloring_10k", "f64"), ("coloring_10k", "f32"),
+                   ("ising_1024", "f64"), ("ising_1024", "f32"), ("coloring_1m_deg6", "f64"),
+                   ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32")}
+    for c in out["configs"]:
+        assert c["parity_checked"] is True and c["parity_test"].startswith("tests/test_gpu_parity.py::")
+        rf = c["roofline"]
+        for key in ("achieved", "frac", "algorithmic_bytes_per_launch", "avg_launch_us", "traffic", "traffic_source"):
+            assert key in rf
+        assert c["ms_per_step"] > 0 and c["iterations_per_s"] > 0
 
 
 def test_bench_rejects_mismatched_world():

@@ -61,6 +61,37 @@ def test_ising_grid_256(oracle_built):
     compare_with_oracle(oracle_built, g, Params(), 0, steps=[20])
 
 
+# BASELINE.json configs[2..4] at their stated sizes, bit-exact against the oracle (OpenMP over
+# factors / variables; the order inside a message is the reference's either way): 32-bit
+# offsets, block_base[] class tables, multi-generation grids and the 24^3 launch grouping of
+# k_factor_nary only show at full size.
+_FULL = {
+    "ising_1024": (lambda: G.ising_grid(1024, 1024, seed=0, names=False), "min", [1, 5]),
+    "coloring_1m_deg6": (lambda: G.random_coloring(1_000_000, avg_degree=6, n_colors=3, seed=0, names=False),
+                         "min", [1, 5]),
+    "meeting_50k": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max", [1, 3]),
+}
+_full_cache = {}
+
+
+def _full_graph(name):
+    if name not in _full_cache:
+        _full_cache.clear()  # one full-size instance in memory at a time (meeting_50k: 5.5 GB of tables)
+        _full_cache[name] = _FULL[name][0]()
+    return _full_cache[name]
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+@pytest.mark.parametrize("name", list(_FULL))
+def test_full_size_bit_exact_vs_oracle(name, dtype, oracle_built):
+    _, mode, steps = _FULL[name]
+    threads = min(64, len(os.sched_getaffinity(0)))
+    compare_with_oracle(oracle_built, _full_graph(name), Params(mode=mode, dtype=dtype), 0,
+                        steps=steps, threads=threads)
+    if dtype == "f32":
+        _full_cache.clear()
+
+
 def test_graph_replay_equals_eager(oracle_built):
     """hipGraph replay of the cycle loop gives the same state as eager launches."""
     g = G.random_coloring(5000, seed=3, names=False)
