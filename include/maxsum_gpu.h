@@ -90,6 +90,14 @@ typedef struct mxs_graph {
                                       replicated on every shard that owns one
                                       of its variables but must be counted
                                       once).  NULL = all.                     */
+    const double  *eval_var_cost;  /* [sum dom_size] variable costs WITHOUT the
+                                      Max-Sum noise, what mxs_eval_cost sums:
+                                      the reference adds its noise inside the
+                                      computation only (VariableNoisyCostFunc,
+                                      maxsum.py:476-487) while DCOP.solution_cost
+                                      (dcop.py:308-367) reads the variables' own
+                                      cost functions.  NULL = var_cost (no noise
+                                      folded in).                              */
 } mxs_graph;
 
 typedef struct mxs_params {

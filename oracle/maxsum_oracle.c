@@ -317,7 +317,7 @@ mso_state *mso_create(const mxs_graph *g, const mxs_params *p) {
     for (int32_t e = 0; e < g->n_edges; ++e)
         s->msg_off[e + 1] = s->msg_off[e] + g->dom_size[g->edge_var[e]];
     const int64_t nc = s->cost_off[g->n_vars], nt = g->table_off[g->n_factors];
-    s->var_cost64 = (double *)dup_mem(g->var_cost, sizeof(double) * nc);
+    s->var_cost64 = (double *)dup_mem(g->eval_var_cost ? g->eval_var_cost : g->var_cost, sizeof(double) * nc);
     s->tables64 = (double *)dup_mem(g->tables, sizeof(double) * nt);
     s->var_cost = (real *)malloc(sizeof(real) * (nc ? nc : 1));
     s->tables = (real *)malloc(sizeof(real) * (nt ? nt : 1));

@@ -141,8 +141,10 @@ def compile_nodes(var_nodes: Iterable, factor_nodes: Iterable,
         if getattr(v, "initial_value", None) is not None:
             init_idx[i] = _domain_index(v, v.initial_value)
     var_cost = np.array(costs, dtype=np.float64)
+    clean_cost = None
     if noise:
         rng = rng or np.random.default_rng()
+        clean_cost = var_cost  # what DCOP.solution_cost sums (dcop.py:352-365): no noise
         var_cost = var_cost + rng.uniform(0.0, noise, size=var_cost.shape)
 
     factor_rowptr = [0]
@@ -181,6 +183,7 @@ def compile_nodes(var_nodes: Iterable, factor_nodes: Iterable,
         var_rowptr=np.array(var_rowptr, dtype=np.int32),
         var_edges=np.array(var_edges, dtype=np.int32),
         init_idx=init_idx if (init_idx >= 0).any() else None,
+        eval_var_cost=clean_cost,
         var_names=[n.name for n in var_nodes],
         factor_names=[n.name for n in factor_nodes],
         domains=[list(v.domain) for v in variables],

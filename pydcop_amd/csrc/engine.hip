@@ -1573,6 +1573,6 @@ int mxs_destroy(mxs_engine* e) {
 
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
-int32_t mxs_version(void) { return 101; }
+int32_t mxs_version(void) { return 200; }  // 2.0: mxs_graph gained eval_var_cost
 
 }  // extern "C"

@@ -286,7 +286,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             L.vcost_off[vi] = coff;
             for (int d = 0; d < g.dom_size[v]; ++d) {
                 L.var_cost[coff + d] = sign * g.var_cost[ext_cost_off[v] + d];
-                L.eval_var_cost[coff + d] = g.var_cost[ext_cost_off[v] + d];
+                L.eval_var_cost[coff + d] = (g.eval_var_cost ? g.eval_var_cost : g.var_cost)[ext_cost_off[v] + d];
             }
             coff += g.dom_size[v];
             if (g.init_idx) L.init_idx[vi] = g.init_idx[v];

@@ -25,6 +25,7 @@ class CGraph(C.Structure):
         ("table_off", C.c_void_p), ("tables", C.c_void_p),
         ("var_rowptr", C.c_void_p), ("var_edges", C.c_void_p),
         ("var_owned", C.c_void_p), ("factor_owned", C.c_void_p),
+        ("eval_var_cost", C.c_void_p),
     ]
 
 
@@ -83,6 +84,10 @@ class FlatGraph:
     init_idx: Optional[np.ndarray] = None   # int32 [n_vars] or None
     var_owned: Optional[np.ndarray] = None  # uint8 [n_vars] or None
     factor_owned: Optional[np.ndarray] = None  # uint8 [n_factors] or None
+    # float64 [sum dom_size] or None: the variables' own costs, WITHOUT the Max-Sum noise that
+    # compile_nodes folds into var_cost -- what the solution cost is evaluated on
+    # (DCOP.solution_cost, pydcop/dcop/dcop.py:308-367, never sees the noise)
+    eval_var_cost: Optional[np.ndarray] = None
     # host-only metadata (names / domain values), optional
     var_names: Optional[List[str]] = None
     factor_names: Optional[List[str]] = None
@@ -104,6 +109,8 @@ class FlatGraph:
             self.var_owned = _arr(self.var_owned, np.uint8)
         if self.factor_owned is not None:
             self.factor_owned = _arr(self.factor_owned, np.uint8)
+        if self.eval_var_cost is not None:
+            self.eval_var_cost = _arr(self.eval_var_cost, np.float64)
 
     # sizes ---------------------------------------------------------------
     @property
@@ -152,6 +159,8 @@ class FlatGraph:
             raise ValueError("every variable needs a non-empty domain")
         if self.var_cost.shape[0] != int(self.dom_size.sum()):
             raise ValueError("var_cost must hold sum(dom_size) entries")
+        if self.eval_var_cost is not None and self.eval_var_cost.shape != self.var_cost.shape:
+            raise ValueError("eval_var_cost must have the shape of var_cost")
         if self.factor_rowptr[0] != 0 or self.factor_rowptr[-1] != ne:
             raise ValueError("factor_rowptr does not span the edges")
         if (np.diff(self.factor_rowptr) < 1).any():
@@ -183,12 +192,12 @@ class FlatGraph:
                       p(self.dom_size), p(self.var_cost), p(self.init_idx),
                       p(self.factor_rowptr), p(self.edge_var), p(self.table_off),
                       p(self.tables), p(self.var_rowptr), p(self.var_edges),
-                      p(self.var_owned), p(self.factor_owned))
+                      p(self.var_owned), p(self.factor_owned), p(self.eval_var_cost))
 
     # compact binary instance format (.npz) beside YAML --------------------------
     _ARRAYS = ("dom_size", "var_cost", "factor_rowptr", "edge_var", "table_off", "tables",
                "var_rowptr", "var_edges")
-    _OPTIONAL = ("init_idx", "var_owned", "factor_owned")
+    _OPTIONAL = ("init_idx", "var_owned", "factor_owned", "eval_var_cost")
 
     def save(self, path: str, objective: str = "min", **meta):
         """Write the compiled instance as one compressed .npz: the flat arrays of the

@@ -201,6 +201,9 @@ def build_shard(g: FlatGraph, part: np.ndarray, rank: int, world: int) -> Shard:
     cidx = np.repeat(cost_off[:-1][local_vars] - np.concatenate([[0], np.cumsum(dom_size)[:-1]]),
                      dom_size) + np.arange(int(dom_size.sum()))
     var_cost = g.var_cost[cidx] if cidx.size else np.zeros(0)
+    eval_var_cost = None
+    if g.eval_var_cost is not None:
+        eval_var_cost = g.eval_var_cost[cidx] if cidx.size else np.zeros(0)
     deg_owned = np.diff(g.var_rowptr)[owned]
     k_src = np.repeat(g.var_rowptr[:-1][owned].astype(np.int64) - np.concatenate([[0], np.cumsum(deg_owned)[:-1]]),
                       deg_owned) + np.arange(int(deg_owned.sum()))
@@ -223,7 +226,7 @@ def build_shard(g: FlatGraph, part: np.ndarray, rank: int, world: int) -> Shard:
     lg = FlatGraph(dom_size=dom_size, var_cost=var_cost, factor_rowptr=factor_rowptr,
                    edge_var=edge_var, table_off=table_off, tables=tables,
                    var_rowptr=var_rowptr, var_edges=var_edges, init_idx=init_idx,
-                   var_owned=var_owned, factor_owned=factor_owned)
+                   var_owned=var_owned, factor_owned=factor_owned, eval_var_cost=eval_var_cost)
 
     # ---- halo lists -----------------------------------------------------------------
     # The V->F message of global edge e=(f, u) goes from owner(u) to every other

@@ -155,6 +155,31 @@ def test_yaml_export_to_instance_file(pydcop_ready, name, tmp_path, capsys):
     assert abs(a["cost"] - b["cost"]) < 1e-9
 
 
+@pytest.mark.parametrize("name", ["graph_coloring1.yaml", "secp_simple1.yaml"])
+def test_noise_never_reaches_the_reported_cost(pydcop_ready, name, tmp_path, capsys):
+    """The Max-Sum noise (maxsum.py:476-487) breaks ties inside the computations only: the
+    cost of an instance exported WITH noise (the default, 0.01) is DCOP.solution_cost of
+    the selected values (dcop.py:308-367), on the device as on the host, curve included."""
+    from emu.build_emu import build
+    from pydcop_amd import api
+    from pydcop_amd.graph import FlatGraph
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    out = str(tmp_path / "noisy.npz")
+    api.main(["--export", out, "-p", "noise:0.5", "-p", "seed:3", os.path.join(INST, name)])
+    capsys.readouterr()
+    g, header = FlatGraph.load(out)
+    assert g.eval_var_cost is not None and (g.var_cost != g.eval_var_cost).any()
+    res = api.solve_flat(g, header["objective"], 12, lib_path=build(), infinity=float("inf"), cost_every=4)
+    dcop = load_dcop_from_file([os.path.join(INST, name)])
+    violation, cost = dcop.solution_cost(res["assignment"], float("inf"))
+    assert res["violation"] == violation and abs(res["cost"] - cost) < 1e-9
+    assert abs(res["cost_curve"][-1][1] - cost) < 1e-9
+    # same through the YAML path
+    res2 = api.solve_yaml(os.path.join(INST, name), cycles=12, noise=0.5, seed=3, lib_path=build(),
+                          infinity=float("inf"), cost_every=4)
+    assert res2["assignment"] == res["assignment"] and abs(res2["cost_curve"][-1][1] - res2["cost"]) < 1e-9
+
+
 def test_plugin_uses_fast_graph_when_asked(pydcop_ready):
     from pydcop.algorithms import load_algorithm_module
     mod = load_algorithm_module("maxsum_gpu")
