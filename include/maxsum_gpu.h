@@ -306,6 +306,13 @@ const char *mxs_last_error(void);
 /* Library/ABI version (major*100+minor). */
 int32_t mxs_version(void);
 
+/* What this binary is: 1 = the product, compiled by hipcc for gfx950; 0 = the host
+ * emulation of the very same sources that the CPU tests build (tests/emu, g++ against a
+ * fake HIP runtime).  pydcop_amd/engine.py refuses a library of kind 0 unless a test has
+ * registered it from Python: the product has no CPU path, by environment variable or
+ * otherwise. */
+int32_t mxs_build_kind(void);
+
 #ifdef __cplusplus
 }
 #endif

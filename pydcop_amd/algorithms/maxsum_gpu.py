@@ -61,11 +61,6 @@ algo_params = [
     AlgoParameterDef("chunk", "int", None, 10),
 ]
 
-# Test hook ONLY: tests/test_plugin.py points this at the emulated-engine build to
-# check the plumbing in the GPU-less container.  None = the HIP library.
-_ENGINE_LIB_PATH: Optional[str] = None
-
-
 def computation_memory(computation: Union[FactorComputationNode, VariableComputationNode]) -> float:
     """Same footprint model as pydcop/algorithms/maxsum.py:127-171."""
     if isinstance(computation, FactorComputationNode):
@@ -100,10 +95,10 @@ class _Session:
         self.engine = None
         self.graph = None
         self.var_index: Dict[str, int] = {}
-        self.idx = None
-        self.belief = None
-        self.cycles = 0
-        self.generation = 0
+        # (idx, belief, cycles, generation) of the last fetch: replaced as ONE tuple, so a
+        # proxy on another agent thread never pairs a value with another generation's belief
+        self.snapshot = (None, None, 0, 0)
+        self.started = set()
         self.done = False
         self.stopped = False
         self.error: Optional[Exception] = None
@@ -135,15 +130,22 @@ class _Session:
         params = Params(mode=algo.mode, damping=float(p["damping"]),
                         damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
                         start_messages=p["start_messages"], dtype=p["precision"])
-        self.engine = MaxSumEngine(self.graph, params, lib_path=_ENGINE_LIB_PATH)
+        self.engine = MaxSumEngine(self.graph, params)
         self.stop_cycle = int(p["stop_cycle"])
         self.chunk = max(1, int(p["chunk"]))
         self._fetch()
 
+    @property
+    def cycles(self) -> int:
+        return self.snapshot[2]
+
+    @property
+    def generation(self) -> int:
+        return self.snapshot[3]
+
     def _fetch(self):
-        self.idx, self.belief = self.engine.assignment()
-        self.cycles = self.engine.cycle_count
-        self.generation += 1
+        idx, belief = self.engine.assignment()
+        self.snapshot = (idx, belief, self.engine.cycle_count, self.snapshot[3] + 1)
 
     def advance(self):
         """Called from any proxy's agent thread: make progress if nobody else is."""
@@ -189,11 +191,22 @@ class _Session:
             self.engine.update_factor_table(self.graph.factor_names.index(name), t)
 
     def value_of(self, name):
+        idx, belief, _, _ = self.snapshot
         i = self.var_index[name]
-        return self.graph.domains[i][int(self.idx[i])], float(self.belief[i])
+        return self.graph.domains[i][int(idx[i])], float(belief[i])
 
-    def stop(self):
+    def proxy_started(self, name):
         with self.lock:
+            self.started.add(name)
+
+    def proxy_stopped(self, name):
+        """One computation stopped (end of the run, but also a scenario event or an agent
+        removal in the middle of it): the others keep their engine.  It is closed when the
+        last started proxy has stopped."""
+        with self.lock:
+            self.started.discard(name)
+            if self.started:
+                return
             self.stopped = True
             if self.engine is not None:
                 self.engine.close()
@@ -238,6 +251,7 @@ class _ProxyMixin:
 
     def on_start(self):
         s = self._session
+        s.proxy_started(self.name)
         s.wait_open()            # first proxy started compiles + creates the engine
         self._report()
         if not self._reported_done:
@@ -255,6 +269,9 @@ class _ProxyMixin:
         s = self._session
         if s.generation != self._seen_generation:
             self._seen_generation = s.generation
+            # cycle statistics (`--collect_on cycle_change`, computations.py:915-928): one event
+            # per report, carrying the engine's cycle count (`chunk:1` gives one per cycle)
+            self.new_cycle()
             self._publish()
         if s.done and not self._reported_done:
             self._reported_done = True
@@ -268,7 +285,7 @@ class _ProxyMixin:
         pass
 
     def on_stop(self):
-        self._session.stop()
+        self._session.proxy_stopped(self.name)
 
 
 class MaxSumGpuFactorComputation(_ProxyMixin, DcopComputation):

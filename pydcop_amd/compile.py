@@ -16,6 +16,7 @@ from .graph import FlatGraph
 
 _TABLE_CACHE = {}       # (code of the cost function, domains in scope order) -> table
 _TABLE_CACHE_MAX = 4096
+_VERIFY_ALL_BELOW = 4096   # vectorised tables up to this size are checked entry by entry
 
 
 def _function_key(constraint, dims):
@@ -65,13 +66,26 @@ def _vectorised_table(constraint, dims, shape):
         out = np.broadcast_to(np.asarray(out, dtype=np.float64), shape).copy()
     except Exception:
         return None
-    # trust, but verify: corners + a few pseudo-random entries through the scalar path
+    # trust, but verify through the scalar path: EVERY entry of a small table; for a large one
+    # the corners, pseudo-random entries and every entry where numpy and Python arithmetic are
+    # known to part (non-finite results: Python raises ZeroDivisionError / OverflowError where
+    # numpy yields inf or nan; magnitudes beyond 2^53: int64 wraps where Python ints do not)
     names = [v.name for v in dims]
     size = int(np.prod(shape))
-    probe = {0, size - 1} | {(k * 2654435761) % size for k in range(1, 15)}
+    if size <= _VERIFY_ALL_BELOW:
+        probe = range(size)
+    else:
+        flat = out.reshape(-1)
+        suspect = np.flatnonzero(~np.isfinite(flat) | (np.abs(flat) >= 2.0 ** 53))
+        if suspect.shape[0] > 256:
+            return None
+        probe = {0, size - 1} | {(k * 2654435761) % size for k in range(1, 64)} | {int(i) for i in suspect}
     for lin in probe:
         idx = np.unravel_index(lin, shape)
-        want = constraint(**{n: dims[i].domain[int(j)] for i, (n, j) in enumerate(zip(names, idx))})
+        try:
+            want = constraint(**{n: dims[i].domain[int(j)] for i, (n, j) in enumerate(zip(names, idx))})
+        except ArithmeticError:
+            return None  # the scalar path raises here: let the caller's enumeration surface it
         got = out[idx]
         if not (got == want or (np.isnan(got) and want != want)):
             return None
@@ -94,8 +108,11 @@ def tensorise_constraint(constraint) -> np.ndarray:
     if isinstance(m, np.ndarray) and m.shape == shape:
         return np.ascontiguousarray(m, dtype=np.float64)
     key = _function_key(constraint, dims)
-    if key is not None and key in _TABLE_CACHE:
-        return _TABLE_CACHE[key]
+    try:
+        if key is not None and key in _TABLE_CACHE:
+            return _TABLE_CACHE[key]
+    except TypeError:  # an unhashable domain value inside the key: no caching for this one
+        key = None
     out = _vectorised_table(constraint, dims, shape)
     if out is None:
         names = [v.name for v in dims]

@@ -510,6 +510,11 @@ struct Engine : EngineBase {
 
     int reset() override {
         HIP_TRY(hipSetDevice(device));
+        // Nothing enqueued before the reset may still write after the memsets below: an unpack
+        // or a direct RCCL receive of the previous run (comm stream) would leave stale ghost
+        // V->F messages where cycle 0 expects zeros.  Callers need not sync first.
+        if (comm) HIP_TRY(hipStreamSynchronize(comm));
+        HIP_TRY(hipStreamSynchronize(stream));
         for (int b = 0; b < 2; ++b) {
             HIP_TRY(hipMemsetAsync(v2f[b].p, 0, std::max<size_t>(v2f[b].n, 1) * sizeof(T), stream));
             HIP_TRY(hipMemsetAsync(f2v[b].p, 0, std::max<size_t>(f2v[b].n, 1) * sizeof(T), stream));
@@ -519,7 +524,6 @@ struct Engine : EngineBase {
         HIP_TRY(hipMemsetAsync(sel.p, 0, std::max<size_t>(sel.n, 1) * sizeof(int32_t), stream));
         HIP_TRY(hipMemsetAsync(belief.p, 0, std::max<size_t>(belief.n, 1) * sizeof(T), stream));
         if (!p2p) HIP_TRY(hipMemsetAsync(halo_flags.p, 0, 64 * sizeof(uint32_t), stream));  // (peers write a p2p shard's)
-        if (comm) HIP_TRY(hipStreamSynchronize(comm));  // no unpack of the previous run is still writing
         unpacks = 0;
         cur = 0;
         cycles = 0;
@@ -1573,6 +1577,14 @@ int mxs_destroy(mxs_engine* e) {
 
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
-int32_t mxs_version(void) { return 200; }  // 2.0: mxs_graph gained eval_var_cost
+int32_t mxs_version(void) { return 200; }
+int32_t mxs_build_kind(void) {
+#if defined(__HIPCC__)
+    return 1;  // hipcc, gfx950
+#else
+    return 0;  // host emulation (tests/emu): test infrastructure only
+#endif
+}
+  // 2.0: mxs_graph gained eval_var_cost
 
 }  // extern "C"

@@ -640,13 +640,20 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
                 }
             }
         }
+        // The polling lane ends with an ACQUIRE at the scope of the writers (other GPUs: system)
+        // -- the documented pairing with the publisher's release; workgroup scope is not an
+        // acquire for data written by other CUs or devices.  The barrier below then orders every
+        // wave of the block behind it.
+        if (n_peers > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     }
     __syncthreads();
     if (n_peers > 0) {
-        // peer-store mode: the ghost records are read with system-scope loads (Msg::load_sys),
-        // which no cache of this GPU serves stale; only the order "flag, then records" matters.
-        // (An acquire fence here would invalidate the L2 once per cut block and wave -- measured:
-        // 37.5 instead of 2x us per launch with 535 cut blocks.)
+        // peer-store mode: the ghost records themselves are read with system-scope loads
+        // (Msg::load_sys), which no cache of this GPU serves stale.  (A per-WAVE agent-scope
+        // fence here, i.e. an L2 invalidation per wave of every cut block, measured 37.5
+        // instead of 28 us per launch with 535 cut blocks; the per-block system-scope acquire
+        // of the polling lane above is the price of correctness over xGMI and is paid only in
+        // this opt-in mode.)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     } else {
         // fused launch over RCCL: the unpack kernel wrote the ghost slots through another XCD's

@@ -16,8 +16,22 @@ import numpy as np
 from .graph import CGraph, CParams, FlatGraph, Params
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# $MAXSUM_HIP_LIB selects another build of the same library (kernel experiments)
+# $MAXSUM_HIP_LIB selects another HIP build of the same library (kernel A/B experiments:
+# `make -C pydcop_amd/csrc variant NAME=x` -> libmaxsum_hip_x.so).  It cannot select anything
+# that is not a hipcc build: load_library checks mxs_build_kind().
 DEFAULT_LIB = os.environ.get("MAXSUM_HIP_LIB") or os.path.join(_HERE, "csrc", "libmaxsum_hip.so")
+_TEST_ENGINES = set()
+
+
+def register_test_engine(path: str, make_default: bool = False):
+    """TESTS ONLY (tests/conftest.py, tests/emu/run_emulated.py): allow the host emulation of
+    the engine sources (tests/emu, mxs_build_kind() == 0) to be loaded in this process.  There
+    is deliberately no environment variable or parameter that does this: the product path
+    cannot be pointed at a CPU build from outside."""
+    global DEFAULT_LIB
+    _TEST_ENGINES.add(os.path.abspath(path))
+    if make_default:
+        DEFAULT_LIB = os.path.abspath(path)
 
 # every symbol include/maxsum_gpu.h declares
 ABI_SYMBOLS = (
@@ -28,6 +42,7 @@ ABI_SYMBOLS = (
     "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded", "mxs_shard_mode",
     "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
+    "mxs_build_kind",
 )
 
 
@@ -96,9 +111,18 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         raise MaxSumGpuError(
             f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). maxsum_gpu has no CPU fallback.")
-    if os.path.basename(path).startswith("libmaxsum_hip"):
-        _load_hip_runtime()  # the emulated test build carries its own fake runtime
+    registered_test = path in _TEST_ENGINES
+    if not registered_test:
+        if not os.path.basename(path).startswith("libmaxsum_hip"):
+            raise MaxSumGpuError(
+                f"{path} is not a build of libmaxsum_hip: maxsum_gpu has no CPU fallback and loads "
+                "only the gfx950 library (pydcop_amd/csrc/libmaxsum_hip*.so)")
+        _load_hip_runtime()  # (the emulated test build carries its own fake runtime)
     lib = C.CDLL(path)
+    lib.mxs_build_kind.restype = C.c_int32
+    if lib.mxs_build_kind() != 1 and not registered_test:
+        raise MaxSumGpuError(f"{path} is not a hipcc/gfx950 build (mxs_build_kind() == "
+                             f"{lib.mxs_build_kind()}): maxsum_gpu has no CPU fallback")
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     protos = {
         "mxs_device_count": ([C.POINTER(i32)], C.c_int),
@@ -132,6 +156,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_destroy": ([vp], C.c_int),
         "mxs_last_error": ([], C.c_char_p),
         "mxs_version": ([], i32),
+        "mxs_build_kind": ([], i32),
     }
     for name, (argtypes, restype) in protos.items():
         fn = getattr(lib, name)  # AttributeError if the library misses a symbol

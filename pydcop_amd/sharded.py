@@ -11,8 +11,11 @@ leave a GPU are those of cut factors' remote variables:
                comm stream      pack (after the variables of cycle t) -> all-to-all
                                 (RCCL over xGMI) -> unpack into the ghost slots
 
-Three exchanges, fastest first (`collective=`, default "auto" = the first that applies):
-"p2p" -- no collective at all: the ranks of one node map each other's ghost buffers through
+Three exchanges (`collective=`; default "auto" = "rccl" on GPUs -- the RCCL all-to-all that
+BASELINE.json's north_star names -- and "torch" for host-memory engines):
+"p2p" (OPT-IN: `collective="p2p"` or MAXSUM_COLLECTIVE=p2p; fastest in the one-GPU loopback
+measurements but never yet run between two physical GPUs, so not the default) -- no collective
+at all: the ranks of one node map each other's ghost buffers through
 hipIpc, the variable kernel stores cut-edge records straight into the peer's ghost region
 (xGMI peer stores), and a cycle is ONE launch whose cut factor blocks poll flag words the
 peers publish (mxs_peer_export / mxs_peer_connect; shards with binary cut factors only);
@@ -68,9 +71,10 @@ class ShardedMaxSum:
         self._on_gpu = backend == "nccl"
         collective = os.environ.get("MAXSUM_COLLECTIVE") or collective
         if collective == "auto":
-            # GPUs of one node: peer stores (no collective) when every shard qualifies, else the
-            # engine's own RCCL exchange; host-memory engines (tests): torch's all_to_all
-            collective = ("p2p" if 2 <= world <= 8 else "rccl") if self._on_gpu else "torch"
+            # GPUs: the engine's own RCCL all-to-all (north_star's exchange); host-memory engines
+            # (tests): torch's all_to_all.  Peer stores are opt-in until a run on two or more
+            # physical GPUs has shown bit-parity with the single engine (bench.py checks it).
+            collective = "rccl" if self._on_gpu else "torch"
         if collective not in ("p2p", "rccl", "torch"):
             raise ValueError("collective must be 'auto', 'p2p', 'rccl' or 'torch'")
         self._p2p = collective == "p2p" and self._init_p2p()

@@ -20,6 +20,11 @@ if ROOT not in sys.path:
 
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
+# The CPU tests load the host emulation of the engine sources (tests/emu) where the product
+# loads libmaxsum_hip.so; the product refuses such a library unless a test registers it.
+from pydcop_amd import engine as _engine  # noqa: E402
+_engine.register_test_engine(os.path.join(ROOT, "tests", "emu", "_build", "libmaxsum_emu.so"))
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")

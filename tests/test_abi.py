@@ -48,6 +48,31 @@ def test_no_cpu_fallback_without_gpu(hip_lib):
         MaxSumEngine(G.random_coloring(10, seed=0), Params())
 
 
+def test_product_cannot_be_pointed_at_the_emulated_engine(hip_lib):
+    """No CPU fallback by parameter or environment variable: outside the tests' own registration
+    (pydcop_amd.engine.register_test_engine, a Python call) the host emulation of the engine
+    sources is refused -- by name and by what the binary says it is (mxs_build_kind)."""
+    import shutil
+    import subprocess
+    import sys
+    import tempfile
+    from emu.build_emu import build
+    emu = build()
+    assert hip_lib.mxs_build_kind() == 1
+    with tempfile.TemporaryDirectory() as d:
+        disguised = os.path.join(d, "libmaxsum_hip_fast.so")  # an emulated build under a product name
+        shutil.copy(emu, disguised)
+        for env, arg in (({"MAXSUM_HIP_LIB": emu}, "None"), ({"MAXSUM_HIP_LIB": disguised}, "None"),
+                         ({}, repr(emu)), ({}, repr(disguised))):
+            code = ("import sys; sys.path.insert(0, %r)\n"
+                    "from pydcop_amd.engine import load_library, MaxSumGpuError\n"
+                    "try:\n    load_library(%s)\nexcept MaxSumGpuError as e:\n    print('REFUSED', e)\n"
+                    "else:\n    print('LOADED')\n" % (ROOT, arg))
+            r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env),
+                               capture_output=True, text=True, timeout=120)
+            assert "REFUSED" in r.stdout and "no CPU fallback" in r.stdout, (env, arg, r.stdout, r.stderr[-500:])
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "pydcop_amd")
     for dirpath, _, files in os.walk(pkg):

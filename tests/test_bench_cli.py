@@ -25,11 +25,12 @@ def _free_port():
 @pytest.mark.parametrize("collective", ["torch", "rccl"])
 def test_bench_two_ranks_gloo(collective, tmp_path):
     from emu.build_emu import build, build_fake_rccl
-    env = dict(os.environ, MAXSUM_HIP_LIB=build(), MAXSUM_COLLECTIVE=collective,
+    build()
+    env = dict(os.environ, MAXSUM_COLLECTIVE=collective,
                MAXSUM_RCCL_LIB=build_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path), OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+           os.path.join(ROOT, "tests", "emu", "run_emulated.py"), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
            "--backend", "gloo", "--vars-per-gpu", "300"]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
@@ -66,13 +67,14 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     from emu.build_emu import build
     code = (
         "import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400']\n"
+        f"from pydcop_amd import engine; engine.register_test_engine({build()!r}, make_default=True)\n"
         "import pydcop_amd.generators as G\n"
         "_ising, _meet, _col = G.ising_grid, G.meeting_like, G.random_coloring\n"
         "G.ising_grid = lambda r, c, **k: _ising(12, 12, **k)\n"
         "G.meeting_like = lambda n, **k: _meet(40, **{**k, 'dom': 6})\n"
         "G.random_coloring = lambda n, **k: _col(min(n, 600), **k)\n"
         f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
-    env = dict(os.environ, MAXSUM_HIP_LIB=build(), OMP_NUM_THREADS="1")
+    env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]

@@ -115,6 +115,37 @@ def test_vectorised_expression_and_cache_key(pydcop_ready):
     assert np.array_equal(t3, 10.0 * np.eye(6))
 
 
+def test_vectorised_tables_never_trusted_where_numpy_and_python_differ(pydcop_ready):
+    """int64 wrap-around and division by zero: numpy evaluates silently where Python gives the
+    exact integer / raises.  The vectorised table is verified against the scalar path (every
+    entry of a small table; every non-finite or > 2^53 entry of a large one)."""
+    from pydcop.dcop.objects import Domain, Variable
+    from pydcop.dcop.relations import constraint_from_str
+    from pydcop_amd import compile as comp
+    d = Domain("d", "", list(range(0, 12)))
+    x, y = Variable("x", d), Variable("y", d)
+    big = constraint_from_str("big", "x ** 30 + y", [x, y])        # 11 ** 30 wraps in int64
+    t = comp.tensorise_constraint(big)
+    posx = [v.name for v in big.dimensions].index("x")
+    idx = [3, 3]
+    idx[posx] = 11
+    assert t[tuple(idx)] == float(11 ** 30 + 3)
+    div = constraint_from_str("div", "x / y", [x, y])              # y = 0 is in the domain
+    with pytest.raises(ZeroDivisionError):
+        comp.tensorise_constraint(div)
+    # large table (> 4096 entries): the suspect entries are checked, not just 16 samples
+    d3 = Domain("d3", "", list(range(0, 20)))
+    a, b, c = Variable("a", d3), Variable("b", d3), Variable("c", d3)
+    div3 = constraint_from_str("div3", "a / (b - 7) + c", [a, b, c])
+    with pytest.raises(ZeroDivisionError):
+        comp.tensorise_constraint(div3)
+    # unhashable domain values: no cache key, still tensorised
+    dl = Domain("dl", "", [[0], [1]])
+    u = Variable("u", dl)
+    cu = constraint_from_str("cu", "len(u) + u[0]", [u])
+    assert np.array_equal(comp.tensorise_constraint(cu), np.array([1.0, 2.0]))
+
+
 @pytest.mark.parametrize("name,expected,cost", [
     ("graph_coloring1.yaml", {"v1": "R", "v2": "G", "v3": "R"}, -0.1),
     ("secp_simple1.yaml", {"l1": 0, "l2": 3, "l3": 4, "m1": 3}, None),

@@ -67,10 +67,10 @@ def test_solve_flat_and_cli_on_npz(emu_lib, tmp_path):
     assert res["assignment"] == {n: g.domains[i][int(idx[i])] for i, n in enumerate(g.var_names)}
     # the CLI, in a process that never imports pyDCOP
     code = ("import sys, runpy; sys.argv = ['api', '-c', '25', '-p', 'precision:f64', %r]; "
+            "from pydcop_amd import engine; engine.register_test_engine(%r, make_default=True); "
             "runpy.run_module('pydcop_amd.api', run_name='__main__'); "
-            "assert 'pydcop' not in sys.modules" % path)
-    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300,
-                       env=dict(os.environ, MAXSUM_HIP_LIB=emu_lib))
+            "assert 'pydcop' not in sys.modules" % (path, emu_lib))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     out = json.loads(r.stdout)
     assert out["status"] == "FINISHED" and out["cycle"] == 25 and out["violation"] == viol

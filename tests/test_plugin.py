@@ -38,7 +38,8 @@ def pydcop_ready(emu_lib):
     plugin.install()
     from pydcop.algorithms import load_algorithm_module
     mod = load_algorithm_module("maxsum_gpu")
-    mod._ENGINE_LIB_PATH = emu_lib  # test hook: emulated engine (no GPU in this container)
+    from pydcop_amd import engine
+    engine.register_test_engine(emu_lib, make_default=True)  # emulated engine (no GPU in this container)
     return mod
 
 
@@ -99,9 +100,8 @@ def test_cli_solve_json(emu_lib, tmp_path):
     unmodified orchestrator (docs/tutorials/analysing_results.rst:31-48)."""
     code = (
         "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
-        "from pydcop_amd import plugin; plugin.install()\n"
-        "from pydcop.algorithms import load_algorithm_module\n"
-        "load_algorithm_module('maxsum_gpu')._ENGINE_LIB_PATH = %r\n"
+        "from pydcop_amd import plugin, engine; plugin.install()\n"
+        "engine.register_test_engine(%r, make_default=True)\n"
         "sys.argv = ['pydcop', '-t', '20', 'solve', '--algo', 'maxsum_gpu', '-p', 'stop_cycle:20',\n"
         "            '-p', 'noise:0', '-d', 'adhoc', %r]\n"
         "from pydcop import dcop_cli; dcop_cli.main()\n"
