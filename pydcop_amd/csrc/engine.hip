@@ -189,6 +189,7 @@ struct Engine : EngineBase {
     DevBuf<int64_t> vcost_off, eval_tab_off, halo_send_off, halo_recv_off, timeline;
     bool timeline_on = false;
     DevBuf<FactorGen> fgen;
+    DevBuf<uint32_t> sched;     // block schedule of launch 0 (Layout::sched), may be empty
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
     DevBuf<ClassInfo> classes_f; // both lists as ONE grid (fused sharded launch), cut classes last
@@ -304,6 +305,7 @@ struct Engine : EngineBase {
         for (int i = 0; i < MAX_CLASSES; ++i)
             a.block_base[i] = i < a.n_classes ? L.classes[order[i]].block_base : INT32_MAX;
         a.classes = phase == 1 ? classes.p : classes2.p;
+        a.sched = (phase == 1 && !L.sched.empty()) ? sched.p : nullptr;
         return a;
     }
 
@@ -492,6 +494,7 @@ struct Engine : EngineBase {
             }
             HIP_TRY(classes_f.upload(order, stream));
         }
+        HIP_TRY(sched.upload(L.sched, stream));
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         // solution_cost data

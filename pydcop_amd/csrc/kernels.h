@@ -133,6 +133,10 @@ struct SweepArgs {
     // before the block can start.
     int32_t block_base[MAX_CLASSES];
     const ClassInfo* classes;  // [n_classes] in launch order
+    // Block schedule (layout.h, Layout::sched): workgroup b works on block (sched[b] & 0xffffff)
+    // of class (sched[b] >> 24) -- one scalar load that depends on nothing but blockIdx, in place
+    // of the compares on block_base[].  NULL: blocks in class order.
+    const uint32_t* sched;
 };
 
 template <typename T>
@@ -664,11 +668,17 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
 
 template <typename T, int DSEL, bool P2P = false>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
-    int c = 0;
+    int c = 0, blk = -1;
+    if (a.sched != nullptr) {
+        const uint32_t s = a.sched[blockIdx.x];
+        c = (int)(s >> 24);
+        blk = (int)(s & 0xffffffu);
+    } else {
 #pragma unroll
-    for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
+        for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
+    }
     const ClassInfo ci = a.classes[c];
-    const int item = ((int)blockIdx.x - ci.block_base) * ci.per_block;
+    const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
     if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;

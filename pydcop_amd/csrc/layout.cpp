@@ -24,6 +24,9 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.factors_second = MXS_FACTORS_SECOND_DEFAULT != 0;
     if (f & 512) o.factors_second = true;    // bit9: shard: every factor class in the second launch
     if (f & 1024) o.factors_second = false;  // bit10: shard: only the cut factor classes
+    o.schedule = MXS_SCHEDULE_DEFAULT != 0;
+    if (f & 4096) o.schedule = true;   // bit12: co-scheduled, XCD-contiguous block order
+    if (f & 2048) o.schedule = false;  // bit11: blocks in class order
     return o;
 }
 
@@ -536,6 +539,60 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         }
         for (int c : L.sweep_order)
             if (!L.classes[c].start_only) L.sweep_regular = true;
+        // ---- block schedule of launch 0 (see Layout::sched) ------------------------------
+        if (L.opt.schedule && L.n_blocks_sweep >= 2 && !(p.layout_flags & (32 | 64))) {
+            struct Blk { double key; int prio; uint32_t code; };
+            std::vector<Blk> blks;
+            blks.reserve(L.n_blocks_sweep);
+            auto first_var_of_factor = [&](int fi) { return (double)L.edge_var_int[L.frowptr[fi]]; };
+            for (size_t slot = 0; slot < L.sweep_order.size(); ++slot) {
+                const ClassInfo& ci = L.classes[L.sweep_order[slot]];
+                const int nbc = (ci.count + ci.per_block - 1) / ci.per_block;
+                if (nbc >= (1 << 24)) { blks.clear(); break; }
+                for (int j = 0; j < nbc; ++j) {
+                    const int64_t i0 = (int64_t)j * ci.per_block;
+                    const int64_t i1 = std::min<int64_t>(ci.count, i0 + ci.per_block) - 1;
+                    double k0 = 0, k1 = 0;
+                    int prio = 1;
+                    switch (ci.kind) {
+                        case K_V_PACK: {  // lanes -> the wave's first variable
+                            const WaveMeta& w0 = L.vwave[(ci.ell_base + i0) >> 6];
+                            const WaveMeta& w1 = L.vwave[(ci.ell_base + i1) >> 6];
+                            k0 = w0.first_var;
+                            k1 = w1.first_var + (int)(((uint32_t)w1.deg_nv >> 8) & 255u) - 1;
+                            prio = 0;
+                            break;
+                        }
+                        case K_V_GEN:
+                            k0 = (double)(ci.first + i0);
+                            k1 = (double)(ci.first + i1);
+                            prio = 0;
+                            break;
+                        case K_F_UNARY:
+                        case K_F_BIN:
+                            k0 = first_var_of_factor((int)(ci.first + i0));
+                            k1 = first_var_of_factor((int)(ci.first + i1));
+                            break;
+                        default:  // K_F_GEN: thread per edge
+                            k0 = (double)L.edge_var_int[L.fgen[L.edge_gen_factor[ci.edge_base + i0]].edge_base];
+                            k1 = (double)L.edge_var_int[L.fgen[L.edge_gen_factor[ci.edge_base + i1]].edge_base];
+                            break;
+                    }
+                    blks.push_back(Blk{0.5 * (k0 + k1), prio, (uint32_t)(slot << 24) | (uint32_t)j});
+                }
+            }
+            if ((int)blks.size() == L.n_blocks_sweep) {
+                std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) {
+                    return a.key != b.key ? a.key < b.key : a.prio < b.prio;
+                });
+                // XCD x runs the workgroups b = x, x + 8, x + 16, ...: hand it the x-th
+                // contiguous piece of the order
+                L.sched.assign(L.n_blocks_sweep, 0);
+                int64_t m = 0;
+                for (int x = 0; x < NUM_XCD; ++x)
+                    for (int64_t b = x; b < L.n_blocks_sweep; b += NUM_XCD) L.sched[b] = blks[m++].code;
+            }
+        }
         // one compile-time D for every register / wave class -> leaner kernel
         int dsel = -1;
         std::vector<int32_t> both = L.sweep_order;

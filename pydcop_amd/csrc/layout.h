@@ -67,6 +67,10 @@ constexpr int BLOCK = MXS_BLOCK;
 #ifndef MXS_SORT_FACTORS_DEFAULT
 #define MXS_SORT_FACTORS_DEFAULT 1  // layout_flags bit7 forces it on, bit8 off
 #endif
+#ifndef MXS_SCHEDULE_DEFAULT
+#define MXS_SCHEDULE_DEFAULT 1  // layout_flags bit11 (2048) forces the block schedule off, bit12 (4096) on
+#endif
+constexpr int NUM_XCD = 8;  // MI355X: workgroup b of a grid runs on XCD b % 8 (observed; used for speed only)
 constexpr int MAX_REG_D = 4;
 constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
@@ -139,6 +143,7 @@ struct LayoutOptions {
     bool nary = true;            // use the workgroup-per-factor kernel (K_F_NARY)
     bool sort_factors = false;   // inside a class, factors follow their first variable's order
     bool factors_second = false; // shard: all register factor classes go to the second launch
+    bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
 };
 
 struct Layout {
@@ -165,6 +170,17 @@ struct Layout {
     int32_t n_blocks_fused = 0;        // 0: no fused launch possible (too many classes)
     int32_t n_blocks_sweep2 = 0;
     int32_t n_blocks_sweep = 0;        // grid size of launch 0
+    // Block schedule of launch 0 (empty: block b works on the class whose block range holds b).
+    // sched[b] = (position of the class in sweep_order) << 24 | block of that class.  The blocks
+    // are ordered by where their work sits along the internal VARIABLE order -- a variable
+    // block, then the factor blocks whose first scope variables it holds (sort_factors) -- and
+    // every XCD gets one contiguous eighth of that order (workgroup b runs on XCD b % 8): the
+    // variable side and the factor side of an edge then read the edge's two records through
+    // the SAME 4-MB L2 at about the same time, and the second read of a record -- as the
+    // other side's "own previous message" -- is an L2 hit instead of a second trip to the
+    // Infinity Cache / HBM.  Placement is a speed matter only: any bijection gives the same
+    // result.
+    std::vector<uint32_t> sched;
     bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)
     std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)
     std::vector<NaryLaunch> nary_launches;

@@ -105,6 +105,9 @@ class LocalShards:
 def rank_main(argv):
     world, rank, port = int(argv[0]), int(argv[1]), int(argv[2])
     lib = None if argv[3] == "-" else argv[3]
+    if lib:  # the emulated engine of the CPU tests
+        from pydcop_amd import engine
+        engine.register_test_engine(lib)
     out, case = argv[4], argv[5]
     steps = [int(x) for x in argv[6:]]
     import torch
