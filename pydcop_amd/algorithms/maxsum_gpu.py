@@ -24,6 +24,10 @@ Extra parameters
   seed        seed of the noise draw (the reference's noise is unseeded,
               pydcop/dcop/objects.py:566-567)
   chunk       cycles per device run between two reports when stop_cycle == 0
+  devices     number of GPUs of this node to partition the factor graph over (default 1):
+              k > 1 runs `pydcop_amd.sharded.LocalShardedMaxSum` -- one engine per GPU,
+              boundary V->F messages exchanged once per cycle by the engines' own RCCL
+              all-to-all -- and gives the same result as one GPU
 
 Only thread mode with all computations in one process can be served (the whole
 graph must be visible to one engine); anything else raises ComputationException.
@@ -59,6 +63,7 @@ algo_params = [
     AlgoParameterDef("precision", "str", ["f64", "f32"], "f64"),
     AlgoParameterDef("seed", "int", None, 0),
     AlgoParameterDef("chunk", "int", None, 10),
+    AlgoParameterDef("devices", "int", None, 1),
 ]
 
 def computation_memory(computation: Union[FactorComputationNode, VariableComputationNode]) -> float:
@@ -130,7 +135,16 @@ class _Session:
         params = Params(mode=algo.mode, damping=float(p["damping"]),
                         damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
                         start_messages=p["start_messages"], dtype=p["precision"])
-        self.engine = MaxSumEngine(self.graph, params)
+        n_dev = int(p.get("devices", 1) or 1)
+        if n_dev > 1:
+            from pydcop_amd.engine import device_count
+            from pydcop_amd.sharded import LocalShardedMaxSum
+            if device_count() < n_dev:
+                raise ComputationException(
+                    f"maxsum_gpu: devices:{n_dev} asked, {device_count()} GPU(s) visible")
+            self.engine = LocalShardedMaxSum(self.graph, params, list(range(n_dev)))
+        else:
+            self.engine = MaxSumEngine(self.graph, params)
         self.stop_cycle = int(p["stop_cycle"])
         self.chunk = max(1, int(p["chunk"]))
         self._fetch()

@@ -16,6 +16,16 @@ from .compile import assignment_to_values, compile_nodes
 from .graph import FlatGraph, Params
 
 
+def _engine_for(graph: FlatGraph, params: Params, device: int, devices: int, lib_path):
+    """One engine on `device`, or -- devices > 1 -- the graph partitioned over GPUs 0..devices-1
+    of this node (pydcop_amd.sharded.LocalShardedMaxSum: same surface, same result)."""
+    from .engine import MaxSumEngine
+    if devices and int(devices) > 1:
+        from .sharded import LocalShardedMaxSum
+        return LocalShardedMaxSum(graph, params, list(range(int(devices))), lib_path=lib_path)
+    return MaxSumEngine(graph, params, device=device, lib_path=lib_path)
+
+
 def compile_dcop(dcop, noise: float = 0.0, seed: int = 0) -> FlatGraph:
     """DCOP -> FlatGraph in the node / links order the reference's factor graph has
     (pydcop/computations_graph/factor_graph.py:245-296), built in O(E)."""
@@ -31,7 +41,7 @@ def compile_dcop(dcop, noise: float = 0.0, seed: int = 0) -> FlatGraph:
 def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: str = "both",
                stability: float = 0.1, noise: float = 0.01, start_messages: str = "leafs",
                precision: str = "f64", seed: int = 0, infinity: float = 10000, device: int = 0,
-               cost_every: int = 0, lib_path: Optional[str] = None) -> Dict:
+               cost_every: int = 0, lib_path: Optional[str] = None, devices: int = 1) -> Dict:
     """Synchronous Max-Sum for exactly `cycles` cycles; parameters and defaults are those
     of `pydcop.algorithms.maxsum` (maxsum.py:212-220), `infinity` that of
     `pydcop.infrastructure.run.solve` (run.py:49).
@@ -46,7 +56,7 @@ def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: s
     params = Params(mode=dcop.objective, damping=damping, damping_nodes=damping_nodes,
                     stability=stability, start_messages=start_messages, dtype=precision)
     curve: List[Tuple[int, float, int]] = []
-    with MaxSumEngine(graph, params, device=device, lib_path=lib_path) as eng:
+    with _engine_for(graph, params, device, devices, lib_path) as eng:
         done = 0
         while done < cycles:
             n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
@@ -65,7 +75,7 @@ def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: s
 def solve_flat(graph: FlatGraph, objective: str = "min", cycles: int = 30, *, damping: float = 0.5,
                damping_nodes: str = "both", stability: float = 0.1, start_messages: str = "leafs",
                precision: str = "f64", infinity: float = 10000, device: int = 0, cost_every: int = 0,
-               lib_path: Optional[str] = None) -> Dict:
+               lib_path: Optional[str] = None, devices: int = 1) -> Dict:
     """`solve_dcop` for an already compiled instance (`FlatGraph`, e.g. loaded from the
     .npz instance format): no pyDCOP import at all.  Cost and violations come from the
     device (`mxs_eval_cost` = DCOP.solution_cost, pydcop/dcop/dcop.py:308-367); noise, if
@@ -74,7 +84,7 @@ def solve_flat(graph: FlatGraph, objective: str = "min", cycles: int = 30, *, da
     params = Params(mode=objective, damping=damping, damping_nodes=damping_nodes,
                     stability=stability, start_messages=start_messages, dtype=precision)
     curve: List[Tuple[int, float, int]] = []
-    with MaxSumEngine(graph, params, device=device, lib_path=lib_path) as eng:
+    with _engine_for(graph, params, device, devices, lib_path) as eng:
         done = 0
         while done < cycles:
             n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
@@ -124,7 +134,7 @@ def main(argv=None):
                     help="compile the YAML DCOP (noise folded in) and write it as an instance file")
     args = ap.parse_args(argv)
     kinds = {"damping": float, "stability": float, "noise": float, "seed": int,
-             "damping_nodes": str, "start_messages": str, "precision": str}
+             "damping_nodes": str, "start_messages": str, "precision": str, "devices": int}
     kw = {}
     for item in args.algo_params:
         name, _, value = item.partition(":")

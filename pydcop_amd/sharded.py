@@ -281,3 +281,137 @@ class ShardedMaxSum:
 
     def close(self):
         self.engine.close()
+
+
+class LocalShardedMaxSum:
+    """The sharded path driven from ONE process: k shards on k GPUs, one thread per GPU.
+
+    This is what the plugin's `devices` parameter and `api.solve_*(devices=k)` use -- pyDCOP's
+    thread mode hosts every computation in one process, so the ranks of
+    the exchange are threads of that process, each stepping its own engine through the
+    library's cycle loop (`mxs_run_sharded`) over the engine-owned RCCL communicator
+    (`mxs_comm_init`; one communicator rank per device, created concurrently from the k threads
+    as RCCL requires).  ctypes releases the GIL inside every C-ABI call, so the k ranks really
+    run side by side.  Same surface as `MaxSumEngine`; same arithmetic as one engine sweeping
+    the whole graph (a shard inherits the global orders, `partition.build_shard`)."""
+
+    def __init__(self, graph: FlatGraph, params: Optional[Params], devices, part: Optional[np.ndarray] = None,
+                 lib_path: Optional[str] = None, rccl: Optional[str] = None):
+        self.graph = graph
+        self.params = params or Params()
+        self.devices = [int(d) for d in devices]
+        k = self.world = len(self.devices)
+        if k < 1:
+            raise ValueError("at least one device")
+        if len(set(self.devices)) != k:
+            raise ValueError("devices must be distinct (RCCL refuses two ranks on one GPU)")
+        self.part = partition_variables(graph, k) if part is None else np.asarray(part, dtype=np.int32)
+        self.shards = [build_shard(graph, self.part, r, k) for r in range(k)]
+        self.engines = [None] * k
+        self.collective = "rccl" if k > 1 else "none"
+        uid = comm_unique_id(lib_path, rccl) if k > 1 else None
+
+        def boot(r):
+            s = self.shards[r]
+            e = MaxSumEngine(s.graph, self.params, device=self.devices[r], lib_path=lib_path)
+            self.engines[r] = e
+            if k > 1:
+                e.halo_setup(s.send_edges, s.recv_edges)
+                e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=rccl)
+                e.comm_exchange()  # the start messages of cycle 0
+                e.step_unpack()
+            e.sync()
+        try:
+            self._each(boot)
+        except Exception:
+            self.close()
+            raise
+
+    def _each(self, fn):
+        """fn(rank) on one thread per rank; the first exception is re-raised here."""
+        if self.world == 1:
+            return [fn(0)]
+        import threading
+        out, errors = [None] * self.world, []
+
+        def work(r):
+            try:
+                out[r] = fn(r)
+            except Exception as e:  # surfaced in the calling thread
+                errors.append((r, e))
+        threads = [threading.Thread(target=work, args=(r,), name=f"maxsum-gpu-rank{r}") for r in range(self.world)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        if errors:
+            r, e = errors[0]
+            raise MaxSumGpuError(f"rank {r} (device {self.devices[r]}): {e}") from e
+        return out
+
+    def run(self, n_cycles: int):
+        n = int(n_cycles)
+
+        def go(r):
+            e = self.engines[r]
+            if self.world > 1:
+                e.run_sharded(n)
+                e.sync()
+            else:
+                e.run(n)
+        self._each(go)
+
+    def sync(self):
+        self._each(lambda r: self.engines[r].sync())
+
+    def reset(self):
+        def go(r):
+            e = self.engines[r]
+            e.reset()
+            if self.world > 1:
+                e.comm_exchange()
+                e.step_unpack()
+            e.sync()
+        self._each(go)
+
+    @property
+    def cycle_count(self) -> int:
+        return self.engines[0].cycle_count
+
+    def assignment(self) -> Tuple[np.ndarray, np.ndarray]:
+        idx = np.empty(self.graph.n_vars, dtype=np.int32)
+        belief = np.empty(self.graph.n_vars, dtype=np.float64)
+        for s, e in zip(self.shards, self.engines):
+            i, b = e.assignment()
+            idx[s.local_vars[:s.n_owned]] = i[:s.n_owned]
+            belief[s.local_vars[:s.n_owned]] = b[:s.n_owned]
+        return idx, belief
+
+    def eval_cost(self, idx=None, infinity: float = float("inf")) -> Tuple[float, int]:
+        if idx is None:
+            idx = self.assignment()[0]
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        parts = [e.eval_cost(idx[s.local_vars], infinity) for s, e in zip(self.shards, self.engines)]
+        return float(sum(p[0] for p in parts)), int(sum(p[1] for p in parts))
+
+    def update_factor_table(self, factor: int, table):
+        """`MaxSumEngine.update_factor_table` on every shard that holds a replica of the factor."""
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        for s, e in zip(self.shards, self.engines):
+            pos = np.searchsorted(s.local_factors, factor)
+            if pos < s.local_factors.shape[0] and s.local_factors[pos] == factor:
+                e.update_factor_table(int(pos), t)
+        lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
+        self.graph.tables[lo:hi] = t
+
+    def close(self):
+        for e in self.engines:
+            if e is not None:
+                e.close()
+        self.engines = [None] * self.world
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -50,7 +50,11 @@ struct hipDeviceProp_t {
 
 inline const char* hipGetErrorString(hipError_t) { return "emulated HIP error"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) {  // $EMU_HIP_DEVICES pretend-GPUs (tests of the multi-device path)
+    const char* e = std::getenv("EMU_HIP_DEVICES");
+    *n = e ? std::atoi(e) : 1;
+    return hipSuccess;
+}
 inline hipError_t hipSetDevice(int) { return hipSuccess; }
 inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     std::strcpy(p->gcnArchName, "gfx950:emulated-on-host");

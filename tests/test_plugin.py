@@ -95,6 +95,26 @@ def test_api_solve(pydcop_ready, instance, expected):
     assert assignment == expected
 
 
+@pytest.mark.parametrize("instance,expected", [
+    ("graph_coloring1.yaml", {"v1": "R", "v2": "G", "v3": "R"}),
+    ("secp_simple1.yaml", {"l1": 0, "l2": 3, "l3": 4, "m1": 3}),
+])
+def test_api_solve_on_two_devices(pydcop_ready, instance, expected, tmp_path, monkeypatch):
+    """`-p devices:2`: the plugin partitions the compiled graph over two (emulated) GPUs --
+    LocalShardedMaxSum, the engines' own exchange over the fake RCCL -- same answers."""
+    from emu.build_emu import build_fake_rccl
+    from pydcop.algorithms import AlgorithmDef
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop.infrastructure.run import solve
+    monkeypatch.setenv("EMU_HIP_DEVICES", "2")
+    monkeypatch.setenv("MAXSUM_RCCL_LIB", build_fake_rccl())
+    monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    dcop = load_dcop_from_file([os.path.join(INST, instance)])
+    algo = AlgorithmDef.build_with_default_param(
+        "maxsum_gpu", {"stop_cycle": 20, "noise": 0, "devices": 2}, mode=dcop.objective)
+    assert solve(dcop, algo, "adhoc", timeout=20) == expected
+
+
 def test_cli_solve_json(emu_lib, tmp_path):
     """`pydcop solve --algo maxsum_gpu` through the launcher, result JSON of the
     unmodified orchestrator (docs/tutorials/analysing_results.rst:31-48)."""

@@ -479,3 +479,40 @@ def test_nccl_world1_code_path(collective, tmp_path):
     one.run(25)
     np.testing.assert_array_equal(z["idx_25"], one.assignment()[0])
     np.testing.assert_array_equal(z["bel_25"], one.assignment()[1])
+
+
+@pytest.mark.parametrize("case,k", [("coloring", 2), ("ising", 3), ("mixed_max", 2), ("coloring_2k", 4)])
+def test_local_sharded_one_process_equals_single_engine(case, k, emu_lib, fake_rccl, tmp_path, monkeypatch):
+    """pydcop_amd.sharded.LocalShardedMaxSum (what the plugin's `devices` parameter runs): k
+    shards on k (emulated) devices driven by k threads of ONE process through the library's own
+    cycle loop and exchange -- bit-identical to one engine, through reset and a table update."""
+    from pydcop_amd.sharded import LocalShardedMaxSum
+    monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    monkeypatch.setenv("EMU_HIP_DEVICES", str(k))
+    g, kw = make_case(case)
+    p = Params(**kw)
+    one = MaxSumEngine(g, p, lib_path=emu_lib)
+    with LocalShardedMaxSum(g, p, list(range(k)), lib_path=emu_lib, rccl=fake_rccl) as many:
+        assert many.collective == "rccl" and many.world == k
+        done = 0
+        for n in (0, 1, 2, 6):
+            one.run(n), many.run(n)
+            done += n
+            assert many.cycle_count == one.cycle_count == done
+            np.testing.assert_array_equal(many.assignment()[0], one.assignment()[0])
+            np.testing.assert_array_equal(many.assignment()[1], one.assignment()[1])
+            a, b = many.eval_cost(), one.eval_cost()
+            assert a[1] == b[1] and abs(a[0] - b[0]) <= 1e-9 * max(1.0, abs(b[0]))
+        # change_factor_function on a replicated factor, then carry on
+        f = int(np.flatnonzero(np.diff(g.factor_rowptr) == 2)[0])
+        t = np.arange(int(g.table_off[f + 1] - g.table_off[f]), dtype=np.float64)[::-1].copy()
+        one.update_factor_table(f, t), many.update_factor_table(f, t)
+        one.run(3), many.run(3)
+        np.testing.assert_array_equal(many.assignment()[0], one.assignment()[0])
+        np.testing.assert_array_equal(many.assignment()[1], one.assignment()[1])
+        one.reset(), many.reset()
+        one.run(4), many.run(4)
+        np.testing.assert_array_equal(many.assignment()[1], one.assignment()[1])
+    with pytest.raises(ValueError):
+        LocalShardedMaxSum(g, p, [0, 0], lib_path=emu_lib, rccl=fake_rccl)
+    one.close()
