@@ -164,6 +164,17 @@ int mxs_get_assignment(mxs_engine *e, int32_t *idx, double *belief);
 int mxs_get_messages(mxs_engine *e, double *v2f, double *f2v,
                      uint8_t *count_v2f, uint8_t *count_f2v);
 
+/* The inverse of mxs_get_messages + mxs_get_assignment: put the engine into the state
+ * described by the caller's arrays (same layouts), as if `cycles` cycles had produced it.
+ * Checkpoint / resume of a run, and the way a run survives a change of the graph itself
+ * (maxsum_dynamic.py:234-271, DynamicFactorComputation.change_factor_function with a new
+ * scope; :352-405 REMOVE / ADD on the variable side): the host builds the new flat graph, a
+ * new engine, and carries the messages of the surviving edges over (pydcop_amd/dynamic.py).
+ * NULL = leave that part as it is.  Not available on a shard with an exchange set up. */
+int mxs_set_state(mxs_engine *e, const double *v2f, const double *f2v,
+                  const uint8_t *count_v2f, const uint8_t *count_f2v,
+                  const int32_t *idx, const double *belief, int64_t cycles);
+
 /* DCOP.solution_cost (pydcop/dcop/dcop.py:308-367): sum of factor costs and
  * variable costs of an assignment; a term exactly equal to `infinity` counts
  * as one violation instead.  idx == NULL evaluates the current selection. */
@@ -180,6 +191,20 @@ int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
  * carry on from where they are: change_factor_function of
  * pydcop/algorithms/maxsum_dynamic.py:80-104 without rebuilding the graph. */
 int mxs_update_factor_table(mxs_engine *e, int32_t factor, const double *table, int64_t n_entries);
+
+/* Factors whose relation also depends on external (read-only) variables
+ * (maxsum_dynamic.py:113-186 FactorWithReadOnlyVariableComputation, :188-232 and :273-288
+ * DynamicFactorComputation): the engine keeps the whole relation -- `parent`, row-major over
+ * `n_dims` dimensions of sizes `dims`, `is_external[i]` = 1 for a read-only dimension; the other
+ * dimensions, in order, are the factor's scope -- on the device, and
+ * mxs_slice_factor(external_idx: one value index per external dimension, in order) makes the
+ * factor's active table the slice at those values (relation.slice, relations.py:760-810) with
+ * one small kernel: no table crosses PCIe when a sensor value changes.  Like
+ * mxs_update_factor_table the messages carry on (the reference swaps `self._factor` and goes
+ * on, maxsum_dynamic.py:100-104). */
+int mxs_set_parent_table(mxs_engine *e, int32_t factor, const double *parent, int32_t n_dims,
+                         const int32_t *dims, const uint8_t *is_external);
+int mxs_slice_factor(mxs_engine *e, int32_t factor, const int32_t *external_idx);
 
 /* Profiling only: run ONE more cycle in which every block of the sweep launch
  * records {start, end} (wall_clock64 ticks, 100 MHz) and its class kind;

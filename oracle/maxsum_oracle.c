@@ -361,6 +361,24 @@ void mso_get_messages(const mso_state *s, double *v2f, double *f2v, uint8_t *cv,
     if (cf) memcpy(cf, s->cnt_f[s->cur], s->n_edges);
 }
 
+/* The inverse of mso_get_messages / mso_get_assignment (mxs_set_state on the device):
+ * checkpoint / resume, and carrying a run over to a changed graph. */
+void mso_set_state(mso_state *s, const double *v2f, const double *f2v, const uint8_t *cv,
+                   const uint8_t *cf, const int32_t *idx, const double *belief, int64_t cycles) {
+    const int64_t nm = s->msg_off[s->n_edges];
+    for (int64_t i = 0; i < nm; ++i) {
+        if (v2f) s->v2f[s->cur][i] = (real)v2f[i];
+        if (f2v) s->f2v[s->cur][i] = (real)f2v[i];
+    }
+    if (cv) memcpy(s->cnt_v[s->cur], cv, s->n_edges);
+    if (cf) memcpy(s->cnt_f[s->cur], cf, s->n_edges);
+    for (int32_t v = 0; v < s->n_vars; ++v) {
+        if (idx) s->sel[v] = idx[v];
+        if (belief) s->belief[v] = (real)belief[v];
+    }
+    s->cycles = cycles;
+}
+
 /* Overwrite the V->F message a ghost edge holds (what mxs_halo_* does on the
  * device); lets the sharding logic be tested on CPU. */
 void mso_set_v2f(mso_state *s, int32_t e, const double *msg, uint8_t cnt) {

@@ -42,6 +42,7 @@ def _lib(dtype):
         lib.mso_get_assignment.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         lib.mso_get_messages.argtypes = [C.c_void_p] + [C.c_void_p] * 4
         lib.mso_set_v2f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_uint8]
+        lib.mso_set_state.argtypes = [C.c_void_p] + [C.c_void_p] * 6 + [C.c_int64]
         lib.mso_eval_cost.argtypes = [C.c_void_p, C.c_void_p, C.c_double,
                                       C.POINTER(C.c_double), C.POINTER(C.c_int64)]
         lib.mso_update_table.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -85,6 +86,22 @@ class OracleMaxSum:
         self._lib.mso_get_messages(self._h, v2f.ctypes.data, f2v.ctypes.data,
                                    cv.ctypes.data, cf.ctypes.data)
         return v2f, f2v, cv, cf
+
+    def state(self) -> dict:
+        v2f, f2v, cv, cf = self.messages()
+        idx, belief = self.assignment()
+        return {"v2f": v2f, "f2v": f2v, "count_v2f": cv, "count_f2v": cf, "idx": idx, "belief": belief,
+                "cycles": self.cycle_count}
+
+    def set_state(self, v2f=None, f2v=None, count_v2f=None, count_f2v=None, idx=None, belief=None,
+                  cycles=None):
+        keep, ptrs = [], []
+        for a, dt in ((v2f, np.float64), (f2v, np.float64), (count_v2f, np.uint8), (count_f2v, np.uint8),
+                      (idx, np.int32), (belief, np.float64)):
+            a = None if a is None else np.ascontiguousarray(a, dtype=dt)
+            keep.append(a)
+            ptrs.append(None if a is None else a.ctypes.data)
+        self._lib.mso_set_state(self._h, *ptrs, self.cycle_count if cycles is None else int(cycles))
 
     def set_v2f(self, edge: int, msg, cnt: int):
         msg = np.ascontiguousarray(msg, dtype=np.float64)

@@ -144,7 +144,9 @@ class _Session:
                     f"maxsum_gpu: devices:{n_dev} asked, {device_count()} GPU(s) visible")
             self.engine = LocalShardedMaxSum(self.graph, params, list(range(n_dev)))
         else:
-            self.engine = MaxSumEngine(self.graph, params)
+            # (DynamicMaxSum = a MaxSumEngine that survives scope changes of its factors)
+            from pydcop_amd.dynamic import DynamicMaxSum
+            self.engine = DynamicMaxSum(self.graph, params)
         self.stop_cycle = int(p["stop_cycle"])
         self.chunk = max(1, int(p["chunk"]))
         self._fetch()
@@ -194,15 +196,29 @@ class _Session:
                 raise self.error
 
     def update_factor(self, name, old, fn):
-        """Tensorise `fn` in the scope order of the factor it replaces and upload it."""
+        """Tensorise `fn` and hand it to the engine: same variables -> the table is swapped in
+        place; other variables -> the scope change of maxsum_dynamic.py:234-271 (re-layout, the
+        messages of the surviving edges carried over; one GPU only)."""
         from pydcop_amd.compile import tensorise_constraint
         with self.lock:
             if self.engine is None:
                 raise ComputationException("maxsum_gpu: the engine is not running")
             t = tensorise_constraint(fn)
-            src = [v.name for v in fn.dimensions]
-            t = np.transpose(t, [src.index(v.name) for v in old.dimensions])
-            self.engine.update_factor_table(self.graph.factor_names.index(name), t)
+            f = self.graph.factor_names.index(name)
+            same = {v.name for v in old.dimensions} == {v.name for v in fn.dimensions}
+            if hasattr(self.engine, "change_factor_function"):
+                unknown = [v.name for v in fn.dimensions if v.name not in self.var_index]
+                if unknown:
+                    raise ValueError("maxsum_gpu: the new function of {} depends on variables without a "
+                                     "computation: {}".format(name, ", ".join(unknown)))
+                self.engine.change_factor_function(f, t, scope=[self.var_index[v.name] for v in fn.dimensions])
+                self.graph = self.engine.graph
+            elif same:
+                src = [v.name for v in fn.dimensions]
+                t = np.transpose(t, [src.index(v.name) for v in old.dimensions])
+                self.engine.update_factor_table(f, t)
+            else:
+                raise ValueError("maxsum_gpu: changing the scope of a factor needs devices:1")
 
     def value_of(self, name):
         idx, belief, _, _ = self.snapshot
@@ -311,15 +327,14 @@ class MaxSumGpuFactorComputation(_ProxyMixin, DcopComputation):
         self._init_proxy(comp_def)
 
     def change_factor_function(self, fn):
-        """New cost function over the same variables
-        (pydcop/algorithms/maxsum_dynamic.py:80-104): its table replaces the old one on
-        the device, the iteration carries on."""
-        factor = self.computation_def.node.factor
-        if len(factor.dimensions) != len(fn.dimensions) or \
-                {v.name for v in factor.dimensions} != {v.name for v in fn.dimensions}:
-            raise ValueError("Dimensions must be the same when changing function in "
-                             "MaxSumGpuFactorComputation")
+        """New cost function: over the same variables
+        (pydcop/algorithms/maxsum_dynamic.py:80-104) its table replaces the old one on the device
+        and the iteration carries on; over other variables (DynamicFactorComputation,
+        maxsum_dynamic.py:234-271) the factor's edges are re-laid out and the messages of the
+        surviving edges carried over (pydcop_amd/dynamic.py)."""
+        factor = getattr(self, "_current_factor", None) or self.computation_def.node.factor
         self._session.update_factor(self.name, factor, fn)
+        self._current_factor = fn
 
 
 class MaxSumGpuVariableComputation(_ProxyMixin, VariableComputation):

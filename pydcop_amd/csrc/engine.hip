@@ -151,6 +151,8 @@ struct EngineBase {
     virtual int run_timed(int n, float* ms) = 0;
     virtual int get_assignment(int32_t* idx, double* belief) = 0;
     virtual int get_messages(double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) = 0;
+    virtual int set_state(const double* v2f, const double* f2v, const uint8_t* cv, const uint8_t* cf,
+                          const int32_t* idx, const double* belief, int64_t cyc) = 0;
     virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
     virtual int halo_setup(const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) = 0;
     virtual int halo_buffers(void** s, int64_t* sb, void** r, int64_t* rb) = 0;
@@ -168,6 +170,8 @@ struct EngineBase {
     virtual bool peer_mode() const = 0;
     virtual int debug_timeline(int64_t* out, int32_t cap, int32_t* n_blocks) = 0;
     virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
+    virtual int set_parent(int32_t factor, const double* parent, int32_t nd, const int32_t* dims, const uint8_t* ext) = 0;
+    virtual int slice_factor(int32_t factor, const int32_t* ext_idx) = 0;
     Layout L;
     mxs_params params{};
     int64_t cycles = 0;
@@ -700,6 +704,74 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    // mxs_set_state: the caller's arrays (layouts of get_messages / get_assignment) -> device
+    // records of the CURRENT buffers.  Read-modify-write of whole buffers: padding, null blocks
+    // and whatever the caller leaves out stay as they are.
+    int set_state(const double* v2f_in, const double* f2v_in, const uint8_t* cv, const uint8_t* cf,
+                  const int32_t* idx, const double* bel, int64_t cyc) override {
+        HIP_TRY(hipSetDevice(device));
+        { int rc = sync(); if (rc) return rc; }
+        if (halo_ready || p2p) return fail(MXS_E_STATE, "mxs_set_state on a shard with an exchange set up");
+        if (cyc < 0) return fail(MXS_E_INVALID, "negative cycle count");
+        const int nE = L.n_edges, nV = L.n_vars;
+        std::vector<T> hv((size_t)L.v2f_elems), hf((size_t)L.f2v_elems);
+        std::vector<uint8_t> hcF(nE), hcV((size_t)L.n_cv);
+        if (L.v2f_elems) HIP_TRY(copy_sync(hv.data(), v2f[cur].p, sizeof(T) * hv.size(), hipMemcpyDeviceToHost, stream));
+        if (L.f2v_elems) HIP_TRY(copy_sync(hf.data(), f2v[cur].p, sizeof(T) * hf.size(), hipMemcpyDeviceToHost, stream));
+        if (nE) {
+            HIP_TRY(copy_sync(hcF.data(), cF.p, nE, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hcV.data(), cV.p, (size_t)L.n_cv, hipMemcpyDeviceToHost, stream));
+        }
+        std::vector<int64_t> ext_off(nE + 1, 0);
+        for (int e = 0; e < nE; ++e) ext_off[e + 1] = ext_off[e] + L.edge_dom[L.edge_e2i[e]];
+        const double sign = L.is_max ? -1.0 : 1.0;
+        for (int ei = 0; ei < nE; ++ei) {
+            const int e = L.edge_i2e[ei];
+            const int D = L.edge_dom[ei];
+            for (int d = 0; d < D; ++d) {
+                if (v2f_in) hv[L.v2f_off[ei] + d] = (T)(sign * v2f_in[ext_off[e] + d]);
+                if (f2v_in) hf[L.f2v_off[ei] + d] = (T)(sign * f2v_in[ext_off[e] + d]);
+            }
+            if (cf) {
+                if (cf[e] > SAME_COUNT) return fail(MXS_E_INVALID, "send counter above SAME_COUNT");
+                if (L.edge_fcim[ei]) hf[L.f2v_off[ei] + D] = (T)(int)cf[e];
+                else hcF[ei] = cf[e];
+            }
+        }
+        if (cv)
+            for (int k = 0; k < nE; ++k) {
+                const int ei = L.vslot_edge[k];
+                const uint8_t c = cv[L.edge_i2e[ei]];
+                if (c > SAME_COUNT) return fail(MXS_E_INVALID, "send counter above SAME_COUNT");
+                if (L.edge_vcim[ei]) hv[L.v2f_off[ei] + L.edge_dom[ei]] = (T)(int)c;
+                else hcV[L.vslot_cv[k]] = c;
+            }
+        if (L.v2f_elems) HIP_TRY(copy_sync(v2f[cur].p, hv.data(), sizeof(T) * hv.size(), hipMemcpyHostToDevice, stream));
+        if (L.f2v_elems) HIP_TRY(copy_sync(f2v[cur].p, hf.data(), sizeof(T) * hf.size(), hipMemcpyHostToDevice, stream));
+        if (nE) {
+            HIP_TRY(copy_sync(cF.p, hcF.data(), nE, hipMemcpyHostToDevice, stream));
+            HIP_TRY(copy_sync(cV.p, hcV.data(), (size_t)L.n_cv, hipMemcpyHostToDevice, stream));
+        }
+        if ((idx || bel) && nV) {
+            std::vector<int32_t> hs(nV);
+            std::vector<T> hb(nV);
+            HIP_TRY(copy_sync(hs.data(), sel.p, sizeof(int32_t) * nV, hipMemcpyDeviceToHost, stream));
+            HIP_TRY(copy_sync(hb.data(), belief.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+            for (int vi = 0; vi < nV; ++vi) {
+                const int v = L.var_i2e[vi];
+                if (idx) {
+                    if (idx[v] < 0 || idx[v] >= L.vdom[vi]) return fail(MXS_E_INVALID, "selection index out of the domain");
+                    hs[vi] = idx[v];
+                }
+                if (bel) hb[vi] = (T)(sign * bel[v]);
+            }
+            HIP_TRY(copy_sync(sel.p, hs.data(), sizeof(int32_t) * nV, hipMemcpyHostToDevice, stream));
+            HIP_TRY(copy_sync(belief.p, hb.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+        }
+        cycles = cyc;
+        return MXS_OK;
+    }
+
     int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) override {
         HIP_TRY(hipSetDevice(device));
         { int rc = sync(); if (rc) return rc; }
@@ -796,6 +868,81 @@ struct Engine : EngineBase {
         HIP_TRY(hipGetLastError());
         HIP_TRY(copy_sync(eval_tables.p + L.eval_tab_off[fi], table, sizeof(double) * (size_t)n,
                           hipMemcpyHostToDevice, stream));  // also waits for the kernel above
+        return MXS_OK;
+    }
+
+    // ---- external (read-only) variables: parent relations sliced on the device -------------
+    struct ParentTab {
+        DevBuf<double> buf;
+        std::vector<int32_t> dims;
+        std::vector<uint8_t> ext;
+    };
+    std::map<int, std::unique_ptr<ParentTab>> parents;  // by internal factor id
+
+    int set_parent(int32_t factor, const double* parent, int32_t nd, const int32_t* dims, const uint8_t* ext) override {
+        HIP_TRY(hipSetDevice(device));
+        if (factor < 0 || factor >= L.n_factors) return fail(MXS_E_INVALID, "factor out of range");
+        if (!parent || !dims || !ext || nd < 1 || nd > 32) return fail(MXS_E_INVALID, "bad parent relation");
+        const int fi = L.factor_e2i[factor];
+        const int e0 = L.frowptr[fi], ar = L.frowptr[fi + 1] - e0;
+        int64_t total = 1;
+        int w = 0;
+        for (int i = 0; i < nd; ++i) {
+            if (dims[i] < 1) return fail(MXS_E_INVALID, "bad parent dimension");
+            total *= dims[i];
+            if (total > ((int64_t)1 << 40)) return fail(MXS_E_INVALID, "parent relation too large");
+            if (!ext[i]) {  // the writable dimensions, in order, are the factor's scope
+                if (w >= ar || dims[i] != L.edge_dom[e0 + w])
+                    return fail(MXS_E_INVALID, "the writable dimensions of the parent relation must be the factor's scope");
+                ++w;
+            }
+        }
+        if (w != ar) return fail(MXS_E_INVALID, "the writable dimensions of the parent relation must be the factor's scope");
+        auto pt = std::make_unique<ParentTab>();
+        pt->dims.assign(dims, dims + nd);
+        pt->ext.assign(ext, ext + nd);
+        std::vector<double> h(parent, parent + total);
+        HIP_TRY(pt->buf.upload(h, stream));
+        parents[fi] = std::move(pt);
+        return MXS_OK;
+    }
+
+    int slice_factor(int32_t factor, const int32_t* ext_idx) override {
+        HIP_TRY(hipSetDevice(device));
+        if (factor < 0 || factor >= L.n_factors) return fail(MXS_E_INVALID, "factor out of range");
+        const int fi = L.factor_e2i[factor];
+        auto it = parents.find(fi);
+        if (it == parents.end()) return fail(MXS_E_STATE, "no parent relation registered for this factor");
+        const ParentTab& pt = *it->second;
+        const int nd = (int)pt.dims.size();
+        SliceDims sd{};
+        int64_t stride = 1;
+        std::vector<int64_t> strides(nd);
+        for (int i = nd - 1; i >= 0; --i) {
+            strides[i] = stride;
+            stride *= pt.dims[i];
+        }
+        int j = 0;
+        for (int i = 0; i < nd; ++i) {
+            if (pt.ext[i]) {
+                const int32_t x = ext_idx ? ext_idx[j] : -1;
+                if (x < 0 || x >= pt.dims[i]) return fail(MXS_E_INVALID, "external value index out of its domain");
+                sd.base += (int64_t)x * strides[i];
+                ++j;
+            } else {
+                sd.dom[sd.n] = pt.dims[i];
+                sd.stride[sd.n] = strides[i];
+                ++sd.n;
+            }
+        }
+        { int rc = sync(); if (rc) return rc; }
+        const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
+        hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
+                           tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
+                           eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
+                           L.is_max ? -1.0 : 1.0, n);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
     }
 
@@ -1487,6 +1634,23 @@ int mxs_get_assignment(mxs_engine* e, int32_t* idx, double* belief) {
 int mxs_get_messages(mxs_engine* e, double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) {
     CHECK_HANDLE(e);
     return e->impl->get_messages(v2f, f2v, cv, cf);
+}
+
+int mxs_set_state(mxs_engine* e, const double* v2f, const double* f2v, const uint8_t* cv, const uint8_t* cf,
+                  const int32_t* idx, const double* belief, int64_t cycles) {
+    CHECK_HANDLE(e);
+    return e->impl->set_state(v2f, f2v, cv, cf, idx, belief, cycles);
+}
+
+int mxs_set_parent_table(mxs_engine* e, int32_t factor, const double* parent, int32_t n_dims,
+                         const int32_t* dims, const uint8_t* is_external) {
+    CHECK_HANDLE(e);
+    return e->impl->set_parent(factor, parent, n_dims, dims, is_external);
+}
+
+int mxs_slice_factor(mxs_engine* e, int32_t factor, const int32_t* external_idx) {
+    CHECK_HANDLE(e);
+    return e->impl->slice_factor(factor, external_idx);
 }
 
 int mxs_eval_cost(mxs_engine* e, const int32_t* idx, double infinity, double* cost, int64_t* viol) {

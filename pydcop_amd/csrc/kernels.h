@@ -1289,6 +1289,33 @@ __global__ void __launch_bounds__(BLOCK) k_table_update(T* tables, int64_t base,
     if (k < n) tables[base + k * stride] = src[k];
 }
 
+// mxs_slice_factor: the active table of a factor = its parent relation sliced at the current
+// values of the external (read-only) dimensions (maxsum_dynamic.py:113-186, relation.slice).
+// Entry k of the active table (row-major over the writable dimensions) comes from
+// parent[base + sum_i digit_i(k) * stride[i]].
+struct SliceDims {
+    int32_t n;                 // writable dimensions
+    int32_t dom[16];           // their sizes, in scope order
+    int64_t stride[16];        // their strides in the parent table
+    int64_t base;              // offset contributed by the external dimensions' values
+};
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_base, int64_t tab_stride,
+                                                       double* eval_tables, const double* parent,
+                                                       SliceDims sd, double sign, int64_t n) {
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    int64_t rem = k, lin = sd.base;
+    for (int i = sd.n - 1; i >= 0; --i) {
+        const int64_t digit = rem % sd.dom[i];
+        rem /= sd.dom[i];
+        lin += digit * sd.stride[i];
+    }
+    const double v = parent[lin];
+    tables[tab_base + k * tab_stride] = (T)(sign * v);
+    eval_tables[k] = v;
+}
+
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_halo_pack(const T* rec, const int64_t* elem_off, T* out,
                                                      int64_t n) {

@@ -42,7 +42,7 @@ ABI_SYMBOLS = (
     "mxs_comm_unique_id", "mxs_comm_init", "mxs_comm_exchange", "mxs_run_sharded", "mxs_shard_mode",
     "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
-    "mxs_build_kind",
+    "mxs_build_kind", "mxs_set_state", "mxs_set_parent_table", "mxs_slice_factor",
 )
 
 
@@ -136,6 +136,9 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_get_assignment": ([vp, vp, vp], C.c_int),
         "mxs_get_messages": ([vp, vp, vp, vp, vp], C.c_int),
         "mxs_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
+        "mxs_set_state": ([vp, vp, vp, vp, vp, vp, vp, i64], C.c_int),
+        "mxs_set_parent_table": ([vp, i32, vp, i32, vp, vp], C.c_int),
+        "mxs_slice_factor": ([vp, i32, vp], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
@@ -273,6 +276,38 @@ class MaxSumEngine:
                                                cv.ctypes.data, cf.ctypes.data))
         return v2f, f2v, cv, cf
 
+    def state(self) -> dict:
+        """Everything a run needs to carry on elsewhere: messages, send counters, selection,
+        beliefs (caller's orders) and the cycle count -- `set_state` of another engine on the
+        same graph resumes it bit for bit (checkpoint / resume)."""
+        v2f, f2v, cv, cf = self.messages()
+        idx, belief = self.assignment()
+        return {"v2f": v2f, "f2v": f2v, "count_v2f": cv, "count_f2v": cf, "idx": idx, "belief": belief,
+                "cycles": self.cycle_count}
+
+    def set_state(self, v2f=None, f2v=None, count_v2f=None, count_f2v=None, idx=None, belief=None,
+                  cycles: Optional[int] = None):
+        """The inverse of `messages()` / `assignment()` (mxs_set_state); None = keep."""
+        nm, ne, nv = int(self.graph.msg_off[-1]), self.graph.n_edges, self.graph.n_vars
+
+        def arr(a, dtype, n, what):
+            if a is None:
+                return None, None
+            a = np.ascontiguousarray(a, dtype=dtype)
+            if a.shape != (n,):
+                raise ValueError(f"{what} must have {n} entries")
+            return a, a.ctypes.data
+        keep = []
+        ptrs = []
+        for a, dt, n, what in ((v2f, np.float64, nm, "v2f"), (f2v, np.float64, nm, "f2v"),
+                               (count_v2f, np.uint8, ne, "count_v2f"), (count_f2v, np.uint8, ne, "count_f2v"),
+                               (idx, np.int32, nv, "idx"), (belief, np.float64, nv, "belief")):
+            a, p = arr(a, dt, n, what)
+            keep.append(a)
+            ptrs.append(p)
+        cyc = self.cycle_count if cycles is None else int(cycles)
+        self._check(self._lib.mxs_set_state(self._h, *ptrs, cyc))
+
     def eval_cost(self, idx=None, infinity: float = float("inf")) -> Tuple[float, int]:
         """(cost, violations) as DCOP.solution_cost (pydcop/dcop/dcop.py:319-367)."""
         cost, viol = C.c_double(0), C.c_int64(0)
@@ -298,6 +333,37 @@ class MaxSumEngine:
         self._check(self._lib.mxs_update_factor_table(self._h, int(factor), t.ctypes.data, t.shape[0]))
         lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
         self.graph.tables[lo:hi] = t  # keep the host copy of the graph in step
+
+    def set_parent_table(self, factor: int, parent, is_external):
+        """Register the whole relation of a factor that also depends on external (read-only)
+        variables: `parent` = ndarray over ALL its dimensions, `is_external[i]` true for the
+        read-only ones; the others, in order, are the factor's scope (maxsum_dynamic.py:113-186)."""
+        parent = np.ascontiguousarray(parent, dtype=np.float64)
+        dims = np.ascontiguousarray(parent.shape, dtype=np.int32)
+        ext = np.ascontiguousarray(is_external, dtype=np.uint8)
+        if ext.shape != (parent.ndim,):
+            raise ValueError("one is_external flag per dimension of the parent relation")
+        self._check(self._lib.mxs_set_parent_table(self._h, int(factor), parent.ctypes.data, parent.ndim,
+                                                   dims.ctypes.data, ext.ctypes.data))
+        self._parents = getattr(self, "_parents", {})
+        self._parents[int(factor)] = (parent, ext.astype(bool))
+
+    def slice_factor(self, factor: int, external_idx):
+        """The factor's active table becomes the slice of its parent relation at these value
+        indices of the external dimensions (one per external dimension, in order); sliced on
+        the device.  The iteration carries on."""
+        idx = np.ascontiguousarray(external_idx, dtype=np.int32)
+        self._check(self._lib.mxs_slice_factor(self._h, int(factor), idx.ctypes.data))
+        parent, ext = self._parents[int(factor)]   # keep the host copy of the graph in step
+        sel, j = [], 0
+        for i in range(parent.ndim):
+            if ext[i]:
+                sel.append(int(idx[j]))
+                j += 1
+            else:
+                sel.append(slice(None))
+        lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
+        self.graph.tables[lo:hi] = parent[tuple(sel)].reshape(-1)
 
     def debug_timeline(self) -> np.ndarray:
         """Profiling: run one more cycle with per-block timestamps; returns an int64

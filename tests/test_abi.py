@@ -14,7 +14,7 @@ def hip_lib():
     import __graft_entry__ as ge
     ge.build()
     from pydcop_amd.engine import load_library
-    return load_library()
+    return load_library(os.path.join(ROOT, "pydcop_amd", "csrc", "libmaxsum_hip.so"))
 
 
 def test_header_symbols_are_exported(hip_lib):
@@ -45,7 +45,8 @@ def test_no_cpu_fallback_without_gpu(hip_lib):
     if device_count() > 0:
         pytest.skip("a GPU is visible")
     with pytest.raises(MaxSumGpuError, match="no CPU fallback|no HIP device"):
-        MaxSumEngine(G.random_coloring(10, seed=0), Params())
+        MaxSumEngine(G.random_coloring(10, seed=0), Params(),
+                     lib_path=os.path.join(ROOT, "pydcop_amd", "csrc", "libmaxsum_hip.so"))
 
 
 def test_product_cannot_be_pointed_at_the_emulated_engine(hip_lib):

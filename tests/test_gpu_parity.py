@@ -191,3 +191,12 @@ def _empty_graph_checks(oracle_mod, lib_path=None):
 
 def test_empty_and_invalid_graphs(oracle_built):
     _empty_graph_checks(oracle_built)
+
+
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_dynamic_maxsum(dtype, oracle_built):
+    """maxsum_dynamic on the device: table swaps, scope changes (re-layout + mxs_set_state),
+    external values sliced by mxs_slice_factor, checkpoint / resume -- bit-exact vs the oracle."""
+    from dynamic_common import check_dynamic_run
+    for seed in (1, 2):
+        check_dynamic_run(oracle_built, dtype=dtype, seed=seed)

@@ -164,6 +164,12 @@ def test_change_factor_function_and_stop_of_one_proxy(plugin_mod):
     at = session.cycles
     agent.pump(lambda: session.cycles >= at + 30 and comps["b"].cycle_count >= at + 30)
     assert (comps["a"].current_value, comps["b"].current_value) == (0, 1)
+    # a new function over OTHER variables (maxsum_dynamic.py:234-271): `eq` lets go of a
+    comps["eq"].change_factor_function(Table("eq", [b], [0.0, 3.0]))            # now: b = 0
+    at = session.cycles
+    agent.pump(lambda: session.cycles >= at + 30 and comps["b"].cycle_count >= at + 30)
+    assert (comps["a"].current_value, comps["b"].current_value) == (0, 0)
+    assert session.engine.relayouts == 1 and session.graph.n_edges == 2
     comps["pa"].stop()                                   # e.g. an agent removal
     assert session.engine is not None and not session.stopped
     at = session.cycles

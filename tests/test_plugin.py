@@ -39,8 +39,10 @@ def pydcop_ready(emu_lib):
     from pydcop.algorithms import load_algorithm_module
     mod = load_algorithm_module("maxsum_gpu")
     from pydcop_amd import engine
+    before = engine.DEFAULT_LIB
     engine.register_test_engine(emu_lib, make_default=True)  # emulated engine (no GPU in this container)
-    return mod
+    yield mod
+    engine.DEFAULT_LIB = before
 
 
 def test_discovered_like_a_builtin_algorithm(pydcop_ready):

@@ -76,13 +76,35 @@ def run_threads(n, k, timeout):
     per = (len(names) + k - 1) // k
     mapping = {a.name: names[i * per:(i + 1) * per] for i, a in enumerate(agents)}
     algo = AlgorithmDef.build_with_default_param("maxsum", {}, mode="min")
+    # the agents are created inside run_local_thread_dcop and not handed back: remember them, so
+    # that the cycle every computation reached can be read directly when the run ends (the
+    # orchestrator's own figure is max over computations of what the agents REPORTED -- an
+    # isolated variable spins through cycles on its own, and a busy agent may not report at all)
+    import pydcop.infrastructure.run as run_mod
+    made = []
+
+    class RecordingAgent(run_mod.OrchestratedAgent):
+        def __init__(self, *a, **k):
+            super().__init__(*a, **k)
+            made.append(self)
+    orig_agent = run_mod.OrchestratedAgent
+    run_mod.OrchestratedAgent = RecordingAgent
     t0 = time.perf_counter()
-    orchestrator = run_local_thread_dcop(algo, cg, Distribution(mapping), dcop, INFINITY)
+    try:
+        orchestrator = run_local_thread_dcop(algo, cg, Distribution(mapping), dcop, INFINITY)
+    finally:
+        run_mod.OrchestratedAgent = orig_agent
+    connected = {n.name for n in cg.nodes if n.neighbors}
+    reached = []
     try:
         orchestrator.deploy_computations()
         t1 = time.perf_counter()
         orchestrator.run(timeout=timeout)
         t2 = time.perf_counter()
+        for a in made:
+            for c in a.computations():
+                if c.name in connected:
+                    reached.append(int(c.cycle_count))
         m = orchestrator.end_metrics()
     finally:
         try:
@@ -91,9 +113,13 @@ def run_threads(n, k, timeout):
         except Exception:
             pass
         logging.disable(logging.NOTSET)
-    cycles, secs = int(m["cycle"]), float(m["time"])
+    secs = float(m["time"]) or (t2 - t1)
+    reached.sort()
+    cycles = reached[len(reached) // 2] if reached else 0   # median over the connected computations
     return {"mode": "threads", "n_vars": n, "n_factors": g.n_factors, "n_edges": g.n_edges, "agents": k,
-            "timeout_s": timeout, "status": m["status"], "cycle": cycles, "time_s": round(secs, 3),
+            "timeout_s": timeout, "status": m["status"], "time_s": round(secs, 3),
+            "cycle_median": cycles, "cycle_min": reached[0] if reached else 0, "cycle_max": reached[-1] if reached else 0,
+            "cycle_orchestrator": int(m["cycle"]),
             "deploy_s": round(t1 - t0, 2), "run_wall_s": round(t2 - t1, 2),
             "iterations_per_s": round(cycles / secs, 4) if secs > 0 else None,
             "edge_messages_per_s": round(cycles * 2 * g.n_edges / secs, 1) if secs > 0 else None,
