@@ -186,6 +186,15 @@ int mxs_eval_cost(mxs_engine *e, const int32_t *idx, double infinity,
 int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
                     int32_t *launches_per_cycle);
 
+/* How the cost tables are stored on the device: factors[t] = number of factors whose table is
+ * kept as t = 0 full width (the engine's arithmetic type), 1 f32, 2 int16, 3 int8, and the table
+ * bytes one cycle reads.  A register class (unary / binary factors, D <= 4) whose every entry
+ * is exactly representable in a narrower type is stored in it and widened on load: lossless --
+ * the arithmetic and every result are bit for bit those of full-width tables -- and up to 4.5x
+ * fewer table bytes per cycle.  An update that does not fit (mxs_update_factor_table,
+ * mxs_set_parent_table) moves the class back to full width. */
+int mxs_table_storage(const mxs_engine *e, int64_t factors[4], int64_t *table_bytes_per_cycle);
+
 /* Replace the cost table of factor `factor` (caller's factor index) by one of the
  * same shape, row-major over its scope; messages, counters and the selection
  * carry on from where they are: change_factor_function of

@@ -194,6 +194,7 @@ struct Engine : EngineBase {
     bool timeline_on = false;
     DevBuf<FactorGen> fgen;
     DevBuf<uint32_t> sched;     // block schedule of launch 0 (Layout::sched), may be empty
+    DevBuf<uint8_t> ctables;    // compact table records (Layout::ctables), may be empty
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
     DevBuf<ClassInfo> classes_f; // both lists as ONE grid (fused sharded launch), cut classes last
@@ -243,6 +244,8 @@ struct Engine : EngineBase {
         a.f2v_old = f2v[from].p;
         a.f2v_new = f2v[from ^ 1].p;
         a.tables = tables.p;
+        a.ctables = ctables.p;
+        a.tab_neg = L.is_max ? 1 : 0;
         a.var_cost = var_cost.p;
         a.cF = cF.p;
         a.cV = cV.p;
@@ -406,6 +409,38 @@ struct Engine : EngineBase {
         return launch_phase(from, start, 2);
     }
 
+    // The ClassInfo arrays of the three launch flavours (from L.classes).
+    int upload_class_arrays() {
+        std::vector<ClassInfo> order;
+        for (int c : L.sweep_order) order.push_back(L.classes[c]);
+        HIP_TRY(classes.upload(order, stream));
+        order.clear();
+        for (int c : L.sweep_order2) order.push_back(L.classes[c]);
+        HIP_TRY(classes2.upload(order, stream));
+        order.clear();
+        if (L.n_blocks_fused > 0) {
+            for (int c : L.sweep_order) order.push_back(L.classes[c]);
+            for (int c : L.sweep_order2) order.push_back(L.classes[c]);
+            for (size_t i = 0; i < order.size(); ++i) order[i].block_base = L.fused_block_base[i];
+        }
+        HIP_TRY(classes_f.upload(order, stream));
+        return MXS_OK;
+    }
+
+    // A new table entry does not fit the narrow type a class stores its tables in: from now on
+    // the class reads the full-width image, which every update keeps current.
+    int promote_class(int cls) {
+        if (L.classes[cls].tab_type == TAB_FULL) return MXS_OK;
+        { int rc = sync(); if (rc) return rc; }
+        L.classes[cls].tab_type = TAB_FULL;
+        if (graph_exec) {  // the captured cycle loop holds the pointers of the old class arrays
+            (void)hipGraphExecDestroy(graph_exec);
+            graph_exec = nullptr;
+            graph_tried = false;
+        }
+        return upload_class_arrays();
+    }
+
     int init(const mxs_graph& g, const mxs_params& p, int dev) override {
         params = p;
         device = dev;
@@ -467,6 +502,7 @@ struct Engine : EngineBase {
         HIP_TRY(vslot_f2v.upload(L.vslot_f2v, stream));
         HIP_TRY(vslot_v2f.upload(L.vslot_v2f, stream));
         HIP_TRY(tables.upload(conv(L.tables), stream));
+        HIP_TRY(ctables.upload(L.ctables, stream));
         HIP_TRY(var_cost.upload(conv(L.var_cost), stream));
         HIP_TRY(cF.alloc((size_t)L.n_edges));
         HIP_TRY(cV.alloc((size_t)L.n_cv));
@@ -483,21 +519,7 @@ struct Engine : EngineBase {
         HIP_TRY(belief.alloc((size_t)L.n_vars));
         HIP_TRY(vcost_off.upload(L.vcost_off, stream));
         HIP_TRY(fgen.upload(L.fgen, stream));
-        {
-            std::vector<ClassInfo> order;
-            for (int c : L.sweep_order) order.push_back(L.classes[c]);
-            HIP_TRY(classes.upload(order, stream));
-            order.clear();
-            for (int c : L.sweep_order2) order.push_back(L.classes[c]);
-            HIP_TRY(classes2.upload(order, stream));
-            order.clear();
-            if (L.n_blocks_fused > 0) {
-                for (int c : L.sweep_order) order.push_back(L.classes[c]);
-                for (int c : L.sweep_order2) order.push_back(L.classes[c]);
-                for (size_t i = 0; i < order.size(); ++i) order[i].block_base = L.fused_block_base[i];
-            }
-            HIP_TRY(classes_f.upload(order, stream));
-        }
+        { int rc = upload_class_arrays(); if (rc) return rc; }
         HIP_TRY(sched.upload(L.sched, stream));
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
@@ -868,6 +890,19 @@ struct Engine : EngineBase {
         HIP_TRY(hipGetLastError());
         HIP_TRY(copy_sync(eval_tables.p + L.eval_tab_off[fi], table, sizeof(double) * (size_t)n,
                           hipMemcpyHostToDevice, stream));  // also waits for the kernel above
+        const int cls = L.f_class[fi];
+        if (cls >= 0 && L.classes[cls].tab_type != TAB_FULL) {  // the class stores narrow records
+            const int t = L.classes[cls].tab_type;
+            const int fit = narrowest_tab_type(table, n, (int)sizeof(T));
+            if (fit >= t) {  // (TAB_I8 > TAB_I16 > TAB_F32: at least as narrow as the class's type)
+                std::vector<uint8_t> rec((size_t)L.classes[cls].ctab_rec, 0);
+                encode_tab_record(table, (int)n, t, rec.data());
+                HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
+            } else {
+                int rc = promote_class(cls);
+                if (rc) return rc;
+            }
+        }
         return MXS_OK;
     }
 
@@ -904,6 +939,13 @@ struct Engine : EngineBase {
         std::vector<double> h(parent, parent + total);
         HIP_TRY(pt->buf.upload(h, stream));
         parents[fi] = std::move(pt);
+        // every slice of this relation must fit the narrow type its class stores tables in
+        const int cls = L.f_class[fi];
+        if (cls >= 0 && L.classes[cls].tab_type != TAB_FULL &&
+            narrowest_tab_type(parent, total, (int)sizeof(T)) < L.classes[cls].tab_type) {
+            int rc = promote_class(cls);
+            if (rc) return rc;
+        }
         return MXS_OK;
     }
 
@@ -937,10 +979,13 @@ struct Engine : EngineBase {
         }
         { int rc = sync(); if (rc) return rc; }
         const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
+        const int cls = L.f_class[fi];
+        const int ctype = cls >= 0 ? L.classes[cls].tab_type : TAB_FULL;
         hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
                            tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
                            eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
-                           L.is_max ? -1.0 : 1.0, n);
+                           L.is_max ? -1.0 : 1.0, n,
+                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
@@ -1640,6 +1685,22 @@ int mxs_set_state(mxs_engine* e, const double* v2f, const double* f2v, const uin
                   const int32_t* idx, const double* belief, int64_t cycles) {
     CHECK_HANDLE(e);
     return e->impl->set_state(v2f, f2v, cv, cf, idx, belief, cycles);
+}
+
+int mxs_table_storage(const mxs_engine* e, int64_t factors[4], int64_t* table_bytes) {
+    CHECK_HANDLE(e);
+    const mxs::Layout& L = e->impl->L;
+    const int64_t w = L.opt.word;
+    int64_t n[4] = {0, 0, 0, 0}, bytes = 0;
+    for (int fi = 0; fi < L.n_factors; ++fi) {
+        const int cls = L.f_class[fi];
+        const int t = cls >= 0 ? L.classes[cls].tab_type : mxs::TAB_FULL;
+        n[t] += 1;
+        bytes += t == mxs::TAB_FULL ? (L.eval_tab_off[fi + 1] - L.eval_tab_off[fi]) * w : L.classes[cls].ctab_rec;
+    }
+    if (factors) std::memcpy(factors, n, sizeof(n));
+    if (table_bytes) *table_bytes = bytes;
+    return MXS_OK;
 }
 
 int mxs_set_parent_table(mxs_engine* e, int32_t factor, const double* parent, int32_t n_dims,

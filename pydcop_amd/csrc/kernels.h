@@ -77,6 +77,8 @@ struct SweepArgs {
     const T* f2v_old;   // F->V messages of cycle t-1 (factor-major)
     T* f2v_new;
     const T* tables;
+    const uint8_t* ctables;  // compact table records of the classes with ClassInfo::tab_type != TAB_FULL
+    int32_t tab_neg;         // 1 (max mode): compact records hold un-negated values, negate on load
     const T* var_cost;
     uint8_t* cF;        // [n_edges] factor-major send counters
     uint8_t* cV;        // [n_cv] variable-side send counters (CSR slots + class tables)
@@ -226,6 +228,56 @@ struct Msg {
     }
 };
 
+// The N table entries of factor j of a register class.  Full width: entry-major (SoA), a wave
+// reads each entry as one coalesced segment.  Compact types (layout.h, TabType): one record of
+// back-to-back narrow entries per factor, read with whole-dword vector loads (consecutive lanes
+// read consecutive records) and widened here -- every value is exactly what the full-width
+// image holds, including the sign of a negated zero.
+template <typename T, int N>
+__device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInfo& ci, int j, T (&tab)[N]) {
+    if (ci.tab_type == TAB_FULL) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
+        return;
+    }
+    if (ci.tab_type == TAB_I8) {
+        constexpr int REC = tab_record_bytes(N, 1);
+        uint32_t w[REC / 4];
+        const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
+            a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
+#pragma unroll
+        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) tab[k] = (T)(int)(int8_t)(uint8_t)(w[k >> 2] >> (8 * (k & 3)));
+    } else if (ci.tab_type == TAB_I16) {
+        constexpr int REC = tab_record_bytes(N, 2);
+        uint32_t w[REC / 4];
+        const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
+            a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
+#pragma unroll
+        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) tab[k] = (T)(int)(int16_t)(uint16_t)(w[k >> 1] >> (16 * (k & 1)));
+    } else {  // TAB_F32
+        constexpr int REC = tab_record_bytes(N, 4);
+        uint32_t w[REC / 4];
+        const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
+            a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
+#pragma unroll
+        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            float f;
+            __builtin_memcpy(&f, &w[k], 4);
+            tab[k] = (T)f;
+        }
+    }
+    if (a.tab_neg) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) tab[k] = -tab[k];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Factor side, register classes (thread per factor).
 // factor_costs_for_var, maxsum.py:382-447:  out_i[d] = min over the other
@@ -237,16 +289,17 @@ __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassI
     const int64_t fo = ci.f2v_base + (int64_t)j * H;
     const int e = ci.edge_base + j;
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
-    T out[D], prev[D];
+    T out[D], prev[D], tab[D];
     uint8_t cn;
     if constexpr (CIM) cn = Msg<T, D>::load_c(a.f2v_old + fo, prev);
     else {
         Msg<T, D>::load(a.f2v_old + fo, prev);
         cn = a.cF[e];
     }
+    load_table<T, D>(a, ci, j, tab);
 #pragma unroll
     for (int d = 0; d < D; ++d)  // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
-        out[d] = a.tables[ci.tab_base + (int64_t)d * ci.count + j] + (T)0;
+        out[d] = tab[d] + (T)0;
     uint8_t c = 0;
     if (!a.start)  // on_start (maxsum.py:311-319): unary factors send in every mode, counter stays 0
         c = damp_and_filter<T, D>(out, prev, cn, a.damp_f != 0, a.damping, a.stability);
@@ -278,8 +331,7 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         Msg<T, D>::load(a.f2v_old + fo0, p0);
         Msg<T, D>::load(a.f2v_old + fo1, p1);
     }
-#pragma unroll
-    for (int k = 0; k < D * D; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
+    load_table<T, D * D>(a, ci, j, tab);
     // the two gathers
     // (peer-store mode: the message of a ghost variable lives in the ghost region)
     if constexpr (P2P) {
@@ -1302,7 +1354,8 @@ struct SliceDims {
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_base, int64_t tab_stride,
                                                        double* eval_tables, const double* parent,
-                                                       SliceDims sd, double sign, int64_t n) {
+                                                       SliceDims sd, double sign, int64_t n,
+                                                       uint8_t* crec, int ctype) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int64_t rem = k, lin = sd.base;
@@ -1314,6 +1367,11 @@ __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_ba
     const double v = parent[lin];
     tables[tab_base + k * tab_stride] = (T)(sign * v);
     eval_tables[k] = v;
+    if (crec != nullptr) {  // the factor's compact record too (the parent was checked to fit)
+        if (ctype == TAB_I8) ((int8_t*)crec)[k] = (int8_t)v;
+        else if (ctype == TAB_I16) ((int16_t*)crec)[k] = (int16_t)v;
+        else ((float*)crec)[k] = (float)v;
+    }
 }
 
 template <typename T>

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <numeric>
 #include <sstream>
 
@@ -27,6 +28,9 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.schedule = MXS_SCHEDULE_DEFAULT != 0;
     if (f & 4096) o.schedule = true;   // bit12: co-scheduled, XCD-contiguous block order
     if (f & 2048) o.schedule = false;  // bit11: blocks in class order
+    o.compact_tables = MXS_COMPACT_TABLES_DEFAULT != 0;
+    if (f & 16384) o.compact_tables = true;   // bit14: narrow storage of exactly-representable tables
+    if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     return o;
 }
 
@@ -98,6 +102,38 @@ std::string validate(const mxs_graph& g) {
 }
 
 }  // namespace
+
+int narrowest_tab_type(const double* v, int64_t n, int word) {
+    bool i8 = true, i16 = true, f32 = true;
+    for (int64_t k = 0; k < n; ++k) {
+        const double x = v[k];
+        const bool integral = std::isfinite(x) && x == std::floor(x) && !(x == 0.0 && std::signbit(x));
+        if (!integral || std::fabs(x) > 127.0) i8 = false;
+        if (!integral || std::fabs(x) > 32767.0) i16 = false;
+        if (!((double)(float)x == x || (x != x))) f32 = false;  // (NaN stays NaN; its payload is not compared)
+        if (x != x) i8 = i16 = false;
+        if (!i16 && !f32) break;
+    }
+    if (i8) return TAB_I8;
+    if (i16) return TAB_I16;
+    if (f32 && word == 8) return TAB_F32;
+    return TAB_FULL;
+}
+
+void encode_tab_record(const double* v, int entries, int t, uint8_t* dst) {
+    for (int k = 0; k < entries; ++k) {
+        if (t == TAB_I8) {
+            const int8_t x = (int8_t)v[k];
+            std::memcpy(dst + k, &x, 1);
+        } else if (t == TAB_I16) {
+            const int16_t x = (int16_t)v[k];
+            std::memcpy(dst + 2 * k, &x, 2);
+        } else {
+            const float x = (float)v[k];
+            std::memcpy(dst + 4 * k, &x, 4);
+        }
+    }
+}
 
 std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     {
@@ -200,6 +236,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     for (int fi = 0; fi < nF; ++fi) L.factor_e2i[L.factor_i2e[fi]] = fi;
     L.f_tab_base.assign(nF, 0);
     L.f_tab_stride.assign(nF, 1);
+    L.f_ctab_off.assign(nF, -1);
+    L.f_class.assign(nF, -1);
 
     // ---- internal edges, F2V array (factor-major) ------------------------------
     L.edge_i2e.resize(nE);
@@ -351,6 +389,23 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             }
             if (ci.H > ci.D)  // counters ride in the records' padding (kernels.h, Msg::CNT_IN_MSG)
                 for (int e = L.frowptr[fi]; e < L.frowptr[fj]; ++e) L.edge_fcim[e] = 1;
+            // compact storage: the narrowest type every entry of the class fits exactly
+            if (L.opt.compact_tables) {
+                const int64_t lo = L.eval_tab_off[fi], hi = L.eval_tab_off[fj];
+                const int t = narrowest_tab_type(L.eval_tables.data() + lo, hi - lo, L.opt.word);
+                if (t != TAB_FULL) {
+                    ci.tab_type = t;
+                    ci.ctab_rec = tab_record_bytes(entries, tab_elem_bytes(t));
+                    ci.ctab_base = (int64_t)((L.ctables.size() + 255) / 256 * 256);
+                    L.ctables.resize((size_t)(ci.ctab_base + (int64_t)n * ci.ctab_rec), 0);
+                    for (int j = 0; j < n; ++j) {
+                        L.f_ctab_off[fi + j] = ci.ctab_base + (int64_t)j * ci.ctab_rec;
+                        encode_tab_record(L.eval_tables.data() + L.eval_tab_off[fi + j], entries, t,
+                                          L.ctables.data() + L.f_ctab_off[fi + j]);
+                    }
+                }
+            }
+            for (int j = 0; j < n; ++j) L.f_class[fi + j] = cls;
             L.classes.push_back(ci);
             sweep_class(cls, BLOCK, key.cut || second);
         } else {

@@ -43,6 +43,7 @@ ABI_SYMBOLS = (
     "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
     "mxs_build_kind", "mxs_set_state", "mxs_set_parent_table", "mxs_slice_factor",
+    "mxs_table_storage",
 )
 
 
@@ -139,6 +140,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_set_state": ([vp, vp, vp, vp, vp, vp, vp, i64], C.c_int),
         "mxs_set_parent_table": ([vp, i32, vp, i32, vp, vp], C.c_int),
         "mxs_slice_factor": ([vp, i32, vp], C.c_int),
+        "mxs_table_storage": ([vp, vp, C.POINTER(i64)], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
@@ -325,6 +327,15 @@ class MaxSumEngine:
         b, n = C.c_int64(0), C.c_int32(0)
         self._check(self._lib.mxs_cycle_bytes(self._h, C.byref(b), C.byref(n)))
         return int(b.value), int(n.value)
+
+    def table_storage(self) -> dict:
+        """{"full", "f32", "i16", "i8"}: factors per table storage type, and "bytes_per_cycle": the
+        table bytes one cycle reads (mxs_table_storage; narrow types are lossless)."""
+        n = (C.c_int64 * 4)()
+        b = C.c_int64(0)
+        self._check(self._lib.mxs_table_storage(self._h, n, C.byref(b)))
+        return {"full": int(n[0]), "f32": int(n[1]), "i16": int(n[2]), "i8": int(n[3]),
+                "bytes_per_cycle": int(b.value)}
 
     def update_factor_table(self, factor: int, table):
         """New cost table (same shape, row-major over the scope) for one factor; the

@@ -94,11 +94,12 @@ def check_rescope_semantics(seed=0):
         assert ns["cycles"] == 9
 
 
-def check_dynamic_run(oracle_mod, lib_path=None, dtype="f64", seed=1):
+def check_dynamic_run(oracle_mod, lib_path=None, dtype="f64", seed=1, float_tables=True):
     """A run with every kind of change in it, engine == oracle bit for bit all along: table swap
     (other order of the same variables), scope changes (shrink, grow, replace), external values
     sliced on the device, checkpoint / resume."""
-    g = G.random_mixed(40, 60, seed=seed, max_arity=3, dom_choices=(2, 3, 4), names=False)
+    g = G.random_mixed(40, 60, seed=seed, max_arity=3, dom_choices=(2, 3, 4), names=False,
+                       float_tables=float_tables)   # integer tables: classes store narrow records
     p = Params(dtype=dtype, start_messages="leafs_vars")
     rng = np.random.default_rng(seed)
 
@@ -159,7 +160,7 @@ def check_dynamic_run(oracle_mod, lib_path=None, dtype="f64", seed=1):
     gg = run.graph
     sc = [int(x) for x in gg.edge_var[gg.factor_rowptr[f2]:gg.factor_rowptr[f2 + 1]]]
     dims = [int(gg.dom_size[sc[0]]), 5, int(gg.dom_size[sc[1]])]   # the sensor sits in the middle
-    parent = rng.uniform(-3, 3, dims)
+    parent = rng.uniform(-3, 3, dims) if float_tables else rng.integers(-9, 9, dims).astype(float)
     run.register_external(f2, parent, [0, 1, 0])
     for sensor in (3, 0, 4):
         run.set_external_values(f2, [sensor])

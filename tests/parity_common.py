@@ -93,8 +93,21 @@ def parity_cases():
         return FlatGraph(dom_size=dom, var_cost=cost, factor_rowptr=rowptr, edge_var=edge_var,
                          table_off=toff, tables=tables, var_rowptr=vr, var_edges=ve).validate()
 
+    def scaled(g, factor, neg_zero=False):
+        t = g.tables * factor
+        if neg_zero:
+            t[t == 0] = -0.0     # an entry no integer type holds (the sign of the zero)
+        g.tables = t
+        return g
+
     return [
         ("coloring3_soft", lambda: G.random_coloring(300, seed=1), {}),
+        # table storage types (layout.h TabType): quarters fit f32 but no integer type; max mode
+        # negates on load; a -0.0 entry; hard 1000 * I is i16
+        ("tables_quarters_max", lambda: scaled(G.random_coloring(200, seed=31), 0.25), {"mode": "max"}),
+        ("tables_neg_zero", lambda: scaled(G.random_coloring(150, n_colors=2, seed=32), 1.0, True),
+         {"mode": "max", "start_messages": "all"}),
+        ("tables_i8_max_unary", lambda: G.ising_grid(8, 6, seed=33, bin_range=1.6, un_range=0.05), {"mode": "max"}),
         ("coloring3_hard_all", lambda: G.random_coloring(300, seed=2, variant="hard"),
          {"start_messages": "all", "damping_nodes": "vars"}),
         ("coloring2_deg6_max", lambda: G.random_coloring(200, avg_degree=6, n_colors=2, seed=3),
@@ -153,6 +166,20 @@ def check_table_updates(oracle_mod, graph, params: Params, lib_path=None, seed=0
         for x, y in zip(eng.messages(), ora.messages()):
             np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(eng.assignment()[0], ora.assignment()[0])
+        np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
+        ce, co = eng.eval_cost(), ora.eval_cost()
+        assert ce[1] == co[1] and abs(ce[0] - co[0]) <= 1e-9 * max(1.0, abs(co[0]))
+    # values that no narrow table type holds (a class storing i8 / i16 / f32 records falls back
+    # to its full-width image, layout.h TabType), then small integers again
+    for k, f in enumerate(picks[:3]):
+        n = int(graph.table_off[f + 1] - graph.table_off[f])
+        t = rng.integers(-5, 15, n).astype(np.float64)
+        t[0] = (300.0, 1e6 + 0.25, 0.1)[k]
+        eng.update_factor_table(int(f), t)
+        ora.update_factor_table(int(f), t)
+        eng.run(2), ora.run(2)
+        for x, y in zip(eng.messages(), ora.messages()):
+            np.testing.assert_array_equal(x, y)
         np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
         ce, co = eng.eval_cost(), ora.eval_cost()
         assert ce[1] == co[1] and abs(ce[0] - co[0]) <= 1e-9 * max(1.0, abs(co[0]))

@@ -12,6 +12,7 @@ def test_rescope_bookkeeping_follows_the_reference_handlers(seed):
 
 
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
-def test_dynamic_run_on_the_emulated_engine(dtype, oracle_built):
+@pytest.mark.parametrize("float_tables", [True, False])
+def test_dynamic_run_on_the_emulated_engine(dtype, float_tables, oracle_built):
     from emu.build_emu import build
-    check_dynamic_run(oracle_built, lib_path=build(), dtype=dtype)
+    check_dynamic_run(oracle_built, lib_path=build(), dtype=dtype, float_tables=float_tables)

@@ -25,7 +25,8 @@ def emu_lib():
 
 # 0 = production (factors of a class follow their first variable: bit 7 is the default)
 LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16,
-           "unsorted_factors": 256, "sorted_keep_order": 128 + 8}
+           "unsorted_factors": 256, "sorted_keep_order": 128 + 8,
+           "class_order_blocks": 2048, "full_width_tables": 8192, "r01_layout": 2048 + 8192}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])

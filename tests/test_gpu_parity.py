@@ -29,7 +29,7 @@ def test_bit_exact_vs_oracle(case, dtype, oracle_built):
                         steps=[0, 1, 1, 2, 8, 30])
 
 
-@pytest.mark.parametrize("flags", [4, 8, 16, 4 + 8 + 16, 128, 256, 128 + 8, 2048, 2048 + 256, 4096 + 8])
+@pytest.mark.parametrize("flags", [4, 8, 16, 4 + 8 + 16, 128, 256, 128 + 8, 2048, 2048 + 256, 4096 + 8, 8192, 8192 + 2048])
 def test_layout_variants(flags, oracle_built):
     for name, make, kw in parity_cases():
         compare_with_oracle(oracle_built, make(), Params(layout_flags=flags, **kw), 0, steps=[1, 9])
@@ -200,3 +200,4 @@ def test_dynamic_maxsum(dtype, oracle_built):
     from dynamic_common import check_dynamic_run
     for seed in (1, 2):
         check_dynamic_run(oracle_built, dtype=dtype, seed=seed)
+    check_dynamic_run(oracle_built, dtype=dtype, seed=3, float_tables=False)
