@@ -136,7 +136,15 @@ def cpu_baseline(graph, mode, dtype, budget_s=12.0):
     return out
 
 
-def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None):
+def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None, graph=None, storage=None):
+    """`achieved` / `frac`: SURVEY.md section 8(d)'s ALGORITHMIC bytes per cycle (every cost table
+    counted at the arithmetic width) over the measured time.  The engine stores tables whose
+    every entry is exactly representable in a narrower type in that type (lossless, results
+    bit-identical; include/maxsum_gpu.h mxs_table_storage): `stored_bytes_per_launch` is the
+    same count with the tables at their stored width and `frac_of_stored_bytes` the fraction of
+    the HBM peak those bytes correspond to -- the one to read as "how close to the memory system"
+    (a table-dominated workload can show `frac` > 1: it reads fewer bytes than the algorithmic
+    count)."""
     kernel_s = max(kernel_s, 1e-12)  # (the emulated engine of the CPU tests has no event clock)
     achieved = bytes_cycle / kernel_s / 1e9
     traffic, source = measured_traffic(workload, dtype)
@@ -146,6 +154,12 @@ def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None):
          "algorithmic_bytes_per_launch": bytes_cycle, "avg_launch_us": kernel_s * 1e6}
     if launches is not None:
         r["launches_per_cycle"] = launches
+    if graph is not None and storage is not None:
+        word = 8 if dtype == "f64" else 4
+        stored = bytes_cycle - int(graph.table_off[-1]) * word + storage["bytes_per_cycle"]
+        r["table_storage"] = {k: v for k, v in storage.items() if k != "bytes_per_cycle" and v}
+        r["stored_bytes_per_launch"] = stored
+        r["frac_of_stored_bytes"] = stored / kernel_s / 1e9 / HBM_PEAK_GBPS
     return r
 
 
@@ -169,11 +183,12 @@ def time_config(workload, dtype, graph, mode, budget_s=1.5):
         eng.sync()
         wall = time.perf_counter() - t0
         _, launches = eng.cycle_bytes()
+        storage = eng.table_storage()
     bytes_cycle = graph.cycle_bytes(word)
     return {"workload": workload, "dtype": dtype, "n_vars": graph.n_vars, "n_factors": graph.n_factors,
             "n_edges": graph.n_edges, "steps": steps, "ms_per_step": 1e3 * wall / steps,
             "iterations_per_s": steps / wall, "edge_messages_per_s": steps / wall * 2 * graph.n_edges,
-            "roofline": roofline_of(workload, dtype, bytes_cycle, event_ms * 1e-3 / steps, launches)}
+            "roofline": roofline_of(workload, dtype, bytes_cycle, event_ms * 1e-3 / steps, launches, graph, storage)}
 
 
 def extra_configs(skip=()):
@@ -322,6 +337,7 @@ def main():
         runner.sync()
         elapsed = time.perf_counter() - t0
         _, launches = runner.cycle_bytes()
+        storage = runner.table_storage()
         runner.close()
         out.update({
             "value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak",
@@ -331,7 +347,8 @@ def main():
                        "params": "damping 0.5/both, stability 0.1, start leafs",
                        "parallelism": "one GPU, one k_sweep launch per cycle",
                        "parity_checked": True, "parity_test": MAIN_PARITY_TEST},
-            "roofline": roofline_of(workload, args.dtype, bytes_cycle, event_ms * 1e-3 / args.steps, launches),
+            "roofline": roofline_of(workload, args.dtype, bytes_cycle, event_ms * 1e-3 / args.steps, launches,
+                                    graph, storage),
         })
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)

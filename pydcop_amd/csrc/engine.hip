@@ -433,12 +433,28 @@ struct Engine : EngineBase {
         if (L.classes[cls].tab_type == TAB_FULL) return MXS_OK;
         { int rc = sync(); if (rc) return rc; }
         L.classes[cls].tab_type = TAB_FULL;
+        for (int fi = 0; fi < L.n_factors; ++fi)
+            if (L.f_class[fi] == cls) L.f_tab_type[fi] = (uint8_t)TAB_FULL;
         if (graph_exec) {  // the captured cycle loop holds the pointers of the old class arrays
             (void)hipGraphExecDestroy(graph_exec);
             graph_exec = nullptr;
             graph_tried = false;
         }
         return upload_class_arrays();
+    }
+
+    // Factor fi can no longer be read from its narrow image: a register class goes back to full
+    // width as a whole; a workgroup-per-factor factor just gets its descriptor switched.
+    int widen_factor(int fi) {
+        if (L.f_tab_type[fi] == TAB_FULL) return MXS_OK;
+        if (L.f_class[fi] >= 0) return promote_class(L.f_class[fi]);
+        { int rc = sync(); if (rc) return rc; }
+        NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+        d.tab_off = L.f_tab_base[fi];
+        d.arity &= 255;
+        L.f_tab_type[fi] = (uint8_t)TAB_FULL;
+        HIP_TRY(copy_sync(ndesc.p + L.f_ndesc[fi], &d, sizeof(NaryDesc), hipMemcpyHostToDevice, stream));
+        return MXS_OK;
     }
 
     int init(const mxs_graph& g, const mxs_params& p, int dev) override {
@@ -890,16 +906,18 @@ struct Engine : EngineBase {
         HIP_TRY(hipGetLastError());
         HIP_TRY(copy_sync(eval_tables.p + L.eval_tab_off[fi], table, sizeof(double) * (size_t)n,
                           hipMemcpyHostToDevice, stream));  // also waits for the kernel above
-        const int cls = L.f_class[fi];
-        if (cls >= 0 && L.classes[cls].tab_type != TAB_FULL) {  // the class stores narrow records
-            const int t = L.classes[cls].tab_type;
+        if (L.f_tab_type[fi] != TAB_FULL) {  // the factor's table is read from a narrow image
+            const int t = L.f_tab_type[fi];
             const int fit = narrowest_tab_type(table, n, (int)sizeof(T));
-            if (fit >= t) {  // (TAB_I8 > TAB_I16 > TAB_F32: at least as narrow as the class's type)
-                std::vector<uint8_t> rec((size_t)L.classes[cls].ctab_rec, 0);
-                encode_tab_record(table, (int)n, t, rec.data());
+            if (fit >= t) {  // (TAB_I8 > TAB_I16 > TAB_F32: at least as narrow as the stored type)
+                const int cls = L.f_class[fi];
+                std::vector<uint8_t> rec((size_t)(cls >= 0 ? L.classes[cls].ctab_rec : n * tab_elem_bytes(t)), 0);
+                for (int64_t k0 = 0; k0 < n; k0 += 1 << 20)
+                    encode_tab_record(table + k0, (int)std::min<int64_t>(n - k0, 1 << 20), t,
+                                      rec.data() + k0 * tab_elem_bytes(t));
                 HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
             } else {
-                int rc = promote_class(cls);
+                int rc = widen_factor(fi);
                 if (rc) return rc;
             }
         }
@@ -940,10 +958,8 @@ struct Engine : EngineBase {
         HIP_TRY(pt->buf.upload(h, stream));
         parents[fi] = std::move(pt);
         // every slice of this relation must fit the narrow type its class stores tables in
-        const int cls = L.f_class[fi];
-        if (cls >= 0 && L.classes[cls].tab_type != TAB_FULL &&
-            narrowest_tab_type(parent, total, (int)sizeof(T)) < L.classes[cls].tab_type) {
-            int rc = promote_class(cls);
+        if (L.f_tab_type[fi] != TAB_FULL && narrowest_tab_type(parent, total, (int)sizeof(T)) < L.f_tab_type[fi]) {
+            int rc = widen_factor(fi);
             if (rc) return rc;
         }
         return MXS_OK;
@@ -979,8 +995,7 @@ struct Engine : EngineBase {
         }
         { int rc = sync(); if (rc) return rc; }
         const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
-        const int cls = L.f_class[fi];
-        const int ctype = cls >= 0 ? L.classes[cls].tab_type : TAB_FULL;
+        const int ctype = L.f_tab_type[fi];
         hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
                            tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
                            eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
@@ -1307,7 +1322,7 @@ struct Engine : EngineBase {
         }
         for (int k = 0; k < nE; ++k) L.vslot_v2f[k] = L.v2f_off[L.vslot_edge[k]];
         for (NaryDesc& d : L.ndesc)
-            for (int i = 0; i < d.arity; ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
+            for (int i = 0; i < (d.arity & 255); ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
         HIP_TRY(hipMemcpyAsync(edge_v2f.p, L.v2f_off.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
         HIP_TRY(hipMemcpyAsync(vslot_v2f.p, L.vslot_v2f.data(), sizeof(int32_t) * (size_t)nE, hipMemcpyHostToDevice, stream));
         if (!L.ndesc.empty())
@@ -1693,10 +1708,11 @@ int mxs_table_storage(const mxs_engine* e, int64_t factors[4], int64_t* table_by
     const int64_t w = L.opt.word;
     int64_t n[4] = {0, 0, 0, 0}, bytes = 0;
     for (int fi = 0; fi < L.n_factors; ++fi) {
-        const int cls = L.f_class[fi];
-        const int t = cls >= 0 ? L.classes[cls].tab_type : mxs::TAB_FULL;
+        const int t = L.f_tab_type[fi];
+        const int64_t entries = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         n[t] += 1;
-        bytes += t == mxs::TAB_FULL ? (L.eval_tab_off[fi + 1] - L.eval_tab_off[fi]) * w : L.classes[cls].ctab_rec;
+        if (t == mxs::TAB_FULL) bytes += entries * w;
+        else bytes += L.f_class[fi] >= 0 ? L.classes[L.f_class[fi]].ctab_rec : entries * mxs::tab_elem_bytes(t);
     }
     if (factors) std::memcpy(factors, n, sizeof(n));
     if (table_bytes) *table_bytes = bytes;

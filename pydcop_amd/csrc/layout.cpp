@@ -238,6 +238,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     L.f_tab_stride.assign(nF, 1);
     L.f_ctab_off.assign(nF, -1);
     L.f_class.assign(nF, -1);
+    L.f_ndesc.assign(nF, -1);
+    L.f_tab_type.assign(nF, (uint8_t)TAB_FULL);
 
     // ---- internal edges, F2V array (factor-major) ------------------------------
     L.edge_i2e.resize(nE);
@@ -399,6 +401,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     ci.ctab_base = (int64_t)((L.ctables.size() + 255) / 256 * 256);
                     L.ctables.resize((size_t)(ci.ctab_base + (int64_t)n * ci.ctab_rec), 0);
                     for (int j = 0; j < n; ++j) {
+                        L.f_tab_type[fi + j] = (uint8_t)t;
                         L.f_ctab_off[fi + j] = ci.ctab_base + (int64_t)j * ci.ctab_rec;
                         encode_tab_record(L.eval_tables.data() + L.eval_tab_off[fi + j], entries, t,
                                           L.ctables.data() + L.f_ctab_off[fi + j]);
@@ -439,6 +442,26 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.f2v_off[i] = in ? L.f2v_off[d.edge_base + i] : 0;
                         d.v2f_off[i] = 0;  // filled in once the variable side is laid out
                     }
+                    // compact storage of THIS factor's table (row-major, like the full-width image)
+                    if (L.opt.compact_tables) {
+                        const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];
+                        const int t = narrowest_tab_type(L.eval_tables.data() + L.eval_tab_off[f2], ne, L.opt.word);
+                        if (t != TAB_FULL) {
+                            const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
+                            L.ctables.resize((size_t)(at + ne * tab_elem_bytes(t)), 0);
+                            // (entries back to back: encode_tab_record takes int counts)
+                            for (int64_t k0 = 0; k0 < ne; k0 += 1 << 20) {
+                                const int cnt = (int)std::min<int64_t>(ne - k0, 1 << 20);
+                                encode_tab_record(L.eval_tables.data() + L.eval_tab_off[f2] + k0, cnt, t,
+                                                  L.ctables.data() + at + k0 * tab_elem_bytes(t));
+                            }
+                            L.f_tab_type[f2] = (uint8_t)t;
+                            L.f_ctab_off[f2] = at;
+                            d.tab_off = at;
+                            d.arity |= t << 8;
+                        }
+                    }
+                    L.f_ndesc[f2] = (int32_t)L.ndesc.size();
                     L.ndesc.push_back(d);
                 }
                 L.nary_launches.push_back(nl);
@@ -543,7 +566,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     L.v2f_elems = voff;
     for (int k = 0; k < nE; ++k) L.v2f_off[L.vslot_edge[k]] = L.vslot_v2f[k];
     for (NaryDesc& d : L.ndesc)
-        for (int i = 0; i < d.arity; ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
+        for (int i = 0; i < (d.arity & 255); ++i) d.v2f_off[i] = L.v2f_off[d.edge_base + i];
 
     // Launch order of the sweep classes: the longest per-thread chains first
     // (generic classes, then the gathering variable classes, then the streaming

@@ -126,7 +126,9 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
                    // needs, read with ONE scalar load (no chain of dependent loads)
     int64_t tab_off;     // element offset of its row-major table
     int32_t edge_base;   // internal id of its first edge
-    int32_t arity;
+    int32_t arity;       // low byte: the arity; next byte: TabType of its table -- tab_off is then
+                         // a BYTE offset into the compact image (ctables) instead of an element
+                         // offset into the full-width one
     int32_t dom[4];      // domain sizes in dimensions order (1 beyond the arity)
     int32_t v2f_off[4];  // V2F offsets of the incoming messages
     int32_t f2v_off[4];  // F2V offsets of the outgoing messages
@@ -226,6 +228,8 @@ struct Layout {
                                      // (UN-negated values: the kernel flips the sign on load in max mode)
     std::vector<int64_t> f_ctab_off; // [n_factors] byte offset of the factor's compact record, -1 = none
     std::vector<int32_t> f_class;    // [n_factors] index into classes of the factor's class (-1: n-ary launch)
+    std::vector<int32_t> f_ndesc;    // [n_factors] index into ndesc (K_F_NARY factors), else -1
+    std::vector<uint8_t> f_tab_type; // [n_factors] TabType the factor's table is read as
     // variables (internal order)
     std::vector<int32_t> vrowptr;    // [n_vars+1] var-major slot ranges (CSR)
     std::vector<int32_t> vslot_edge; // [n_edges] internal edge id of the slot
