@@ -140,6 +140,63 @@ def run_reference_maxsum(dcop, cycles, params=None, cg=None, return_comps=False)
     return values, costs
 
 
+def run_reference_amaxsum(dcop, max_generations=-1, params=None, cg=None, max_messages=None):
+    """The reference's ASYNCHRONOUS Max-Sum computations (pydcop/algorithms/amaxsum.py) under
+    FIFO delivery: every computation started in graph order, ONE queue, messages handled first
+    in first out -- the delivery order oracle/amaxsum_oracle.c restates.  Generation 0 = the
+    start messages; a message sent while handling one of generation g belongs to g + 1; only
+    generations < max_generations are delivered (all of them: -1; the run ends by itself when the
+    send rule of amaxsum.py:222-244 has silenced every edge).
+
+    Returns ({var: value}, {var: cost}, info) with info = {"delivered", "generation_sizes",
+    "comps"}."""
+    install_shims()
+    from pydcop.algorithms import AlgorithmDef, ComputationDef, load_algorithm_module
+    from pydcop.computations_graph import factor_graph
+
+    p = {"noise": 0}
+    p.update(params or {})
+    algo = AlgorithmDef.build_with_default_param("amaxsum", p, mode=dcop.objective)
+    if cg is None:
+        cg = factor_graph.build_computation_graph(dcop)
+    module = load_algorithm_module("amaxsum")
+    import logging
+    logging.disable(logging.CRITICAL)
+    comps = {}
+    q = deque()
+    sizes = {}
+    handling = [-1]
+
+    def sender(src, dest, msg, prio=None, on_error=None):
+        g = handling[0] + 1
+        sizes[g] = sizes.get(g, 0) + 1
+        q.append((src, dest, msg, g))
+
+    delivered = 0
+    try:
+        for node in cg.nodes:
+            comps[node.name] = module.build_computation(ComputationDef(node, algo))
+            comps[node.name].message_sender = sender
+        for c in comps.values():
+            c.start()
+        while q:
+            if max_generations >= 0 and q[0][3] >= max_generations:
+                break
+            if max_messages is not None and delivered >= max_messages:
+                break
+            s, d, m, g = q.popleft()
+            handling[0] = g
+            comps[d].on_message(s, m, 0.0)
+            delivered += 1
+    finally:
+        logging.disable(logging.NOTSET)
+    values = {v: comps[v].current_value for v in dcop.variables}
+    costs = {v: comps[v].current_cost for v in dcop.variables}
+    info = {"delivered": delivered, "generation_sizes": [sizes[k] for k in sorted(sizes)], "comps": comps,
+            "pending": len(q)}
+    return values, costs, info
+
+
 def flat_to_dcop(graph, mode="min", name="flat"):
     """Build reference objects (DCOP + ComputationsFactorGraph) from a FlatGraph:
     VariableWithCostDict variables (pydcop/dcop/objects.py:410) and extensional

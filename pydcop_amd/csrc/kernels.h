@@ -30,6 +30,7 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
 
 #include "layout.h"
 
@@ -1076,8 +1077,9 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
 
 // blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
 // layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
-// The storage type of the factor's table rides in its descriptor (block-uniform branch).
-template <typename T, int A, int NJ>
+// TT = storage type of the group's tables (NaryLaunch::tab_type): one instantiation per type,
+// so that none pays for another's registers.
+template <typename T, int A, int NJ, typename TT>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
     __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
@@ -1086,16 +1088,11 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     __shared__ int s_nomatch[NARY_MAX_ARITY];
     __shared__ int s_cnt[NARY_MAX_ARITY];
     const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
-    const int ttype = fd.arity >> 8;        // layout.h TabType (the arity itself is the template's A)
-    const bool neg = a.tab_neg != 0;
-    if (ttype == TAB_I8)
-        nary_block<T, A, NJ, int8_t>(a, fd, (const int8_t*)(a.ctables + fd.tab_off), neg, s_msg, s_key, s_prev, s_nomatch, s_cnt);
-    else if (ttype == TAB_I16)
-        nary_block<T, A, NJ, int16_t>(a, fd, (const int16_t*)(a.ctables + fd.tab_off), neg, s_msg, s_key, s_prev, s_nomatch, s_cnt);
-    else if (ttype == TAB_F32)
-        nary_block<T, A, NJ, float>(a, fd, (const float*)(a.ctables + fd.tab_off), neg, s_msg, s_key, s_prev, s_nomatch, s_cnt);
-    else
+    if constexpr (std::is_same<TT, T>::value)
         nary_block<T, A, NJ, T>(a, fd, a.tables + fd.tab_off, false, s_msg, s_key, s_prev, s_nomatch, s_cnt);
+    else
+        nary_block<T, A, NJ, TT>(a, fd, (const TT*)(a.ctables + fd.tab_off), a.tab_neg != 0, s_msg, s_key, s_prev,
+                                 s_nomatch, s_cnt);
 }
 
 // ---------------------------------------------------------------------------

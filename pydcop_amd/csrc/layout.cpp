@@ -31,6 +31,8 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.compact_tables = MXS_COMPACT_TABLES_DEFAULT != 0;
     if (f & 16384) o.compact_tables = true;   // bit14: narrow storage of exactly-representable tables
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
+    o.nary_narrow_ints = MXS_NARY_NARROW_INTS_DEFAULT != 0;
+    if (f & 32768) o.nary_narrow_ints = !o.nary_narrow_ints;  // bit15: the other n-ary policy
     return o;
 }
 
@@ -204,7 +206,15 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 if (R >= 64 && R <= 1024 && sumd <= 1024) {
                     const int nj = (int)((R + BLOCK - 1) / BLOCK);
                     const int waves = (int)(((R + nj - 1) / nj + 63) / 64);  // 1..4
-                    k = FKey{K_F_NARY, (ar * 16 + nj) * 16 + waves};
+                    // storage type of this factor's table: one launch group (= one kernel
+                    // instantiation) per type
+                    int t = TAB_FULL;
+                    if (L.opt.compact_tables) {
+                        t = narrowest_tab_type(g.tables + g.table_off[f], g.table_off[f + 1] - g.table_off[f], L.opt.word);
+                        if (!L.opt.nary_narrow_ints && (t == TAB_I8 || t == TAB_I16))
+                            t = L.opt.word == 8 ? TAB_F32 : TAB_FULL;  // (every int16 is a float)
+                    }
+                    k = FKey{K_F_NARY, ((ar * 16 + nj) * 16 + waves) * 4 + t};
                 }
             }
         }
@@ -429,7 +439,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.classes.push_back(ci);
                 sweep_class(cls, BLOCK, key.cut || second);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
-                NaryLaunch nl{key.D / 256, (key.D / 16) % 16, (key.D % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut};
+                const int code = key.D / 4, t = key.D % 4;
+                NaryLaunch nl{code / 256, (code / 16) % 16, (code % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut, t};
                 for (int j = 0; j < n; ++j) {
                     const int f2 = fi + j;
                     NaryDesc d{};
@@ -443,9 +454,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.v2f_off[i] = 0;  // filled in once the variable side is laid out
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
-                    if (L.opt.compact_tables) {
+                    {
                         const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];
-                        const int t = narrowest_tab_type(L.eval_tables.data() + L.eval_tab_off[f2], ne, L.opt.word);
                         if (t != TAB_FULL) {
                             const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
                             L.ctables.resize((size_t)(at + ne * tab_elem_bytes(t)), 0);
@@ -458,7 +468,6 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                             L.f_tab_type[f2] = (uint8_t)t;
                             L.f_ctab_off[f2] = at;
                             d.tab_off = at;
-                            d.arity |= t << 8;
                         }
                     }
                     L.f_ndesc[f2] = (int32_t)L.ndesc.size();

@@ -70,6 +70,9 @@ constexpr int BLOCK = MXS_BLOCK;
 #ifndef MXS_SCHEDULE_DEFAULT
 #define MXS_SCHEDULE_DEFAULT 1  // layout_flags bit11 (2048) forces the block schedule off, bit12 (4096) on
 #endif
+#ifndef MXS_NARY_NARROW_INTS_DEFAULT
+#define MXS_NARY_NARROW_INTS_DEFAULT 0  // layout_flags bit15 (32768) flips it
+#endif
 #ifndef MXS_COMPACT_TABLES_DEFAULT
 #define MXS_COMPACT_TABLES_DEFAULT 1  // layout_flags bit13 (8192) forces full-width tables, bit14 (16384) compact
 #endif
@@ -124,11 +127,10 @@ struct ClassInfo {       // one per class, read with one scalar load
 
 struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block
                    // needs, read with ONE scalar load (no chain of dependent loads)
-    int64_t tab_off;     // element offset of its row-major table
+    int64_t tab_off;     // element offset of its row-major table in the full-width image -- or, in a
+                         // launch group with a narrow NaryLaunch::tab_type, BYTE offset in ctables
     int32_t edge_base;   // internal id of its first edge
-    int32_t arity;       // low byte: the arity; next byte: TabType of its table -- tab_off is then
-                         // a BYTE offset into the compact image (ctables) instead of an element
-                         // offset into the full-width one
+    int32_t arity;
     int32_t dom[4];      // domain sizes in dimensions order (1 beyond the arity)
     int32_t v2f_off[4];  // V2F offsets of the incoming messages
     int32_t f2v_off[4];  // F2V offsets of the outgoing messages
@@ -141,6 +143,7 @@ struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY fa
     int32_t first;       // first descriptor of the group
     int32_t count;
     int32_t cut;         // 1: factors reading ghost variables (second phase of a sharded cycle)
+    int32_t tab_type;    // TabType the tables of the group are stored in (one kernel instantiation each)
 };
 
 struct WaveMeta {  // per wave of a K_V_PACK class: read with ONE scalar load, so a lane
@@ -164,7 +167,8 @@ struct LayoutOptions {
     bool sort_factors = false;   // inside a class, factors follow their first variable's order
     bool factors_second = false; // shard: all register factor classes go to the second launch
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
-    bool compact_tables = false; // register classes store exactly-representable tables in a narrow type
+    bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
+    bool nary_narrow_ints = false; // workgroup-per-factor tables may use int8 / int16 (else: f32 at most)
 };
 
 struct Layout {

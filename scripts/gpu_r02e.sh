@@ -4,7 +4,7 @@ TAG=${1:-r02e}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 : > $OUT/ab.txt
 for w in "meeting_50k --steps 100 --warmup 10" "meeting_50k --dtype f32 --steps 100 --warmup 10"; do
-  for f in 0 8192; do
+  for f in 0 32768 8192; do
     timeout 600 python bench.py --no-cpu-baseline --configs main --workload $w --layout-flags $f 2>&1 | tail -1 | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); r = d['roofline']
