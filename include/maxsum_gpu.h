@@ -337,6 +337,38 @@ int mxs_destroy(mxs_engine *e);
 /* Message of the last error on this thread ("" if none). */
 const char *mxs_last_error(void);
 
+/* ---- asynchronous Max-Sum (pydcop/algorithms/amaxsum.py) -------------------------------------
+ * The reference's amaxsum runs one handler per DELIVERED message (factor: amaxsum.py:191-250,
+ * waits until every variable has been heard from, answers everyone but the sender; variable:
+ * :366-424, selects its value and answers every factor but the sender), so what it computes
+ * depends on the delivery order.  This engine reproduces it under the one order that is defined
+ * without a thread scheduler: every computation started in graph order (variables, then
+ * factors) and ONE first-in-first-out queue -- handled a GENERATION at a time (generation 0 = the
+ * start messages, generation g + 1 = the messages sent while handling generation g; a FIFO
+ * handles all of g before any of g + 1).  Bit for bit the reference's own computations under that
+ * order (oracle/amaxsum_oracle.c, pinned by tests/test_amaxsum_oracle_vs_reference.py).  The run
+ * ends by itself when the send rule (approx_match + SAME_COUNT, amaxsum.py:222-244) has silenced
+ * every edge.  Same flat graph and parameters as mxs_create; messages in the msg_off layout. */
+typedef struct mxs_amaxsum mxs_amaxsum;
+/* start() of every computation (amaxsum.py:140-160, 295-332): generation 0 is queued. */
+int mxs_amaxsum_create(const mxs_graph *g, const mxs_params *p, int32_t device, mxs_amaxsum **out);
+int mxs_amaxsum_reset(mxs_amaxsum *e);
+/* Deliver whole generations while the next one's number is < max_generations (< 0: until no
+ * message is left); *delivered = messages handled by this call. */
+int mxs_amaxsum_run(mxs_amaxsum *e, int32_t max_generations, int64_t *delivered);
+/* Number of the generation waiting in the queue, its size (0 = quiescent), messages handled so far. */
+int mxs_amaxsum_status(const mxs_amaxsum *e, int32_t *next_generation, int64_t *pending, int64_t *delivered);
+/* Messages per generation so far (the waiting one included); *n = number of generations. */
+int mxs_amaxsum_generation_sizes(const mxs_amaxsum *e, int64_t *out, int32_t cap, int32_t *n);
+/* (current_value index, current_cost) of every variable (value_selection, amaxsum.py:381-383). */
+int mxs_amaxsum_get_assignment(mxs_amaxsum *e, int32_t *idx, double *belief);
+/* Parity/debug: per edge, what the factor holds from the variable (f_cost, f_has) and last sent
+ * to it (f_prev, f_cnt = _prev_messages count), and the same on the variable side. */
+int mxs_amaxsum_get_messages(mxs_amaxsum *e, double *f_cost, double *v_cost, double *f_prev, double *v_prev,
+                             uint8_t *f_has, uint8_t *v_has, uint8_t *f_cnt, uint8_t *v_cnt);
+int mxs_amaxsum_eval_cost(mxs_amaxsum *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
+int mxs_amaxsum_destroy(mxs_amaxsum *e);
+
 /* Library/ABI version (major*100+minor). */
 int32_t mxs_version(void);
 

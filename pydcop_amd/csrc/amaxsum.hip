@@ -1,0 +1,775 @@
+// amaxsum.hip -- the reference's ASYNCHRONOUS Max-Sum (pydcop/algorithms/amaxsum.py) on gfx950,
+// under first-in-first-out delivery, one GENERATION of messages per step.
+//
+// The reference runs one handler per delivered message (`_on_maxsum_msg`, amaxsum.py:191-250 for
+// factors, :366-424 for variables); what it computes depends on the order messages arrive in.
+// The one order that is defined without a thread scheduler is a single FIFO queue with the
+// computations started in graph order (variables, then factors) -- what oracle/ref_harness.py
+// runs the reference's own objects under, and what oracle/amaxsum_oracle.c restates.  A FIFO
+// handles every message of generation g (generation 0 = the start messages) before any of
+// generation g + 1 (= those sent while handling generation g), and two messages of one
+// generation interact only when they go to the SAME computation.  So a generation is processed
+// as a batch:
+//
+//   k_dest      per message: its destination computation and how many messages its handler
+//               can send at most (the destination's other neighbours)
+//   scan        exclusive sum of those capacities = the message's block of output slots, in
+//               FIFO order
+//   sort        stable radix sort of the messages by destination (hipCUB)
+//   k_process   one thread per destination: handles ITS messages one after the other in FIFO
+//               order, exactly like the reference's handler (same expressions, same order of
+//               additions -- select_value in first-arrival order of the factors, maxsum.py:609),
+//               writing what it sends into the trigger's output slots
+//   compact     the slots that hold a message, in slot order = the FIFO order of generation g + 1
+//
+// Nothing here is a dense contraction: integer bookkeeping + a few adds per message element.
+// The run ends by itself when the send rule (approx_match + SAME_COUNT) has silenced every edge.
+//
+// Built into libmaxsum_hip.so by hipcc; the host emulation of the CPU tests compiles the
+// C-ABI entry points as stubs (the batch primitives are hipCUB's).
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/maxsum_gpu.h"
+
+extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+namespace amx {
+
+constexpr int SAME_COUNT = 4;  // maxsum.py:106
+constexpr int TPB = 256;
+
+template <typename U>
+struct Buf {
+    U* p = nullptr;
+    size_t n = 0;
+    hipError_t reserve(size_t count) {  // contents are NOT kept
+        if (count <= n && p) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = count + count / 2 + 1024;
+        return hipMalloc((void**)&p, n * sizeof(U));
+    }
+    hipError_t upload(const std::vector<U>& h) {
+        hipError_t e = reserve(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpy(p, h.data(), h.size() * sizeof(U), hipMemcpyHostToDevice);
+    }
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+template <typename T>
+struct Dev {  // what the kernels see
+    int32_t n_vars, n_factors, n_edges, dmax, is_max, start_mode, damp_f, damp_v;
+    T damping, stability;
+    const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *init_idx;
+    const int64_t *table_off, *cost_off, *msg_off;
+    const T *tables, *var_cost;
+    T *f_cost, *f_prev, *v_cost, *v_prev;
+    uint8_t *f_has, *f_cnt, *v_has, *v_cnt;
+    int32_t *f_nhas, *v_narr, *v_order, *sel;
+    T* belief;
+};
+
+template <typename T>
+__device__ __forceinline__ T absT(T x) { return x < (T)0 ? -x : x; }
+
+// approx_match, maxsum.py:688-710, one component
+template <typename T>
+__device__ __forceinline__ bool comp_match(T c, T prev_c, T stability) {
+    if (prev_c != c) {
+        const T delta = absT(prev_c - c);
+        if (prev_c + c != (T)0) {
+            if (!(((T)2 * delta / absT(prev_c + c)) < stability)) return false;
+        } else {
+            return false;
+        }
+    }
+    return true;
+}
+
+// factor_costs_for_var (maxsum.py:382-447), value d of the variable at scope position pos:
+// opt over the other variables' assignments of  f_val + sum_cost,  a variable not heard from
+// contributing nothing (:430-436).  Scalar loops, no local arrays.
+template <typename T>
+__device__ T factor_value(const Dev<T>& g, int f, int pos, int d, int64_t others) {
+    const int e0 = g.factor_rowptr[f], arity = g.factor_rowptr[f + 1] - e0;
+    T best = g.is_max ? -(T)INFINITY : (T)INFINITY;
+    for (int64_t lin = 0; lin < others; ++lin) {
+        int64_t rem = others, l = lin, t = 0;
+        T sum_cost = (T)0;
+        for (int i = 0; i < arity; ++i) {
+            const int e = e0 + i;
+            const int Di = g.dom_size[g.edge_var[e]];
+            int digit;
+            if (i == pos) {
+                digit = d;
+            } else {
+                rem /= Di;
+                digit = (int)(l / rem);
+                l -= (int64_t)digit * rem;
+                if (g.f_has[e]) sum_cost += g.f_cost[g.msg_off[e] + digit];
+            }
+            t = t * Di + digit;
+        }
+        const T cur = g.tables[g.table_off[f] + t] + sum_cost;
+        if (g.is_max ? best < cur : best > cur) best = cur;
+    }
+    return best;
+}
+
+// apply_damping + the send rule (amaxsum.py:213-244 / 386-424) on the message sitting in `msg`
+// (D values, global memory).  Returns true if it is sent (prev / count updated).
+template <typename T>
+__device__ bool damp_and_decide(const Dev<T>& g, T* msg, T* prev, uint8_t* cnt, int D, bool damp_on) {
+    const uint8_t c = *cnt;
+    bool match = c > 0;
+    for (int d = 0; d < D; ++d) {
+        T m = msg[d];
+        if (c > 0 && damp_on) m = g.damping * prev[d] + ((T)1 - g.damping) * m;  // apply_damping: identity when prev is None
+        msg[d] = m;
+        if (match) match = comp_match(m, prev[d], g.stability);
+    }
+    if (match && c >= SAME_COUNT) return false;  // same and already sent SAME_COUNT times
+    for (int d = 0; d < D; ++d) prev[d] = msg[d];
+    *cnt = match ? (uint8_t)(c + 1) : (uint8_t)1;
+    return true;
+}
+
+// select_value (maxsum.py:584-620): held costs summed in first-arrival order, first index wins ties
+template <typename T>
+__device__ void select_value(const Dev<T>& g, int v) {
+    const int D = g.dom_size[v], k0 = g.var_rowptr[v], na = g.v_narr[v];
+    const T* c = g.var_cost + g.cost_off[v];
+    int best = 0;
+    T best_c = (T)0;
+    for (int d = 0; d < D; ++d) {
+        T b = c[d];
+        for (int r = 0; r < na; ++r) b += g.v_cost[g.msg_off[g.v_order[k0 + r]] + d];
+        if (d == 0 || (g.is_max ? b > best_c : b < best_c)) {
+            best = d;
+            best_c = b;
+        }
+    }
+    g.sel[v] = best;
+    g.belief[v] = best_c;
+}
+
+// costs_for_factor (maxsum.py:623-676) for the slot k of variable v, written to out[0..D)
+template <typename T>
+__device__ void costs_for_factor(const Dev<T>& g, int v, int kout, T* out) {
+    const int D = g.dom_size[v], k0 = g.var_rowptr[v], k1 = g.var_rowptr[v + 1];
+    const T* c = g.var_cost + g.cost_off[v];
+    T sum_cost = (T)0;
+    for (int d = 0; d < D; ++d) {
+        T m = c[d];
+        for (int k = k0; k < k1; ++k) {
+            const int e = g.var_edges[k];
+            if (k == kout || !g.v_has[e]) continue;
+            const T x = g.v_cost[g.msg_off[e] + d];
+            sum_cost += x;
+            m += x;
+        }
+        out[d] = m;
+    }
+    const T avg = sum_cost / (T)D;
+    for (int d = 0; d < D; ++d) out[d] = out[d] - avg;
+}
+
+// ---- start(): variables then factors, messages straight into the generation-0 queue -------
+// q_code = edge * 2 + dir (dir 0: variable -> factor, 1: factor -> variable)
+template <typename T>
+__global__ void k_start_count(Dev<T> g, int32_t* cnt) {  // cnt[node] = start messages of the node
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < g.n_vars) {
+        const int deg = g.var_rowptr[i + 1] - g.var_rowptr[i];
+        const bool sends = (deg == 1 && g.start_mode == MXS_START_LEAFS) || g.start_mode != MXS_START_LEAFS;
+        cnt[i] = sends ? deg : 0;
+    } else if (i < g.n_vars + g.n_factors) {
+        const int f = i - g.n_vars;
+        const int ar = g.factor_rowptr[f + 1] - g.factor_rowptr[f];
+        const bool sends = (ar == 1 && g.start_mode != MXS_START_ALL) || g.start_mode == MXS_START_ALL;
+        cnt[i] = sends ? ar : 0;
+    }
+}
+
+template <typename T>
+__global__ void k_start_emit(Dev<T> g, const int32_t* base, int32_t* q_code, T* q_pay) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < g.n_vars) {
+        const int v = i;
+        if (g.init_idx && g.init_idx[v] >= 0) {  // value_selection(initial_value, None)
+            g.sel[v] = g.init_idx[v];
+            g.belief[v] = (T)0;
+        } else {
+            select_value(g, v);
+        }
+        const int k0 = g.var_rowptr[v], deg = g.var_rowptr[v + 1] - k0;
+        const bool sends = (deg == 1 && g.start_mode == MXS_START_LEAFS) || g.start_mode != MXS_START_LEAFS;
+        if (!sends) return;
+        for (int k = 0; k < deg; ++k) {
+            const int64_t at = (int64_t)base[i] + k;
+            costs_for_factor(g, v, k0 + k, q_pay + at * g.dmax);
+            q_code[at] = g.var_edges[k0 + k] * 2;
+        }
+    } else if (i < g.n_vars + g.n_factors) {
+        const int f = i - g.n_vars;
+        const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
+        const bool sends = (ar == 1 && g.start_mode != MXS_START_ALL) || g.start_mode == MXS_START_ALL;
+        if (!sends) return;
+        for (int p = 0; p < ar; ++p) {
+            const int64_t at = (int64_t)base[i] + p;
+            int64_t others = 1;
+            for (int q = 0; q < ar; ++q)
+                if (q != p) others *= g.dom_size[g.edge_var[e0 + q]];
+            const int D = g.dom_size[g.edge_var[e0 + p]];
+            for (int d = 0; d < D; ++d) q_pay[at * g.dmax + d] = factor_value(g, f, p, d, others);
+            q_code[at] = (e0 + p) * 2 + 1;
+        }
+    }
+}
+
+// ---- one generation --------------------------------------------------------------------------
+template <typename T>
+__global__ void k_dest(Dev<T> g, const int32_t* q_code, int64_t n, int32_t* dest, int32_t* cap) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int e = q_code[i] >> 1, dir = q_code[i] & 1;
+    if (dir == 0) {
+        const int f = g.edge_factor[e];
+        dest[i] = g.n_vars + f;
+        cap[i] = g.factor_rowptr[f + 1] - g.factor_rowptr[f] - 1;
+    } else {
+        const int v = g.edge_var[e];
+        dest[i] = v;
+        cap[i] = g.var_rowptr[v + 1] - g.var_rowptr[v] - 1;
+    }
+}
+
+template <typename T>
+__device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_code, T* s_pay) {
+    const int e = code >> 1;
+    const int v = g.edge_var[e], f = g.edge_factor[e];
+    const int D = g.dom_size[v];
+    if ((code & 1) == 0) {  // variable -> factor: amaxsum.py:191-250
+        for (int d = 0; d < D; ++d) g.f_cost[g.msg_off[e] + d] = pay[d];
+        if (!g.f_has[e]) {
+            g.f_has[e] = 1;
+            g.f_nhas[f] += 1;
+        }
+        const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
+        if (g.f_nhas[f] != ar) return;  // still waiting for some variable (:206)
+        int slot = 0;
+        for (int p = 0; p < ar; ++p) {
+            const int e2 = e0 + p;
+            if (e2 == e) continue;  // not back to the sender
+            const int D2 = g.dom_size[g.edge_var[e2]];
+            int64_t others = 1;
+            for (int q = 0; q < ar; ++q)
+                if (q != p) others *= g.dom_size[g.edge_var[e0 + q]];
+            T* out = s_pay + (int64_t)slot * g.dmax;
+            for (int d = 0; d < D2; ++d) out[d] = factor_value(g, f, p, d, others);
+            if (damp_and_decide(g, out, g.f_prev + g.msg_off[e2], &g.f_cnt[e2], D2, g.damp_f != 0))
+                s_code[slot] = e2 * 2 + 1;
+            ++slot;
+        }
+    } else {  // factor -> variable: amaxsum.py:366-424
+        for (int d = 0; d < D; ++d) g.v_cost[g.msg_off[e] + d] = pay[d];
+        const int k0 = g.var_rowptr[v], k1 = g.var_rowptr[v + 1];
+        if (!g.v_has[e]) {
+            g.v_has[e] = 1;
+            g.v_order[k0 + g.v_narr[v]] = e;
+            g.v_narr[v] += 1;
+        }
+        select_value(g, v);
+        int slot = 0;
+        for (int k = k0; k < k1; ++k) {
+            const int e2 = g.var_edges[k];
+            if (e2 == e) continue;
+            T* out = s_pay + (int64_t)slot * g.dmax;
+            costs_for_factor(g, v, k, out);
+            if (damp_and_decide(g, out, g.v_prev + g.msg_off[e2], &g.v_cnt[e2], D, g.damp_v != 0))
+                s_code[slot] = e2 * 2;
+            ++slot;
+        }
+    }
+}
+
+// order[p]: FIFO index of the p-th message after the stable sort by destination
+template <typename T>
+__global__ void k_process(Dev<T> g, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
+                          const int32_t* order, int64_t n, const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= n) return;
+    if (p > 0 && dest_sorted[p] == dest_sorted[p - 1]) return;  // not the first of its destination
+    const int32_t dst = dest_sorted[p];
+    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {  // its messages, in FIFO order
+        const int64_t i = order[r];
+        handle(g, q_code[i], q_pay + i * g.dmax, s_code + slot_base[i], s_pay + slot_base[i] * g.dmax);
+    }
+}
+
+template <typename T>
+__global__ void k_gather(const int32_t* s_code, const T* s_pay, const int64_t* pos, int64_t n_slots, int dmax,
+                         int32_t* q_code, T* q_pay) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots || s_code[s] < 0) return;
+    const int64_t at = pos[s];
+    q_code[at] = s_code[s];
+    for (int d = 0; d < dmax; ++d) q_pay[at * dmax + d] = s_pay[s * dmax + d];
+}
+
+__global__ void k_flags(const int32_t* s_code, int64_t n, int64_t* flag) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) flag[s] = s_code[s] >= 0 ? 1 : 0;
+}
+
+struct Base {
+    virtual ~Base() {}
+    virtual int init(const mxs_graph& g, const mxs_params& p, int device) = 0;
+    virtual int reset() = 0;
+    virtual int run(int32_t max_generations, int64_t* delivered) = 0;
+    virtual int get_assignment(int32_t* idx, double* belief) = 0;
+    virtual int get_messages(double* fc, double* vc, double* fp, double* vp, uint8_t* fh, uint8_t* vh, uint8_t* fn,
+                             uint8_t* vn) = 0;
+    virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
+    int32_t next_generation = 0;
+    int64_t pending = 0, delivered_total = 0;
+    std::vector<int64_t> gen_sizes;
+};
+
+static int fail(int code, const std::string& msg) {
+    mxs_set_last_error(msg.c_str());
+    return code;
+}
+#define AMX_TRY(call)                                                                        \
+    do {                                                                                     \
+        hipError_t e__ = (call);                                                             \
+        if (e__ != hipSuccess)                                                               \
+            return fail(MXS_E_HIP, std::string(#call) + ": " + hipGetErrorString(e__));       \
+    } while (0)
+
+template <typename T>
+struct Engine : Base {
+    int device = 0;
+    Dev<T> g{};
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_vrow, h_vedges;
+    std::vector<int64_t> h_toff, h_coff, h_moff;
+    std::vector<double> h_tables, h_eval_cost;
+    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx;
+    Buf<int64_t> table_off, cost_off, msg_off;
+    Buf<T> tables, var_cost, f_cost, f_prev, v_cost, v_prev, belief;
+    Buf<uint8_t> f_has, f_cnt, v_has, v_cnt;
+    Buf<int32_t> f_nhas, v_narr, v_order, sel;
+    // queue of the current generation, work arrays of a step
+    Buf<int32_t> q_code, q_code2, dest, dest_sorted, order, order_in, cap, s_code, start_cnt, start_base;
+    Buf<T> q_pay, q_pay2, s_pay;
+    Buf<int64_t> slot_base, flag, pos, cap64;
+    Buf<uint8_t> temp;
+    int64_t nm = 0;
+
+    int grid(int64_t n) const { return (int)((n + TPB - 1) / TPB); }
+
+    int init(const mxs_graph& G, const mxs_params& p, int dev) override {
+        device = dev;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(MXS_E_NODEVICE, "no HIP device visible: the Max-Sum engine has no CPU fallback");
+        if (dev < 0 || dev >= count) return fail(MXS_E_INVALID, "device index out of range");
+        AMX_TRY(hipSetDevice(dev));
+        const int nV = G.n_vars, nF = G.n_factors, nE = G.n_edges;
+        if (nV < 0 || nF < 0 || nE < 0) return fail(MXS_E_INVALID, "negative size");
+        h_dom.assign(G.dom_size, G.dom_size + nV);
+        h_frow.assign(G.factor_rowptr, G.factor_rowptr + nF + 1);
+        h_evar.assign(G.edge_var, G.edge_var + nE);
+        h_vrow.assign(G.var_rowptr, G.var_rowptr + nV + 1);
+        h_vedges.assign(G.var_edges, G.var_edges + nE);
+        h_toff.assign(G.table_off, G.table_off + nF + 1);
+        int dmax = 1;
+        h_coff.assign(nV + 1, 0);
+        for (int v = 0; v < nV; ++v) {
+            if (h_dom[v] < 1 || h_dom[v] > 4096) return fail(MXS_E_INVALID, "domain size not in 1..4096");
+            dmax = std::max(dmax, h_dom[v]);
+            h_coff[v + 1] = h_coff[v] + h_dom[v];
+        }
+        h_moff.assign(nE + 1, 0);
+        std::vector<int32_t> h_efac(nE);
+        for (int f = 0; f < nF; ++f) {
+            if (h_frow[f + 1] <= h_frow[f] || h_frow[f + 1] - h_frow[f] > 16) return fail(MXS_E_INVALID, "bad factor arity");
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) h_efac[e] = f;
+        }
+        for (int e = 0; e < nE; ++e) {
+            if (h_evar[e] < 0 || h_evar[e] >= nV) return fail(MXS_E_INVALID, "edge_var out of range");
+            h_moff[e + 1] = h_moff[e] + h_dom[h_evar[e]];
+        }
+        nm = h_moff[nE];
+        h_tables.assign(G.tables, G.tables + h_toff[nF]);
+        const double* ev = G.eval_var_cost ? G.eval_var_cost : G.var_cost;
+        h_eval_cost.assign(ev, ev + h_coff[nV]);
+        std::vector<T> tt(h_tables.size()), vc((size_t)h_coff[nV]);
+        for (size_t i = 0; i < tt.size(); ++i) tt[i] = (T)h_tables[i];
+        for (size_t i = 0; i < vc.size(); ++i) vc[i] = (T)G.var_cost[i];
+        AMX_TRY(dom_size.upload(h_dom));
+        AMX_TRY(factor_rowptr.upload(h_frow));
+        AMX_TRY(edge_var.upload(h_evar));
+        AMX_TRY(edge_factor.upload(h_efac));
+        AMX_TRY(var_rowptr.upload(h_vrow));
+        AMX_TRY(var_edges.upload(h_vedges));
+        AMX_TRY(table_off.upload(h_toff));
+        AMX_TRY(cost_off.upload(h_coff));
+        AMX_TRY(msg_off.upload(h_moff));
+        AMX_TRY(tables.upload(tt));
+        AMX_TRY(var_cost.upload(vc));
+        if (G.init_idx) {
+            std::vector<int32_t> ii(G.init_idx, G.init_idx + nV);
+            AMX_TRY(init_idx.upload(ii));
+        }
+        AMX_TRY(f_cost.reserve(nm + 1));
+        AMX_TRY(f_prev.reserve(nm + 1));
+        AMX_TRY(v_cost.reserve(nm + 1));
+        AMX_TRY(v_prev.reserve(nm + 1));
+        AMX_TRY(f_has.reserve(nE + 1));
+        AMX_TRY(f_cnt.reserve(nE + 1));
+        AMX_TRY(v_has.reserve(nE + 1));
+        AMX_TRY(v_cnt.reserve(nE + 1));
+        AMX_TRY(v_order.reserve(nE + 1));
+        AMX_TRY(f_nhas.reserve(nF + 1));
+        AMX_TRY(v_narr.reserve(nV + 1));
+        AMX_TRY(sel.reserve(nV + 1));
+        AMX_TRY(belief.reserve(nV + 1));
+        g.n_vars = nV; g.n_factors = nF; g.n_edges = nE; g.dmax = dmax;
+        g.is_max = p.mode == MXS_MODE_MAX;
+        g.start_mode = p.start_messages;
+        g.damp_f = (p.damping_nodes & MXS_DAMP_FACTORS) ? 1 : 0;
+        g.damp_v = (p.damping_nodes & MXS_DAMP_VARS) ? 1 : 0;
+        g.damping = (T)p.damping;
+        g.stability = (T)p.stability;
+        g.dom_size = dom_size.p; g.factor_rowptr = factor_rowptr.p; g.edge_var = edge_var.p;
+        g.edge_factor = edge_factor.p; g.var_rowptr = var_rowptr.p; g.var_edges = var_edges.p;
+        g.init_idx = G.init_idx ? init_idx.p : nullptr;
+        g.table_off = table_off.p; g.cost_off = cost_off.p; g.msg_off = msg_off.p;
+        g.tables = tables.p; g.var_cost = var_cost.p;
+        g.f_cost = f_cost.p; g.f_prev = f_prev.p; g.v_cost = v_cost.p; g.v_prev = v_prev.p;
+        g.f_has = f_has.p; g.f_cnt = f_cnt.p; g.v_has = v_has.p; g.v_cnt = v_cnt.p;
+        g.f_nhas = f_nhas.p; g.v_narr = v_narr.p; g.v_order = v_order.p; g.sel = sel.p; g.belief = belief.p;
+        return reset();
+    }
+
+    // exclusive prefix sum of int32 counts into int64 (hipCUB), total read back
+    int scan32(const int32_t* in, int64_t* out, int64_t n, int64_t* total) {
+        *total = 0;
+        if (n == 0) return MXS_OK;
+        size_t bytes = 0;
+        hipcub::TransformInputIterator<int64_t, hipcub::CastOp<int64_t>, const int32_t*> it(in, hipcub::CastOp<int64_t>());
+        AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, it, out, (int)n));
+        AMX_TRY(temp.reserve(bytes));
+        AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, it, out, (int)n));
+        int64_t last_off = 0;
+        int32_t last_cnt = 0;
+        AMX_TRY(hipMemcpy(&last_off, out + n - 1, 8, hipMemcpyDeviceToHost));
+        AMX_TRY(hipMemcpy(&last_cnt, in + n - 1, 4, hipMemcpyDeviceToHost));
+        *total = last_off + last_cnt;
+        return MXS_OK;
+    }
+
+    int reset() override {
+        AMX_TRY(hipSetDevice(device));
+        AMX_TRY(hipMemset(f_cost.p, 0, sizeof(T) * (nm + 1)));
+        AMX_TRY(hipMemset(f_prev.p, 0, sizeof(T) * (nm + 1)));
+        AMX_TRY(hipMemset(v_cost.p, 0, sizeof(T) * (nm + 1)));
+        AMX_TRY(hipMemset(v_prev.p, 0, sizeof(T) * (nm + 1)));
+        AMX_TRY(hipMemset(f_has.p, 0, g.n_edges + 1));
+        AMX_TRY(hipMemset(f_cnt.p, 0, g.n_edges + 1));
+        AMX_TRY(hipMemset(v_has.p, 0, g.n_edges + 1));
+        AMX_TRY(hipMemset(v_cnt.p, 0, g.n_edges + 1));
+        AMX_TRY(hipMemset(f_nhas.p, 0, sizeof(int32_t) * (g.n_factors + 1)));
+        AMX_TRY(hipMemset(v_narr.p, 0, sizeof(int32_t) * (g.n_vars + 1)));
+        AMX_TRY(hipMemset(sel.p, 0, sizeof(int32_t) * (g.n_vars + 1)));
+        AMX_TRY(hipMemset(belief.p, 0, sizeof(T) * (g.n_vars + 1)));
+        next_generation = 0;
+        delivered_total = 0;
+        gen_sizes.clear();
+        // start(): every computation in graph order; its messages are generation 0
+        const int64_t nodes = (int64_t)g.n_vars + g.n_factors;
+        pending = 0;
+        if (nodes > 0) {
+            AMX_TRY(start_cnt.reserve(nodes));
+            AMX_TRY(slot_base.reserve(nodes));
+            hipLaunchKernelGGL((k_start_count<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_cnt.p);
+            AMX_TRY(hipGetLastError());
+            int64_t total = 0;
+            { int rc = scan32(start_cnt.p, slot_base.p, nodes, &total); if (rc) return rc; }
+            // (node bases fit 32 bits: at most one message per directed edge)
+            AMX_TRY(start_base.reserve(nodes));
+            {
+                std::vector<int64_t> hb(nodes);
+                AMX_TRY(hipMemcpy(hb.data(), slot_base.p, 8 * nodes, hipMemcpyDeviceToHost));
+                std::vector<int32_t> hb32(nodes);
+                for (int64_t i = 0; i < nodes; ++i) hb32[i] = (int32_t)hb[i];
+                AMX_TRY(hipMemcpy(start_base.p, hb32.data(), 4 * nodes, hipMemcpyHostToDevice));
+            }
+            AMX_TRY(q_code.reserve(total + 1));
+            AMX_TRY(q_pay.reserve((total + 1) * g.dmax));
+            AMX_TRY(hipMemset(q_pay.p, 0, sizeof(T) * (total + 1) * g.dmax));
+            hipLaunchKernelGGL((k_start_emit<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_base.p, q_code.p, q_pay.p);
+            AMX_TRY(hipGetLastError());
+            AMX_TRY(hipDeviceSynchronize());
+            pending = total;
+        }
+        if (pending) gen_sizes.push_back(pending);
+        return MXS_OK;
+    }
+
+    int step() {  // deliver the whole pending generation
+        const int64_t n = pending;
+        if (n > (int64_t)1 << 30) return fail(MXS_E_NOMEM, "amaxsum: more than 2^30 messages in one generation");
+        AMX_TRY(dest.reserve(n));
+        AMX_TRY(dest_sorted.reserve(n));
+        AMX_TRY(order.reserve(n));
+        AMX_TRY(order_in.reserve(n));
+        AMX_TRY(cap.reserve(n));
+        AMX_TRY(slot_base.reserve(n));
+        hipLaunchKernelGGL((k_dest<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, q_code.p, n, dest.p, cap.p);
+        AMX_TRY(hipGetLastError());
+        int64_t n_slots = 0;
+        { int rc = scan32(cap.p, slot_base.p, n, &n_slots); if (rc) return rc; }
+        {   // FIFO indices 0..n-1, then the stable sort by destination
+            std::vector<int32_t> iota((size_t)n);
+            for (int64_t i = 0; i < n; ++i) iota[i] = (int32_t)i;
+            AMX_TRY(hipMemcpy(order_in.p, iota.data(), 4 * n, hipMemcpyHostToDevice));
+            size_t bytes = 0;
+            int bits = 1;
+            while (((int64_t)1 << bits) < (int64_t)g.n_vars + g.n_factors + 1) ++bits;
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dest.p, dest_sorted.p, order_in.p, order.p, (int)n, 0, bits));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, dest.p, dest_sorted.p, order_in.p, order.p, (int)n, 0, bits));
+        }
+        AMX_TRY(s_code.reserve(n_slots + 1));
+        AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
+        AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
+        AMX_TRY(hipMemset(s_pay.p, 0, sizeof(T) * (n_slots + 1) * g.dmax));
+        hipLaunchKernelGGL((k_process<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, q_code.p, q_pay.p, dest_sorted.p, order.p,
+                           n, slot_base.p, s_code.p, s_pay.p);
+        AMX_TRY(hipGetLastError());
+        // compaction of the filled slots, slot order = FIFO order of the next generation
+        int64_t n_next = 0;
+        if (n_slots > 0) {
+            AMX_TRY(flag.reserve(n_slots));
+            AMX_TRY(pos.reserve(n_slots));
+            hipLaunchKernelGGL(k_flags, dim3(grid(n_slots)), dim3(TPB), 0, 0, s_code.p, n_slots, flag.p);
+            AMX_TRY(hipGetLastError());
+            size_t bytes = 0;
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag.p, pos.p, (int)n_slots));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, flag.p, pos.p, (int)n_slots));
+            int64_t last_pos = 0, last_flag = 0;
+            AMX_TRY(hipMemcpy(&last_pos, pos.p + n_slots - 1, 8, hipMemcpyDeviceToHost));
+            AMX_TRY(hipMemcpy(&last_flag, flag.p + n_slots - 1, 8, hipMemcpyDeviceToHost));
+            n_next = last_pos + last_flag;
+            AMX_TRY(q_code2.reserve(n_next + 1));
+            AMX_TRY(q_pay2.reserve((n_next + 1) * g.dmax));
+            hipLaunchKernelGGL((k_gather<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, s_code.p, s_pay.p, pos.p, n_slots,
+                               g.dmax, q_code2.p, q_pay2.p);
+            AMX_TRY(hipGetLastError());
+        }
+        AMX_TRY(hipDeviceSynchronize());
+        std::swap(q_code.p, q_code2.p);
+        std::swap(q_code.n, q_code2.n);
+        std::swap(q_pay.p, q_pay2.p);
+        std::swap(q_pay.n, q_pay2.n);
+        delivered_total += n;
+        next_generation += 1;
+        pending = n_next;
+        if (n_next) gen_sizes.push_back(n_next);
+        return MXS_OK;
+    }
+
+    int run(int32_t max_generations, int64_t* delivered) override {
+        AMX_TRY(hipSetDevice(device));
+        int64_t done = 0;
+        while (pending > 0 && (max_generations < 0 || next_generation < max_generations)) {
+            const int64_t n = pending;
+            int rc = step();
+            if (rc) return rc;
+            done += n;
+        }
+        if (delivered) *delivered = done;
+        return MXS_OK;
+    }
+
+    int get_assignment(int32_t* idx, double* bel) override {
+        AMX_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        std::vector<int32_t> hs(nV);
+        std::vector<T> hb(nV);
+        if (nV) {
+            AMX_TRY(hipMemcpy(hs.data(), sel.p, 4 * nV, hipMemcpyDeviceToHost));
+            AMX_TRY(hipMemcpy(hb.data(), belief.p, sizeof(T) * nV, hipMemcpyDeviceToHost));
+        }
+        for (int v = 0; v < nV; ++v) {
+            if (idx) idx[v] = hs[v];
+            if (bel) bel[v] = (double)hb[v];
+        }
+        return MXS_OK;
+    }
+
+    int get_messages(double* fc, double* vc, double* fp, double* vp, uint8_t* fh, uint8_t* vh, uint8_t* fn,
+                     uint8_t* vn) override {
+        AMX_TRY(hipSetDevice(device));
+        std::vector<T> h((size_t)nm);
+        auto pull = [&](const T* src, double* dst) -> hipError_t {
+            if (!dst || !nm) return hipSuccess;
+            hipError_t e = hipMemcpy(h.data(), src, sizeof(T) * nm, hipMemcpyDeviceToHost);
+            for (int64_t i = 0; i < nm; ++i) dst[i] = (double)h[i];
+            return e;
+        };
+        AMX_TRY(pull(f_cost.p, fc));
+        AMX_TRY(pull(v_cost.p, vc));
+        AMX_TRY(pull(f_prev.p, fp));
+        AMX_TRY(pull(v_prev.p, vp));
+        const int nE = g.n_edges;
+        if (nE) {
+            if (fh) AMX_TRY(hipMemcpy(fh, f_has.p, nE, hipMemcpyDeviceToHost));
+            if (vh) AMX_TRY(hipMemcpy(vh, v_has.p, nE, hipMemcpyDeviceToHost));
+            if (fn) AMX_TRY(hipMemcpy(fn, f_cnt.p, nE, hipMemcpyDeviceToHost));
+            if (vn) AMX_TRY(hipMemcpy(vn, v_cnt.p, nE, hipMemcpyDeviceToHost));
+        }
+        return MXS_OK;
+    }
+
+    // DCOP.solution_cost (dcop.py:308-367) of the selection: reporting, evaluated on the host
+    int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) override {
+        std::vector<int32_t> cur;
+        if (!idx) {
+            cur.resize(g.n_vars);
+            int rc = get_assignment(cur.data(), nullptr);
+            if (rc) return rc;
+            idx = cur.data();
+        }
+        double soft = 0;
+        int64_t hard = 0;
+        for (int f = 0; f < g.n_factors; ++f) {
+            int64_t lin = 0;
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                const int v = h_evar[e];
+                if (idx[v] < 0 || idx[v] >= h_dom[v]) return fail(MXS_E_INVALID, "assignment index out of the domain");
+                lin = lin * h_dom[v] + idx[v];
+            }
+            const double r = h_tables[h_toff[f] + lin];
+            if (r != infinity) soft += r; else hard += 1;
+        }
+        for (int v = 0; v < g.n_vars; ++v) {
+            const double c = h_eval_cost[h_coff[v] + idx[v]];
+            if (c != infinity) soft += c; else hard += 1;
+        }
+        if (cost) *cost = soft;
+        if (viol) *viol = hard;
+        return MXS_OK;
+    }
+};
+
+}  // namespace amx
+
+struct mxs_amaxsum {
+    amx::Base* impl;
+};
+
+extern "C" {
+
+int mxs_amaxsum_create(const mxs_graph* g, const mxs_params* p, int32_t device, mxs_amaxsum** out) {
+    if (!g || !p || !out) return amx::fail(MXS_E_INVALID, "null argument");
+    *out = nullptr;
+    if (p->mode != MXS_MODE_MIN && p->mode != MXS_MODE_MAX) return amx::fail(MXS_E_INVALID, "invalid mode");
+    if (p->damping_nodes < 0 || p->damping_nodes > 3) return amx::fail(MXS_E_INVALID, "invalid damping_nodes");
+    if (p->start_messages < 0 || p->start_messages > 2) return amx::fail(MXS_E_INVALID, "invalid start_messages");
+    try {
+        amx::Base* impl = p->dtype == MXS_DTYPE_F32 ? (amx::Base*)new amx::Engine<float>() : (amx::Base*)new amx::Engine<double>();
+        int rc = impl->init(*g, *p, device);
+        if (rc) {
+            delete impl;
+            return rc;
+        }
+        *out = new mxs_amaxsum{impl};
+        return MXS_OK;
+    } catch (const std::exception& ex) {
+        return amx::fail(MXS_E_NOMEM, ex.what());
+    }
+}
+int mxs_amaxsum_reset(mxs_amaxsum* e) { return e ? e->impl->reset() : amx::fail(MXS_E_INVALID, "null handle"); }
+int mxs_amaxsum_run(mxs_amaxsum* e, int32_t max_generations, int64_t* delivered) {
+    if (!e) return amx::fail(MXS_E_INVALID, "null handle");
+    try {
+        return e->impl->run(max_generations, delivered);
+    } catch (const std::exception& ex) {
+        return amx::fail(MXS_E_NOMEM, ex.what());
+    }
+}
+int mxs_amaxsum_status(const mxs_amaxsum* e, int32_t* next_generation, int64_t* pending, int64_t* delivered) {
+    if (!e) return amx::fail(MXS_E_INVALID, "null handle");
+    if (next_generation) *next_generation = e->impl->next_generation;
+    if (pending) *pending = e->impl->pending;
+    if (delivered) *delivered = e->impl->delivered_total;
+    return MXS_OK;
+}
+int mxs_amaxsum_generation_sizes(const mxs_amaxsum* e, int64_t* out, int32_t cap, int32_t* n) {
+    if (!e) return amx::fail(MXS_E_INVALID, "null handle");
+    const std::vector<int64_t>& s = e->impl->gen_sizes;
+    for (size_t i = 0; i < s.size() && (int32_t)i < cap; ++i) out[i] = s[i];
+    if (n) *n = (int32_t)s.size();
+    return MXS_OK;
+}
+int mxs_amaxsum_get_assignment(mxs_amaxsum* e, int32_t* idx, double* belief) {
+    return e ? e->impl->get_assignment(idx, belief) : amx::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_amaxsum_get_messages(mxs_amaxsum* e, double* f_cost, double* v_cost, double* f_prev, double* v_prev,
+                             uint8_t* f_has, uint8_t* v_has, uint8_t* f_cnt, uint8_t* v_cnt) {
+    return e ? e->impl->get_messages(f_cost, v_cost, f_prev, v_prev, f_has, v_has, f_cnt, v_cnt)
+             : amx::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_amaxsum_eval_cost(mxs_amaxsum* e, const int32_t* idx, double infinity, double* cost, int64_t* violations) {
+    return e ? e->impl->eval_cost(idx, infinity, cost, violations) : amx::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_amaxsum_destroy(mxs_amaxsum* e) {
+    if (e) {
+        delete e->impl;
+        delete e;
+    }
+    return MXS_OK;
+}
+
+}  // extern "C"
+
+#else  // host emulation of the CPU tests: the batch primitives are hipCUB's, gfx950 only
+
+struct mxs_amaxsum {
+    int unused;
+};
+static int amx_unavailable() {
+    mxs_set_last_error("amaxsum runs on the gfx950 build only (not in the host emulation of the CPU tests)");
+    return MXS_E_STATE;
+}
+extern "C" {
+int mxs_amaxsum_create(const mxs_graph*, const mxs_params*, int32_t, mxs_amaxsum** out) {
+    if (out) *out = nullptr;
+    return amx_unavailable();
+}
+int mxs_amaxsum_reset(mxs_amaxsum*) { return amx_unavailable(); }
+int mxs_amaxsum_run(mxs_amaxsum*, int32_t, int64_t*) { return amx_unavailable(); }
+int mxs_amaxsum_status(const mxs_amaxsum*, int32_t*, int64_t*, int64_t*) { return amx_unavailable(); }
+int mxs_amaxsum_generation_sizes(const mxs_amaxsum*, int64_t*, int32_t, int32_t*) { return amx_unavailable(); }
+int mxs_amaxsum_get_assignment(mxs_amaxsum*, int32_t*, double*) { return amx_unavailable(); }
+int mxs_amaxsum_get_messages(mxs_amaxsum*, double*, double*, double*, double*, uint8_t*, uint8_t*, uint8_t*, uint8_t*) {
+    return amx_unavailable();
+}
+int mxs_amaxsum_eval_cost(mxs_amaxsum*, const int32_t*, double, double*, int64_t*) { return amx_unavailable(); }
+int mxs_amaxsum_destroy(mxs_amaxsum*) { return MXS_OK; }
+}
+#endif

@@ -36,6 +36,12 @@ static int fail(int code, const std::string& msg) {
     return code;
 }
 
+}  // namespace mxs
+// the error slot of the calling thread, for the other translation units of the library
+// (amaxsum.hip); not part of the C-ABI: hidden
+extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg) { mxs::g_err = msg ? msg : ""; }
+namespace mxs {
+
 static hipError_t copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind,
                             hipStream_t st) {
     if (!bytes) return hipSuccess;
@@ -350,16 +356,9 @@ struct Engine : EngineBase {
             if (nl.cut != cut) continue;
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
-#define MXS_NARY_CASE(AR, NJ)                                                                            \
-    case (AR) * 16 + (NJ):                                                                                \
-        if (nl.tab_type == TAB_I8)                                                                        \
-            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ, int8_t>), grid, block, 0, stream, a, d);         \
-        else if (nl.tab_type == TAB_I16)                                                                  \
-            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ, int16_t>), grid, block, 0, stream, a, d);        \
-        else if (nl.tab_type == TAB_F32 && sizeof(T) == 8)                                                \
-            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ, float>), grid, block, 0, stream, a, d);          \
-        else                                                                                              \
-            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ, T>), grid, block, 0, stream, a, d);              \
+#define MXS_NARY_CASE(AR, NJ)                                                               \
+    case (AR) * 16 + (NJ):                                                                   \
+        hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);        \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
@@ -455,47 +454,7 @@ struct Engine : EngineBase {
     int widen_factor(int fi) {
         if (L.f_tab_type[fi] == TAB_FULL) return MXS_OK;
         if (L.f_class[fi] >= 0) return promote_class(L.f_class[fi]);
-        { int rc = sync(); if (rc) return rc; }
-        // the factor moves to the full-width launch group of its (arity, size): regroup the
-        // descriptors (stable: every other factor keeps its relative place)
-        struct Item { int cut, code, type, fi; NaryDesc d; };
-        std::vector<int> fi_of(L.ndesc.size(), -1);
-        for (int f2 = 0; f2 < L.n_factors; ++f2)
-            if (L.f_ndesc[f2] >= 0) fi_of[L.f_ndesc[f2]] = f2;
-        std::vector<Item> items;
-        for (const NaryLaunch& nl : L.nary_launches)
-            for (int j = 0; j < nl.count; ++j) {
-                Item it{nl.cut, (nl.arity * 16 + nl.nj) * 16 + nl.threads / 64, nl.tab_type, fi_of[nl.first + j], L.ndesc[nl.first + j]};
-                if (it.fi == fi) {
-                    it.type = TAB_FULL;
-                    it.d.tab_off = L.f_tab_base[fi];
-                }
-                items.push_back(it);
-            }
-        std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
-            return x.cut != y.cut ? x.cut < y.cut : x.code != y.code ? x.code < y.code : x.type < y.type;
-        });
-        L.ndesc.clear();
-        L.nary_launches.clear();
-        for (size_t i = 0; i < items.size(); ++i) {
-            const Item& it = items[i];
-            if (i == 0 || it.cut != items[i - 1].cut || it.code != items[i - 1].code || it.type != items[i - 1].type)
-                L.nary_launches.push_back(NaryLaunch{it.code / 256, (it.code / 16) % 16, (it.code % 16) * 64,
-                                                     (int32_t)i, 0, it.cut, it.type});
-            L.nary_launches.back().count += 1;
-            L.f_ndesc[it.fi] = (int32_t)i;
-            L.ndesc.push_back(it.d);
-        }
-        L.f_tab_type[fi] = (uint8_t)TAB_FULL;
-        if (graph_exec) {  // the captured loop has the old launch groups
-            (void)hipGraphExecDestroy(graph_exec);
-            graph_exec = nullptr;
-            graph_tried = false;
-        }
-        HIP_TRY(ndesc.upload(L.ndesc, stream));
-        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
-                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
-        return MXS_OK;
+        return fail(MXS_E_STATE, "no narrow table image for this factor");
     }
 
     int init(const mxs_graph& g, const mxs_params& p, int dev) override {

@@ -30,7 +30,6 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
-#include <type_traits>
 
 #include "layout.h"
 
@@ -902,19 +901,18 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
     }
 }
 
-// One factor's block.  TT = the type its row-major table is stored in (layout.h TabType: T itself,
-// or a narrower type that holds every entry exactly -- then un-negated, NEG flips the sign on
-// load in max mode); every entry is widened to T before anything is computed with it, so the
-// arithmetic is that of a full-width table, bit for bit.
-template <typename T, int A, int NJ, typename TT>
-__device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc& fd, const TT* tab, const bool neg,
-                                           T* s_msg, typename OrdKey<T>::U* s_key, T* s_prev,
-                                           int* s_nomatch, int* s_cnt) {
+// blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
+// layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
+template <typename T, int A, int NJ>
+__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
+    typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
-    auto ld = [neg](TT x) -> T {
-        const T v = (T)x;
-        return neg ? -v : v;
-    };
+    __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
+    __shared__ U s_key[NARY_MAX_SUMD];   // running minima of the outgoing messages (ordered keys)
+    __shared__ T s_prev[NARY_MAX_SUMD];  // epilogue: the messages sent last
+    __shared__ int s_nomatch[NARY_MAX_ARITY];
+    __shared__ int s_cnt[NARY_MAX_ARITY];
+    const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     int Dm[A], off[A];
     int sumd = 0;
@@ -928,6 +926,7 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
 #pragma unroll
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
+    const T* tab = a.tables + fd.tab_off;
     // own q's (clamped into the table so that every load is in range)
     int qc[NJ];
     bool live[NJ];
@@ -943,7 +942,7 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) cur[u][j] = ld(tab[(int64_t)u * R + qc[j]]);
+            for (int j = 0; j < NJ; ++j) cur[u][j] = tab[(int64_t)u * R + qc[j]];
     }
     // stage the incoming messages, arm the minima (the table loads above are in flight)
 #pragma unroll
@@ -983,7 +982,7 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) nxt[u][j] = ld(tab[(int64_t)(d0 + UNR + u) * R + qc[j]]);
+                for (int j = 0; j < NJ; ++j) nxt[u][j] = tab[(int64_t)(d0 + UNR + u) * R + qc[j]];
         } else {
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
@@ -1003,7 +1002,7 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                cur[u][j] = ld(tab[(int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]]);
+                cur[u][j] = tab[(int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]];
         nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
     }
 #pragma unroll
@@ -1073,26 +1072,6 @@ __device__ __forceinline__ void nary_block(const SweepArgs<T>& a, const NaryDesc
         w[d] = val;
         if (d == 0) a.cF[e] = (uint8_t)out;
     }
-}
-
-// blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
-// layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
-// TT = storage type of the group's tables (NaryLaunch::tab_type): one instantiation per type,
-// so that none pays for another's registers.
-template <typename T, int A, int NJ, typename TT>
-__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
-    typedef typename OrdKey<T>::U U;
-    __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
-    __shared__ U s_key[NARY_MAX_SUMD];   // running minima of the outgoing messages (ordered keys)
-    __shared__ T s_prev[NARY_MAX_SUMD];  // epilogue: the messages sent last
-    __shared__ int s_nomatch[NARY_MAX_ARITY];
-    __shared__ int s_cnt[NARY_MAX_ARITY];
-    const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
-    if constexpr (std::is_same<TT, T>::value)
-        nary_block<T, A, NJ, T>(a, fd, a.tables + fd.tab_off, false, s_msg, s_key, s_prev, s_nomatch, s_cnt);
-    else
-        nary_block<T, A, NJ, TT>(a, fd, (const TT*)(a.ctables + fd.tab_off), a.tab_neg != 0, s_msg, s_key, s_prev,
-                                 s_nomatch, s_cnt);
 }
 
 // ---------------------------------------------------------------------------

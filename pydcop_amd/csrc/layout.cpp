@@ -31,8 +31,6 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.compact_tables = MXS_COMPACT_TABLES_DEFAULT != 0;
     if (f & 16384) o.compact_tables = true;   // bit14: narrow storage of exactly-representable tables
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
-    o.nary_narrow_ints = MXS_NARY_NARROW_INTS_DEFAULT != 0;
-    if (f & 32768) o.nary_narrow_ints = !o.nary_narrow_ints;  // bit15: the other n-ary policy
     return o;
 }
 
@@ -206,14 +204,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 if (R >= 64 && R <= 1024 && sumd <= 1024) {
                     const int nj = (int)((R + BLOCK - 1) / BLOCK);
                     const int waves = (int)(((R + nj - 1) / nj + 63) / 64);  // 1..4
-                    // storage type of this factor's table: one launch group (= one kernel
-                    // instantiation) per type
-                    int t = TAB_FULL;
-                    if (L.opt.compact_tables) {
-                        t = narrowest_tab_type(g.tables + g.table_off[f], g.table_off[f + 1] - g.table_off[f], L.opt.word);
-                        if (!L.opt.nary_narrow_ints && (t == TAB_I8 || t == TAB_I16))
-                            t = L.opt.word == 8 ? TAB_F32 : TAB_FULL;  // (every int16 is a float)
-                    }
+                    // (the workgroup-per-factor kernel is bound by its wavefront reductions, not by
+                    // table bytes -- measured: f32 / int8 tables change nothing -- so its tables stay
+                    // full width: TAB_FULL)
+                    const int t = TAB_FULL;
                     k = FKey{K_F_NARY, ((ar * 16 + nj) * 16 + waves) * 4 + t};
                 }
             }

@@ -70,9 +70,6 @@ constexpr int BLOCK = MXS_BLOCK;
 #ifndef MXS_SCHEDULE_DEFAULT
 #define MXS_SCHEDULE_DEFAULT 1  // layout_flags bit11 (2048) forces the block schedule off, bit12 (4096) on
 #endif
-#ifndef MXS_NARY_NARROW_INTS_DEFAULT
-#define MXS_NARY_NARROW_INTS_DEFAULT 0  // layout_flags bit15 (32768) flips it
-#endif
 #ifndef MXS_COMPACT_TABLES_DEFAULT
 #define MXS_COMPACT_TABLES_DEFAULT 1  // layout_flags bit13 (8192) forces full-width tables, bit14 (16384) compact
 #endif
@@ -168,7 +165,6 @@ struct LayoutOptions {
     bool factors_second = false; // shard: all register factor classes go to the second launch
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
-    bool nary_narrow_ints = false; // workgroup-per-factor tables may use int8 / int16 (else: f32 at most)
 };
 
 struct Layout {

@@ -44,6 +44,9 @@ ABI_SYMBOLS = (
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
     "mxs_build_kind", "mxs_set_state", "mxs_set_parent_table", "mxs_slice_factor",
     "mxs_table_storage",
+    "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
+    "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
+    "mxs_amaxsum_eval_cost", "mxs_amaxsum_destroy",
 )
 
 
@@ -141,6 +144,15 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_set_parent_table": ([vp, i32, vp, i32, vp, vp], C.c_int),
         "mxs_slice_factor": ([vp, i32, vp], C.c_int),
         "mxs_table_storage": ([vp, vp, C.POINTER(i64)], C.c_int),
+        "mxs_amaxsum_create": ([C.POINTER(CGraph), C.POINTER(CParams), i32, C.POINTER(vp)], C.c_int),
+        "mxs_amaxsum_reset": ([vp], C.c_int),
+        "mxs_amaxsum_run": ([vp, i32, C.POINTER(i64)], C.c_int),
+        "mxs_amaxsum_status": ([vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)], C.c_int),
+        "mxs_amaxsum_generation_sizes": ([vp, vp, i32, C.POINTER(i32)], C.c_int),
+        "mxs_amaxsum_get_assignment": ([vp, vp, vp], C.c_int),
+        "mxs_amaxsum_get_messages": ([vp] + [vp] * 8, C.c_int),
+        "mxs_amaxsum_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
+        "mxs_amaxsum_destroy": ([vp], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),

