@@ -1,0 +1,38 @@
+"""Throughput of the asynchronous Max-Sum engine (messages handled per second, FIFO generations)
+on the benchmark family, next to the oracle (C, one thread) on the same instance.
+usage: python tools/amaxsum_bench.py [n_vars ...]"""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from pydcop_amd import generators as G  # noqa: E402
+from pydcop_amd.amaxsum import AMaxSumEngine  # noqa: E402
+from pydcop_amd.graph import Params  # noqa: E402
+
+for n in [int(x) for x in sys.argv[1:]] or [10_000, 100_000]:
+    g = G.random_coloring(n, avg_degree=4, n_colors=3, seed=0, names=False)
+    p = Params(start_messages="leafs_vars")
+    gens = 16
+    eng = AMaxSumEngine(g, p)
+    t0 = time.perf_counter()
+    done = eng.run(gens)
+    dt = time.perf_counter() - t0
+    sizes = eng.generation_sizes()
+    rec = {"n_vars": n, "n_edges": g.n_edges, "generations": gens, "messages": done, "seconds": round(dt, 4),
+           "messages_per_s": round(done / dt, 1), "largest_generation": int(sizes.max()), "pending": eng.pending}
+    eng.close()
+    try:
+        from oracle.amaxsum_oracle import OracleAMaxSum
+        from oracle.maxsum_oracle import build
+        build()
+        ora = OracleAMaxSum(g, p)
+        t0 = time.perf_counter()
+        d2 = ora.run(gens)
+        rec["oracle_messages_per_s"] = round(d2 / (time.perf_counter() - t0), 1)
+        rec["same_message_count_as_oracle"] = bool(d2 == done)
+        ora.close()
+    except Exception as e:  # the oracle is test infrastructure: optional here
+        rec["oracle"] = repr(e)
+    print(json.dumps(rec), flush=True)
