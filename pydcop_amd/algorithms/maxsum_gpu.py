@@ -135,6 +135,15 @@ class _Session:
         params = Params(mode=algo.mode, damping=float(p["damping"]),
                         damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
                         start_messages=p["start_messages"], dtype=p["precision"])
+        self.engine = self._make_engine(params, p)
+        self.stop_cycle = int(p["stop_cycle"])
+        self.chunk = max(1, int(p["chunk"]))
+        self._fetch()
+
+    ALGO = "maxsum_gpu"
+
+    def _make_engine(self, params, p):
+        """The engine of this kind of session (amaxsum_gpu overrides it)."""
         n_dev = int(p.get("devices", 1) or 1)
         if n_dev > 1:
             from pydcop_amd.engine import device_count
@@ -142,14 +151,10 @@ class _Session:
             if device_count() < n_dev:
                 raise ComputationException(
                     f"maxsum_gpu: devices:{n_dev} asked, {device_count()} GPU(s) visible")
-            self.engine = LocalShardedMaxSum(self.graph, params, list(range(n_dev)))
-        else:
-            # (DynamicMaxSum = a MaxSumEngine that survives scope changes of its factors)
-            from pydcop_amd.dynamic import DynamicMaxSum
-            self.engine = DynamicMaxSum(self.graph, params)
-        self.stop_cycle = int(p["stop_cycle"])
-        self.chunk = max(1, int(p["chunk"]))
-        self._fetch()
+            return LocalShardedMaxSum(self.graph, params, list(range(n_dev)))
+        # (DynamicMaxSum = a MaxSumEngine that survives scope changes of its factors)
+        from pydcop_amd.dynamic import DynamicMaxSum
+        return DynamicMaxSum(self.graph, params)
 
     @property
     def cycles(self) -> int:
@@ -176,10 +181,14 @@ class _Session:
                     self.engine.run(self.stop_cycle)
                     self._fetch()
                     self.done = True
+                elif getattr(self.engine, "quiescent", False):
+                    self.done = True
                 return
             if self.stop_cycle == 0:
                 self.engine.run(self.chunk)
                 self._fetch()
+                if getattr(self.engine, "quiescent", False):  # (amaxsum: no message left)
+                    self.done = True
         except Exception as e:  # surfaced by every proxy
             self.error = e
             raise
@@ -244,18 +253,19 @@ class _Session:
 
 
 _registry_lock = threading.Lock()
-_current: Optional[_Session] = None
+_current: Dict[str, _Session] = {}
+SESSION_CLASSES = {"maxsum_gpu": _Session}   # algorithm name -> session class (amaxsum_gpu adds its own)
 
 
 def _session_for(comp_def: ComputationDef) -> _Session:
-    """The open session, or a new one when the previous solve is over / already
-    holds a computation of that name (a new run in the same process)."""
-    global _current
+    """The open session of the computation's algorithm, or a new one when the previous solve is
+    over / already holds a computation of that name (a new run in the same process)."""
+    algo = comp_def.algo.algo
     with _registry_lock:
-        s = _current
+        s = _current.get(algo)
         if (s is None or s.stopped or s.engine is not None or s.error is not None
                 or comp_def.node.name in s.comp_defs):
-            s = _current = _Session()
+            s = _current[algo] = SESSION_CLASSES[algo]()
         s.register(comp_def)
         return s
 
@@ -266,7 +276,7 @@ class _ProxyMixin:
     POLL_PERIOD = 0.02
 
     def _init_proxy(self, comp_def):
-        assert comp_def.algo.algo == "maxsum_gpu"
+        assert comp_def.algo.algo in SESSION_CLASSES
         self._session = _session_for(comp_def)
         self._seen_generation = 0
         self._poll_handle = None

@@ -67,13 +67,13 @@ def _nodes(variables, constraints):
             [FactorComputationNode(c) for c in constraints])
 
 
-def _solve_through_plugin(plugin_mod, variables, constraints, mode="min", **params):
+def _solve_through_plugin(plugin_mod, variables, constraints, mode="min", algo_name="maxsum_gpu", **params):
     """What run_local_thread_dcop + one agent do, on this thread: one computation per node
     through build_computation, start them all, serve their periodic actions until every one
     has called finished()."""
     from pydcop.algorithms import AlgorithmDef, ComputationDef
     from pydcop.infrastructure.computations import MiniAgent
-    algo = AlgorithmDef.build_with_default_param("maxsum_gpu", params, mode=mode,
+    algo = AlgorithmDef.build_with_default_param(algo_name, params, mode=mode,
                                                  parameters_definitions=plugin_mod.algo_params)
     vnodes, fnodes = _nodes(variables, constraints)
     comps = [plugin_mod.build_computation(ComputationDef(n, algo)) for n in vnodes + fnodes]
@@ -176,3 +176,30 @@ def test_change_factor_function_and_stop_of_one_proxy(plugin_mod):
     agent.pump(lambda: session.cycles >= at + 10)
     agent.stop_all()
     assert session.engine is None and session.stopped
+
+
+def test_amaxsum_gpu_through_the_proxies_equals_oracle(plugin_mod, oracle_built):
+    """`--algo amaxsum_gpu`: the asynchronous schedule (FIFO generations) through the same proxies;
+    runs until no message is left (stop_cycle 0) and publishes what the oracle holds at quiescence."""
+    from pydcop.algorithms import load_algorithm_module
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    from pydcop_amd.graph import Params
+    amod = load_algorithm_module("amaxsum_gpu")
+    rng = np.random.default_rng(9)
+    n, m = 40, 70
+    vs = [Var(f"y{i:02d}", [0, 1, 2], (lambda i: (lambda d: 0.001 * ((d + 2 * i) % 3)))(i)) for i in range(n)]
+    cons, seen = [], set()
+    while len(cons) < m:
+        a, b = (int(x) for x in rng.integers(0, n, 2))
+        if a == b or (min(a, b), max(a, b)) in seen:
+            continue
+        seen.add((min(a, b), max(a, b)))
+        cons.append(Table(f"k{len(cons):02d}", [vs[a], vs[b]], rng.integers(0, 10, (3, 3))))
+    values, cycles, graph, _ = _solve_through_plugin(amod, vs, cons, algo_name="amaxsum_gpu", noise=0,
+                                                     start_messages="leafs_vars", chunk=8)
+    ora = OracleAMaxSum(graph, Params(start_messages="leafs_vars"))
+    ora.run(-1)
+    assert ora.pending == 0 and cycles == {ora.generation + 1}
+    idx, belief = ora.assignment()
+    for i, name in enumerate(graph.var_names):
+        assert values[name] == (graph.domains[i][int(idx[i])], belief[i])

@@ -57,6 +57,16 @@ def test_discovered_like_a_builtin_algorithm(pydcop_ready):
         assert mine[name] == spec
 
 
+def test_amaxsum_gpu_is_discovered_with_the_reference_parameters(pydcop_ready):
+    from pydcop.algorithms import list_available_algorithms, load_algorithm_module
+    assert "amaxsum_gpu" in list_available_algorithms()
+    ref, mod = load_algorithm_module("amaxsum"), load_algorithm_module("amaxsum_gpu")
+    assert mod.GRAPH_TYPE == ref.GRAPH_TYPE
+    refp = {p.name: (p.type, p.values, p.default_value) for p in ref.algo_params}
+    mine = {p.name: (p.type, p.values, p.default_value) for p in mod.algo_params}
+    assert all(mine[k] == v for k, v in refp.items())
+
+
 def test_param_validation_matches_reference(pydcop_ready):
     from pydcop.algorithms import AlgorithmDef
     a = AlgorithmDef.build_with_default_param("maxsum_gpu", {"stop_cycle": "30", "damping": "0.7"}, mode="min")
