@@ -855,6 +855,39 @@ __device__ __forceinline__ T wave_min(T x) {  // all 64 lanes get the minimum
 __device__ __forceinline__ double min2(double x, double y) { return __builtin_fmin(x, y); }
 __device__ __forceinline__ float min2(float x, float y) { return __builtin_fminf(x, y); }
 
+// Wavefront minimum with DPP moves instead of ds_bpermute shuffles: quad swaps, row half mirror,
+// row mirror (every lane of a 16-lane row then holds the row minimum), row_bcast15 / row_bcast31
+// (rows 1,3 <- lane 15 of rows 0,2; rows 2,3 <- lane 31): LANE 63 ends up with the minimum of the
+// wave.  Plain VALU moves: nothing goes through the LDS crossbar.
+#ifndef MXS_NARY_DPP
+#define MXS_NARY_DPP 0
+#endif
+#if defined(__HIPCC__) && MXS_NARY_DPP
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_mov(float x) {
+    int b = __float_as_int(x);
+    b = __builtin_amdgcn_update_dpp(b, b, CTRL, ROW_MASK, 0xf, false);
+    return __int_as_float(b);
+}
+template <typename T>
+__device__ __forceinline__ T wave_min_to_lane63(T x) {
+    x = min2(x, dpp_mov<0xB1, 0xf>(x));   // quad_perm [1,0,3,2]
+    x = min2(x, dpp_mov<0x4E, 0xf>(x));   // quad_perm [2,3,0,1]
+    x = min2(x, dpp_mov<0x141, 0xf>(x));  // row_half_mirror
+    x = min2(x, dpp_mov<0x140, 0xf>(x));  // row_mirror
+    x = min2(x, dpp_mov<0x142, 0xa>(x));  // row_bcast15 -> rows 1, 3
+    x = min2(x, dpp_mov<0x143, 0xc>(x));  // row_bcast31 -> rows 2, 3
+    return x;
+}
+#endif
+
 constexpr int NARY_UNR = 4;  // values of d0 per batch: UNR * NJ table loads per lane in flight,
                              // and the next batch is requested before this one is reduced
 
@@ -887,6 +920,11 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
         }
         best0[u] = b0;
     }
+#if defined(__HIPCC__) && MXS_NARY_DPP
+#pragma unroll
+    for (int u = 0; u < NARY_UNR; ++u) best0[u] = wave_min_to_lane63(best0[u]);
+    if ((threadIdx.x & 63) == 63) {
+#else
     // UNR independent wavefront reductions, interleaved step by step
 #pragma unroll
     for (int sft = 32; sft > 0; sft >>= 1) {
@@ -895,6 +933,7 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
             best0[u] = min2(best0[u], __shfl(best0[u], (int)((threadIdx.x & 63) ^ sft), 64));
     }
     if ((threadIdx.x & 63) == 0) {
+#endif
 #pragma unroll
         for (int u = 0; u < NARY_UNR; ++u)
             if (!MASKED || d0 + u < D0) atomicMin(&s_key0[d0 + u], OrdKey<T>::enc(best0[u]));
