@@ -369,6 +369,28 @@ int mxs_amaxsum_get_messages(mxs_amaxsum *e, double *f_cost, double *v_cost, dou
 int mxs_amaxsum_eval_cost(mxs_amaxsum *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
 int mxs_amaxsum_destroy(mxs_amaxsum *e);
 
+/* ---- MGM (pydcop/algorithms/mgm.py) on the same flat arrays ------------------------------------
+ * Factors = the constraints of the constraints hypergraph (mgm.py:68), variables = the MGM
+ * computations.  One round = every variable's `_handle_value_message` once all values are in
+ * (mgm.py:335-391: cost of the current value on the first round, best unilateral move, gain) and
+ * `_handle_gain_message` once all gains are in (:499-540: the largest gain of a neighbourhood moves,
+ * ties by name :566-588) -- n rounds = the reference with stop_cycle = n + 1.  `name_rank[v]` = rank
+ * of the variable's name in sorted order (NULL: index order).  The reference's draws from the
+ * unseeded `random` module are fixed: first domain value at start (unless init_idx), first of
+ * equally good values.  Bit for bit the reference's own MgmComputation objects under those
+ * choices (oracle/mgm_oracle.c, pinned by tests/test_mgm_oracle_vs_reference.py). */
+typedef struct mxs_mgm mxs_mgm;
+int mxs_mgm_create(const mxs_graph *g, const mxs_params *p, const int32_t *name_rank, int32_t device,
+                   mxs_mgm **out);
+int mxs_mgm_reset(mxs_mgm *e);
+int mxs_mgm_run(mxs_mgm *e, int32_t n_rounds);
+int mxs_mgm_rounds(const mxs_mgm *e, int64_t *rounds);
+/* current value index, the cost the computation holds (has_cost = 0: still None, mgm.py:349),
+ * last gain and the move it would make; any pointer may be NULL */
+int mxs_mgm_get_state(mxs_mgm *e, int32_t *idx, double *cost, uint8_t *has_cost, double *gain, int32_t *new_value);
+int mxs_mgm_eval_cost(mxs_mgm *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
+int mxs_mgm_destroy(mxs_mgm *e);
+
 /* Library/ABI version (major*100+minor). */
 int32_t mxs_version(void);
 

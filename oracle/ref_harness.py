@@ -197,6 +197,64 @@ def run_reference_amaxsum(dcop, max_generations=-1, params=None, cg=None, max_me
     return values, costs, info
 
 
+def run_reference_mgm(dcop, rounds, cg=None):
+    """The reference's own MgmComputation objects (pydcop/algorithms/mgm.py) for exactly `rounds`
+    rounds of (values, gains, decision): stop_cycle = rounds + 1 (mgm.py:407-411), FIFO delivery
+    (MGM parks early messages, so any order gives the same result).  The reference's three draws
+    from the unseeded `random` module are made deterministic: random.choice -> the first element
+    (initial value, choice among equally good values), random.random -> 0.
+
+    Returns ({var: value}, {var: cost}, comps)."""
+    install_shims()
+    from pydcop.algorithms import AlgorithmDef, ComputationDef, load_algorithm_module
+    from pydcop.computations_graph import constraints_hypergraph as chg
+    import pydcop.algorithms.mgm as mgm
+    import logging
+
+    class _FirstChoice:
+        def __getattr__(self, name):
+            import random as _r
+            return getattr(_r, name)
+
+        @staticmethod
+        def choice(seq):
+            return seq[0]
+
+        @staticmethod
+        def random():
+            return 0.0
+
+    saved = mgm.random
+    mgm.random = _FirstChoice()
+    logging.disable(logging.CRITICAL)
+    try:
+        if cg is None:
+            cg = chg.build_computation_graph(dcop)
+        algo = AlgorithmDef.build_with_default_param("mgm", {"stop_cycle": rounds + 1}, mode=dcop.objective)
+        module = load_algorithm_module("mgm")
+        comps, q = {}, deque()
+
+        def sender(src, dest, msg, prio=None, on_error=None):
+            q.append((src, dest, msg))
+
+        for node in cg.nodes:
+            c = module.build_computation(ComputationDef(node, algo))
+            c.message_sender = sender
+            c._on_finished = lambda *a, **k: None   # (no agent to tell)
+            comps[node.name] = c
+        for c in comps.values():
+            c.start()
+        while q:
+            s, d, m = q.popleft()
+            comps[d].on_message(s, m, 0.0)
+    finally:
+        mgm.random = saved
+        logging.disable(logging.NOTSET)
+    values = {v: comps[v].current_value for v in dcop.variables}
+    costs = {v: comps[v].current_cost for v in dcop.variables}
+    return values, costs, comps
+
+
 def flat_to_dcop(graph, mode="min", name="flat"):
     """Build reference objects (DCOP + ComputationsFactorGraph) from a FlatGraph:
     VariableWithCostDict variables (pydcop/dcop/objects.py:410) and extensional

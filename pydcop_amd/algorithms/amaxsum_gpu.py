@@ -5,7 +5,7 @@ The reference's amaxsum handles one message at a time and what it computes depen
 the agents' threads deliver them in.  This module runs it under the one order that is defined
 without a scheduler -- every computation started in graph order, one first-in-first-out queue --
 a GENERATION of messages per device step (pydcop_amd/csrc/amaxsum.hip; bit for bit the
-reference's own computations under that order, tests/test_amaxsum_oracle_vs_reference.py).
+reference's own computations under that order -- pinned in tests/).
 
 Parameters: those of amaxsum (= maxsum's, amaxsum.py:105) plus
   stop_cycle  int, default 0   > 0: deliver exactly that many generations, then finished();

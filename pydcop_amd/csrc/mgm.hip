@@ -1,0 +1,446 @@
+// mgm.hip -- the reference's MGM (pydcop/algorithms/mgm.py: Maheswaran, Pearce, Tambe 2004) on
+// gfx950, on the same flat factor-graph arrays as the Max-Sum engine (SURVEY.md section 8(f).4:
+// "per-variable segmented argmin over neighbour values -- same layout, different semiring").
+//
+// MGM is bulk-synchronous by construction (a computation handles a round's values only when ALL
+// its neighbours' values are in, then the gains; early messages are parked, mgm.py:311-333,
+// 476-497): one round = two launches over all variables,
+//   k_mgm_gain   values in  -> the best unilateral move and its gain   (mgm.py:335-391, 428-454)
+//   k_mgm_move   gains in   -> the largest gain of a neighbourhood moves, ties by name (:499-588)
+// thread per variable; the reads are the variable's constraints' tables at the neighbours'
+// current values (CSR walk, integer index arithmetic + a handful of adds).  The reference's quirks
+// are restated as they are and listed in oracle/mgm_oracle.c, whose arithmetic this file follows
+// expression for expression (the oracle is pinned against the reference's own MgmComputation).
+// The reference's draws from the unseeded `random` module are fixed the way the oracle fixes them:
+// first domain value at start, first of equally good values.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/maxsum_gpu.h"
+
+extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
+
+namespace mgm {
+
+constexpr int TPB = 256;
+
+static int fail(int code, const std::string& msg) {
+    mxs_set_last_error(msg.c_str());
+    return code;
+}
+#define MGM_TRY(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return fail(MXS_E_HIP, std::string(#call) + " failed");     \
+    } while (0)
+
+template <typename U>
+struct Buf {
+    U* p = nullptr;
+    size_t n = 0;
+    hipError_t upload(const std::vector<U>& h, hipStream_t st) {
+        n = h.size();
+        hipError_t e = hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
+        if (e != hipSuccess || h.empty()) return e;
+        e = hipMemcpyAsync(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    }
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
+    }
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+template <typename T>
+struct Dev {
+    int32_t n_vars, is_max;
+    const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *init_idx, *name_rank, *n_neigh;
+    const int64_t *table_off, *cost_off;
+    const T *tables, *var_cost;
+    const int32_t* cur;    // values of the round being handled
+    const T* cost;
+    int32_t* cur_out;      // k_mgm_move: after the round
+    T* cost_out;
+    uint8_t* has_cost;
+    T* gain;
+    int32_t* newv;
+};
+
+// c.slice(neighbours' values)(x): the table entry with v at x, every other scope variable at its value
+template <typename T>
+__device__ T constraint_at(const Dev<T>& g, int f, int v, int x) {
+    int64_t lin = 0;
+    for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
+        const int u = g.edge_var[e];
+        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[u]);
+    }
+    return g.tables[g.table_off[f] + lin];
+}
+
+// functools.reduce(operator.add, [f(x) for f in reduced_cs]): utilities order, no initial 0
+template <typename T>
+__device__ T utilities_at(const Dev<T>& g, int v, int x) {
+    T acc = (T)0;
+    bool first = true;
+    for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k) {
+        const T f = constraint_at(g, g.edge_factor[g.var_edges[k]], v, x);
+        acc = first ? f : acc + f;
+        first = false;
+    }
+    return acc;
+}
+
+// acc += cost_for_val of every distinct variable of v's constraints (v included) at its current
+// value, in ascending variable index (the reference iterates a set, see oracle/mgm_oracle.c)
+template <typename T>
+__device__ T add_concerned_costs(const Dev<T>& g, int v, T acc) {
+    int last = -1;
+    for (;;) {
+        int best = INT32_MAX;
+        for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k) {
+            const int f = g.edge_factor[g.var_edges[k]];
+            for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
+                const int u = g.edge_var[e];
+                if (u > last && u < best) best = u;
+            }
+        }
+        if (best == INT32_MAX) break;
+        acc += g.var_cost[g.cost_off[best] + g.cur[best]];
+        last = best;
+    }
+    return acc;
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars || g.n_neigh[v] == 0) return;
+    T cost = cost_rw[v];
+    if (!g.has_cost[v]) {  // first round: the cost of the current value (mgm.py:349-372)
+        cost = add_concerned_costs(g, v, utilities_at(g, v, g.cur[v]));
+        cost_rw[v] = cost;
+        g.has_cost[v] = 1;
+    }
+    T best = (T)0;
+    int best_x = -1;
+    for (int x = 0; x < g.dom_size[v]; ++x) {  // find_arg_optimal: strictly better starts a new list
+        const T r = utilities_at(g, v, x);
+        if (best_x < 0 || (g.is_max ? best < r : best > r)) {
+            best = r;
+            best_x = x;
+        }
+    }
+    const T val_cost = add_concerned_costs(g, v, best);  // own cost at the CURRENT value (:449-450)
+    const T gain = cost - val_cost;
+    g.gain[v] = gain;
+    g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars) return;
+    int cur = g.cur[v];
+    T cost = g.cost[v];
+    if (g.n_neigh[v] != 0) {
+        T max_n = (T)0;
+        bool first = true;
+        for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k) {
+            const int f = g.edge_factor[g.var_edges[k]];
+            for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
+                const int u = g.edge_var[e];
+                if (u == v) continue;
+                if (first || g.gain[u] > max_n) max_n = g.gain[u];  // max() also in max mode (:513)
+                first = false;
+            }
+        }
+        bool wins_tie = true;
+        for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k) {
+            const int f = g.edge_factor[g.var_edges[k]];
+            for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
+                const int u = g.edge_var[e];
+                if (u != v && g.gain[u] == max_n && g.name_rank[u] < g.name_rank[v]) wins_tie = false;
+            }
+        }
+        const T gain = g.gain[v];
+        if (gain > max_n || (gain == max_n && wins_tie)) {  // :514-525, lexic ties :566-588
+            cur = g.newv[v];
+            cost = cost - gain;
+        }
+    }
+    g.cur_out[v] = cur;
+    g.cost_out[v] = cost;
+}
+
+struct Base {
+    virtual ~Base() {}
+    virtual int init(const mxs_graph& G, const mxs_params& p, const int32_t* rank, int device) = 0;
+    virtual int reset() = 0;
+    virtual int run(int32_t n) = 0;
+    virtual int get_state(int32_t* idx, double* cost, uint8_t* has, double* gain, int32_t* newv) = 0;
+    virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
+    int64_t rounds = 0;
+};
+
+template <typename T>
+struct Engine : Base {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev<T> g{};
+    int which = 0;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn;
+    std::vector<int64_t> h_toff, h_coff;
+    std::vector<double> h_tables, h_eval_cost, h_var_cost;
+    bool has_init = false;
+    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx, name_rank, n_neigh, newv;
+    Buf<int32_t> cur[2];
+    Buf<int64_t> table_off, cost_off;
+    Buf<T> tables, var_cost, gain;
+    Buf<T> cost[2];
+    Buf<uint8_t> has_cost;
+
+    ~Engine() override {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int init(const mxs_graph& G, const mxs_params& p, const int32_t* rank, int dev) override {
+        device = dev;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(MXS_E_NODEVICE, "no HIP device visible: the engine has no CPU fallback");
+        if (dev < 0 || dev >= count) return fail(MXS_E_INVALID, "device index out of range");
+        MGM_TRY(hipSetDevice(dev));
+        MGM_TRY(hipStreamCreateWithFlags(&stream, 0));
+        const int nV = G.n_vars, nF = G.n_factors, nE = G.n_edges;
+        if (nV < 0 || nF < 0 || nE < 0) return fail(MXS_E_INVALID, "negative size");
+        if (p.mode != MXS_MODE_MIN && p.mode != MXS_MODE_MAX) return fail(MXS_E_INVALID, "invalid mode");
+        h_dom.assign(G.dom_size, G.dom_size + nV);
+        h_frow.assign(G.factor_rowptr, G.factor_rowptr + nF + 1);
+        h_evar.assign(G.edge_var, G.edge_var + nE);
+        h_toff.assign(G.table_off, G.table_off + nF + 1);
+        h_coff.assign(nV + 1, 0);
+        for (int v = 0; v < nV; ++v) {
+            if (h_dom[v] < 1) return fail(MXS_E_INVALID, "empty domain");
+            h_coff[v + 1] = h_coff[v] + h_dom[v];
+        }
+        std::vector<int32_t> efac(nE), vrow(G.var_rowptr, G.var_rowptr + nV + 1), vedges(G.var_edges, G.var_edges + nE);
+        for (int f = 0; f < nF; ++f) {
+            if (h_frow[f + 1] <= h_frow[f]) return fail(MXS_E_INVALID, "factor without variable");
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                if (h_evar[e] < 0 || h_evar[e] >= nV) return fail(MXS_E_INVALID, "edge_var out of range");
+                efac[e] = f;
+            }
+        }
+        h_nn.assign(nV, 0);
+        for (int f = 0; f < nF; ++f)
+            if (h_frow[f + 1] - h_frow[f] > 1)
+                for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) h_nn[h_evar[e]] = 1;
+        std::vector<int32_t> rk(nV);
+        for (int v = 0; v < nV; ++v) rk[v] = rank ? rank[v] : v;
+        has_init = G.init_idx != nullptr;
+        h_init.assign(nV, -1);
+        if (has_init)
+            for (int v = 0; v < nV; ++v) {
+                if (G.init_idx[v] >= h_dom[v]) return fail(MXS_E_INVALID, "init_idx out of the domain");
+                h_init[v] = G.init_idx[v];
+            }
+        h_tables.assign(G.tables, G.tables + h_toff[nF]);
+        h_var_cost.assign(G.var_cost, G.var_cost + h_coff[nV]);
+        const double* ev = G.eval_var_cost ? G.eval_var_cost : G.var_cost;
+        h_eval_cost.assign(ev, ev + h_coff[nV]);
+        std::vector<T> tt(h_tables.size()), vc(h_var_cost.size());
+        for (size_t i = 0; i < tt.size(); ++i) tt[i] = (T)h_tables[i];
+        for (size_t i = 0; i < vc.size(); ++i) vc[i] = (T)h_var_cost[i];
+        MGM_TRY(dom_size.upload(h_dom, stream));
+        MGM_TRY(factor_rowptr.upload(h_frow, stream));
+        MGM_TRY(edge_var.upload(h_evar, stream));
+        MGM_TRY(edge_factor.upload(efac, stream));
+        MGM_TRY(var_rowptr.upload(vrow, stream));
+        MGM_TRY(var_edges.upload(vedges, stream));
+        MGM_TRY(name_rank.upload(rk, stream));
+        MGM_TRY(n_neigh.upload(h_nn, stream));
+        MGM_TRY(table_off.upload(h_toff, stream));
+        MGM_TRY(cost_off.upload(h_coff, stream));
+        MGM_TRY(tables.upload(tt, stream));
+        MGM_TRY(var_cost.upload(vc, stream));
+        for (int b = 0; b < 2; ++b) {
+            MGM_TRY(cur[b].alloc(nV));
+            MGM_TRY(cost[b].alloc(nV));
+        }
+        MGM_TRY(has_cost.alloc(nV));
+        MGM_TRY(gain.alloc(nV));
+        MGM_TRY(newv.alloc(nV));
+        g.n_vars = nV;
+        g.is_max = p.mode == MXS_MODE_MAX;
+        g.dom_size = dom_size.p; g.factor_rowptr = factor_rowptr.p; g.edge_var = edge_var.p;
+        g.edge_factor = edge_factor.p; g.var_rowptr = var_rowptr.p; g.var_edges = var_edges.p;
+        g.init_idx = nullptr; g.name_rank = name_rank.p; g.n_neigh = n_neigh.p;
+        g.table_off = table_off.p; g.cost_off = cost_off.p; g.tables = tables.p; g.var_cost = var_cost.p;
+        g.has_cost = has_cost.p; g.gain = gain.p; g.newv = newv.p;
+        return reset();
+    }
+
+    int reset() override {
+        MGM_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        std::vector<int32_t> c0(nV);
+        std::vector<T> k0(nV, (T)0);
+        std::vector<uint8_t> h0(nV, 0);
+        for (int v = 0; v < nV; ++v) {
+            if (h_nn[v] == 0) {  // on_start without neighbours: optimal_cost_value (mgm.py:279-290)
+                int best = 0;
+                for (int d = 1; d < h_dom[v]; ++d) {
+                    const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
+                    if (g.is_max ? a >= b : a < b) best = d;
+                }
+                c0[v] = best;
+                k0[v] = (T)h_var_cost[h_coff[v] + best];
+                h0[v] = 1;
+            } else {  // the initial value, else the first of the domain (random.choice fixed)
+                c0[v] = h_init[v] >= 0 ? h_init[v] : 0;
+            }
+        }
+        which = 0;
+        if (nV) {
+            MGM_TRY(hipMemcpyAsync(cur[0].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
+            MGM_TRY(hipMemcpyAsync(cost[0].p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+            MGM_TRY(hipMemcpyAsync(has_cost.p, h0.data(), nV, hipMemcpyHostToDevice, stream));
+            MGM_TRY(hipMemcpyAsync(newv.p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
+            MGM_TRY(hipMemsetAsync(gain.p, 0, sizeof(T) * nV, stream));
+            MGM_TRY(hipStreamSynchronize(stream));
+        }
+        rounds = 0;
+        return MXS_OK;
+    }
+
+    int run(int32_t n) override {
+        MGM_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        if (nV == 0) {
+            rounds += n > 0 ? n : 0;
+            return MXS_OK;
+        }
+        const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
+        for (int32_t r = 0; r < n; ++r) {
+            g.cur = cur[which].p;
+            g.cost = cost[which].p;
+            g.cur_out = cur[which ^ 1].p;
+            g.cost_out = cost[which ^ 1].p;
+            hipLaunchKernelGGL((k_mgm_gain<T>), grid, block, 0, stream, g, cost[which].p);
+            MGM_TRY(hipGetLastError());
+            hipLaunchKernelGGL((k_mgm_move<T>), grid, block, 0, stream, g);
+            MGM_TRY(hipGetLastError());
+            which ^= 1;
+            rounds += 1;
+        }
+        MGM_TRY(hipStreamSynchronize(stream));
+        return MXS_OK;
+    }
+
+    int get_state(int32_t* idx, double* cst, uint8_t* has, double* gn, int32_t* nv) override {
+        MGM_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        if (!nV) return MXS_OK;
+        std::vector<T> hc(nV), hg(nV);
+        if (idx) MGM_TRY(hipMemcpyAsync(idx, cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
+        if (nv) MGM_TRY(hipMemcpyAsync(nv, newv.p, 4 * nV, hipMemcpyDeviceToHost, stream));
+        if (has) MGM_TRY(hipMemcpyAsync(has, has_cost.p, nV, hipMemcpyDeviceToHost, stream));
+        MGM_TRY(hipMemcpyAsync(hc.data(), cost[which].p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+        MGM_TRY(hipMemcpyAsync(hg.data(), gain.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+        MGM_TRY(hipStreamSynchronize(stream));
+        for (int v = 0; v < nV; ++v) {
+            if (cst) cst[v] = (double)hc[v];
+            if (gn) gn[v] = (double)hg[v];
+        }
+        return MXS_OK;
+    }
+
+    int eval_cost(const int32_t* idx, double infinity, double* cst, int64_t* viol) override {
+        std::vector<int32_t> c;
+        if (!idx) {
+            c.resize(g.n_vars);
+            int rc = get_state(c.data(), nullptr, nullptr, nullptr, nullptr);
+            if (rc) return rc;
+            idx = c.data();
+        }
+        double soft = 0;
+        int64_t hard = 0;
+        const int nF = (int)h_frow.size() - 1;
+        for (int f = 0; f < nF; ++f) {
+            int64_t lin = 0;
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                const int v = h_evar[e];
+                if (idx[v] < 0 || idx[v] >= h_dom[v]) return fail(MXS_E_INVALID, "assignment index out of the domain");
+                lin = lin * h_dom[v] + idx[v];
+            }
+            const double r = h_tables[h_toff[f] + lin];
+            if (r != infinity) soft += r; else hard += 1;
+        }
+        for (int v = 0; v < g.n_vars; ++v) {
+            const double x = h_eval_cost[h_coff[v] + idx[v]];
+            if (x != infinity) soft += x; else hard += 1;
+        }
+        if (cst) *cst = soft;
+        if (viol) *viol = hard;
+        return MXS_OK;
+    }
+};
+
+}  // namespace mgm
+
+struct mxs_mgm {
+    mgm::Base* impl;
+};
+
+extern "C" {
+
+int mxs_mgm_create(const mxs_graph* g, const mxs_params* p, const int32_t* name_rank, int32_t device, mxs_mgm** out) {
+    if (!g || !p || !out) return mgm::fail(MXS_E_INVALID, "null argument");
+    *out = nullptr;
+    try {
+        mgm::Base* impl = p->dtype == MXS_DTYPE_F32 ? (mgm::Base*)new mgm::Engine<float>() : (mgm::Base*)new mgm::Engine<double>();
+        int rc = impl->init(*g, *p, name_rank, device);
+        if (rc) {
+            delete impl;
+            return rc;
+        }
+        *out = new mxs_mgm{impl};
+        return MXS_OK;
+    } catch (const std::exception& ex) {
+        return mgm::fail(MXS_E_NOMEM, ex.what());
+    }
+}
+int mxs_mgm_reset(mxs_mgm* e) { return e ? e->impl->reset() : mgm::fail(MXS_E_INVALID, "null handle"); }
+int mxs_mgm_run(mxs_mgm* e, int32_t n_rounds) {
+    if (!e) return mgm::fail(MXS_E_INVALID, "null handle");
+    if (n_rounds < 0) return mgm::fail(MXS_E_INVALID, "negative round count");
+    return e->impl->run(n_rounds);
+}
+int mxs_mgm_rounds(const mxs_mgm* e, int64_t* rounds) {
+    if (!e) return mgm::fail(MXS_E_INVALID, "null handle");
+    if (rounds) *rounds = e->impl->rounds;
+    return MXS_OK;
+}
+int mxs_mgm_get_state(mxs_mgm* e, int32_t* idx, double* cost, uint8_t* has_cost, double* gain, int32_t* new_value) {
+    return e ? e->impl->get_state(idx, cost, has_cost, gain, new_value) : mgm::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_mgm_eval_cost(mxs_mgm* e, const int32_t* idx, double infinity, double* cost, int64_t* violations) {
+    return e ? e->impl->eval_cost(idx, infinity, cost, violations) : mgm::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_mgm_destroy(mxs_mgm* e) {
+    if (e) {
+        delete e->impl;
+        delete e;
+    }
+    return MXS_OK;
+}
+
+}  // extern "C"

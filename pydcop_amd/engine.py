@@ -47,6 +47,8 @@ ABI_SYMBOLS = (
     "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
     "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
     "mxs_amaxsum_eval_cost", "mxs_amaxsum_destroy",
+    "mxs_mgm_create", "mxs_mgm_reset", "mxs_mgm_run", "mxs_mgm_rounds", "mxs_mgm_get_state",
+    "mxs_mgm_eval_cost", "mxs_mgm_destroy",
 )
 
 
@@ -153,6 +155,13 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_amaxsum_get_messages": ([vp] + [vp] * 8, C.c_int),
         "mxs_amaxsum_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
         "mxs_amaxsum_destroy": ([vp], C.c_int),
+        "mxs_mgm_create": ([C.POINTER(CGraph), C.POINTER(CParams), vp, i32, C.POINTER(vp)], C.c_int),
+        "mxs_mgm_reset": ([vp], C.c_int),
+        "mxs_mgm_run": ([vp, i32], C.c_int),
+        "mxs_mgm_rounds": ([vp, C.POINTER(i64)], C.c_int),
+        "mxs_mgm_get_state": ([vp, vp, vp, vp, vp, vp], C.c_int),
+        "mxs_mgm_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
+        "mxs_mgm_destroy": ([vp], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),

@@ -1,0 +1,15 @@
+"""MGM on the emulated engine build (the very same mgm.hip, g++ against the fake HIP runtime)
+against the oracle, bit for bit -- the CPU twin of tests/test_gpu_mgm.py."""
+import pytest
+
+from mgm_common import compare_mgm, mgm_cases
+from pydcop_amd.graph import Params
+
+
+@pytest.mark.parametrize("case", mgm_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_mgm_emu_bit_exact_vs_oracle(case, dtype, oracle_built):
+    from emu.build_emu import build
+    from oracle.mgm_oracle import OracleMgm
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(dtype=dtype, **kw), lib_path=build())
