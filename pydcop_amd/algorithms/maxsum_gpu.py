@@ -125,22 +125,31 @@ class _Session:
         any_def = next(iter(self.comp_defs.values()))
         algo = any_def.algo
         p = algo.params
-        var_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "VariableComputation"]
-        fac_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "FactorComputation"]
-        var_nodes.sort(key=lambda n: n.name)
-        fac_nodes.sort(key=lambda n: n.name)
-        self.graph = compile_nodes(var_nodes, fac_nodes, noise=float(p["noise"]),
-                                   rng=np.random.default_rng(int(p["seed"])))
+        self.graph = self._compile_graph(p)
         self.var_index = {n: i for i, n in enumerate(self.graph.var_names)}
-        params = Params(mode=algo.mode, damping=float(p["damping"]),
-                        damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
-                        start_messages=p["start_messages"], dtype=p["precision"])
-        self.engine = self._make_engine(params, p)
-        self.stop_cycle = int(p["stop_cycle"])
+        self.engine = self._make_engine(self._engine_params(algo, p), p)
+        self.stop_cycle = self._cycles_to_run(p)
         self.chunk = max(1, int(p["chunk"]))
         self._fetch()
 
     ALGO = "maxsum_gpu"
+
+    # -- what a session of another algorithm overrides (amaxsum_gpu, mgm_gpu) ----------------
+    def _compile_graph(self, p):
+        var_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "VariableComputation"]
+        fac_nodes = [cd.node for cd in self.comp_defs.values() if cd.node.type == "FactorComputation"]
+        var_nodes.sort(key=lambda n: n.name)
+        fac_nodes.sort(key=lambda n: n.name)
+        return compile_nodes(var_nodes, fac_nodes, noise=float(p["noise"]),
+                             rng=np.random.default_rng(int(p["seed"])))
+
+    def _engine_params(self, algo, p):
+        return Params(mode=algo.mode, damping=float(p["damping"]),
+                      damping_nodes=p["damping_nodes"], stability=float(p["stability"]),
+                      start_messages=p["start_messages"], dtype=p["precision"])
+
+    def _cycles_to_run(self, p) -> int:
+        return int(p["stop_cycle"])
 
     def _make_engine(self, params, p):
         """The engine of this kind of session (amaxsum_gpu overrides it)."""

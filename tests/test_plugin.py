@@ -127,6 +127,29 @@ def test_api_solve_on_two_devices(pydcop_ready, instance, expected, tmp_path, mo
     assert solve(dcop, algo, "adhoc", timeout=20) == expected
 
 
+@pytest.mark.parametrize("instance", ["graph_coloring1.yaml", "graph_coloring_tuto.yaml", "secp_simple1.yaml",
+                                      "graph_coloring_3agts_10vars.yaml"])
+def test_mgm_gpu_equals_the_reference_mgm(pydcop_ready, instance):
+    """`--algo mgm_gpu` through the unmodified orchestrator / agents == the reference's own
+    MgmComputation objects with the same deterministic choices (first value at start, first of
+    equally good values), after the same number of rounds; module attributes like the reference's."""
+    from oracle.ref_harness import run_reference_mgm
+    from pydcop.algorithms import AlgorithmDef, load_algorithm_module
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop.infrastructure.run import solve
+    ref, mod = load_algorithm_module("mgm"), load_algorithm_module("mgm_gpu")
+    assert mod.GRAPH_TYPE == ref.GRAPH_TYPE == "constraints_hypergraph"
+    refp = {p.name: (p.type, p.values, p.default_value) for p in ref.algo_params}
+    mine = {p.name: (p.type, p.values, p.default_value) for p in mod.algo_params}
+    assert all(mine[k] == v for k, v in refp.items())
+    dcop = load_dcop_from_file([os.path.join(INST, instance)])
+    algo = AlgorithmDef.build_with_default_param("mgm_gpu", {"stop_cycle": 9}, mode=dcop.objective)
+    got = solve(dcop, algo, "adhoc", timeout=20)
+    dcop2 = load_dcop_from_file([os.path.join(INST, instance)])
+    want, _, _ = run_reference_mgm(dcop2, 8)
+    assert got == want
+
+
 def test_cli_solve_json(emu_lib, tmp_path):
     """`pydcop solve --algo maxsum_gpu` through the launcher, result JSON of the
     unmodified orchestrator (docs/tutorials/analysing_results.rst:31-48)."""
