@@ -356,9 +356,16 @@ struct Engine : EngineBase {
             if (nl.cut != cut) continue;
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
-#define MXS_NARY_CASE(AR, NJ)                                                               \
-    case (AR) * 16 + (NJ):                                                                   \
-        hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);        \
+#define MXS_NARY_CASE(AR, NJ)                                                                              \
+    case (AR) * 16 + (NJ):                                                                                  \
+        if (nl.tab_type == TAB_I8)                                                                          \
+            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, int8_t>), grid, block, 0, stream, a, d);    \
+        else if (nl.tab_type == TAB_I16)                                                                    \
+            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, int16_t>), grid, block, 0, stream, a, d);   \
+        else if (nl.tab_type == TAB_F32)                                                                    \
+            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, float>), grid, block, 0, stream, a, d);     \
+        else                                                                                                \
+            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);                   \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
@@ -454,7 +461,47 @@ struct Engine : EngineBase {
     int widen_factor(int fi) {
         if (L.f_tab_type[fi] == TAB_FULL) return MXS_OK;
         if (L.f_class[fi] >= 0) return promote_class(L.f_class[fi]);
-        return fail(MXS_E_STATE, "no narrow table image for this factor");
+        { int rc = sync(); if (rc) return rc; }
+        // the factor moves to the full-width launch group of its (arity, size): regroup the
+        // descriptors (stable: every other factor keeps its relative place)
+        struct Item { int cut, code, type, fi; NaryDesc d; };
+        std::vector<int> fi_of(L.ndesc.size(), -1);
+        for (int f2 = 0; f2 < L.n_factors; ++f2)
+            if (L.f_ndesc[f2] >= 0) fi_of[L.f_ndesc[f2]] = f2;
+        std::vector<Item> items;
+        for (const NaryLaunch& nl : L.nary_launches)
+            for (int j = 0; j < nl.count; ++j) {
+                Item it{nl.cut, (nl.arity * 16 + nl.nj) * 16 + nl.threads / 64, nl.tab_type, fi_of[nl.first + j], L.ndesc[nl.first + j]};
+                if (it.fi == fi) {
+                    it.type = TAB_FULL;
+                    it.d.tab_off = L.f_tab_base[fi];
+                }
+                items.push_back(it);
+            }
+        std::stable_sort(items.begin(), items.end(), [](const Item& x, const Item& y) {
+            return x.cut != y.cut ? x.cut < y.cut : x.code != y.code ? x.code < y.code : x.type < y.type;
+        });
+        L.ndesc.clear();
+        L.nary_launches.clear();
+        for (size_t i = 0; i < items.size(); ++i) {
+            const Item& it = items[i];
+            if (i == 0 || it.cut != items[i - 1].cut || it.code != items[i - 1].code || it.type != items[i - 1].type)
+                L.nary_launches.push_back(NaryLaunch{it.code / 256, (it.code / 16) % 16, (it.code % 16) * 64,
+                                                     (int32_t)i, 0, it.cut, it.type});
+            L.nary_launches.back().count += 1;
+            L.f_ndesc[it.fi] = (int32_t)i;
+            L.ndesc.push_back(it.d);
+        }
+        L.f_tab_type[fi] = (uint8_t)TAB_FULL;
+        if (graph_exec) {  // the captured loop has the old launch groups
+            (void)hipGraphExecDestroy(graph_exec);
+            graph_exec = nullptr;
+            graph_tried = false;
+        }
+        HIP_TRY(ndesc.upload(L.ndesc, stream));
+        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
+                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
+        return MXS_OK;
     }
 
     int init(const mxs_graph& g, const mxs_params& p, int dev) override {
@@ -911,10 +958,23 @@ struct Engine : EngineBase {
             const int fit = narrowest_tab_type(table, n, (int)sizeof(T));
             if (fit >= t) {  // (TAB_I8 > TAB_I16 > TAB_F32: at least as narrow as the stored type)
                 const int cls = L.f_class[fi];
-                std::vector<uint8_t> rec((size_t)(cls >= 0 ? L.classes[cls].ctab_rec : n * tab_elem_bytes(t)), 0);
-                for (int64_t k0 = 0; k0 < n; k0 += 1 << 20)
-                    encode_tab_record(table + k0, (int)std::min<int64_t>(n - k0, 1 << 20), t,
-                                      rec.data() + k0 * tab_elem_bytes(t));
+                std::vector<uint8_t> rec;
+                if (cls >= 0) {  // register class: one record of back-to-back entries
+                    rec.assign((size_t)L.classes[cls].ctab_rec, 0);
+                    encode_tab_record(table, (int)n, t, rec.data());
+                } else {  // workgroup-per-factor: the lane-packed image (layout.h, nary_packed_pos)
+                    const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+                    const NaryLaunch* nl = nullptr;
+                    for (const NaryLaunch& x : L.nary_launches)
+                        if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) nl = &x;
+                    const int elem = tab_elem_bytes(t), slot = nary_slot_bytes(nl->nj, elem);
+                    const int64_t D0f = d.dom[0], Rf = n / D0f;
+                    rec.assign((size_t)(D0f * nl->threads * slot), 0);
+                    for (int64_t d0 = 0; d0 < D0f; ++d0)
+                        for (int64_t q = 0; q < Rf; ++q)
+                            encode_tab_record(table + d0 * Rf + q, 1, t,
+                                              rec.data() + nary_packed_pos(d0, q, nl->threads, slot, elem));
+                }
                 HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
             } else {
                 int rc = widen_factor(fi);
@@ -996,11 +1056,23 @@ struct Engine : EngineBase {
         { int rc = sync(); if (rc) return rc; }
         const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         const int ctype = L.f_tab_type[fi];
+        int p_nt = 0, p_slot = 0;   // lane-packed narrow image of a workgroup-per-factor table
+        int64_t p_R = 1;
+        if (ctype != TAB_FULL && L.f_class[fi] < 0) {
+            const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+            for (const NaryLaunch& x : L.nary_launches)
+                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) {
+                    p_nt = x.threads;
+                    p_slot = nary_slot_bytes(x.nj, tab_elem_bytes(ctype));
+                }
+            p_R = n / d.dom[0];
+        }
         hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
                            tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
                            eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
                            L.is_max ? -1.0 : 1.0, n,
-                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype);
+                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype,
+                           p_nt, p_slot, p_R);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
@@ -1712,7 +1784,13 @@ int mxs_table_storage(const mxs_engine* e, int64_t factors[4], int64_t* table_by
         const int64_t entries = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         n[t] += 1;
         if (t == mxs::TAB_FULL) bytes += entries * w;
-        else bytes += L.f_class[fi] >= 0 ? L.classes[L.f_class[fi]].ctab_rec : entries * mxs::tab_elem_bytes(t);
+        else if (L.f_class[fi] >= 0) bytes += L.classes[L.f_class[fi]].ctab_rec;
+        else {  // lane-packed image: D0 * threads * slot
+            for (const mxs::NaryLaunch& x : L.nary_launches)
+                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count)
+                    bytes += (int64_t)L.ndesc[L.f_ndesc[fi]].dom[0] * x.threads *
+                             mxs::nary_slot_bytes(x.nj, mxs::tab_elem_bytes(t));
+        }
     }
     if (factors) std::memcpy(factors, n, sizeof(n));
     if (table_bytes) *table_bytes = bytes;

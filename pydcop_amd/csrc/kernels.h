@@ -1113,6 +1113,197 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     }
 }
 
+// The same factor block for a table stored in a NARROW type (layout.h TabType), LANE-PACKED
+// (nary_packed_pos): per d0 and lane one slot of 4 / 8 / 16 bytes with the lane's NJ entries, read
+// with one aligned vector load.  k_factor_nary above streams full-width tables at the HBM ceiling;
+// with fewer bytes per entry the limit becomes how many loads are in flight, so here PF batches
+// of d0 are requested ahead (a slot is 1-4 registers where NJ full-width entries were 2 * NJ).
+// Every entry is widened to T (and negated in max mode: narrow images hold un-negated values)
+// before anything is computed with it: the arithmetic is that of the full-width kernel, bit for bit.
+template <int SW>
+struct alignas(SW * 4) NarySlot {
+    uint32_t w[SW];
+};
+template <typename T, typename TT>
+__device__ __forceinline__ T nary_slot_entry(const uint32_t* w, int j) {
+    if constexpr (sizeof(TT) == 1) return (T)(int)(int8_t)(uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    else if constexpr (sizeof(TT) == 2) return (T)(int)(int16_t)(uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+    else {
+        float f;
+        __builtin_memcpy(&f, &w[j], 4);
+        return (T)f;
+    }
+}
+
+template <typename T, int A, int NJ, typename TT>
+__global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs) {
+    typedef typename OrdKey<T>::U U;
+    constexpr int UNR = NARY_UNR;
+    constexpr int PF = 4;                                   // batches requested ahead
+    constexpr int SW = nary_slot_bytes(NJ, (int)sizeof(TT)) / 4;
+    __shared__ T s_msg[NARY_MAX_SUMD];
+    __shared__ U s_key[NARY_MAX_SUMD];
+    __shared__ T s_prev[NARY_MAX_SUMD];
+    __shared__ int s_nomatch[NARY_MAX_ARITY];
+    __shared__ int s_cnt[NARY_MAX_ARITY];
+    const NaryDesc fd = descs[blockIdx.x];
+    const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
+    int Dm[A], off[A];
+    int sumd = 0;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        Dm[i] = fd.dom[i];
+        off[i] = sumd;
+        sumd += Dm[i];
+    }
+    int R = 1;
+#pragma unroll
+    for (int i = 1; i < A; ++i) R *= Dm[i];
+    const int D0 = Dm[0];
+    const NarySlot<SW>* slots = (const NarySlot<SW>*)(a.ctables + fd.tab_off);  // [D0][NT]
+    const bool neg = a.tab_neg != 0;
+    int qc[NJ];
+    bool live[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int q = tid + j * NT;
+        live[j] = q < R;
+        qc[j] = live[j] ? q : R - 1;
+    }
+    const int n_batches = (D0 + UNR - 1) / UNR;
+    NarySlot<SW> buf[PF][UNR];
+    // the first PF batches: requested before anything else (rows past D0 clamp to the last one)
+#pragma unroll
+    for (int pb = 0; pb < PF; ++pb)
+        if (pb < n_batches) {
+#pragma unroll
+            for (int u = 0; u < UNR; ++u) {
+                const int row = pb * UNR + u < D0 ? pb * UNR + u : D0 - 1;
+                buf[pb][u] = slots[(int64_t)row * NT + tid];
+            }
+        }
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        const int vo = fd.v2f_off[i];
+        for (int d = tid; d < Dm[i]; d += NT) {
+            s_msg[off[i] + d] = a.v2f_old[vo + d];
+            s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
+        }
+    }
+    if (tid < NARY_MAX_ARITY) s_nomatch[tid] = 0;
+    __syncthreads();
+    T ms[NJ][A], acc[NJ][A], s0[NJ];
+    int dig[NJ][A];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        int rem = qc[j];
+#pragma unroll
+        for (int i = A - 1; i >= 1; --i) {
+            dig[j][i] = rem % Dm[i];
+            rem /= Dm[i];
+            ms[j][i] = s_msg[off[i] + dig[j][i]];
+            acc[j][i] = pos_inf<T>();
+        }
+        T s = (T)0;
+#pragma unroll
+        for (int i = 1; i < A; ++i) s += ms[j][i];
+        s0[j] = s;
+    }
+    const bool all_live = R == NJ * NT;  // block-uniform
+    for (int b0 = 0; b0 < n_batches; b0 += PF) {
+#pragma unroll
+        for (int pb = 0; pb < PF; ++pb) {
+            const int b = b0 + pb;
+            if (b < n_batches) {  // block-uniform
+                T tv[UNR][NJ];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) {
+                        const T v = nary_slot_entry<T, TT>(buf[pb][u].w, j);
+                        tv[u][j] = neg ? -v : v;
+                    }
+                if (b + PF < n_batches) {  // this buffer's next tenant
+#pragma unroll
+                    for (int u = 0; u < UNR; ++u) {
+                        const int row = (b + PF) * UNR + u < D0 ? (b + PF) * UNR + u : D0 - 1;
+                        buf[pb][u] = slots[(int64_t)row * NT + tid];
+                    }
+                }
+                const int d0 = b * UNR;
+                if (all_live && d0 + UNR <= D0)
+                    nary_batch<T, A, NJ, false>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+                else
+                    nary_batch<T, A, NJ, true>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+        if (live[j]) {
+#pragma unroll
+            for (int p = 1; p < A; ++p) atomicMin(&s_key[off[p] + dig[j][p]], OrdKey<T>::enc(acc[j][p]));
+        }
+    __syncthreads();
+    // apply_damping + the send rule: as in k_factor_nary
+    for (int idx = tid; idx < sumd; idx += NT) {
+        int i = 0, off_i = 0, fo_i = fd.f2v_off[0];
+#pragma unroll
+        for (int ii = 1; ii < A; ++ii)
+            if (idx >= off[ii]) {
+                i = ii;
+                off_i = off[ii];
+                fo_i = fd.f2v_off[ii];
+            }
+        const int d = idx - off_i;
+        T m = OrdKey<T>::dec(s_key[idx]);
+        if (a.start) {
+            s_msg[idx] = a.start_mode == MXS_START_ALL ? m : (T)0;
+            continue;
+        }
+        const T p = a.f2v_old[fo_i + d];
+        const int cnt = a.cF[fd.edge_base + i];
+        if (cnt > 0 && a.damp_f) m = a.damping * p + ((T)1 - a.damping) * m;
+        if (cnt > 0 && !comp_match(m, p, a.stability)) s_nomatch[i] = 1;
+        if (d == 0) s_cnt[i] = cnt;
+        s_msg[idx] = m;
+        s_prev[idx] = p;
+    }
+    __syncthreads();
+    for (int idx = tid; idx < sumd; idx += NT) {
+        int i = 0, off_i = 0, fo_i = fd.f2v_off[0];
+#pragma unroll
+        for (int ii = 1; ii < A; ++ii)
+            if (idx >= off[ii]) {
+                i = ii;
+                off_i = off[ii];
+                fo_i = fd.f2v_off[ii];
+            }
+        const int d = idx - off_i;
+        const int e = fd.edge_base + i;
+        T* w = a.f2v_new + fo_i;
+        if (a.start) {
+            w[d] = s_msg[idx];
+            if (d == 0) a.cF[e] = 0;
+            continue;
+        }
+        const int cnt = s_cnt[i];
+        const bool match = cnt > 0 && !s_nomatch[i];
+        int out = 1;
+        T val = s_msg[idx];
+        if (match) {
+            if (cnt < SAME_COUNT) {
+                out = cnt + 1;
+            } else {
+                out = cnt;
+                val = s_prev[idx];
+            }
+        }
+        w[d] = val;
+        if (d == 0) a.cF[e] = (uint8_t)out;
+    }
+}
+
 // ---------------------------------------------------------------------------
 // Variable side, wide class: ONE WAVE PER VARIABLE, for domains too large for the
 // packed class (5 <= D <= 256) or degrees above 64, as long as deg * D <= 1024, deg <= 256.
@@ -1394,7 +1585,7 @@ template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_base, int64_t tab_stride,
                                                        double* eval_tables, const double* parent,
                                                        SliceDims sd, double sign, int64_t n,
-                                                       uint8_t* crec, int ctype) {
+                                                       uint8_t* crec, int ctype, int nt, int slot, int64_t R) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int64_t rem = k, lin = sd.base;
@@ -1406,10 +1597,13 @@ __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_ba
     const double v = parent[lin];
     tables[tab_base + k * tab_stride] = (T)(sign * v);
     eval_tables[k] = v;
-    if (crec != nullptr) {  // the factor's compact record too (the parent was checked to fit)
-        if (ctype == TAB_I8) ((int8_t*)crec)[k] = (int8_t)v;
-        else if (ctype == TAB_I16) ((int16_t*)crec)[k] = (int16_t)v;
-        else ((float*)crec)[k] = (float)v;
+    if (crec != nullptr) {  // the factor's narrow image too (the parent was checked to fit):
+        // entry k of a register class's record, or the lane-packed place of a workgroup-per-factor table
+        const int elem = tab_elem_bytes(ctype);
+        uint8_t* at = crec + (nt > 0 ? nary_packed_pos(k / R, k % R, nt, slot, elem) : k * elem);
+        if (ctype == TAB_I8) *(int8_t*)at = (int8_t)v;
+        else if (ctype == TAB_I16) *(int16_t*)at = (int16_t)v;
+        else *(float*)at = (float)v;
     }
 }
 

@@ -204,10 +204,18 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 if (R >= 64 && R <= 1024 && sumd <= 1024) {
                     const int nj = (int)((R + BLOCK - 1) / BLOCK);
                     const int waves = (int)(((R + nj - 1) / nj + 63) / 64);  // 1..4
-                    // (the workgroup-per-factor kernel is bound by its wavefront reductions, not by
-                    // table bytes -- measured: f32 / int8 tables change nothing -- so its tables stay
-                    // full width: TAB_FULL)
-                    const int t = TAB_FULL;
+                    // storage type of this factor's table (one launch group = one kernel
+                    // instantiation per type): narrow + lane-packed when that is at most three
+                    // quarters of the full-width bytes
+                    int t = TAB_FULL;
+                    if (L.opt.compact_tables) {
+                        const int64_t ne = g.table_off[f + 1] - g.table_off[f];
+                        const int cand = narrowest_tab_type(g.tables + g.table_off[f], ne, L.opt.word);
+                        if (cand != TAB_FULL) {
+                            const int64_t packed = (int64_t)D0 * (waves * 64) * nary_slot_bytes(nj, tab_elem_bytes(cand));
+                            if (4 * packed <= 3 * ne * L.opt.word) t = cand;
+                        }
+                    }
                     k = FKey{K_F_NARY, ((ar * 16 + nj) * 16 + waves) * 4 + t};
                 }
             }
@@ -448,21 +456,21 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.v2f_off[i] = 0;  // filled in once the variable side is laid out
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
-                    {
-                        const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];
-                        if (t != TAB_FULL) {
-                            const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
-                            L.ctables.resize((size_t)(at + ne * tab_elem_bytes(t)), 0);
-                            // (entries back to back: encode_tab_record takes int counts)
-                            for (int64_t k0 = 0; k0 < ne; k0 += 1 << 20) {
-                                const int cnt = (int)std::min<int64_t>(ne - k0, 1 << 20);
-                                encode_tab_record(L.eval_tables.data() + L.eval_tab_off[f2] + k0, cnt, t,
-                                                  L.ctables.data() + at + k0 * tab_elem_bytes(t));
-                            }
-                            L.f_tab_type[f2] = (uint8_t)t;
-                            L.f_ctab_off[f2] = at;
-                            d.tab_off = at;
-                        }
+                    if (t != TAB_FULL) {  // lane-packed narrow image (layout.h, nary_packed_pos)
+                        const int elem = tab_elem_bytes(t), slot = nary_slot_bytes(nl.nj, elem);
+                        const int64_t D0f = d.dom[0];
+                        int64_t Rf = 1;
+                        for (int i = 1; i < d.arity; ++i) Rf *= d.dom[i];
+                        const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
+                        L.ctables.resize((size_t)(at + D0f * nl.threads * slot), 0);
+                        const double* src = L.eval_tables.data() + L.eval_tab_off[f2];
+                        for (int64_t d0 = 0; d0 < D0f; ++d0)
+                            for (int64_t q = 0; q < Rf; ++q)
+                                encode_tab_record(src + d0 * Rf + q, 1, t,
+                                                  L.ctables.data() + at + nary_packed_pos(d0, q, nl.threads, slot, elem));
+                        L.f_tab_type[f2] = (uint8_t)t;
+                        L.f_ctab_off[f2] = at;
+                        d.tab_off = at;
                     }
                     L.f_ndesc[f2] = (int32_t)L.ndesc.size();
                     L.ndesc.push_back(d);

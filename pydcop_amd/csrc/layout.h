@@ -85,6 +85,18 @@ constexpr int tab_record_bytes(int entries, int elem) {
     const int b = entries * elem;
     return b <= 4 ? 4 : b <= 8 ? 8 : (b + 15) / 16 * 16;
 }
+// Workgroup-per-factor tables in a narrow type are stored LANE-PACKED: for every d0 and every
+// lane of the factor's block one slot of 4 / 8 / 16 bytes holding the lane's NJ entries
+// (q = lane + j * NT) back to back -- one aligned vector load per (d0, lane) brings what NJ
+// full-width loads brought, so that several d0-batches can be in flight at once.
+constexpr int nary_slot_bytes(int nj, int elem) {
+    const int b = nj * elem;
+    return b <= 4 ? 4 : b <= 8 ? 8 : 16;
+}
+// position of table entry (d0, q) in the lane-packed image of a factor (bytes from its start)
+constexpr int64_t nary_packed_pos(int64_t d0, int64_t q, int nt, int slot, int elem) {
+    return (d0 * nt + q % nt) * slot + (q / nt) * elem;
+}
 constexpr int NUM_XCD = 8;  // MI355X: workgroup b of a grid runs on XCD b % 8 (observed; used for speed only)
 constexpr int MAX_REG_D = 4;
 constexpr int MAX_PACK_DEG = 64;  // one wave

@@ -64,9 +64,9 @@ def test_amaxsum_oracle_equals_reference(name, make, mode, params, gens, oracle_
     g = make()
     dcop, cg = ref_harness.flat_to_dcop(g, mode)
     vals, costs, info = ref_harness.run_reference_amaxsum(dcop, gens, params, cg=cg,
-                                                          max_messages=None if gens >= 0 else 400_000)
+                                                          max_messages=None if gens >= 0 else 40_000)
     o = OracleAMaxSum(g, Params(mode=mode, **params))
-    n = o.run(gens, -1 if gens >= 0 else 400_000)
+    n = o.run(gens, -1 if gens >= 0 else 40_000)
     assert n == info["delivered"] and o.pending == info["pending"]
     np.testing.assert_array_equal(o.generation_sizes(), info["generation_sizes"])
     idx, belief = o.assignment()
@@ -78,4 +78,4 @@ def test_amaxsum_oracle_equals_reference(name, make, mode, params, gens, oracle_
     for k in held:
         np.testing.assert_array_equal(mine[k], held[k], err_msg=k)
     if gens == -1:
-        assert o.pending == 0 or n == 400_000
+        assert o.pending == 0 or n == 40_000

@@ -41,7 +41,7 @@ def test_emu_bit_exact_vs_oracle(case, dtype, emu_lib, oracle_built):
 def test_emu_layout_variants(layout, emu_lib, oracle_built):
     cases = parity_cases() if layout == "unsorted_factors" else parity_cases()[:3] + parity_cases()[6:8]
     for name, make, kw in cases:
-        for dtype in (("f64", "f32") if layout == "unsorted_factors" else ("f64",)):
+        for dtype in (("f64", "f32") if (layout == "unsorted_factors" and name in ("coloring3_soft", "mixed", "nary_meeting_d8")) else ("f64",)):
             compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], dtype=dtype, **kw), 0,
                                 lib_path=emu_lib, steps=[1, 6])
 
