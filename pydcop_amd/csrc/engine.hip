@@ -211,6 +211,13 @@ struct Engine : EngineBase {
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // The wide variable kernels (latency-bound, few waves) and the workgroup-per-factor launches
+    // (compute-bound since their tables are narrow) of one cycle read the same old buffers and
+    // write disjoint new ones (Jacobi): the wide kernels go to a side stream and run beside the
+    // n-ary launches.  Eager launches only; $MAXSUM_NARY_OVERLAP=0 keeps one stream.
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    bool overlap = false, capturing = false;
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
     bool halo_pending = false;
@@ -235,6 +242,9 @@ struct Engine : EngineBase {
             (void)rccl->CommDestroy(nccl_comm);
         }
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
+        if (side) (void)hipStreamDestroy(side);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (ev_p1) (void)hipEventDestroy(ev_p1);
@@ -402,14 +412,25 @@ struct Engine : EngineBase {
             // isolated variables only act in cycle 0
             int rc = launch_sweep(a, (start || L.sweep_regular) ? L.n_blocks_sweep : 0);
             if (rc) return rc;
+            const bool fork = overlap && !capturing && !L.wide_classes.empty() && !L.nary_launches.empty();
+            hipStream_t ws = stream;
+            if (fork) {  // the side stream starts where the compute stream is now
+                HIP_TRY(hipEventRecord(ev_fork, stream));
+                HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
+                ws = side;
+            }
             for (int c : L.wide_classes) {
                 const ClassInfo& ci = L.classes[c];
                 const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
-                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
-                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
+                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, ws, a, ci);
+                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, ws, a, ci);
                 HIP_TRY(hipGetLastError());
             }
-            return launch_nary(a, 0);
+            if (fork) HIP_TRY(hipEventRecord(ev_join, side));
+            rc = launch_nary(a, 0);
+            if (rc) return rc;
+            if (fork) HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));  // the cycle ends when both have
+            return MXS_OK;
         }
         int rc = launch_sweep(a, L.n_blocks_sweep2);
         if (rc) return rc;
@@ -543,6 +564,13 @@ struct Engine : EngineBase {
         }
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
+        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+        {
+            const char* env = getenv("MAXSUM_NARY_OVERLAP");
+            overlap = !(env && env[0] == '0');
+        }
         {   // the comm stream's kernels (pack, RCCL, unpack) go first whenever a slot frees up
             int lo = 0, hi = 0;
             HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
@@ -655,10 +683,12 @@ struct Engine : EngineBase {
         }
         int from = 0;
         bool ok = true;
+        capturing = true;  // (one stream inside a capture)
         for (int i = 0; i < chunk && ok; ++i) {
             ok = launch_cycle(from, false) == MXS_OK;
             from ^= 1;
         }
+        capturing = false;
         if (hipStreamEndCapture(stream, &graph) != hipSuccess || !ok || !graph) {
             (void)hipGetLastError();
             if (graph) (void)hipGraphDestroy(graph);

@@ -1120,6 +1120,9 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 // of d0 are requested ahead (a slot is 1-4 registers where NJ full-width entries were 2 * NJ).
 // Every entry is widened to T (and negated in max mode: narrow images hold un-negated values)
 // before anything is computed with it: the arithmetic is that of the full-width kernel, bit for bit.
+#ifndef MXS_NARY_PF
+#define MXS_NARY_PF 4
+#endif
 template <int SW>
 struct alignas(SW * 4) NarySlot {
     uint32_t w[SW];
@@ -1139,7 +1142,7 @@ template <typename T, int A, int NJ, typename TT>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
-    constexpr int PF = 4;                                   // batches requested ahead
+    constexpr int PF = MXS_NARY_PF;                         // batches requested ahead
     constexpr int SW = nary_slot_bytes(NJ, (int)sizeof(TT)) / 4;
     __shared__ T s_msg[NARY_MAX_SUMD];
     __shared__ U s_key[NARY_MAX_SUMD];
