@@ -886,6 +886,32 @@ __device__ __forceinline__ T wave_min_to_lane63(T x) {
     x = min2(x, dpp_mov<0x143, 0xc>(x));  // row_bcast31 -> rows 2, 3
     return x;
 }
+// FOUR wavefront minima at once, for less than the price of two: lanes trade values before they
+// reduce them.  Step A (partner l^1): even lanes keep b[0], b[1], odd lanes b[2], b[3], each gets
+// the partner's copies of what it keeps; step B (partner l^2): one value per lane is left --
+// value index 2*(l&1) + ((l>>1)&1); then lanes l+4, l+8, l+12 of the row (row_ror keeps l & 3) and
+// the other rows (l^16, l^32).  Every lane returns the wave minimum of ITS value index.
+// 7 minima and 14 moves instead of 24 and 48.
+#ifndef MXS_NARY_REDUCE4
+#define MXS_NARY_REDUCE4 0
+#endif
+template <typename T>
+__device__ __forceinline__ T wave_min4(const T (&b)[4]) {
+    const int l = (int)threadIdx.x & 63;
+    const bool odd = (l & 1) != 0, hi = (l & 2) != 0;
+    T k0 = odd ? b[2] : b[0], k1 = odd ? b[3] : b[1];
+    const T s0 = odd ? b[0] : b[2], s1 = odd ? b[1] : b[3];
+    k0 = min2(k0, dpp_mov<0xB1, 0xf>(s0));
+    k1 = min2(k1, dpp_mov<0xB1, 0xf>(s1));
+    T k = hi ? k1 : k0;
+    const T s = hi ? k0 : k1;
+    k = min2(k, dpp_mov<0x4E, 0xf>(s));
+    k = min2(k, dpp_mov<0x124, 0xf>(k));  // row_ror:4
+    k = min2(k, dpp_mov<0x128, 0xf>(k));  // row_ror:8
+    k = min2(k, __shfl(k, l ^ 16, 64));
+    k = min2(k, __shfl(k, l ^ 32, 64));
+    return k;
+}
 #endif
 
 constexpr int NARY_UNR = 4;  // values of d0 per batch: UNR * NJ table loads per lane in flight,
@@ -920,7 +946,16 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
         }
         best0[u] = b0;
     }
-#if defined(__HIPCC__) && MXS_NARY_DPP
+#if defined(__HIPCC__) && MXS_NARY_DPP && MXS_NARY_REDUCE4
+    static_assert(NARY_UNR == 4, "wave_min4 reduces four values");
+    {
+        const T m = wave_min4(best0);
+        const int l = (int)threadIdx.x & 63;
+        const int u = 2 * (l & 1) + ((l >> 1) & 1);
+        if (l < 4 && (!MASKED || d0 + u < D0)) atomicMin(&s_key0[d0 + u], OrdKey<T>::enc(m));
+    }
+    if (false) {
+#elif defined(__HIPCC__) && MXS_NARY_DPP
 #pragma unroll
     for (int u = 0; u < NARY_UNR; ++u) best0[u] = wave_min_to_lane63(best0[u]);
     if ((threadIdx.x & 63) == 63) {
