@@ -391,6 +391,27 @@ int mxs_mgm_get_state(mxs_mgm *e, int32_t *idx, double *cost, uint8_t *has_cost,
 int mxs_mgm_eval_cost(mxs_mgm *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
 int mxs_mgm_destroy(mxs_mgm *e);
 
+/* ---- DSA (pydcop/algorithms/dsa.py, variants A / B / C) on the same flat arrays --------------
+ * One cycle = every variable's `evaluate_cycle` once all its neighbours' values are in
+ * (dsa.py:319-359: best values and their cost, delta, the variant's rule :361-409, the
+ * probabilistic move :411-419) -- n cycles = the reference with stop_cycle = n.  variant: 0 = A,
+ * 1 = B, 2 = C; `probability` and p_mode arity (1.2 / sum(arity - 1), dsa.py:256-259) as the
+ * reference's parameters.  The reference draws from Python's unseeded `random`; here every draw
+ * comes from a counter-based generator keyed on (seed, variable, cycle, draw), the same function
+ * on the device, in the oracle and -- patched into the reference for the duration of a run -- in
+ * the pinning harness: bit for bit the reference's own DsaComputation objects under that generator
+ * (oracle/dsa_oracle.c, tests/test_dsa_oracle_vs_reference.py), independent of scheduling. */
+typedef struct mxs_dsa mxs_dsa;
+int mxs_dsa_create(const mxs_graph *g, const mxs_params *p, int32_t variant, double probability,
+                   int32_t arity_mode, uint64_t seed, int32_t device, mxs_dsa **out);
+int mxs_dsa_reset(mxs_dsa *e);
+int mxs_dsa_run(mxs_dsa *e, int32_t n_cycles);
+int mxs_dsa_cycles(const mxs_dsa *e, int64_t *cycles);
+/* current value index and the cost the computation holds (0 until its first move) */
+int mxs_dsa_get_state(mxs_dsa *e, int32_t *idx, double *cost);
+int mxs_dsa_eval_cost(mxs_dsa *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
+int mxs_dsa_destroy(mxs_dsa *e);
+
 /* Library/ABI version (major*100+minor). */
 int32_t mxs_version(void);
 

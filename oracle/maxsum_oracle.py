@@ -17,9 +17,9 @@ _LIBS = {}
 
 def build(force=False):
     """Compile the C restatement (both precisions) with gcc."""
-    targets = [os.path.join(_HERE, f"lib{a}_oracle_{p}.so") for a in ("maxsum", "amaxsum", "mgm") for p in ("f64", "f32")]
+    targets = [os.path.join(_HERE, f"lib{a}_oracle_{p}.so") for a in ("maxsum", "amaxsum", "mgm", "dsa") for p in ("f64", "f32")]
     srcs = [os.path.join(_HERE, "maxsum_oracle.c"), os.path.join(_HERE, "amaxsum_oracle.c"),
-            os.path.join(_HERE, "mgm_oracle.c")]
+            os.path.join(_HERE, "mgm_oracle.c"), os.path.join(_HERE, "dsa_oracle.c")]
     newest = max(os.path.getmtime(s) for s in srcs)
     stale = force or any((not os.path.exists(t)) or os.path.getmtime(t) < newest for t in targets)
     if stale:

@@ -255,6 +255,95 @@ def run_reference_mgm(dcop, rounds, cg=None):
     return values, costs, comps
 
 
+_M64 = (1 << 64) - 1
+
+
+def _mix64(z):
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def dsa_uniform(seed, variable, cycle, draw):
+    """The counter-based generator of oracle/dsa_oracle.c (and pydcop_amd/csrc/dsa.hip), bit for bit."""
+    z = (seed + 0x9E3779B97F4A7C15 * (variable + 1)) & _M64
+    z = (_mix64(z) + 0x9E3779B97F4A7C15 * (cycle + 1)) & _M64
+    z = (_mix64(z) + draw) & _M64
+    return (_mix64(z) >> 11) * (1.0 / 9007199254740992.0)
+
+
+def run_reference_dsa(dcop, cycles, variant="B", probability=0.7, p_mode="fixed", seed=0, var_index=None):
+    """The reference's own DsaComputation objects (pydcop/algorithms/dsa.py) for exactly `cycles`
+    evaluations each (stop_cycle = cycles), FIFO delivery (DSA parks early values, dsa.py:300-317,
+    so any order gives the same result).  The reference's draws from the unseeded `random`
+    module are replaced -- for the duration of the run -- by dsa_uniform keyed on (variable,
+    cycle, draw), see oracle/dsa_oracle.c.  Returns ({var: value}, {var: cost}, comps)."""
+    install_shims()
+    from pydcop.algorithms import AlgorithmDef, ComputationDef, load_algorithm_module
+    from pydcop.computations_graph import constraints_hypergraph as chg
+    import pydcop.algorithms.dsa as dsa
+    import pydcop.infrastructure.computations as comps_mod
+    import logging
+
+    names = sorted(dcop.variables) if var_index is None else None
+    index = var_index or {n: i for i, n in enumerate(names)}
+    ctx = {"comp": None, "start": False}
+
+    class _Keyed:
+        def __getattr__(self, name):
+            import random as _r
+            return getattr(_r, name)
+
+        @staticmethod
+        def random():
+            c = ctx["comp"]
+            return dsa_uniform(seed, index[c.name], c.cycle_count + 1, 1)
+
+        @staticmethod
+        def choice(seq):
+            c = ctx["comp"]
+            if ctx["start"]:
+                u = dsa_uniform(seed, index[c.name], 0, 0)
+            else:
+                u = dsa_uniform(seed, index[c.name], c.cycle_count + 1, 2)
+            return seq[int(u * len(seq))]
+
+    saved = (dsa.random, comps_mod.random)
+    dsa.random = comps_mod.random = _Keyed()
+    logging.disable(logging.CRITICAL)
+    try:
+        cg = chg.build_computation_graph(dcop)
+        algo = AlgorithmDef.build_with_default_param(
+            "dsa", {"stop_cycle": cycles, "variant": variant, "probability": probability, "p_mode": p_mode},
+            mode=dcop.objective)
+        module = load_algorithm_module("dsa")
+        comps, q = {}, deque()
+
+        def sender(src, dest, msg, prio=None, on_error=None):
+            q.append((src, dest, msg))
+
+        for node in cg.nodes:
+            c = module.build_computation(ComputationDef(node, algo))
+            c.message_sender = sender
+            c._on_finished = lambda *a, **k: None
+            comps[node.name] = c
+        ctx["start"] = True
+        for c in comps.values():
+            ctx["comp"] = c
+            c.start()
+        ctx["start"] = False
+        while q and cycles > 0:
+            s, d, m = q.popleft()
+            ctx["comp"] = comps[d]
+            comps[d].on_message(s, m, 0.0)
+    finally:
+        dsa.random, comps_mod.random = saved
+        logging.disable(logging.NOTSET)
+    values = {v: comps[v].current_value for v in dcop.variables}
+    costs = {v: comps[v].current_cost for v in dcop.variables}
+    return values, costs, comps
+
+
 def flat_to_dcop(graph, mode="min", name="flat"):
     """Build reference objects (DCOP + ComputationsFactorGraph) from a FlatGraph:
     VariableWithCostDict variables (pydcop/dcop/objects.py:410) and extensional

@@ -1,0 +1,422 @@
+// dsa.hip -- the reference's DSA (pydcop/algorithms/dsa.py: variants A, B, C; Zhang & al. 2005)
+// on gfx950, on the same flat factor-graph arrays as the Max-Sum engine (SURVEY.md section
+// 8(f).4).  DSA is bulk-synchronous by construction (a computation evaluates a cycle once ALL
+// its neighbours' values of that cycle are in and parks the next ones, dsa.py:300-317): one cycle =
+// ONE launch, thread per variable, reading the neighbours' values of the previous cycle and the
+// variable's constraints' tables at them (CSR walk, integer index arithmetic + a few adds).
+//
+// The reference draws from Python's unseeded `random` module (initial value, move test, choice
+// among the best values).  Here every draw comes from a counter-based generator keyed on (seed,
+// variable, cycle, draw) -- dsa_uniform, the same function in oracle/dsa_oracle.c and, patched into
+// the reference's `random` for the duration of a run, in oracle/ref_harness.py -- so that the
+// stochastic algorithm has a pinned parity: bit for bit the reference's own DsaComputation objects
+// under that generator (tests/test_dsa_oracle_vs_reference.py), independent of scheduling.  The
+// reference's quirks are restated as they are (variable costs never enter, initial values are
+// ignored, the held cost is 0 until the first move): see oracle/dsa_oracle.c.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/maxsum_gpu.h"
+
+extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
+
+namespace dsa {
+
+constexpr int TPB = 256;
+
+static int fail(int code, const std::string& msg) {
+    mxs_set_last_error(msg.c_str());
+    return code;
+}
+#define DSA_TRY(call)                                                                     \
+    do {                                                                                  \
+        hipError_t e__ = (call);                                                          \
+        if (e__ != hipSuccess) return fail(MXS_E_HIP, std::string(#call) + " failed");     \
+    } while (0)
+
+template <typename U>
+struct Buf {
+    U* p = nullptr;
+    size_t n = 0;
+    hipError_t upload(const std::vector<U>& h, hipStream_t st) {
+        n = h.size();
+        hipError_t e = hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
+        if (e != hipSuccess || h.empty()) return e;
+        e = hipMemcpyAsync(p, h.data(), n * sizeof(U), hipMemcpyHostToDevice, st);
+        if (e != hipSuccess) return e;
+        return hipStreamSynchronize(st);
+    }
+    hipError_t alloc(size_t count) {
+        n = count;
+        return hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
+    }
+    ~Buf() {
+        if (p) (void)hipFree(p);
+    }
+};
+
+// splitmix64 finaliser over a key of (seed, variable, cycle, draw): oracle/dsa_oracle.c, bit for bit
+__host__ __device__ inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__host__ __device__ inline double uniform(uint64_t seed, int32_t variable, int64_t cycle, int32_t draw) {
+    uint64_t z = seed + 0x9E3779B97F4A7C15ull * ((uint64_t)(uint32_t)variable + 1);
+    z = mix64(z) + 0x9E3779B97F4A7C15ull * ((uint64_t)cycle + 1);
+    z = mix64(z) + (uint64_t)(uint32_t)draw;
+    return (double)(mix64(z) >> 11) * (1.0 / 9007199254740992.0);
+}
+
+template <typename T>
+struct Dev {
+    int32_t n_vars, is_max, variant;
+    uint64_t seed;
+    int64_t cycle;        // cycle_count of the evaluation being made
+    const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *n_neigh;
+    const int64_t* table_off;
+    const T *tables, *f_opt;
+    const double* prob;
+    const int32_t* cur;
+    int32_t* cur_out;
+    T* cost;
+};
+
+template <typename T>
+__device__ T constraint_at(const Dev<T>& g, int f, int v, int x) {
+    int64_t lin = 0;
+    for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
+        const int u = g.edge_var[e];
+        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[u]);
+    }
+    return g.tables[g.table_off[f] + lin];
+}
+
+// assignment_cost (relations.py:1513-1533): cost = 0; cost += c(...) in constraints order
+template <typename T>
+__device__ T assignment_cost(const Dev<T>& g, int v, int x) {
+    T cost = (T)0;
+    for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1]; ++k)
+        cost += constraint_at(g, g.edge_factor[g.var_edges[k]], v, x);
+    return cost;
+}
+
+// evaluate_cycle, dsa.py:319-359 + variant_a/b/c :361-409 + probabilistic_change :411-419
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars) return;
+    const int mine = g.cur[v];
+    int out = mine;
+    if (g.n_neigh[v] != 0) {
+        const int D = g.dom_size[v];
+        T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;   // find_optimal, relations.py:1622-1638
+        int n_best = 0, first_best = -1;
+        bool has_cur = false;
+        for (int x = 0; x < D; ++x) {
+            const T c = assignment_cost(g, v, x);
+            if (c == best_cost) {
+                n_best += 1;
+                if (x == mine) has_cur = true;
+            } else if ((!g.is_max && c < best_cost) || (g.is_max && c > best_cost)) {
+                best_cost = c;
+                n_best = 1;
+                first_best = x;
+                has_cur = x == mine;
+            }
+        }
+        const T current_cost = assignment_cost(g, v, mine);
+        const T diff = current_cost - best_cost;
+        const T delta = diff < (T)0 ? -diff : diff;
+        bool attempt = false, drop_cur = false;
+        if (delta > (T)0) {
+            attempt = true;
+        } else if (delta == (T)0) {
+            if (g.variant == 1) {  // B: some constraint is not at its optimum (dsa.py:421-433)
+                for (int k = g.var_rowptr[v]; k < g.var_rowptr[v + 1] && !attempt; ++k) {
+                    const int f = g.edge_factor[g.var_edges[k]];
+                    if (constraint_at(g, f, v, mine) != g.f_opt[f]) attempt = true;
+                }
+            } else if (g.variant == 2) {
+                attempt = true;
+            }
+            if (attempt && n_best > 1 && has_cur) drop_cur = true;  // best_values.remove(current_value)
+        }
+        if (attempt && g.prob[v] > uniform(g.seed, v, g.cycle + 1, 1)) {
+            const int n = n_best - (drop_cur ? 1 : 0);
+            int j = (int)(uniform(g.seed, v, g.cycle + 1, 2) * n);
+            int pick = first_best;
+            for (int x = 0; x < D; ++x) {  // the j-th best value in domain order, the current one skipped
+                if (assignment_cost(g, v, x) != best_cost) continue;
+                if (drop_cur && x == mine) continue;
+                if (j-- == 0) {
+                    pick = x;
+                    break;
+                }
+            }
+            out = pick;
+            g.cost[v] = best_cost;  // value_selection(choice, best_cost)
+        }
+    }
+    g.cur_out[v] = out;
+}
+
+struct Base {
+    virtual ~Base() {}
+    virtual int init(const mxs_graph& G, const mxs_params& p, int variant, double probability, int arity_mode,
+                     uint64_t seed, int device) = 0;
+    virtual int reset() = 0;
+    virtual int run(int32_t n) = 0;
+    virtual int get_state(int32_t* idx, double* cost) = 0;
+    virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
+    int64_t cycles = 0;
+};
+
+template <typename T>
+struct Engine : Base {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    Dev<T> g{};
+    int which = 0;
+    uint64_t seed = 0;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_nn;
+    std::vector<int64_t> h_toff, h_coff;
+    std::vector<double> h_tables, h_eval_cost, h_var_cost;
+    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, n_neigh;
+    Buf<int32_t> cur[2];
+    Buf<int64_t> table_off;
+    Buf<T> tables, f_opt, cost;
+    Buf<double> prob;
+
+    ~Engine() override {
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+
+    int init(const mxs_graph& G, const mxs_params& p, int variant, double probability, int arity_mode,
+             uint64_t sd, int dev) override {
+        device = dev;
+        seed = sd;
+        int count = 0;
+        if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+            return fail(MXS_E_NODEVICE, "no HIP device visible: the engine has no CPU fallback");
+        if (dev < 0 || dev >= count) return fail(MXS_E_INVALID, "device index out of range");
+        if (variant < 0 || variant > 2) return fail(MXS_E_INVALID, "variant must be 0 (A), 1 (B) or 2 (C)");
+        if (p.mode != MXS_MODE_MIN && p.mode != MXS_MODE_MAX) return fail(MXS_E_INVALID, "invalid mode");
+        DSA_TRY(hipSetDevice(dev));
+        DSA_TRY(hipStreamCreateWithFlags(&stream, 0));
+        const int nV = G.n_vars, nF = G.n_factors, nE = G.n_edges;
+        if (nV < 0 || nF < 0 || nE < 0) return fail(MXS_E_INVALID, "negative size");
+        h_dom.assign(G.dom_size, G.dom_size + nV);
+        h_frow.assign(G.factor_rowptr, G.factor_rowptr + nF + 1);
+        h_evar.assign(G.edge_var, G.edge_var + nE);
+        h_toff.assign(G.table_off, G.table_off + nF + 1);
+        h_coff.assign(nV + 1, 0);
+        for (int v = 0; v < nV; ++v) {
+            if (h_dom[v] < 1) return fail(MXS_E_INVALID, "empty domain");
+            h_coff[v + 1] = h_coff[v] + h_dom[v];
+        }
+        std::vector<int32_t> efac(nE), vrow(G.var_rowptr, G.var_rowptr + nV + 1), vedges(G.var_edges, G.var_edges + nE);
+        for (int f = 0; f < nF; ++f) {
+            if (h_frow[f + 1] <= h_frow[f]) return fail(MXS_E_INVALID, "factor without variable");
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                if (h_evar[e] < 0 || h_evar[e] >= nV) return fail(MXS_E_INVALID, "edge_var out of range");
+                efac[e] = f;
+            }
+        }
+        h_nn.assign(nV, 0);
+        std::vector<int64_t> n_count(nV, 0);
+        for (int f = 0; f < nF; ++f) {
+            const int ar = h_frow[f + 1] - h_frow[f];
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                if (ar > 1) h_nn[h_evar[e]] = 1;
+                n_count[h_evar[e]] += ar - 1;
+            }
+        }
+        std::vector<double> pr(nV);
+        for (int v = 0; v < nV; ++v)  // p_mode arity: 1 / sum(arity - 1) * 1.2 (dsa.py:256-259)
+            pr[v] = (arity_mode && n_count[v] > 0) ? 1.0 / (double)n_count[v] * 1.2 : probability;
+        h_tables.assign(G.tables, G.tables + h_toff[nF]);
+        h_var_cost.assign(G.var_cost, G.var_cost + h_coff[nV]);
+        const double* ev = G.eval_var_cost ? G.eval_var_cost : G.var_cost;
+        h_eval_cost.assign(ev, ev + h_coff[nV]);
+        std::vector<T> tt(h_tables.size()), fo(nF);
+        for (size_t i = 0; i < tt.size(); ++i) tt[i] = (T)h_tables[i];
+        for (int f = 0; f < nF; ++f) {  // find_optimum (relations.py:1367-1401): variant B
+            T opt = tt[h_toff[f]];
+            for (int64_t k = h_toff[f] + 1; k < h_toff[f + 1]; ++k)
+                if (p.mode == MXS_MODE_MAX ? tt[k] > opt : tt[k] < opt) opt = tt[k];
+            fo[f] = opt;
+        }
+        DSA_TRY(dom_size.upload(h_dom, stream));
+        DSA_TRY(factor_rowptr.upload(h_frow, stream));
+        DSA_TRY(edge_var.upload(h_evar, stream));
+        DSA_TRY(edge_factor.upload(efac, stream));
+        DSA_TRY(var_rowptr.upload(vrow, stream));
+        DSA_TRY(var_edges.upload(vedges, stream));
+        DSA_TRY(n_neigh.upload(h_nn, stream));
+        DSA_TRY(table_off.upload(h_toff, stream));
+        DSA_TRY(tables.upload(tt, stream));
+        DSA_TRY(f_opt.upload(fo, stream));
+        DSA_TRY(prob.upload(pr, stream));
+        for (int b = 0; b < 2; ++b) DSA_TRY(cur[b].alloc(nV));
+        DSA_TRY(cost.alloc(nV));
+        g.n_vars = nV;
+        g.is_max = p.mode == MXS_MODE_MAX;
+        g.variant = variant;
+        g.seed = seed;
+        g.dom_size = dom_size.p; g.factor_rowptr = factor_rowptr.p; g.edge_var = edge_var.p;
+        g.edge_factor = edge_factor.p; g.var_rowptr = var_rowptr.p; g.var_edges = var_edges.p;
+        g.n_neigh = n_neigh.p; g.table_off = table_off.p; g.tables = tables.p; g.f_opt = f_opt.p;
+        g.prob = prob.p; g.cost = cost.p;
+        return reset();
+    }
+
+    int reset() override {
+        DSA_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        std::vector<int32_t> c0(nV);
+        std::vector<T> k0(nV, (T)0);
+        for (int v = 0; v < nV; ++v) {
+            if (h_nn[v] == 0) {  // optimal_cost_value (dsa.py:278-289)
+                int best = 0;
+                for (int d = 1; d < h_dom[v]; ++d) {
+                    const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
+                    if (g.is_max ? a >= b : a < b) best = d;
+                }
+                c0[v] = best;
+                k0[v] = (T)h_var_cost[h_coff[v] + best];
+            } else {  // random_value_selection (dsa.py:291): draw 0 of cycle 0
+                c0[v] = (int32_t)(uniform(seed, v, 0, 0) * h_dom[v]);
+            }
+        }
+        which = 0;
+        if (nV) {
+            DSA_TRY(hipMemcpyAsync(cur[0].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
+            DSA_TRY(hipMemcpyAsync(cost.p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+            DSA_TRY(hipStreamSynchronize(stream));
+        }
+        cycles = 0;
+        return MXS_OK;
+    }
+
+    int run(int32_t n) override {
+        DSA_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        if (nV == 0) {
+            cycles += n > 0 ? n : 0;
+            return MXS_OK;
+        }
+        const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
+        for (int32_t r = 0; r < n; ++r) {
+            g.cur = cur[which].p;
+            g.cur_out = cur[which ^ 1].p;
+            g.cycle = cycles;
+            hipLaunchKernelGGL((k_dsa_cycle<T>), grid, block, 0, stream, g);
+            DSA_TRY(hipGetLastError());
+            which ^= 1;
+            cycles += 1;
+        }
+        DSA_TRY(hipStreamSynchronize(stream));
+        return MXS_OK;
+    }
+
+    int get_state(int32_t* idx, double* cst) override {
+        DSA_TRY(hipSetDevice(device));
+        const int nV = g.n_vars;
+        if (!nV) return MXS_OK;
+        std::vector<T> hc(nV);
+        if (idx) DSA_TRY(hipMemcpyAsync(idx, cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
+        DSA_TRY(hipMemcpyAsync(hc.data(), cost.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+        DSA_TRY(hipStreamSynchronize(stream));
+        if (cst)
+            for (int v = 0; v < nV; ++v) cst[v] = (double)hc[v];
+        return MXS_OK;
+    }
+
+    int eval_cost(const int32_t* idx, double infinity, double* cst, int64_t* viol) override {
+        std::vector<int32_t> c;
+        if (!idx) {
+            c.resize(g.n_vars);
+            int rc = get_state(c.data(), nullptr);
+            if (rc) return rc;
+            idx = c.data();
+        }
+        double soft = 0;
+        int64_t hard = 0;
+        const int nF = (int)h_frow.size() - 1;
+        for (int f = 0; f < nF; ++f) {
+            int64_t lin = 0;
+            for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) {
+                const int v = h_evar[e];
+                if (idx[v] < 0 || idx[v] >= h_dom[v]) return fail(MXS_E_INVALID, "assignment index out of the domain");
+                lin = lin * h_dom[v] + idx[v];
+            }
+            const double r = h_tables[h_toff[f] + lin];
+            if (r != infinity) soft += r; else hard += 1;
+        }
+        for (int v = 0; v < g.n_vars; ++v) {
+            const double x = h_eval_cost[h_coff[v] + idx[v]];
+            if (x != infinity) soft += x; else hard += 1;
+        }
+        if (cst) *cst = soft;
+        if (viol) *viol = hard;
+        return MXS_OK;
+    }
+};
+
+}  // namespace dsa
+
+struct mxs_dsa {
+    dsa::Base* impl;
+};
+
+extern "C" {
+
+int mxs_dsa_create(const mxs_graph* g, const mxs_params* p, int32_t variant, double probability, int32_t arity_mode,
+                   uint64_t seed, int32_t device, mxs_dsa** out) {
+    if (!g || !p || !out) return dsa::fail(MXS_E_INVALID, "null argument");
+    *out = nullptr;
+    try {
+        dsa::Base* impl = p->dtype == MXS_DTYPE_F32 ? (dsa::Base*)new dsa::Engine<float>() : (dsa::Base*)new dsa::Engine<double>();
+        int rc = impl->init(*g, *p, variant, probability, arity_mode, seed, device);
+        if (rc) {
+            delete impl;
+            return rc;
+        }
+        *out = new mxs_dsa{impl};
+        return MXS_OK;
+    } catch (const std::exception& ex) {
+        return dsa::fail(MXS_E_NOMEM, ex.what());
+    }
+}
+int mxs_dsa_reset(mxs_dsa* e) { return e ? e->impl->reset() : dsa::fail(MXS_E_INVALID, "null handle"); }
+int mxs_dsa_run(mxs_dsa* e, int32_t n_cycles) {
+    if (!e) return dsa::fail(MXS_E_INVALID, "null handle");
+    if (n_cycles < 0) return dsa::fail(MXS_E_INVALID, "negative cycle count");
+    return e->impl->run(n_cycles);
+}
+int mxs_dsa_cycles(const mxs_dsa* e, int64_t* cycles) {
+    if (!e) return dsa::fail(MXS_E_INVALID, "null handle");
+    if (cycles) *cycles = e->impl->cycles;
+    return MXS_OK;
+}
+int mxs_dsa_get_state(mxs_dsa* e, int32_t* idx, double* cost) {
+    return e ? e->impl->get_state(idx, cost) : dsa::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_dsa_eval_cost(mxs_dsa* e, const int32_t* idx, double infinity, double* cost, int64_t* violations) {
+    return e ? e->impl->eval_cost(idx, infinity, cost, violations) : dsa::fail(MXS_E_INVALID, "null handle");
+}
+int mxs_dsa_destroy(mxs_dsa* e) {
+    if (e) {
+        delete e->impl;
+        delete e;
+    }
+    return MXS_OK;
+}
+
+}  // extern "C"

@@ -49,6 +49,8 @@ ABI_SYMBOLS = (
     "mxs_amaxsum_eval_cost", "mxs_amaxsum_destroy",
     "mxs_mgm_create", "mxs_mgm_reset", "mxs_mgm_run", "mxs_mgm_rounds", "mxs_mgm_get_state",
     "mxs_mgm_eval_cost", "mxs_mgm_destroy",
+    "mxs_dsa_create", "mxs_dsa_reset", "mxs_dsa_run", "mxs_dsa_cycles", "mxs_dsa_get_state",
+    "mxs_dsa_eval_cost", "mxs_dsa_destroy",
 )
 
 
@@ -162,6 +164,14 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_mgm_get_state": ([vp, vp, vp, vp, vp, vp], C.c_int),
         "mxs_mgm_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
         "mxs_mgm_destroy": ([vp], C.c_int),
+        "mxs_dsa_create": ([C.POINTER(CGraph), C.POINTER(CParams), i32, C.c_double, i32, C.c_uint64, i32,
+                            C.POINTER(vp)], C.c_int),
+        "mxs_dsa_reset": ([vp], C.c_int),
+        "mxs_dsa_run": ([vp, i32], C.c_int),
+        "mxs_dsa_cycles": ([vp, C.POINTER(i64)], C.c_int),
+        "mxs_dsa_get_state": ([vp, vp, vp], C.c_int),
+        "mxs_dsa_eval_cost": ([vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(i64)], C.c_int),
+        "mxs_dsa_destroy": ([vp], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),

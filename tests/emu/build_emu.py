@@ -10,7 +10,7 @@ OUT = os.path.join(HERE, "_build", "libmaxsum_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip")]
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "layout.h")] + [
         os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "maxsum_gpu.h")]
     if not force and os.path.exists(OUT) and all(
@@ -18,7 +18,7 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
-           "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], "-o", OUT, "-ldl"]
+           "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], srcs[4], "-o", OUT, "-ldl"]
     subprocess.check_call(cmd)
     return OUT
 

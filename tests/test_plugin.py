@@ -150,6 +150,31 @@ def test_mgm_gpu_equals_the_reference_mgm(pydcop_ready, instance):
     assert got == want
 
 
+@pytest.mark.parametrize("instance,variant", [("graph_coloring1.yaml", "B"), ("graph_coloring_tuto.yaml", "A"),
+                                              ("graph_coloring_3agts_10vars.yaml", "C")])
+def test_dsa_gpu_equals_the_reference_dsa(pydcop_ready, instance, variant):
+    """`--algo dsa_gpu` through the unmodified orchestrator / agents == the reference's own
+    DsaComputation objects drawing from the same keyed generator (same seed), after the same number of
+    cycles; module attributes like the reference's."""
+    from oracle.ref_harness import run_reference_dsa
+    from pydcop.algorithms import AlgorithmDef, load_algorithm_module
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop.infrastructure.run import solve
+    ref, mod = load_algorithm_module("dsa"), load_algorithm_module("dsa_gpu")
+    assert mod.GRAPH_TYPE == ref.GRAPH_TYPE == "constraints_hypergraph"
+    assert (mod.UNIT_SIZE, mod.HEADER_SIZE) == (ref.UNIT_SIZE, ref.HEADER_SIZE)
+    refp = {p.name: (p.type, p.values, p.default_value) for p in ref.algo_params}
+    mine = {p.name: (p.type, p.values, p.default_value) for p in mod.algo_params}
+    assert all(mine[k] == v for k, v in refp.items())
+    dcop = load_dcop_from_file([os.path.join(INST, instance)])
+    algo = AlgorithmDef.build_with_default_param("dsa_gpu", {"stop_cycle": 12, "variant": variant, "seed": 4},
+                                                 mode=dcop.objective)
+    got = solve(dcop, algo, "adhoc", timeout=8)
+    dcop2 = load_dcop_from_file([os.path.join(INST, instance)])
+    want, _, _ = run_reference_dsa(dcop2, 12, variant=variant, seed=4)
+    assert got == want
+
+
 def test_cli_solve_json(emu_lib, tmp_path):
     """`pydcop solve --algo maxsum_gpu` through the launcher, result JSON of the
     unmodified orchestrator (docs/tutorials/analysing_results.rst:31-48)."""
