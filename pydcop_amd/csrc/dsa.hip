@@ -27,7 +27,7 @@ extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const c
 
 namespace dsa {
 
-constexpr int TPB = 256;
+constexpr int TPB = 64;  // one wave per block: 100k variables spread over every CU (latency-bound CSR walks)
 
 static int fail(int code, const std::string& msg) {
     mxs_set_last_error(msg.c_str());

@@ -6,15 +6,16 @@ from pydcop_amd.dsa import DsaEngine
 from pydcop_amd.graph import Params
 
 
-def dsa_cases():
+def dsa_cases(k=1):
+    """k > 1: graphs k times smaller (the emulated engine of the CPU tests is slow)."""
     return [
-        ("coloring_soft_B", lambda: G.random_coloring(400, seed=31), {}, dict(variant="B", probability=0.7)),
-        ("coloring_hard_A", lambda: G.random_coloring(300, seed=32, variant="hard"), {}, dict(variant="A", probability=0.5)),
-        ("coloring_max_C", lambda: G.random_coloring(350, seed=33), {"mode": "max"}, dict(variant="C", probability=0.4)),
-        ("mixed_arity3_B_arity", lambda: G.random_mixed(120, 260, seed=34, dom_choices=(2, 3, 4)), {},
+        ("coloring_soft_B", lambda: G.random_coloring(400 // k, seed=31), {}, dict(variant="B", probability=0.7)),
+        ("coloring_hard_A", lambda: G.random_coloring(300 // k, seed=32, variant="hard"), {}, dict(variant="A", probability=0.5)),
+        ("coloring_max_C", lambda: G.random_coloring(350 // k, seed=33), {"mode": "max"}, dict(variant="C", probability=0.4)),
+        ("mixed_arity3_B_arity", lambda: G.random_mixed(120 // k, 260 // k, seed=34, dom_choices=(2, 3, 4)), {},
          dict(variant="B", p_mode="arity")),
         ("ising_C_always", lambda: G.ising_grid(12, 10, seed=35), {}, dict(variant="C", probability=1.0)),
-        ("sparse_isolated_B", lambda: G.random_coloring(300, avg_degree=1, seed=36), {"mode": "max"}, dict(variant="B")),
+        ("sparse_isolated_B", lambda: G.random_coloring(300 // k, avg_degree=1, seed=36), {"mode": "max"}, dict(variant="B")),
         ("meeting_d6_A", lambda: G.meeting_like(40, dom=6, seed=37), {"mode": "max"}, dict(variant="A", probability=0.9)),
     ]
 

@@ -6,10 +6,10 @@ from dsa_common import compare_dsa, dsa_cases
 from pydcop_amd.graph import Params
 
 
-@pytest.mark.parametrize("case", dsa_cases(), ids=lambda c: c[0])
+@pytest.mark.parametrize("case", dsa_cases(k=4), ids=lambda c: c[0])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_dsa_emu_bit_exact_vs_oracle(case, dtype, oracle_built):
     from emu.build_emu import build
     from oracle.dsa_oracle import OracleDsa
     name, make, kw, dsa_kw = case
-    compare_dsa(OracleDsa, make(), Params(dtype=dtype, **kw), dsa_kw, lib_path=build())
+    compare_dsa(OracleDsa, make(), Params(dtype=dtype, **kw), dsa_kw, lib_path=build(), steps=(0, 1, 1, 3, 10))

@@ -103,7 +103,7 @@ def test_api_solve(pydcop_ready, instance, expected):
     dcop = load_dcop_from_file([os.path.join(INST, instance)])
     algo = AlgorithmDef.build_with_default_param(
         "maxsum_gpu", {"stop_cycle": 20, "noise": 0}, mode=dcop.objective)
-    assignment = solve(dcop, algo, "adhoc", timeout=8)
+    assignment = solve(dcop, algo, "adhoc", timeout=5)
     assert assignment == expected
 
 
@@ -124,7 +124,7 @@ def test_api_solve_on_two_devices(pydcop_ready, instance, expected, tmp_path, mo
     dcop = load_dcop_from_file([os.path.join(INST, instance)])
     algo = AlgorithmDef.build_with_default_param(
         "maxsum_gpu", {"stop_cycle": 20, "noise": 0, "devices": 2}, mode=dcop.objective)
-    assert solve(dcop, algo, "adhoc", timeout=8) == expected
+    assert solve(dcop, algo, "adhoc", timeout=5) == expected
 
 
 @pytest.mark.parametrize("instance", ["graph_coloring1.yaml", "graph_coloring_tuto.yaml", "secp_simple1.yaml",
@@ -144,7 +144,7 @@ def test_mgm_gpu_equals_the_reference_mgm(pydcop_ready, instance):
     assert all(mine[k] == v for k, v in refp.items())
     dcop = load_dcop_from_file([os.path.join(INST, instance)])
     algo = AlgorithmDef.build_with_default_param("mgm_gpu", {"stop_cycle": 9}, mode=dcop.objective)
-    got = solve(dcop, algo, "adhoc", timeout=8)
+    got = solve(dcop, algo, "adhoc", timeout=5)
     dcop2 = load_dcop_from_file([os.path.join(INST, instance)])
     want, _, _ = run_reference_mgm(dcop2, 8)
     assert got == want
@@ -169,7 +169,7 @@ def test_dsa_gpu_equals_the_reference_dsa(pydcop_ready, instance, variant):
     dcop = load_dcop_from_file([os.path.join(INST, instance)])
     algo = AlgorithmDef.build_with_default_param("dsa_gpu", {"stop_cycle": 12, "variant": variant, "seed": 4},
                                                  mode=dcop.objective)
-    got = solve(dcop, algo, "adhoc", timeout=8)
+    got = solve(dcop, algo, "adhoc", timeout=5)
     dcop2 = load_dcop_from_file([os.path.join(INST, instance)])
     want, _, _ = run_reference_dsa(dcop2, 12, variant=variant, seed=4)
     assert got == want
