@@ -17,11 +17,13 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/maxsum_gpu.h"
+#include "local_search.h"
 
 extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
 
@@ -85,6 +87,7 @@ struct Dev {
     const int32_t* cur;
     int32_t* cur_out;
     T* cost;
+    lsearch::Slots slots;
 };
 
 template <typename T>
@@ -166,6 +169,73 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
     g.cur_out[v] = out;
 }
 
+// the same cycle on the slot view (local_search.h): the D costs in registers, one pass over the
+// variable's constraints instead of 2D+1 CSR walks; domains of at most MAXD values
+template <typename T, int MAXD>
+__global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars) return;
+    const int mine = g.cur[v];
+    int out = mine;
+    if (g.n_neigh[v] != 0) {
+        const int D = g.dom_size[v];
+        const int s0 = g.var_rowptr[v], s1 = g.var_rowptr[v + 1];
+        T c[MAXD];
+        lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, s0, s1, D, true, c);
+        T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;
+        int n_best = 0, first_best = -1;
+        bool has_cur = false;
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x)
+            if (x < D) {
+                if (c[x] == best_cost) {
+                    n_best += 1;
+                    if (x == mine) has_cur = true;
+                } else if ((!g.is_max && c[x] < best_cost) || (g.is_max && c[x] > best_cost)) {
+                    best_cost = c[x];
+                    n_best = 1;
+                    first_best = x;
+                    has_cur = x == mine;
+                }
+            }
+        const T diff = lsearch::pick<T, MAXD>(c, mine) - best_cost;
+        const T delta = diff < (T)0 ? -diff : diff;
+        bool attempt = false, drop_cur = false;
+        if (delta > (T)0) {
+            attempt = true;
+        } else if (delta == (T)0) {
+            if (g.variant == 1) {
+                for (int s = s0; s < s1 && !attempt; ++s) {
+                    int64_t off = g.slots.base[s] + (int64_t)mine * g.slots.stride_v[s];
+                    for (int k = g.slots.nb_rowptr[s]; k < g.slots.nb_rowptr[s + 1]; ++k)
+                        off += (int64_t)g.cur[g.slots.nb_var[k]] * g.slots.nb_stride[k];
+                    if (g.tables[off] != g.f_opt[g.edge_factor[g.var_edges[s]]]) attempt = true;
+                }
+            } else if (g.variant == 2) {
+                attempt = true;
+            }
+            if (attempt && n_best > 1 && has_cur) drop_cur = true;
+        }
+        if (attempt && g.prob[v] > uniform(g.seed, v, g.cycle + 1, 1)) {
+            const int n = n_best - (drop_cur ? 1 : 0);
+            int j = (int)(uniform(g.seed, v, g.cycle + 1, 2) * n);
+            int pick = first_best;
+            bool done = false;
+#pragma unroll
+            for (int x = 0; x < MAXD; ++x)
+                if (x < D && !done && c[x] == best_cost && !(drop_cur && x == mine)) {
+                    if (j-- == 0) {
+                        pick = x;
+                        done = true;
+                    }
+                }
+            out = pick;
+            g.cost[v] = best_cost;
+        }
+    }
+    g.cur_out[v] = out;
+}
+
 struct Base {
     virtual ~Base() {}
     virtual int init(const mxs_graph& G, const mxs_params& p, int variant, double probability, int arity_mode,
@@ -192,6 +262,9 @@ struct Engine : Base {
     Buf<int64_t> table_off;
     Buf<T> tables, f_opt, cost;
     Buf<double> prob;
+    Buf<int64_t> sl_base;
+    Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_conc_rowptr, sl_conc_var;
+    int max_dom = 0;
 
     ~Engine() override {
         if (stream) (void)hipStreamDestroy(stream);
@@ -252,6 +325,20 @@ struct Engine : Base {
                 if (p.mode == MXS_MODE_MAX ? tt[k] > opt : tt[k] < opt) opt = tt[k];
             fo[f] = opt;
         }
+        lsearch::HostSlots hs;
+        const std::string bad = hs.build(nV, nF, h_dom, h_frow, h_evar, h_toff, vrow, vedges);
+        if (!bad.empty()) return fail(MXS_E_INVALID, bad);
+        max_dom = 0;
+        for (int v = 0; v < nV; ++v) max_dom = h_dom[v] > max_dom ? h_dom[v] : max_dom;
+        DSA_TRY(sl_base.upload(hs.base, stream));
+        DSA_TRY(sl_stride_v.upload(hs.stride_v, stream));
+        DSA_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
+        DSA_TRY(sl_nb_var.upload(hs.nb_var, stream));
+        DSA_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
+        DSA_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
+        DSA_TRY(sl_conc_var.upload(hs.conc_var, stream));
+        g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
+                                 sl_conc_rowptr.p, sl_conc_var.p};
         DSA_TRY(dom_size.upload(h_dom, stream));
         DSA_TRY(factor_rowptr.upload(h_frow, stream));
         DSA_TRY(edge_var.upload(h_evar, stream));
@@ -312,11 +399,17 @@ struct Engine : Base {
             return MXS_OK;
         }
         const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
+        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernel (A/B, tests)
+        const bool generic = env && env[0] == '1';
         for (int32_t r = 0; r < n; ++r) {
             g.cur = cur[which].p;
             g.cur_out = cur[which ^ 1].p;
             g.cycle = cycles;
-            hipLaunchKernelGGL((k_dsa_cycle<T>), grid, block, 0, stream, g);
+            if (generic || max_dom > 32) hipLaunchKernelGGL((k_dsa_cycle<T>), grid, block, 0, stream, g);
+            else if (max_dom <= 4) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 4>), grid, block, 0, stream, g);
+            else if (max_dom <= 8) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 8>), grid, block, 0, stream, g);
+            else if (max_dom <= 16) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 16>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((k_dsa_cycle_slots<T, 32>), grid, block, 0, stream, g);
             DSA_TRY(hipGetLastError());
             which ^= 1;
             cycles += 1;

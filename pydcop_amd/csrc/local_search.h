@@ -1,0 +1,115 @@
+// local_search.h -- what dsa.hip and mgm.hip share: the flat "slot" view of a variable's
+// constraints.  Both algorithms evaluate, per variable v and per cycle, the cost of EVERY value x
+// of v under the neighbours' current values (dsa.py:319-333 via assignment_cost,
+// relations.py:1513-1533; mgm.py:425-451 via slices + find_arg_optimal).  Walking the factor CSR
+// once per (x, constraint) is a chain of six dependent loads repeated (D+1)*deg times; here each
+// (variable, constraint) pair is a SLOT prepared once on the host:
+//
+//   entry(x) = tables[ base + x * stride_v + sum over the OTHER scope variables u of cur[u] * stride_u ]
+//
+// so a thread computes the offset of a slot once per cycle (one load per other variable) and
+// then reads the D entries, independent loads.  The sums over constraints keep the reference's
+// order (the variable's constraints in var_edges order), so the results are bit for bit those of
+// the CSR walk (kept below as the generic path for domains larger than the register array).
+#pragma once
+#include <algorithm>
+#include <climits>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace lsearch {
+
+struct Slots {  // device pointers; slot s of variable v: var_rowptr[v] <= s < var_rowptr[v+1]
+    const int64_t* base;        // [n_slots] table_off of the slot's constraint
+    const int32_t* stride_v;    // [n_slots] sum of the strides of the positions v holds in the scope
+    const int32_t* nb_rowptr;   // [n_slots+1] the other scope variables of the slot
+    const int32_t* nb_var;
+    const int32_t* nb_stride;
+    const int32_t* conc_rowptr; // [n_vars+1] distinct variables of v's constraints (v included), ascending
+    const int32_t* conc_var;
+};
+
+struct HostSlots {
+    std::vector<int64_t> base;
+    std::vector<int32_t> stride_v, nb_rowptr, nb_var, nb_stride, conc_rowptr, conc_var;
+
+    // "" or what is wrong with the instance
+    std::string build(int nV, int nF, const std::vector<int32_t>& dom, const std::vector<int32_t>& frow,
+                      const std::vector<int32_t>& evar, const std::vector<int64_t>& toff,
+                      const std::vector<int32_t>& vrow, const std::vector<int32_t>& vedges) {
+        const int nE = (int)evar.size();
+        std::vector<int32_t> efac(nE);
+        for (int f = 0; f < nF; ++f)
+            for (int e = frow[f]; e < frow[f + 1]; ++e) efac[e] = f;
+        base.resize(nE);
+        stride_v.resize(nE);
+        nb_rowptr.assign(nE + 1, 0);
+        nb_var.clear();
+        nb_stride.clear();
+        conc_rowptr.assign(nV + 1, 0);
+        conc_var.clear();
+        std::vector<int32_t> seen;
+        for (int v = 0; v < nV; ++v) {
+            seen.clear();
+            seen.push_back(v);
+            for (int s = vrow[v]; s < vrow[v + 1]; ++s) {
+                if (vedges[s] < 0 || vedges[s] >= nE) return "var_edges out of range";
+                const int f = efac[vedges[s]];
+                if (toff[f + 1] - toff[f] > INT32_MAX) return "table too large for the local-search kernels";
+                base[s] = toff[f];
+                int64_t stride = 1, sv = 0;
+                for (int e = frow[f + 1] - 1; e >= frow[f]; --e) {  // row-major: last position is contiguous
+                    const int u = evar[e];
+                    if (u == v) {
+                        sv += stride;
+                    } else {
+                        nb_var.push_back(u);
+                        nb_stride.push_back((int32_t)stride);
+                        seen.push_back(u);
+                    }
+                    stride *= dom[u];
+                }
+                stride_v[s] = (int32_t)sv;
+                nb_rowptr[s + 1] = (int32_t)nb_var.size();
+            }
+            std::sort(seen.begin(), seen.end());
+            seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
+            conc_var.insert(conc_var.end(), seen.begin(), seen.end());
+            conc_rowptr[v + 1] = (int32_t)conc_var.size();
+        }
+        return "";
+    }
+};
+
+// c[x] = sum over v's slots, in order, of the slot's entry at x (x < D <= MAXD); `from_zero`:
+// DSA starts from 0 (assignment_cost), MGM folds without an initial value (functools.reduce)
+template <typename T, int MAXD>
+__device__ inline void costs_of_values(const Slots& sl, const T* __restrict__ tables, const int32_t* __restrict__ cur,
+                                       int s0, int s1, int D, bool from_zero, T (&c)[MAXD]) {
+#pragma unroll
+    for (int x = 0; x < MAXD; ++x) c[x] = (T)0;
+    for (int s = s0; s < s1; ++s) {
+        int64_t off = sl.base[s];
+        for (int k = sl.nb_rowptr[s]; k < sl.nb_rowptr[s + 1]; ++k) off += (int64_t)cur[sl.nb_var[k]] * sl.nb_stride[k];
+        const int sv = sl.stride_v[s];
+        const bool first = !from_zero && s == s0;
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x)
+            if (x < D) {
+                const T t = tables[off + (int64_t)x * sv];
+                c[x] = first ? t : c[x] + t;
+            }
+    }
+}
+
+// c[i] with a run-time i, the array staying in registers
+template <typename T, int MAXD>
+__device__ inline T pick(const T (&c)[MAXD], int i) {
+    T r = c[0];
+#pragma unroll
+    for (int x = 1; x < MAXD; ++x) r = x == i ? c[x] : r;
+    return r;
+}
+
+}  // namespace lsearch

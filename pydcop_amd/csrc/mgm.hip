@@ -16,11 +16,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
 
 #include "../../include/maxsum_gpu.h"
+#include "local_search.h"
 
 extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
 
@@ -72,6 +74,7 @@ struct Dev {
     uint8_t* has_cost;
     T* gain;
     int32_t* newv;
+    lsearch::Slots slots;
 };
 
 // c.slice(neighbours' values)(x): the table entry with v at x, every other scope variable at its value
@@ -180,6 +183,80 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
     g.cost_out[v] = cost;
 }
 
+// ---- the same two kernels on the slot view (local_search.h) ---------------------------------
+// the costs of the D values in registers from one pass over the variable's constraints; the
+// distinct variables of those constraints from a list sorted on the host instead of the
+// repeated minimum search of add_concerned_costs; domains of at most MAXD values
+template <typename T>
+__device__ T add_concerned_costs_listed(const Dev<T>& g, int v, T acc) {
+    for (int k = g.slots.conc_rowptr[v]; k < g.slots.conc_rowptr[v + 1]; ++k) {
+        const int u = g.slots.conc_var[k];
+        acc += g.var_cost[g.cost_off[u] + g.cur[u]];
+    }
+    return acc;
+}
+
+template <typename T, int MAXD>
+__global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars || g.n_neigh[v] == 0) return;
+    const int D = g.dom_size[v];
+    T c[MAXD];
+    lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, g.var_rowptr[v], g.var_rowptr[v + 1], D, false, c);
+    T cost = cost_rw[v];
+    if (!g.has_cost[v]) {
+        cost = add_concerned_costs_listed(g, v, lsearch::pick<T, MAXD>(c, g.cur[v]));
+        cost_rw[v] = cost;
+        g.has_cost[v] = 1;
+    }
+    T best = c[0];
+    int best_x = 0;
+#pragma unroll
+    for (int x = 1; x < MAXD; ++x)
+        if (x < D && (g.is_max ? best < c[x] : best > c[x])) {
+            best = c[x];
+            best_x = x;
+        }
+    const T val_cost = add_concerned_costs_listed(g, v, best);
+    const T gain = cost - val_cost;
+    g.gain[v] = gain;
+    g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+}
+
+template <typename T>
+__global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
+    const int v = blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= g.n_vars) return;
+    int cur = g.cur[v];
+    T cost = g.cost[v];
+    if (g.n_neigh[v] != 0) {
+        const int k0 = g.slots.conc_rowptr[v], k1 = g.slots.conc_rowptr[v + 1];
+        const int my_rank = g.name_rank[v];
+        T max_n = (T)0;
+        bool first = true, wins_tie = true;
+        for (int k = k0; k < k1; ++k) {  // one pass: the largest gain and whether a lower name holds it
+            const int u = g.slots.conc_var[k];
+            if (u == v) continue;
+            const T gu = g.gain[u];
+            const bool lower = g.name_rank[u] < my_rank;
+            if (first || gu > max_n) {
+                max_n = gu;
+                wins_tie = !lower;
+            } else if (gu == max_n && lower) {
+                wins_tie = false;
+            }
+            first = false;
+        }
+        const T gain = g.gain[v];
+        if (gain > max_n || (gain == max_n && wins_tie)) {
+            cur = g.newv[v];
+            cost = cost - gain;
+        }
+    }
+    g.cur_out[v] = cur;
+    g.cost_out[v] = cost;
+}
+
 struct Base {
     virtual ~Base() {}
     virtual int init(const mxs_graph& G, const mxs_params& p, const int32_t* rank, int device) = 0;
@@ -206,6 +283,9 @@ struct Engine : Base {
     Buf<T> tables, var_cost, gain;
     Buf<T> cost[2];
     Buf<uint8_t> has_cost;
+    Buf<int64_t> sl_base;
+    Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_conc_rowptr, sl_conc_var;
+    int max_dom = 0;
 
     ~Engine() override {
         if (stream) (void)hipStreamDestroy(stream);
@@ -259,6 +339,20 @@ struct Engine : Base {
         std::vector<T> tt(h_tables.size()), vc(h_var_cost.size());
         for (size_t i = 0; i < tt.size(); ++i) tt[i] = (T)h_tables[i];
         for (size_t i = 0; i < vc.size(); ++i) vc[i] = (T)h_var_cost[i];
+        lsearch::HostSlots hs;
+        const std::string bad = hs.build(nV, nF, h_dom, h_frow, h_evar, h_toff, vrow, vedges);
+        if (!bad.empty()) return fail(MXS_E_INVALID, bad);
+        max_dom = 0;
+        for (int v = 0; v < nV; ++v) max_dom = h_dom[v] > max_dom ? h_dom[v] : max_dom;
+        MGM_TRY(sl_base.upload(hs.base, stream));
+        MGM_TRY(sl_stride_v.upload(hs.stride_v, stream));
+        MGM_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
+        MGM_TRY(sl_nb_var.upload(hs.nb_var, stream));
+        MGM_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
+        MGM_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
+        MGM_TRY(sl_conc_var.upload(hs.conc_var, stream));
+        g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
+                                 sl_conc_rowptr.p, sl_conc_var.p};
         MGM_TRY(dom_size.upload(h_dom, stream));
         MGM_TRY(factor_rowptr.upload(h_frow, stream));
         MGM_TRY(edge_var.upload(h_evar, stream));
@@ -329,14 +423,22 @@ struct Engine : Base {
             return MXS_OK;
         }
         const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
+        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernels (A/B, tests)
+        const bool generic = env && env[0] == '1';
         for (int32_t r = 0; r < n; ++r) {
             g.cur = cur[which].p;
             g.cost = cost[which].p;
             g.cur_out = cur[which ^ 1].p;
             g.cost_out = cost[which ^ 1].p;
-            hipLaunchKernelGGL((k_mgm_gain<T>), grid, block, 0, stream, g, cost[which].p);
+            T* const cw = cost[which].p;
+            if (generic || max_dom > 32) hipLaunchKernelGGL((k_mgm_gain<T>), grid, block, 0, stream, g, cw);
+            else if (max_dom <= 4) hipLaunchKernelGGL((k_mgm_gain_slots<T, 4>), grid, block, 0, stream, g, cw);
+            else if (max_dom <= 8) hipLaunchKernelGGL((k_mgm_gain_slots<T, 8>), grid, block, 0, stream, g, cw);
+            else if (max_dom <= 16) hipLaunchKernelGGL((k_mgm_gain_slots<T, 16>), grid, block, 0, stream, g, cw);
+            else hipLaunchKernelGGL((k_mgm_gain_slots<T, 32>), grid, block, 0, stream, g, cw);
             MGM_TRY(hipGetLastError());
-            hipLaunchKernelGGL((k_mgm_move<T>), grid, block, 0, stream, g);
+            if (generic) hipLaunchKernelGGL((k_mgm_move<T>), grid, block, 0, stream, g);
+            else hipLaunchKernelGGL((k_mgm_move_listed<T>), grid, block, 0, stream, g);
             MGM_TRY(hipGetLastError());
             which ^= 1;
             rounds += 1;

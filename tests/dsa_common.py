@@ -17,6 +17,10 @@ def dsa_cases(k=1):
         ("ising_C_always", lambda: G.ising_grid(12, 10, seed=35), {}, dict(variant="C", probability=1.0)),
         ("sparse_isolated_B", lambda: G.random_coloring(300 // k, avg_degree=1, seed=36), {"mode": "max"}, dict(variant="B")),
         ("meeting_d6_A", lambda: G.meeting_like(40, dom=6, seed=37), {"mode": "max"}, dict(variant="A", probability=0.9)),
+        # the wider register arrays of the slot kernels (16, 32 values) and the CSR-walk kernel beyond
+        ("meeting_d12_B", lambda: G.meeting_like(24, dom=12, seed=38), {"mode": "max"}, dict(variant="B", probability=0.8)),
+        ("meeting_d24_C", lambda: G.meeting_like(18, dom=24, seed=39), {"mode": "max"}, dict(variant="C", probability=0.6)),
+        ("meeting_d35_A", lambda: G.meeting_like(12, dom=35, seed=40), {}, dict(variant="A", probability=0.9)),
     ]
 
 

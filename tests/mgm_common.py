@@ -29,6 +29,10 @@ def mgm_cases():
         ("ising_unaries", lambda: G.ising_grid(12, 10, seed=26), {}),
         ("sparse_isolated", lambda: G.random_coloring(300, avg_degree=1, seed=27), {"mode": "max"}),
         ("meeting_d6", lambda: G.meeting_like(40, dom=6, seed=28), {"mode": "max"}),
+        # the wider register arrays of the slot kernels (16, 32 values) and the CSR-walk kernel beyond
+        ("meeting_d12", lambda: G.meeting_like(24, dom=12, seed=29), {"mode": "max"}),
+        ("meeting_d24", lambda: with_init(G.meeting_like(18, dom=24, seed=30), 30), {}),
+        ("meeting_d35", lambda: G.meeting_like(12, dom=35, seed=31), {"mode": "max"}),
     ]
 
 

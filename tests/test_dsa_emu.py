@@ -13,3 +13,14 @@ def test_dsa_emu_bit_exact_vs_oracle(case, dtype, oracle_built):
     from oracle.dsa_oracle import OracleDsa
     name, make, kw, dsa_kw = case
     compare_dsa(OracleDsa, make(), Params(dtype=dtype, **kw), dsa_kw, lib_path=build(), steps=(0, 1, 1, 3, 10))
+
+
+@pytest.mark.parametrize("case", dsa_cases(k=4)[:4], ids=lambda c: c[0])
+def test_dsa_emu_csr_walk_kernel(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=1: the CSR-walk kernel (what domains of more than 32 values
+    run on) on the instances the slot kernels were just checked on."""
+    from emu.build_emu import build
+    from oracle.dsa_oracle import OracleDsa
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
+    name, make, kw, dsa_kw = case
+    compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw, lib_path=build(), steps=(0, 1, 3, 6))

@@ -28,3 +28,13 @@ def test_dsa_100k_coloring(oracle_built):
         start = e.eval_cost()[0]
         e.run(60)
         assert e.eval_cost()[0] < 0.6 * start
+
+
+@pytest.mark.parametrize("case", dsa_cases()[:5], ids=lambda c: c[0])
+def test_dsa_csr_walk_kernel(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=1: the CSR-walk kernel (domains of more than 32 values) on
+    the instances of the slot kernels."""
+    from oracle.dsa_oracle import OracleDsa
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
+    name, make, kw, dsa_kw = case
+    compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw)

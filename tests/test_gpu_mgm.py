@@ -29,3 +29,13 @@ def test_mgm_100k_coloring(oracle_built):
         start = e.eval_cost()[0]
         e.run(60)
         assert e.eval_cost()[0] < 0.6 * start     # MGM is monotone: the cost only goes down
+
+
+@pytest.mark.parametrize("case", mgm_cases()[:6], ids=lambda c: c[0])
+def test_mgm_csr_walk_kernels(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=1: the CSR-walk kernels (domains of more than 32 values) on
+    the instances of the slot kernels."""
+    from oracle.mgm_oracle import OracleMgm
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(**kw))

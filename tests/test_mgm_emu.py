@@ -13,3 +13,14 @@ def test_mgm_emu_bit_exact_vs_oracle(case, dtype, oracle_built):
     from oracle.mgm_oracle import OracleMgm
     name, make, kw = case
     compare_mgm(OracleMgm, make(), Params(dtype=dtype, **kw), lib_path=build())
+
+
+@pytest.mark.parametrize("case", mgm_cases()[:5], ids=lambda c: c[0])
+def test_mgm_emu_csr_walk_kernels(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=1: the CSR-walk kernels (what domains of more than 32 values
+    run on) on the instances the slot kernels were just checked on."""
+    from emu.build_emu import build
+    from oracle.mgm_oracle import OracleMgm
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(**kw), lib_path=build(), steps=(0, 1, 3, 6))

@@ -1,0 +1,47 @@
+"""Cycles per second of the DSA and MGM engines (pydcop_amd/csrc/dsa.hip, mgm.hip) on the
+100k-variable colouring instance of the bench and on the meeting instance (24 values, arity 3):
+
+    python tools/local_search_bench.py [--cycles 500]
+
+One JSON line per (algorithm, instance, kernels); "kernels": "slots" = the register-array kernels
+on the slot view (local_search.h), "csr_walk" = the generic kernels (MAXSUM_LOCAL_SEARCH_GENERIC=1).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+
+from pydcop_amd import generators as G  # noqa: E402
+from pydcop_amd.dsa import DsaEngine  # noqa: E402
+from pydcop_amd.graph import Params  # noqa: E402
+from pydcop_amd.mgm import MgmEngine  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cycles", type=int, default=500)
+    ap.add_argument("--lib", default=None)
+    a = ap.parse_args()
+    instances = [("coloring_100k", G.random_coloring(100_000, seed=0, names=False), Params()),
+                 ("meeting_50k", G.meeting_like(50_000, dom=24, seed=0, names=False), Params(mode="max"))]
+    for inst, g, p in instances:
+        for kernels in ("slots", "csr_walk"):
+            os.environ["MAXSUM_LOCAL_SEARCH_GENERIC"] = "1" if kernels == "csr_walk" else "0"
+            for name, make in (("dsa_B", lambda: DsaEngine(g, p, variant="B", seed=1, lib_path=a.lib)),
+                               ("mgm", lambda: MgmEngine(g, p, lib_path=a.lib))):
+                eng = make()
+                eng.run(20)
+                t0 = time.perf_counter()
+                eng.run(a.cycles)
+                dt = time.perf_counter() - t0
+                print(json.dumps({"algo": name, "instance": inst, "kernels": kernels, "n_vars": g.n_vars,
+                                  "cycles_per_s": round(a.cycles / dt, 1), "us_per_cycle": round(1e6 * dt / a.cycles, 2),
+                                  "cost": eng.eval_cost()[0]}), flush=True)
+                eng.close()
+
+
+if __name__ == "__main__":
+    main()
