@@ -10,7 +10,7 @@
 // so a thread computes the offset of a slot once per cycle (one load per other variable) and
 // then reads the D entries, independent loads.  The sums over constraints keep the reference's
 // order (the variable's constraints in var_edges order), so the results are bit for bit those of
-// the CSR walk (kept below as the generic path for domains larger than the register array).
+// the CSR walk (kept in the two files as the generic path for domains larger than the register array).
 #pragma once
 #include <algorithm>
 #include <climits>
@@ -26,13 +26,15 @@ struct Slots {  // device pointers; slot s of variable v: var_rowptr[v] <= s < v
     const int32_t* nb_rowptr;   // [n_slots+1] the other scope variables of the slot
     const int32_t* nb_var;
     const int32_t* nb_stride;
+    const int32_t* nb0_var;     // [n_slots] the first of them again (variable 0, stride 0 when there is
+    const int32_t* nb0_stride;  //           none): a binary constraint costs no walk of the list
     const int32_t* conc_rowptr; // [n_vars+1] distinct variables of v's constraints (v included), ascending
     const int32_t* conc_var;
 };
 
 struct HostSlots {
     std::vector<int64_t> base;
-    std::vector<int32_t> stride_v, nb_rowptr, nb_var, nb_stride, conc_rowptr, conc_var;
+    std::vector<int32_t> stride_v, nb_rowptr, nb_var, nb_stride, nb0_var, nb0_stride, conc_rowptr, conc_var;
 
     // "" or what is wrong with the instance
     std::string build(int nV, int nF, const std::vector<int32_t>& dom, const std::vector<int32_t>& frow,
@@ -45,6 +47,8 @@ struct HostSlots {
         base.resize(nE);
         stride_v.resize(nE);
         nb_rowptr.assign(nE + 1, 0);
+        nb0_var.assign(nE, 0);
+        nb0_stride.assign(nE, 0);
         nb_var.clear();
         nb_stride.clear();
         conc_rowptr.assign(nV + 1, 0);
@@ -72,6 +76,10 @@ struct HostSlots {
                 }
                 stride_v[s] = (int32_t)sv;
                 nb_rowptr[s + 1] = (int32_t)nb_var.size();
+                if (nb_rowptr[s + 1] > nb_rowptr[s]) {
+                    nb0_var[s] = nb_var[nb_rowptr[s]];
+                    nb0_stride[s] = nb_stride[nb_rowptr[s]];
+                }
             }
             std::sort(seen.begin(), seen.end());
             seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
@@ -82,33 +90,72 @@ struct HostSlots {
     }
 };
 
-// c[x] = sum over v's slots, in order, of the slot's entry at x (x < D <= MAXD); `from_zero`:
-// DSA starts from 0 (assignment_cost), MGM folds without an initial value (functools.reduce)
+// c[x] = sum over v's slots, in order, of the slot's entry at x (x < D <= MAXD; c[x] is unspecified
+// for x >= D); `from_zero`: DSA starts from 0 (assignment_cost), MGM folds without an initial
+// value (functools.reduce).  CH slots at a time with every load of a level issued together
+// (clamped indices instead of branches): a variable of degree <= CH pays the four dependent levels
+// (row pointers, slot, neighbour's value, table entries) once instead of once per constraint.
 template <typename T, int MAXD>
 __device__ inline void costs_of_values(const Slots& sl, const T* __restrict__ tables, const int32_t* __restrict__ cur,
                                        int s0, int s1, int D, bool from_zero, T (&c)[MAXD]) {
+    constexpr int CH = MAXD <= 4 ? 4 : (MAXD <= 8 ? 2 : 1);
 #pragma unroll
     for (int x = 0; x < MAXD; ++x) c[x] = (T)0;
-    for (int s = s0; s < s1; ++s) {
-        int64_t off = sl.base[s];
-        for (int k = sl.nb_rowptr[s]; k < sl.nb_rowptr[s + 1]; ++k) off += (int64_t)cur[sl.nb_var[k]] * sl.nb_stride[k];
-        const int sv = sl.stride_v[s];
-        const bool first = !from_zero && s == s0;
+    for (int s = s0; s < s1; s += CH) {
+        int64_t off[CH];
+        int sv[CH], k0[CH], k1[CH], u0[CH], st0[CH];
+        int more = 0;
 #pragma unroll
-        for (int x = 0; x < MAXD; ++x)
-            if (x < D) {
-                const T t = tables[off + (int64_t)x * sv];
-                c[x] = first ? t : c[x] + t;
+        for (int i = 0; i < CH; ++i) {
+            const int si = s + i < s1 ? s + i : s1 - 1;
+            off[i] = sl.base[si];
+            sv[i] = sl.stride_v[si];
+            k0[i] = sl.nb_rowptr[si] + 1;
+            k1[i] = sl.nb_rowptr[si + 1];
+            u0[i] = sl.nb0_var[si];
+            st0[i] = sl.nb0_stride[si];
+            more = k1[i] - k0[i] > more ? k1[i] - k0[i] : more;
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) off[i] += (int64_t)cur[u0[i]] * st0[i];
+        for (int q = 0; q < more; ++q) {  // arity > 2
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const bool in = k0[i] + q < k1[i];
+                const int k = in ? k0[i] + q : k0[i] - 1;
+                off[i] += in ? (int64_t)cur[sl.nb_var[k]] * sl.nb_stride[k] : (int64_t)0;
+            }
+        }
+        T t[CH][MAXD];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+#pragma unroll
+            for (int x = 0; x < MAXD; ++x) t[i][x] = tables[off[i] + (int64_t)(x < D ? x : D - 1) * sv[i]];
+#pragma unroll
+        for (int i = 0; i < CH; ++i)
+            if (s + i < s1) {
+                const bool first = !from_zero && s + i == s0;
+#pragma unroll
+                for (int x = 0; x < MAXD; ++x) c[x] = first ? t[i][x] : c[x] + t[i][x];
             }
     }
 }
 
-// c[i] with a run-time i, the array staying in registers
+// c[i] with a run-time i, the array staying in registers.  A plain chain of `x == i ? c[x] : r`
+// is rewritten by the optimiser into ONE load at a selected address -- a dynamically indexed
+// private array, i.e. scratch memory, from 128 bytes on; the empty asm makes every element a value
+// of its own before the selects.
 template <typename T, int MAXD>
 __device__ inline T pick(const T (&c)[MAXD], int i) {
     T r = c[0];
 #pragma unroll
-    for (int x = 1; x < MAXD; ++x) r = x == i ? c[x] : r;
+    for (int x = 1; x < MAXD; ++x) {
+        T cx = c[x];
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(cx));
+#endif
+        r = x == i ? cx : r;
+    }
     return r;
 }
 

@@ -284,7 +284,7 @@ struct Engine : Base {
     Buf<T> cost[2];
     Buf<uint8_t> has_cost;
     Buf<int64_t> sl_base;
-    Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_conc_rowptr, sl_conc_var;
+    Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
     int max_dom = 0;
 
     ~Engine() override {
@@ -349,10 +349,12 @@ struct Engine : Base {
         MGM_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
         MGM_TRY(sl_nb_var.upload(hs.nb_var, stream));
         MGM_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
+        MGM_TRY(sl_nb0_var.upload(hs.nb0_var, stream));
+        MGM_TRY(sl_nb0_stride.upload(hs.nb0_stride, stream));
         MGM_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
         MGM_TRY(sl_conc_var.upload(hs.conc_var, stream));
         g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
-                                 sl_conc_rowptr.p, sl_conc_var.p};
+                                 sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p};
         MGM_TRY(dom_size.upload(h_dom, stream));
         MGM_TRY(factor_rowptr.upload(h_frow, stream));
         MGM_TRY(edge_var.upload(h_evar, stream));
