@@ -25,8 +25,8 @@
 // Nothing here is a dense contraction: integer bookkeeping + a few adds per message element.
 // The run ends by itself when the send rule (approx_match + SAME_COUNT) has silenced every edge.
 //
-// Built into libmaxsum_hip.so by hipcc; the host emulation of the CPU tests compiles the
-// C-ABI entry points as stubs (the batch primitives are hipCUB's).
+// Built into libmaxsum_hip.so by hipcc.  (The host emulation of the CPU tests compiles this very
+// file against serial stand-ins for the two hipCUB primitives, tests/emu/hipcub/.)
 #include <cstdint>
 #include <cstring>
 #include <string>
@@ -36,7 +36,6 @@
 
 extern "C" __attribute__((visibility("hidden"))) void mxs_set_last_error(const char* msg);  // engine.hip
 
-#if defined(__HIPCC__)
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -255,7 +254,7 @@ __global__ void k_dest(Dev<T> g, const int32_t* q_code, int64_t n, int32_t* dest
 }
 
 template <typename T>
-__device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_code, T* s_pay) {
+__device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_code, T* s_pay, bool last) {
     const int e = code >> 1;
     const int v = g.edge_var[e], f = g.edge_factor[e];
     const int D = g.dom_size[v];
@@ -289,7 +288,9 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
             g.v_order[k0 + g.v_narr[v]] = e;
             g.v_narr[v] += 1;
         }
-        select_value(g, v);
+        // select_value only leaves sel / belief behind: of a run of messages to the same variable,
+        // the one after the last delivery is what the generation ends with
+        if (last) select_value(g, v);
         int slot = 0;
         for (int k = k0; k < k1; ++k) {
             const int e2 = g.var_edges[k];
@@ -303,18 +304,46 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
     }
 }
 
-// order[p]: FIFO index of the p-th message after the stable sort by destination
+// order[p]: FIFO index of the p-th message after the stable sort by destination; seg_first[t]:
+// position of the first message of the t-th destination to run (longest queues first, see step())
 template <typename T>
-__global__ void k_process(Dev<T> g, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
-                          const int32_t* order, int64_t n, const int64_t* slot_base, int32_t* s_code, T* s_pay) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p >= n) return;
-    if (p > 0 && dest_sorted[p] == dest_sorted[p - 1]) return;  // not the first of its destination
+__global__ void __launch_bounds__(64) k_process(Dev<T> g, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
+                          const int32_t* order, int64_t n, const int32_t* seg_first, int64_t n_seg,
+                          const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    const int64_t p = seg_first[t];
     const int32_t dst = dest_sorted[p];
     for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {  // its messages, in FIFO order
         const int64_t i = order[r];
-        handle(g, q_code[i], q_pay + i * g.dmax, s_code + slot_base[i], s_pay + slot_base[i] * g.dmax);
+        const bool last = r + 1 >= n || dest_sorted[r + 1] != dst;
+        handle(g, q_code[i], q_pay + i * g.dmax, s_code + slot_base[i], s_pay + slot_base[i] * g.dmax, last);
     }
+}
+
+__global__ void k_iota(int32_t* out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = (int32_t)i;
+}
+
+// head[p] = 1 where a destination's run starts in the sorted order
+__global__ void k_heads(const int32_t* dest_sorted, int64_t n, int32_t* head) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) head[p] = (p == 0 || dest_sorted[p] != dest_sorted[p - 1]) ? 1 : 0;
+}
+
+// seg_pos[idx[p]] = p for every head p
+__global__ void k_seg_starts(const int32_t* head, const int64_t* idx, int64_t n, int32_t* seg_pos) {
+    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n && head[p]) seg_pos[idx[p]] = (int32_t)p;
+}
+
+// key = ~length: an ascending sort runs the longest queues first
+__global__ void k_seg_keys(const int32_t* seg_pos, int64_t n_seg, int64_t n, uint32_t* key) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_seg) return;
+    const int64_t end = t + 1 < n_seg ? seg_pos[t + 1] : n;
+    key[t] = ~(uint32_t)(end - seg_pos[t]);
 }
 
 template <typename T>
@@ -372,7 +401,9 @@ struct Engine : Base {
     // queue of the current generation, work arrays of a step
     Buf<int32_t> q_code, q_code2, dest, dest_sorted, order, order_in, cap, s_code, start_cnt, start_base;
     Buf<T> q_pay, q_pay2, s_pay;
-    Buf<int64_t> slot_base, flag, pos, cap64;
+    Buf<int64_t> slot_base, flag, pos, cap64, head_idx;
+    Buf<int32_t> head, seg_pos, seg_first;
+    Buf<uint32_t> seg_key, seg_key_sorted;
     Buf<uint8_t> temp;
     int64_t nm = 0;
 
@@ -542,9 +573,8 @@ struct Engine : Base {
         int64_t n_slots = 0;
         { int rc = scan32(cap.p, slot_base.p, n, &n_slots); if (rc) return rc; }
         {   // FIFO indices 0..n-1, then the stable sort by destination
-            std::vector<int32_t> iota((size_t)n);
-            for (int64_t i = 0; i < n; ++i) iota[i] = (int32_t)i;
-            AMX_TRY(hipMemcpy(order_in.p, iota.data(), 4 * n, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_iota, dim3(grid(n)), dim3(TPB), 0, 0, order_in.p, n);
+            AMX_TRY(hipGetLastError());
             size_t bytes = 0;
             int bits = 1;
             while (((int64_t)1 << bits) < (int64_t)g.n_vars + g.n_factors + 1) ++bits;
@@ -552,12 +582,36 @@ struct Engine : Base {
             AMX_TRY(temp.reserve(bytes));
             AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, dest.p, dest_sorted.p, order_in.p, order.p, (int)n, 0, bits));
         }
+        // One thread per DESTINATION that has mail (not per message), the destinations with the
+        // longest queues first: a handler chain is sequential, so the generation lasts as long as
+        // its longest chain or as the total work over the machine, whichever is larger -- full
+        // waves of chains of similar length instead of one or two busy lanes per wave.
+        int64_t n_seg = 0;
+        {
+            AMX_TRY(head.reserve(n));
+            AMX_TRY(head_idx.reserve(n));
+            hipLaunchKernelGGL(k_heads, dim3(grid(n)), dim3(TPB), 0, 0, dest_sorted.p, n, head.p);
+            AMX_TRY(hipGetLastError());
+            { int rc = scan32(head.p, head_idx.p, n, &n_seg); if (rc) return rc; }
+            AMX_TRY(seg_pos.reserve(n_seg));
+            AMX_TRY(seg_first.reserve(n_seg));
+            AMX_TRY(seg_key.reserve(n_seg));
+            AMX_TRY(seg_key_sorted.reserve(n_seg));
+            hipLaunchKernelGGL(k_seg_starts, dim3(grid(n)), dim3(TPB), 0, 0, head.p, head_idx.p, n, seg_pos.p);
+            AMX_TRY(hipGetLastError());
+            hipLaunchKernelGGL(k_seg_keys, dim3(grid(n_seg)), dim3(TPB), 0, 0, seg_pos.p, n_seg, n, seg_key.p);
+            AMX_TRY(hipGetLastError());
+            size_t bytes = 0;
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg));
+        }
         AMX_TRY(s_code.reserve(n_slots + 1));
         AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
         AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
         AMX_TRY(hipMemset(s_pay.p, 0, sizeof(T) * (n_slots + 1) * g.dmax));
-        hipLaunchKernelGGL((k_process<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, q_code.p, q_pay.p, dest_sorted.p, order.p,
-                           n, slot_base.p, s_code.p, s_pay.p);
+        hipLaunchKernelGGL((k_process<T>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, 0, g, q_code.p, q_pay.p,
+                           dest_sorted.p, order.p, n, seg_first.p, n_seg, slot_base.p, s_code.p, s_pay.p);
         AMX_TRY(hipGetLastError());
         // compaction of the filled slots, slot order = FIFO order of the next generation
         int64_t n_next = 0;
@@ -747,29 +801,3 @@ int mxs_amaxsum_destroy(mxs_amaxsum* e) {
 
 }  // extern "C"
 
-#else  // host emulation of the CPU tests: the batch primitives are hipCUB's, gfx950 only
-
-struct mxs_amaxsum {
-    int unused;
-};
-static int amx_unavailable() {
-    mxs_set_last_error("amaxsum runs on the gfx950 build only (not in the host emulation of the CPU tests)");
-    return MXS_E_STATE;
-}
-extern "C" {
-int mxs_amaxsum_create(const mxs_graph*, const mxs_params*, int32_t, mxs_amaxsum** out) {
-    if (out) *out = nullptr;
-    return amx_unavailable();
-}
-int mxs_amaxsum_reset(mxs_amaxsum*) { return amx_unavailable(); }
-int mxs_amaxsum_run(mxs_amaxsum*, int32_t, int64_t*) { return amx_unavailable(); }
-int mxs_amaxsum_status(const mxs_amaxsum*, int32_t*, int64_t*, int64_t*) { return amx_unavailable(); }
-int mxs_amaxsum_generation_sizes(const mxs_amaxsum*, int64_t*, int32_t, int32_t*) { return amx_unavailable(); }
-int mxs_amaxsum_get_assignment(mxs_amaxsum*, int32_t*, double*) { return amx_unavailable(); }
-int mxs_amaxsum_get_messages(mxs_amaxsum*, double*, double*, double*, double*, uint8_t*, uint8_t*, uint8_t*, uint8_t*) {
-    return amx_unavailable();
-}
-int mxs_amaxsum_eval_cost(mxs_amaxsum*, const int32_t*, double, double*, int64_t*) { return amx_unavailable(); }
-int mxs_amaxsum_destroy(mxs_amaxsum*) { return MXS_OK; }
-}
-#endif

@@ -11,14 +11,15 @@ OUT = os.path.join(HERE, "_build", "libmaxsum_emu.so")
 
 def build(force=False):
     srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "layout.h")] + [
-        os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "maxsum_gpu.h")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "layout.h", "local_search.h")] + [
+        os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hipcub", "hipcub.hpp"),
+        os.path.join(ROOT, "include", "maxsum_gpu.h")]
     if not force and os.path.exists(OUT) and all(
             os.path.getmtime(OUT) >= os.path.getmtime(d) for d in deps):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
-           "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], srcs[4], "-o", OUT, "-ldl"]
+           "-DMXS_EMULATED_HIPCUB", "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], srcs[4], "-o", OUT, "-ldl"]
     subprocess.check_call(cmd)
     return OUT
 

@@ -1,0 +1,28 @@
+"""Asynchronous Max-Sum on the emulated engine build (the very same amaxsum.hip, g++ against the
+fake HIP runtime and serial stand-ins for the two hipCUB primitives, tests/emu/hipcub/) against the
+oracle, bit for bit -- the CPU twin of tests/test_gpu_amaxsum.py, on smaller instances."""
+import os
+
+import pytest
+
+from amaxsum_common import amaxsum_cases, check_golden, compare_amaxsum, golden_files
+from pydcop_amd.amaxsum import AMaxSumEngine
+from pydcop_amd.graph import Params
+
+
+@pytest.mark.parametrize("case", amaxsum_cases(k=2), ids=lambda c: c[0])
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_amaxsum_emu_bit_exact_vs_oracle(case, dtype, oracle_built):
+    from emu.build_emu import build
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    name, make, kw = case
+    g = make()
+    p = Params(dtype=dtype, **kw)
+    compare_amaxsum(AMaxSumEngine(g, p, lib_path=build()), OracleAMaxSum(g, p),
+                    first=(1, 2, 3, 6), last_generation=24, largest=20_000)
+
+
+@pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
+def test_amaxsum_emu_golden_reference_vectors(path):
+    from emu.build_emu import build
+    check_golden(lambda g, p: AMaxSumEngine(g, p, lib_path=build()), path)
