@@ -27,7 +27,9 @@
 //
 // Built into libmaxsum_hip.so by hipcc.  (The host emulation of the CPU tests compiles this very
 // file against serial stand-ins for the two hipCUB primitives, tests/emu/hipcub/.)
+#include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -304,16 +306,264 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
     }
 }
 
+// ---- a destination's whole queue of one generation, state in registers ------------------------
+// The handler chain of a destination is sequential, and the destinations with the most mail (the
+// hubs, and the factors next to them) decide how long a generation lasts.  `handle` above costs a
+// couple of hundred DEPENDENT global loads per message; the two chains below load the
+// destination's state once, keep it in registers while its queue is delivered, and write it back.
+
+// damp_and_decide on a message held in registers (D <= N values)
+template <typename T, int N>
+__device__ __forceinline__ bool damp_and_decide_reg(const Dev<T>& g, T (&m)[N], T (&prev)[N], uint8_t& cnt, int D,
+                                                    bool damp_on) {
+    const uint8_t c = cnt;
+    bool match = c > 0;
+#pragma unroll
+    for (int d = 0; d < N; ++d)
+        if (d < D) {
+            T x = m[d];
+            if (c > 0 && damp_on) x = g.damping * prev[d] + ((T)1 - g.damping) * x;
+            m[d] = x;
+            if (match) match = comp_match(x, prev[d], g.stability);
+        }
+    if (match && c >= SAME_COUNT) return false;
+#pragma unroll
+    for (int d = 0; d < N; ++d) prev[d] = m[d];
+    cnt = match ? (uint8_t)(c + 1) : (uint8_t)1;
+    return true;
+}
+
+// A variable of domain size D (template) and degree <= 64: ONE WAVE, lane k = the variable's k-th
+// factor (var_edges order) holding that factor's last message, the message last sent to it and its
+// send counter.  Per delivered message: the sender's lane takes the costs, every other lane builds
+// its factor's message from the held costs of all lanes (D * deg cross-lane reads, the reference's
+// order of additions: d outer, factors inner, maxsum.py:651-665), damps, applies the send rule and
+// writes its output slot.
+template <typename T, int D>
+__device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
+                               const int32_t* order, int64_t p, int64_t n, const int64_t* slot_base, int32_t* s_code,
+                               T* s_pay) {
+    const int lane = (int)threadIdx.x & 63;
+    const int k0 = g.var_rowptr[v], deg = g.var_rowptr[v + 1] - k0;
+    const bool active = lane < deg;
+    const int ek = active ? g.var_edges[k0 + lane] : -1;
+    const int64_t mo = active ? g.msg_off[ek] : 0;
+    T held[D], prev[D], c[D];
+    uint8_t cnt = 0;
+    bool has = false;
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+        held[d] = active ? g.v_cost[mo + d] : (T)0;
+        prev[d] = active ? g.v_prev[mo + d] : (T)0;
+        c[d] = g.var_cost[g.cost_off[v] + d];
+    }
+    if (active) {
+        cnt = g.v_cnt[ek];
+        has = g.v_has[ek] != 0;
+    }
+    int narr = g.v_narr[v];
+    int my_rank = -1;  // first-arrival rank of this lane's factor (select_value sums in that order)
+    for (int r = 0; r < narr; ++r)
+        if (g.v_order[k0 + r] == ek) my_rank = r;
+    const int32_t dst = dest_sorted[p];
+    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {
+        const int64_t i = order[r];
+        const int e = q_code[i] >> 1;
+        const int j = __builtin_ctzll(__ballot(active && ek == e));  // the sender's lane
+        if (lane == j) {
+#pragma unroll
+            for (int d = 0; d < D; ++d) held[d] = q_pay[i * g.dmax + d];
+        }
+        const bool is_new = __ballot(lane == j && !has) != 0;
+        if (lane == j && !has) {
+            has = true;
+            my_rank = narr;
+            g.v_order[k0 + narr] = e;
+        }
+        narr += is_new ? 1 : 0;
+        const unsigned long long hasmask = __ballot(has);
+        // costs_for_factor for this lane's factor
+        T m[D];
+        T sum_cost = (T)0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            T md = c[d];
+            for (int k2 = 0; k2 < deg; ++k2) {
+                const T x = __shfl(held[d], k2, 64);
+                if (k2 != lane && ((hasmask >> k2) & 1ull)) {
+                    sum_cost += x;
+                    md += x;
+                }
+            }
+            m[d] = md;
+        }
+        const T avg = sum_cost / (T)D;
+#pragma unroll
+        for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
+        if (active && lane != j) {
+            if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
+                const int64_t at = slot_base[i] + (lane < j ? lane : lane - 1);
+                s_code[at] = ek * 2;
+#pragma unroll
+                for (int d = 0; d < D; ++d) s_pay[at * g.dmax + d] = m[d];
+            }
+        }
+    }
+    // select_value on what is held now (maxsum.py:584-620): factors in first-arrival order
+    {
+        int best = 0;
+        T best_c = (T)0;
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            T b = c[d];
+            for (int r = 0; r < narr; ++r) {
+                const int src = __builtin_ctzll(__ballot(my_rank == r));
+                b += __shfl(held[d], src, 64);
+            }
+            if (d == 0 || (g.is_max ? b > best_c : b < best_c)) {
+                best = d;
+                best_c = b;
+            }
+        }
+        if (lane == 0) {
+            g.sel[v] = best;
+            g.belief[v] = best_c;
+            g.v_narr[v] = narr;
+        }
+    }
+    if (active) {
+#pragma unroll
+        for (int d = 0; d < D; ++d) {
+            g.v_cost[mo + d] = held[d];
+            g.v_prev[mo + d] = prev[d];
+        }
+        g.v_cnt[ek] = cnt;
+        g.v_has[ek] = has ? 1 : 0;
+    }
+}
+
+// out[y] = opt over the sender's values x of  tab(x, y) + (0 + cost[x])  -- factor_costs_for_var of
+// a binary factor; SENDER_FIRST: the sender is scope position 0 (rows of the table)
+template <typename T, bool SENDER_FIRST>
+__device__ __forceinline__ void factor2_message(const Dev<T>& g, const T (&tab)[16], const T (&cost)[4], int Ds, int Dt,
+                                                T (&out)[4]) {
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        T best = g.is_max ? -(T)INFINITY : (T)INFINITY;
+#pragma unroll
+        for (int x = 0; x < 4; ++x)
+            if (x < Ds && y < Dt) {
+                const T cur = (SENDER_FIRST ? tab[x * 4 + y] : tab[y * 4 + x]) + ((T)0 + cost[x]);
+                if (g.is_max ? best < cur : best > cur) best = cur;
+            }
+        out[y] = best;
+    }
+}
+
+// A binary factor over domains of at most 4 values: one lane, table / held costs / last-sent
+// messages in registers.
+template <typename T>
+__device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
+                              const int32_t* order, int64_t p, int64_t n, const int64_t* slot_base, int32_t* s_code,
+                              T* s_pay) {
+    const int eA = g.factor_rowptr[f], eB = eA + 1;
+    const int DA = g.dom_size[g.edge_var[eA]], DB = g.dom_size[g.edge_var[eB]];
+    const int64_t moA = g.msg_off[eA], moB = g.msg_off[eB];
+    T tab[16], cA[4], cB[4], pA[4], pB[4];
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+#pragma unroll
+        for (int y = 0; y < 4; ++y)
+            tab[x * 4 + y] = g.tables[g.table_off[f] + (int64_t)(x < DA ? x : DA - 1) * DB + (y < DB ? y : DB - 1)];
+        cA[x] = g.f_cost[moA + (x < DA ? x : DA - 1)];
+        pA[x] = g.f_prev[moA + (x < DA ? x : DA - 1)];
+        cB[x] = g.f_cost[moB + (x < DB ? x : DB - 1)];
+        pB[x] = g.f_prev[moB + (x < DB ? x : DB - 1)];
+    }
+    bool hasA = g.f_has[eA] != 0, hasB = g.f_has[eB] != 0;
+    uint8_t cntA = g.f_cnt[eA], cntB = g.f_cnt[eB];
+    const int32_t dst = dest_sorted[p];
+    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {
+        const int64_t i = order[r];
+        const int e = q_code[i] >> 1;
+        const T* pay = q_pay + i * g.dmax;
+        T out[4];
+        if (e == eA) {  // from scope variable 0: the message goes to variable 1
+#pragma unroll
+            for (int x = 0; x < 4; ++x) cA[x] = pay[x < DA ? x : DA - 1];
+            hasA = true;
+            if (!hasB) continue;  // still waiting for the other variable (amaxsum.py:206)
+            factor2_message<T, true>(g, tab, cA, DA, DB, out);
+            if (damp_and_decide_reg<T, 4>(g, out, pB, cntB, DB, g.damp_f != 0)) {
+                const int64_t at = slot_base[i];
+                s_code[at] = eB * 2 + 1;
+#pragma unroll
+                for (int y = 0; y < 4; ++y)
+                    if (y < DB) s_pay[at * g.dmax + y] = out[y];
+            }
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) cB[x] = pay[x < DB ? x : DB - 1];
+            hasB = true;
+            if (!hasA) continue;
+            factor2_message<T, false>(g, tab, cB, DB, DA, out);
+            if (damp_and_decide_reg<T, 4>(g, out, pA, cntA, DA, g.damp_f != 0)) {
+                const int64_t at = slot_base[i];
+                s_code[at] = eA * 2 + 1;
+#pragma unroll
+                for (int x = 0; x < 4; ++x)
+                    if (x < DA) s_pay[at * g.dmax + x] = out[x];
+            }
+        }
+    }
+#pragma unroll
+    for (int x = 0; x < 4; ++x) {
+        if (x < DA) {
+            g.f_cost[moA + x] = cA[x];
+            g.f_prev[moA + x] = pA[x];
+        }
+        if (x < DB) {
+            g.f_cost[moB + x] = cB[x];
+            g.f_prev[moB + x] = pB[x];
+        }
+    }
+    g.f_has[eA] = hasA ? 1 : 0;
+    g.f_has[eB] = hasB ? 1 : 0;
+    g.f_cnt[eA] = cntA;
+    g.f_cnt[eB] = cntB;
+    g.f_nhas[f] = (hasA ? 1 : 0) + (hasB ? 1 : 0);
+}
+
 // order[p]: FIFO index of the p-th message after the stable sort by destination; seg_first[t]:
-// position of the first message of the t-th destination to run (longest queues first, see step())
+// position of the first message of the t-th destination to run (longest queues first, see step()).
+// One wave (= one block) per destination.
 template <typename T>
 __global__ void __launch_bounds__(64) k_process(Dev<T> g, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
                           const int32_t* order, int64_t n, const int32_t* seg_first, int64_t n_seg,
-                          const int64_t* slot_base, int32_t* s_code, T* s_pay) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                          const int64_t* slot_base, int32_t* s_code, T* s_pay, int generic_only) {
+    const int64_t t = blockIdx.x;
     if (t >= n_seg) return;
     const int64_t p = seg_first[t];
     const int32_t dst = dest_sorted[p];
+    if (!generic_only) {
+        if (dst < g.n_vars) {
+            const int D = g.dom_size[dst], deg = g.var_rowptr[dst + 1] - g.var_rowptr[dst];
+            if (deg <= 64 && D >= 2 && D <= 4) {
+                if (D == 2) chain_variable<T, 2>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+                else if (D == 3) chain_variable<T, 3>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+                else chain_variable<T, 4>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+                return;
+            }
+        } else {
+            const int f = dst - g.n_vars, e0 = g.factor_rowptr[f];
+            if (g.factor_rowptr[f + 1] - e0 == 2 && g.dom_size[g.edge_var[e0]] <= 4 && g.dom_size[g.edge_var[e0 + 1]] <= 4) {
+                if ((threadIdx.x & 63) == 0)
+                    chain_factor2<T>(g, f, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+                return;
+            }
+        }
+    }
+    if ((threadIdx.x & 63) != 0) return;
     for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {  // its messages, in FIFO order
         const int64_t i = order[r];
         const bool last = r + 1 >= n || dest_sorted[r + 1] != dst;
@@ -610,8 +860,9 @@ struct Engine : Base {
         AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
         AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
         AMX_TRY(hipMemset(s_pay.p, 0, sizeof(T) * (n_slots + 1) * g.dmax));
-        hipLaunchKernelGGL((k_process<T>), dim3((unsigned)((n_seg + 63) / 64)), dim3(64), 0, 0, g, q_code.p, q_pay.p,
-                           dest_sorted.p, order.p, n, seg_first.p, n_seg, slot_base.p, s_code.p, s_pay.p);
+        const char* env = std::getenv("MAXSUM_AMAXSUM_GENERIC");  // =1: the per-message handler only (A/B, tests)
+        hipLaunchKernelGGL((k_process<T>), dim3((unsigned)n_seg), dim3(64), 0, 0, g, q_code.p, q_pay.p, dest_sorted.p,
+                           order.p, n, seg_first.p, n_seg, slot_base.p, s_code.p, s_pay.p, (env && env[0] == '1') ? 1 : 0);
         AMX_TRY(hipGetLastError());
         // compaction of the filled slots, slot order = FIFO order of the next generation
         int64_t n_next = 0;

@@ -24,6 +24,18 @@ def test_amaxsum_bit_exact_vs_oracle(case, dtype, oracle_built):
     compare_amaxsum(AMaxSumEngine(g, p), OracleAMaxSum(g, p))
 
 
+@pytest.mark.parametrize("case", amaxsum_cases()[:7], ids=lambda c: c[0])
+def test_amaxsum_per_message_handler(case, oracle_built, monkeypatch):
+    """MAXSUM_AMAXSUM_GENERIC=1: every destination on the per-message handler (what large domains,
+    n-ary factors and degrees above 64 run on)."""
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    monkeypatch.setenv("MAXSUM_AMAXSUM_GENERIC", "1")
+    name, make, kw = case
+    g = make()
+    p = Params(**kw)
+    compare_amaxsum(AMaxSumEngine(g, p), OracleAMaxSum(g, p), largest=100_000)
+
+
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])
 def test_amaxsum_golden_reference_vectors(path):
     check_golden(lambda g, p: AMaxSumEngine(g, p), path)
