@@ -206,6 +206,45 @@ def extra_configs(skip=()):
     return out
 
 
+def other_algorithms(n_vars, device=0):
+    """The widened rows of the scope table on the metric's instance:
+    amaxsum under FIFO delivery (messages handled per second over the first generations, the
+    message count exploding as in the reference), DSA-B and MGM (cycles per second).  Labelled
+    extras of the JSON line; never part of `value`."""
+    from pydcop_amd import generators as G
+    from pydcop_amd.amaxsum import AMaxSumEngine
+    from pydcop_amd.dsa import DsaEngine
+    from pydcop_amd.graph import Params
+    from pydcop_amd.mgm import MgmEngine
+    g = G.random_coloring(n_vars, avg_degree=4, n_colors=3, seed=0, names=False)
+    small = g.n_vars < 50_000  # testing only (--vars-per-gpu)
+    out = []
+    gens = 6 if small else 16
+    with AMaxSumEngine(g, Params(start_messages="leafs_vars"), device=device) as eng:
+        t0 = time.perf_counter()
+        done = eng.run(gens)
+        dt = time.perf_counter() - t0
+        out.append({"algo": "amaxsum (FIFO generations)", "workload": "coloring_100k", "n_vars": g.n_vars, "dtype": "f64",
+                    "generations": gens, "messages": int(done), "messages_per_s": done / max(dt, 1e-12),
+                    "largest_generation": int(eng.generation_sizes().max()) if done else 0,
+                    "parity_test": "tests/test_gpu_amaxsum.py::test_amaxsum_bit_exact_vs_oracle"})
+    cycles = 5 if small else 500
+    for name, make, test in (
+            ("dsa (variant B, p 0.7)", lambda: DsaEngine(g, Params(), variant="B", probability=0.7, seed=1, device=device),
+             "tests/test_gpu_dsa.py::test_dsa_100k_coloring"),
+            ("mgm", lambda: MgmEngine(g, Params(), device=device), "tests/test_gpu_mgm.py::test_mgm_100k_coloring")):
+        with make() as eng:
+            start = eng.eval_cost()[0]
+            eng.run(min(cycles, 20))
+            t0 = time.perf_counter()
+            eng.run(cycles)
+            dt = time.perf_counter() - t0
+            out.append({"algo": name, "workload": "coloring_100k", "n_vars": g.n_vars, "dtype": "f64", "cycles": cycles,
+                        "cycles_per_s": cycles / max(dt, 1e-12), "us_per_cycle": 1e6 * dt / cycles,
+                        "cost_at_start": start, "cost_now": eng.eval_cost()[0], "parity_test": test})
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # N > 1
 # ---------------------------------------------------------------------------------------------
@@ -355,6 +394,7 @@ def main():
         if args.configs == "all" and args.workload is None:
             del graph
             out["configs"] = extra_configs(skip={(workload, args.dtype)})
+            out["algorithms"] = other_algorithms(args.vars_per_gpu, device=local_rank)
         print(json.dumps(out), flush=True)
         return
 

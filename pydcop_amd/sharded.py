@@ -174,8 +174,24 @@ class ShardedMaxSum:
             warnings.warn(f"native RCCL exchange unavailable ({err or 'another rank failed'}); "
                           "falling back to torch.distributed.all_to_all_single")
             return False
-        self.engine.comm_init(self.rank, self.world, uid, self.shard.send_counts,
-                              self.shard.recv_counts, rccl=rccl)
+        err = None
+        try:
+            self.engine.comm_init(self.rank, self.world, uid, self.shard.send_counts,
+                                  self.shard.recv_counts, rccl=rccl)
+        except MaxSumGpuError as e:  # e.g. ncclCommInitRank refused on this node
+            err = str(e)
+        if multi:
+            oks = [None] * self.world
+            dist.all_gather_object(oks, err is None, group=self.group)
+            ok = all(oks)
+        else:
+            ok = err is None
+        if not ok:
+            # an engine that joined (or half-joined) a communicator cannot go back
+            warnings.warn(f"native RCCL exchange unavailable ({err or 'another rank failed'}); "
+                          "falling back to torch.distributed.all_to_all_single")
+            self._fresh_engine()
+            return False
         return True
 
     # -- the per-cycle exchange ------------------------------------------------------

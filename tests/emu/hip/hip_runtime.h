@@ -95,14 +95,67 @@ inline hipError_t hipGraphDestroy(hipGraph_t) { return hipSuccess; }
 inline hipError_t hipGraphExecDestroy(hipGraphExec_t) { return hipSuccess; }
 
 // ---- block execution with fibers ------------------------------------------
+// A barrier (and every emulated cross-lane read) switches through all fibers of the block.
+// glibc's swapcontext makes a system call per switch (signal mask); on x86-64 the switch
+// below saves the callee-saved registers and the stack pointer only.
 namespace hipemu {
+#if defined(__x86_64__)
+extern "C" void hipemu_switch(void** save_sp, void* load_sp);
+asm(R"(
+    .text
+    .weak hipemu_switch
+    .hidden hipemu_switch
+    .type hipemu_switch,@function
+hipemu_switch:
+    pushq %rbp
+    pushq %rbx
+    pushq %r12
+    pushq %r13
+    pushq %r14
+    pushq %r15
+    movq %rsp, (%rdi)
+    movq %rsi, %rsp
+    popq %r15
+    popq %r14
+    popq %r13
+    popq %r12
+    popq %rbx
+    popq %rbp
+    ret
+    .size hipemu_switch, .-hipemu_switch
+)");
+struct Context {
+    void* sp = nullptr;
+};
+inline void switch_context(Context* from, Context* to) { hipemu_switch(&from->sp, to->sp); }
+inline void make_context(Context* c, char* stack, size_t size, void (*entry)()) {
+    uintptr_t top = ((uintptr_t)stack + size) & ~(uintptr_t)15;
+    void** sp = (void**)top;
+    *--sp = nullptr;          // the entry function never returns
+    *--sp = (void*)entry;     // popped by the first switch's ret: rsp = top - 8 at entry (ABI)
+    for (int i = 0; i < 6; ++i) *--sp = nullptr;
+    c->sp = sp;
+}
+#else
+struct Context {
+    ucontext_t uc;
+};
+inline void switch_context(Context* from, Context* to) { swapcontext(&from->uc, &to->uc); }
+inline void make_context(Context* c, char* stack, size_t size, void (*entry)()) {
+    getcontext(&c->uc);
+    c->uc.uc_stack.ss_sp = stack;
+    c->uc.uc_stack.ss_size = size;
+    c->uc.uc_link = nullptr;
+    makecontext(&c->uc, entry, 0);
+}
+#endif
 struct Fiber {
-    ucontext_t ctx;
+    Context ctx;
     std::vector<char> stack;
     bool done = false;
 };
 struct BlockRun {
-    ucontext_t sched;
+    Context sched;
     std::vector<Fiber> fibers;
     int current = 0;
     void (*body)(void*) = nullptr;
@@ -115,11 +168,11 @@ inline void trampoline() {
     Fiber& f = r->fibers[r->current];
     r->body(r->arg);
     f.done = true;
-    swapcontext(&f.ctx, &r->sched);
+    for (;;) switch_context(&f.ctx, &r->sched);
 }
 inline void yield_barrier() {  // __syncthreads(): back to the scheduler
     BlockRun* r = g_run;
-    swapcontext(&r->fibers[r->current].ctx, &r->sched);
+    switch_context(&r->fibers[r->current].ctx, &r->sched);
 }
 inline void run_block(unsigned nthreads, void (*body)(void*), void* arg) {
     static thread_local BlockRun run;
@@ -131,11 +184,7 @@ inline void run_block(unsigned nthreads, void (*body)(void*), void* arg) {
         Fiber& f = run.fibers[t];
         if (f.stack.empty()) f.stack.resize(256 * 1024);
         f.done = false;
-        getcontext(&f.ctx);
-        f.ctx.uc_stack.ss_sp = f.stack.data();
-        f.ctx.uc_stack.ss_size = f.stack.size();
-        f.ctx.uc_link = nullptr;
-        makecontext(&f.ctx, trampoline, 0);
+        make_context(&f.ctx, f.stack.data(), f.stack.size(), trampoline);
     }
     bool alive = true;
     while (alive) {  // one pass == everything up to the next barrier
@@ -145,7 +194,7 @@ inline void run_block(unsigned nthreads, void (*body)(void*), void* arg) {
             if (f.done) continue;
             run.current = (int)t;
             threadIdx = dim3(t);
-            swapcontext(&run.sched, &f.ctx);
+            switch_context(&run.sched, &f.ctx);
             if (!f.done) alive = true;
         }
     }

@@ -93,6 +93,15 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
         for key in ("achieved", "frac", "algorithmic_bytes_per_launch", "avg_launch_us", "traffic", "traffic_source"):
             assert key in rf
         assert c["ms_per_step"] > 0 and c["iterations_per_s"] > 0
+    # the widened rows: amaxsum, DSA, MGM on the metric's instance, each naming its parity test
+    algos = out["algorithms"]
+    assert [a["algo"].split()[0] for a in algos] == ["amaxsum", "dsa", "mgm"]
+    assert algos[0]["messages"] > 0 and algos[0]["messages_per_s"] > 0
+    for a in algos[1:]:
+        assert a["cycles_per_s"] > 0 and a["cost_now"] <= a["cost_at_start"]
+    for a in algos:
+        assert a["parity_test"].startswith("tests/test_gpu_") and os.path.exists(
+            os.path.join(ROOT, a["parity_test"].split("::")[0]))
 
 
 def test_bench_rejects_mismatched_world():
