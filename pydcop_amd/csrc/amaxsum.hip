@@ -54,7 +54,11 @@ struct Buf {
         if (count <= n && p) return hipSuccess;
         if (p) (void)hipFree(p);
         p = nullptr;
-        n = count + count / 2 + 1024;
+        // a generation is about three times the previous one while the message count explodes:
+        // head-room of 3x (at most 2^30 elements) so that the buffers are re-allocated every other
+        // generation at most (hipFree + hipMalloc of GB-sized buffers dominated the host side)
+        const size_t room = count * 3 < ((size_t)1 << 30) ? count * 3 : ((size_t)1 << 30);
+        n = count + room + 1024;
         return hipMalloc((void**)&p, n * sizeof(U));
     }
     hipError_t upload(const std::vector<U>& h) {
