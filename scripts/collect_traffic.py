@@ -20,6 +20,9 @@ traffic, profiles/r01_pmc_calibration_v4.txt, r01_pmc_requests_calibration_v4.tx
     edge end is near-sequential, G = 1 per edge; on a graph with locality (Ising grid) the
     gathers merge into line requests, G = 0 and 2 * FETCH is an upper bound.
 usage: python scripts/collect_traffic.py TAG workload/dtype=file.txt:n_gather ...
+A workload whose cycle is several launches (the n-ary classes: k_factor_nary* + k_variable_wide,
+each once per cycle) is given as workload/dtype=file.txt:n_gather:cycle -- the counters of every
+kernel launched once per cycle are summed.
 """
 import json
 import os
@@ -38,6 +41,16 @@ def read_counters(path):
     return out
 
 
+def read_cycle_counters(path):
+    """Sum over the kernels that run once per cycle (n > 1 dispatches in the pass)."""
+    out = {}
+    for line in open(path):
+        m = re.search(r"\b([A-Z][A-Z0-9_]+_SIZE)\s+.*\bn\s+(\d+)\s+mean(?:_KiB)?\s+([0-9.]+)", line)
+        if m and int(m.group(2)) > 1:
+            out[m.group(1)] = out.get(m.group(1), 0.0) + float(m.group(3))
+    return out
+
+
 def main():
     out_path = os.path.join(ROOT, "profiles", "traffic.json")
     try:
@@ -47,9 +60,9 @@ def main():
     tag = sys.argv[1]
     for spec in sys.argv[2:]:
         key, rest = spec.split("=")
-        path, n_gather = rest.split(":")
+        path, n_gather, *mode = rest.split(":")
         n_gather = int(n_gather)
-        c = read_counters(path)
+        c = read_cycle_counters(path) if mode == ["cycle"] else read_counters(path)
         fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
         read_bytes = 2 * fetch - 64 * n_gather
         data[key] = {
