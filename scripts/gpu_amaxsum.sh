@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 2, call O: amaxsum with one thread per destination, longest queues first
-TAG=${1:-r02o}
+# amaxsum: GPU parity tests, messages per second, kernel trace of the 100k-variable run
+TAG=${1:-amaxsum}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 ( time timeout 500 python -m pytest tests/test_gpu_amaxsum.py -x -q -m gpu --durations=4 ) 2>&1 | tail -12 | tee $OUT/pytest.txt
 timeout 200 python tools/amaxsum_bench.py --no-oracle 10000 100000 | tee $OUT/amaxsum_bench.jsonl

@@ -1,22 +1,12 @@
 #!/bin/bash
-# Sharded-cycle measurements on one GPU: parity of k shards, cost of one rank's cycle with the
-# fused launch (default) and with the two-launch schedule, kernel trace of the fused run.
-# usage: gpurun --timeout 400 -- 'bash scripts/gpu_shard.sh TAG'
-TAG=${1:-shard}
+# Peer-store exchange: publish kernel on the comm stream (default) vs inline on the compute stream.
+TAG=${1:-shard4}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
-T0=$(date +%s); lap() { echo "== [$(( $(date +%s) - T0 ))s] $1"; }
-lap "pytest -m gpu (sharded)"
-timeout 300 python -m pytest tests/test_sharded.py -x -q -m gpu 2>&1 | tail -5 | tee $OUT/pytest_sharded.txt
-lap "shard cost: direct exchange (default for the native path)"
-(timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1; timeout 120 python tools/shard_cost.py 2 f64 2>&1 | tail -1) | tee $OUT/shard_cost_direct.jsonl
-lap "shard cost: every factor class in the second launch (layout flag 512)"
-(MAXSUM_LAYOUT_FLAGS=512 timeout 120 python tools/shard_cost.py 8 f64 2>&1 | tail -1; MAXSUM_LAYOUT_FLAGS=512 timeout 120 python tools/shard_cost.py 2 f64 2>&1 | tail -1) | tee $OUT/shard_cost_factors_second.jsonl
-export MAXSUM_LAYOUT_FLAGS=512
-lap "kernel trace of the shard cycle (8-way shard 0, direct exchange, flag 512)"
-( cd /tmp; timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof -o trace -- python $R/tools/shard_cost.py 8 f64 > $OUT/prof.log 2>&1 )
-find $OUT/prof -name "*kernel_stats*.csv" | head -1 | while read f; do head -12 "$f" | cut -c1-200; cp "$f" $OUT/kernel_stats_shard.csv; done
-rm -rf $OUT/prof
-unset MAXSUM_LAYOUT_FLAGS
-lap "bench default"
-timeout 200 python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400 | tee $OUT/bench_default.json
-lap done
+timeout 300 python -m pytest tests/test_sharded.py -x -q -m gpu -k "peer or nccl" 2>&1 | tail -3 | tee $OUT/pytest_sharded.txt
+export MAXSUM_COST_ONLY=d
+: > $OUT/shard_cost_publish.jsonl
+for mode in comm inline; do for n in 8 2; do
+  MAXSUM_P2P_PUBLISH=$mode timeout 100 python tools/shard_cost.py $n f64 2>&1 | grep "^{" | tail -1 | tee -a $OUT/shard_cost_publish.jsonl | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print('publish', '$mode', 'ranks', d['ranks'], 'us/cycle', round(d.get('shard_cycle_us_peer_stores_loopback', -1), 2))"
+done; done

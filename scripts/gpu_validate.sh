@@ -1,6 +1,6 @@
 #!/bin/bash
-# round 2: the full GPU suite, smoke, the bench line, kernel trace of the bench command
-TAG=${1:-r02final}
+# the full GPU suite, smoke, the bench line, kernel trace of the bench command
+TAG=${1:-validate}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 echo "== pytest -m gpu (everything)"
 ( time timeout 1100 python -m pytest tests -x -q -m gpu --durations=12 ) 2>&1 | tail -32 | tee $OUT/pytest_gpu.txt
