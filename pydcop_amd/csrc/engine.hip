@@ -366,16 +366,17 @@ struct Engine : EngineBase {
             if (nl.cut != cut) continue;
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
+#define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
+    do {                                                                                                    \
+        if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, 0, stream, a, d);  \
+        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, 0, stream, a, d);           \
+    } while (0)
 #define MXS_NARY_CASE(AR, NJ)                                                                              \
     case (AR) * 16 + (NJ):                                                                                  \
-        if (nl.tab_type == TAB_I8)                                                                          \
-            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, int8_t>), grid, block, 0, stream, a, d);    \
-        else if (nl.tab_type == TAB_I16)                                                                    \
-            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, int16_t>), grid, block, 0, stream, a, d);   \
-        else if (nl.tab_type == TAB_F32)                                                                    \
-            hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, float>), grid, block, 0, stream, a, d);     \
-        else                                                                                                \
-            hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);                   \
+        if (nl.tab_type == TAB_I8) MXS_NARY_PACKED(AR, NJ, int8_t);                                         \
+        else if (nl.tab_type == TAB_I16) MXS_NARY_PACKED(AR, NJ, int16_t);                                  \
+        else if (nl.tab_type == TAB_F32) MXS_NARY_PACKED(AR, NJ, float);                                    \
+        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);                  \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
@@ -384,6 +385,7 @@ struct Engine : EngineBase {
                 default: return fail(MXS_E_STATE, "no n-ary kernel for this (arity, size) group");
             }
 #undef MXS_NARY_CASE
+#undef MXS_NARY_PACKED
             HIP_TRY(hipGetLastError());
         }
         return MXS_OK;

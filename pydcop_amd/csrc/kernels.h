@@ -1173,7 +1173,9 @@ __device__ __forceinline__ T nary_slot_entry(const uint32_t* w, int j) {
     }
 }
 
-template <typename T, int A, int NJ, typename TT>
+// NEG (max mode: narrow images hold un-negated values) is a template parameter: the negation then
+// folds into the first use of the entry as an operand modifier instead of a 64-bit select per entry.
+template <typename T, int A, int NJ, typename TT, bool NEG>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
@@ -1199,7 +1201,6 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
     const NarySlot<SW>* slots = (const NarySlot<SW>*)(a.ctables + fd.tab_off);  // [D0][NT]
-    const bool neg = a.tab_neg != 0;
     int qc[NJ];
     bool live[NJ];
 #pragma unroll
@@ -1259,7 +1260,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 #pragma unroll
                     for (int j = 0; j < NJ; ++j) {
                         const T v = nary_slot_entry<T, TT>(buf[pb][u].w, j);
-                        tv[u][j] = neg ? -v : v;
+                        tv[u][j] = NEG ? -v : v;
                     }
                 if (b + PF < n_batches) {  // this buffer's next tenant
 #pragma unroll
