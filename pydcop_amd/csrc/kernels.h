@@ -975,6 +975,37 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
     }
 }
 
+// dig[j][1..A-1] = the mixed-radix digits (dimensions 1..A-1, last fastest) of q_j = tid + j * NT,
+// those of R - 1 where q_j is past the table.  Divisions for q_0 and for the block-uniform stride
+// NT only; q_j = q_(j-1) + NT is a digit-wise addition with carry.
+template <int A, int NJ>
+__device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A], const bool (&live)[NJ],
+                                            int (&dig)[NJ][A]) {
+    int step[A];
+    int rem = tid, rs = NT;
+#pragma unroll
+    for (int i = A - 1; i >= 1; --i) {
+        dig[0][i] = rem % Dm[i];
+        rem /= Dm[i];
+        step[i] = rs % Dm[i];
+        rs /= Dm[i];
+    }
+#pragma unroll
+    for (int j = 1; j < NJ; ++j) {
+        int carry = 0;
+#pragma unroll
+        for (int i = A - 1; i >= 1; --i) {
+            const int x = dig[j - 1][i] + step[i] + carry;
+            carry = x >= Dm[i] ? 1 : 0;
+            dig[j][i] = x - (carry ? Dm[i] : 0);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int i = 1; i < A; ++i) dig[j][i] = live[j] ? dig[j][i] : Dm[i] - 1;
+}
+
 // blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
 // layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
 template <typename T, int A, int NJ>
@@ -1032,13 +1063,11 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // per owned q: its digits' messages and the running minima for p >= 1
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
+    nary_digits<A, NJ>(tid, NT, Dm, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        int rem = qc[j];
 #pragma unroll
         for (int i = A - 1; i >= 1; --i) {
-            dig[j][i] = rem % Dm[i];
-            rem /= Dm[i];
             ms[j][i] = s_msg[off[i] + dig[j][i]];
             acc[j][i] = pos_inf<T>();
         }
@@ -1233,13 +1262,11 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
     __syncthreads();
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
+    nary_digits<A, NJ>(tid, NT, Dm, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        int rem = qc[j];
 #pragma unroll
         for (int i = A - 1; i >= 1; --i) {
-            dig[j][i] = rem % Dm[i];
-            rem /= Dm[i];
             ms[j][i] = s_msg[off[i] + dig[j][i]];
             acc[j][i] = pos_inf<T>();
         }
