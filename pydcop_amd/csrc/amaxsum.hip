@@ -27,6 +27,7 @@
 //
 // Built into libmaxsum_hip.so by hipcc.  (The host emulation of the CPU tests compiles this very
 // file against serial stand-ins for the two hipCUB primitives, tests/emu/hipcub/.)
+#include <climits>
 #include <cmath>
 #include <cstdint>
 #include <cstdlib>
@@ -826,6 +827,8 @@ struct Engine : Base {
         AMX_TRY(hipGetLastError());
         int64_t n_slots = 0;
         { int rc = scan32(cap.p, slot_base.p, n, &n_slots); if (rc) return rc; }
+        if (n_slots > (int64_t)INT32_MAX)  // the compaction scans the slots with 32-bit counts
+            return fail(MXS_E_NOMEM, "amaxsum: more than 2^31 output slots in one generation");
         {   // FIFO indices 0..n-1, then the stable sort by destination
             hipLaunchKernelGGL(k_iota, dim3(grid(n)), dim3(TPB), 0, 0, order_in.p, n);
             AMX_TRY(hipGetLastError());
