@@ -338,6 +338,34 @@ __device__ __forceinline__ bool damp_and_decide_reg(const Dev<T>& g, T (&m)[N], 
     return true;
 }
 
+// One delivery, loaded one message AHEAD of its handling: the index chain order[r] -> q_code /
+// q_pay / slot_base is three dependent loads, which would otherwise be the latency of every step of a
+// chain that is sequential anyway (the longest chain of a generation is what the generation lasts).
+template <typename T, int N>
+struct Mail {
+    int32_t code;
+    int64_t base;
+    T pay[N];
+};
+template <typename T, int N>
+__device__ __forceinline__ void fetch_mail(const Dev<T>& g, const int32_t* q_code, const T* q_pay, const int64_t* slot_base,
+                                           int64_t i, Mail<T, N>& m) {
+    m.code = q_code[i];
+    m.base = slot_base[i];
+#pragma unroll
+    for (int d = 0; d < N; ++d) m.pay[d] = q_pay[i * g.dmax + (d < g.dmax ? d : 0)];
+}
+// the walk over a destination's run [p, ...) of the sorted order, two indices ahead
+struct Walk {
+    int64_t r, i_next;
+    bool has_next;
+    __device__ __forceinline__ void start(const int32_t* dest_sorted, const int32_t* order, int64_t p, int64_t n) {
+        r = p;
+        has_next = p + 1 < n && dest_sorted[p + 1] == dest_sorted[p];
+        i_next = p + 1 < n ? order[p + 1] : order[p];
+    }
+};
+
 // A variable of domain size D (template) and degree <= 64: ONE WAVE, lane k = the variable's k-th
 // factor (var_edges order) holding that factor's last message, the message last sent to it and its
 // send counter.  Per delivered message: the sender's lane takes the costs, every other lane builds
@@ -371,13 +399,20 @@ __device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, co
     for (int r = 0; r < narr; ++r)
         if (g.v_order[k0 + r] == ek) my_rank = r;
     const int32_t dst = dest_sorted[p];
-    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {
-        const int64_t i = order[r];
-        const int e = q_code[i] >> 1;
+    Walk w;
+    w.start(dest_sorted, order, p, n);
+    Mail<T, D> cur, nxt;
+    fetch_mail<T, D>(g, q_code, q_pay, slot_base, order[p], cur);
+    for (;;) {
+        fetch_mail<T, D>(g, q_code, q_pay, slot_base, w.i_next, nxt);  // in flight while `cur` is handled
+        const int64_t r2 = w.r + 2;
+        const bool has_nn = w.has_next && r2 < n && dest_sorted[r2] == dst;
+        const int64_t i_nn = r2 < n ? order[r2] : w.i_next;
+        const int e = cur.code >> 1;
         const int j = __builtin_ctzll(__ballot(active && ek == e));  // the sender's lane
         if (lane == j) {
 #pragma unroll
-            for (int d = 0; d < D; ++d) held[d] = q_pay[i * g.dmax + d];
+            for (int d = 0; d < D; ++d) held[d] = cur.pay[d];
         }
         const bool is_new = __ballot(lane == j && !has) != 0;
         if (lane == j && !has) {
@@ -407,12 +442,17 @@ __device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, co
         for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
         if (active && lane != j) {
             if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
-                const int64_t at = slot_base[i] + (lane < j ? lane : lane - 1);
+                const int64_t at = cur.base + (lane < j ? lane : lane - 1);
                 s_code[at] = ek * 2;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s_pay[at * g.dmax + d] = m[d];
             }
         }
+        if (!w.has_next) break;
+        cur = nxt;
+        w.r += 1;
+        w.i_next = i_nn;
+        w.has_next = has_nn;
     }
     // select_value on what is held now (maxsum.py:584-620): factors in first-arrival order
     {
@@ -488,38 +528,51 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, con
     bool hasA = g.f_has[eA] != 0, hasB = g.f_has[eB] != 0;
     uint8_t cntA = g.f_cnt[eA], cntB = g.f_cnt[eB];
     const int32_t dst = dest_sorted[p];
-    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {
-        const int64_t i = order[r];
-        const int e = q_code[i] >> 1;
-        const T* pay = q_pay + i * g.dmax;
+    Walk w;
+    w.start(dest_sorted, order, p, n);
+    Mail<T, 4> cur, nxt;
+    fetch_mail<T, 4>(g, q_code, q_pay, slot_base, order[p], cur);
+    for (;;) {
+        fetch_mail<T, 4>(g, q_code, q_pay, slot_base, w.i_next, nxt);  // in flight while `cur` is handled
+        const int64_t r2 = w.r + 2;
+        const bool has_nn = w.has_next && r2 < n && dest_sorted[r2] == dst;
+        const int64_t i_nn = r2 < n ? order[r2] : w.i_next;
+        const int e = cur.code >> 1;
         T out[4];
         if (e == eA) {  // from scope variable 0: the message goes to variable 1
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cA[x] = pay[x < DA ? x : DA - 1];
+            for (int x = 0; x < 4; ++x) cA[x] = cur.pay[x < DA ? x : 0];
             hasA = true;
-            if (!hasB) continue;  // still waiting for the other variable (amaxsum.py:206)
-            factor2_message<T, true>(g, tab, cA, DA, DB, out);
-            if (damp_and_decide_reg<T, 4>(g, out, pB, cntB, DB, g.damp_f != 0)) {
-                const int64_t at = slot_base[i];
-                s_code[at] = eB * 2 + 1;
+            if (hasB) {  // else: still waiting for the other variable (amaxsum.py:206)
+                factor2_message<T, true>(g, tab, cA, DA, DB, out);
+                if (damp_and_decide_reg<T, 4>(g, out, pB, cntB, DB, g.damp_f != 0)) {
+                    const int64_t at = cur.base;
+                    s_code[at] = eB * 2 + 1;
 #pragma unroll
-                for (int y = 0; y < 4; ++y)
-                    if (y < DB) s_pay[at * g.dmax + y] = out[y];
+                    for (int y = 0; y < 4; ++y)
+                        if (y < DB) s_pay[at * g.dmax + y] = out[y];
+                }
             }
         } else {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cB[x] = pay[x < DB ? x : DB - 1];
+            for (int x = 0; x < 4; ++x) cB[x] = cur.pay[x < DB ? x : 0];
             hasB = true;
-            if (!hasA) continue;
-            factor2_message<T, false>(g, tab, cB, DB, DA, out);
-            if (damp_and_decide_reg<T, 4>(g, out, pA, cntA, DA, g.damp_f != 0)) {
-                const int64_t at = slot_base[i];
-                s_code[at] = eA * 2 + 1;
+            if (hasA) {
+                factor2_message<T, false>(g, tab, cB, DB, DA, out);
+                if (damp_and_decide_reg<T, 4>(g, out, pA, cntA, DA, g.damp_f != 0)) {
+                    const int64_t at = cur.base;
+                    s_code[at] = eA * 2 + 1;
 #pragma unroll
-                for (int x = 0; x < 4; ++x)
-                    if (x < DA) s_pay[at * g.dmax + x] = out[x];
+                    for (int x = 0; x < 4; ++x)
+                        if (x < DA) s_pay[at * g.dmax + x] = out[x];
+                }
             }
         }
+        if (!w.has_next) break;
+        cur = nxt;
+        w.r += 1;
+        w.i_next = i_nn;
+        w.has_next = has_nn;
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
