@@ -366,20 +366,30 @@ struct Walk {
     }
 };
 
-// A variable of domain size D (template) and degree <= 64: ONE WAVE, lane k = the variable's k-th
-// factor (var_edges order) holding that factor's last message, the message last sent to it and its
-// send counter.  Per delivered message: the sender's lane takes the costs, every other lane builds
-// its factor's message from the held costs of all lanes (D * deg cross-lane reads, the reference's
-// order of additions: d outer, factors inner, maxsum.py:651-665), damps, applies the send rule and
-// writes its output slot.
-template <typename T, int D>
-__device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
-                               const int32_t* order, int64_t p, int64_t n, const int64_t* slot_base, int32_t* s_code,
-                               T* s_pay) {
+// A variable of domain size D (template) and degree <= GROUP: a group of GROUP lanes (8, 16 or the
+// whole wave), lane k of the group = the variable's k-th factor (var_edges order) holding that
+// factor's last message, the message last sent to it and its send counter.  Per delivered message:
+// the sender's lane takes the costs, every other lane builds its factor's message from the held costs
+// of the group (D * deg cross-lane reads, the reference's order of additions: d outer, factors inner,
+// maxsum.py:651-665), damps, applies the send rule and writes its output slot.  The groups of a
+// wave walk their own queues in lock step (a group whose queue is done idles: the destinations are
+// sorted by queue length, so the queues of a wave are about equally long); `t` = the group's
+// destination in seg_first, groups past `seg_end` have none.
+template <typename T, int D, int GROUP>
+__device__ void chain_variable(const Dev<T>& g, const int32_t* seg_first, int64_t t, int64_t seg_end, const int32_t* q_code,
+                               const T* q_pay, const int32_t* dest_sorted, const int32_t* order, int64_t n,
+                               const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+    constexpr bool WHOLE = GROUP == 64;
     const int lane = (int)threadIdx.x & 63;
-    const int k0 = g.var_rowptr[v], deg = g.var_rowptr[v + 1] - k0;
-    const bool active = lane < deg;
-    const int ek = active ? g.var_edges[k0 + lane] : -1;
+    const int gl = lane % GROUP, gbase = lane - gl;
+    const unsigned long long gmask = WHOLE ? ~0ull : (((1ull << (GROUP % 64)) - 1ull) << gbase);
+    const bool valid = t < seg_end;
+    const int64_t p = valid ? seg_first[t] : 0;
+    const int32_t dst = dest_sorted[p];
+    const int v = valid ? dst : 0;
+    const int k0 = g.var_rowptr[v], deg = valid ? g.var_rowptr[v + 1] - k0 : 0;
+    const bool active = gl < deg;
+    const int ek = active ? g.var_edges[k0 + gl] : -1;
     const int64_t mo = active ? g.msg_off[ek] : 0;
     T held[D], prev[D], c[D];
     uint8_t cnt = 0;
@@ -394,45 +404,58 @@ __device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, co
         cnt = g.v_cnt[ek];
         has = g.v_has[ek] != 0;
     }
-    int narr = g.v_narr[v];
+    int narr = valid ? g.v_narr[v] : 0;
     int my_rank = -1;  // first-arrival rank of this lane's factor (select_value sums in that order)
     for (int r = 0; r < narr; ++r)
         if (g.v_order[k0 + r] == ek) my_rank = r;
-    const int32_t dst = dest_sorted[p];
     Walk w;
     w.start(dest_sorted, order, p, n);
     Mail<T, D> cur, nxt;
     fetch_mail<T, D>(g, q_code, q_pay, slot_base, order[p], cur);
-    for (;;) {
+    bool alive = valid;
+    while (__ballot(alive) != 0ull) {
         fetch_mail<T, D>(g, q_code, q_pay, slot_base, w.i_next, nxt);  // in flight while `cur` is handled
         const int64_t r2 = w.r + 2;
         const bool has_nn = w.has_next && r2 < n && dest_sorted[r2] == dst;
         const int64_t i_nn = r2 < n ? order[r2] : w.i_next;
         const int e = cur.code >> 1;
-        const int j = __builtin_ctzll(__ballot(active && ek == e));  // the sender's lane
-        if (lane == j) {
+        const unsigned long long from = __ballot(alive && active && ek == e) & gmask;
+        const int j = from ? __builtin_ctzll(from) - gbase : -1;  // the sender's lane of the group
+        const bool mine = alive && gl == j;
+        if (mine) {
 #pragma unroll
             for (int d = 0; d < D; ++d) held[d] = cur.pay[d];
         }
-        const bool is_new = __ballot(lane == j && !has) != 0;
-        if (lane == j && !has) {
+        const bool is_new = (__ballot(mine && !has) & gmask) != 0ull;
+        if (mine && !has) {
             has = true;
             my_rank = narr;
             g.v_order[k0 + narr] = e;
         }
         narr += is_new ? 1 : 0;
-        const unsigned long long hasmask = __ballot(has);
+        const unsigned long long hasmask = (__ballot(has) & gmask) >> gbase;
         // costs_for_factor for this lane's factor
         T m[D];
         T sum_cost = (T)0;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             T md = c[d];
-            for (int k2 = 0; k2 < deg; ++k2) {
-                const T x = __shfl(held[d], k2, 64);
-                if (k2 != lane && ((hasmask >> k2) & 1ull)) {
-                    sum_cost += x;
-                    md += x;
+            if constexpr (WHOLE) {
+                for (int k2 = 0; k2 < deg; ++k2) {  // deg is wave-uniform here
+                    const T x = __shfl(held[d], k2, 64);
+                    if (k2 != gl && ((hasmask >> k2) & 1ull)) {
+                        sum_cost += x;
+                        md += x;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k2 = 0; k2 < GROUP; ++k2) {
+                    const T x = __shfl(held[d], k2, GROUP);
+                    if (k2 != gl && ((hasmask >> k2) & 1ull)) {  // lanes past the degree never "have"
+                        sum_cost += x;
+                        md += x;
+                    }
                 }
             }
             m[d] = md;
@@ -440,15 +463,15 @@ __device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, co
         const T avg = sum_cost / (T)D;
 #pragma unroll
         for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-        if (active && lane != j) {
+        if (alive && active && gl != j) {
             if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
-                const int64_t at = cur.base + (lane < j ? lane : lane - 1);
+                const int64_t at = cur.base + (gl < j ? gl : gl - 1);
                 s_code[at] = ek * 2;
 #pragma unroll
                 for (int d = 0; d < D; ++d) s_pay[at * g.dmax + d] = m[d];
             }
         }
-        if (!w.has_next) break;
+        alive = alive && w.has_next;
         cur = nxt;
         w.r += 1;
         w.i_next = i_nn;
@@ -458,19 +481,22 @@ __device__ void chain_variable(const Dev<T>& g, int v, const int32_t* q_code, co
     {
         int best = 0;
         T best_c = (T)0;
+        const int rmax = WHOLE ? narr : GROUP;
 #pragma unroll
         for (int d = 0; d < D; ++d) {
             T b = c[d];
-            for (int r = 0; r < narr; ++r) {
-                const int src = __builtin_ctzll(__ballot(my_rank == r));
-                b += __shfl(held[d], src, 64);
+            for (int r = 0; r < rmax; ++r) {
+                const unsigned long long who = __ballot(my_rank == r) & gmask;
+                const int src = who ? __builtin_ctzll(who) - gbase : 0;
+                const T x = __shfl(held[d], src, GROUP);
+                if (r < narr) b += x;
             }
             if (d == 0 || (g.is_max ? b > best_c : b < best_c)) {
                 best = d;
                 best_c = b;
             }
         }
-        if (lane == 0) {
+        if (valid && gl == 0) {
             g.sel[v] = best;
             g.belief[v] = best_c;
             g.v_narr[v] = narr;
@@ -541,7 +567,7 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, con
         T out[4];
         if (e == eA) {  // from scope variable 0: the message goes to variable 1
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cA[x] = cur.pay[x < DA ? x : 0];
+            for (int x = 0; x < 4; ++x) cA[x] = cur.pay[x];  // past the domain: the zero padding of the slot
             hasA = true;
             if (hasB) {  // else: still waiting for the other variable (amaxsum.py:206)
                 factor2_message<T, true>(g, tab, cA, DA, DB, out);
@@ -555,7 +581,7 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, con
             }
         } else {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cB[x] = cur.pay[x < DB ? x : 0];
+            for (int x = 0; x < 4; ++x) cB[x] = cur.pay[x];
             hasB = true;
             if (hasA) {
                 factor2_message<T, false>(g, tab, cB, DB, DA, out);
@@ -592,36 +618,68 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, con
     g.f_nhas[f] = (hasA ? 1 : 0) + (hasB ? 1 : 0);
 }
 
-// order[p]: FIFO index of the p-th message after the stable sort by destination; seg_first[t]:
-// position of the first message of the t-th destination to run (longest queues first, see step()).
-// One wave (= one block) per destination.
+// Destination classes of a generation (what runs its queue):
+constexpr int CLS_FACTOR2 = 0;  // binary factor, domains <= 4: a lane (chain_factor2), 64 per wave
+constexpr int CLS_VAR8 = 1;     // variable, domain 2..4, degree <= 8: 8 lanes, 8 per wave
+constexpr int CLS_VAR16 = 2;    //                        degree <= 16: 16 lanes, 4 per wave
+constexpr int CLS_VAR64 = 3;    //                        degree <= 64: the wave
+constexpr int CLS_GENERIC = 4;  // everything else: a lane on the per-message handler, 64 per wave
+constexpr int N_CLS = 5;
+
 template <typename T>
-__global__ void __launch_bounds__(64) k_process(Dev<T> g, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
-                          const int32_t* order, int64_t n, const int32_t* seg_first, int64_t n_seg,
-                          const int64_t* slot_base, int32_t* s_code, T* s_pay, int generic_only) {
-    const int64_t t = blockIdx.x;
-    if (t >= n_seg) return;
+__device__ __forceinline__ int class_of(const Dev<T>& g, int32_t dst) {
+    if (dst < g.n_vars) {
+        const int D = g.dom_size[dst], deg = g.var_rowptr[dst + 1] - g.var_rowptr[dst];
+        if (D < 2 || D > 4 || deg > 64) return CLS_GENERIC;
+        return deg <= 8 ? CLS_VAR8 : (deg <= 16 ? CLS_VAR16 : CLS_VAR64);
+    }
+    const int f = dst - g.n_vars, e0 = g.factor_rowptr[f];
+    return (g.factor_rowptr[f + 1] - e0 == 2 && g.dom_size[g.edge_var[e0]] <= 4 && g.dom_size[g.edge_var[e0 + 1]] <= 4)
+               ? CLS_FACTOR2 : CLS_GENERIC;
+}
+
+template <typename T, int GROUP>
+__device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const int32_t* seg_first, int64_t seg_begin,
+                                                  int64_t seg_end, const int32_t* q_code, const T* q_pay,
+                                                  const int32_t* dest_sorted, const int32_t* order, int64_t n,
+                                                  const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+    constexpr int PER_WAVE = 64 / GROUP;
+    const int lane = (int)threadIdx.x & 63;
+    const int64_t t = seg_begin + (int64_t)blockIdx.x * PER_WAVE + lane / GROUP;
+    // the domain sizes of the wave's variables: one pass per size present (wave-uniform branches)
+    const int myD = t < seg_end ? g.dom_size[dest_sorted[seg_first[t]]] : 0;
+    for (int D = 2; D <= 4; ++D) {
+        if (__ballot(myD == D) == 0ull) continue;
+        const int64_t tt = myD == D ? t : seg_end;  // the other groups sit this pass out
+        if (D == 2) chain_variable<T, 2, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+        else if (D == 3) chain_variable<T, 3, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+        else chain_variable<T, 4, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+    }
+}
+
+// order[p]: FIFO index of the p-th message after the stable sort by destination; seg_first[t]:
+// position of the first message of the t-th destination to run -- by class, longest queues first
+// (step()); a launch runs the destinations [seg_begin, seg_end) of one class.  Blocks of one wave;
+// a kernel per class, so that each has the registers of its own path only.
+template <typename T, int GROUP>
+__global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, const int32_t* q_code, const T* q_pay,
+                          const int32_t* dest_sorted, const int32_t* order, int64_t n, const int32_t* seg_first,
+                          int64_t seg_begin, int64_t seg_end, const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+    variables_of_wave<T, GROUP>(g, seg_first, seg_begin, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+}
+
+template <typename T>
+__global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, const int32_t* q_code, const T* q_pay,
+                          const int32_t* dest_sorted, const int32_t* order, int64_t n, const int32_t* seg_first,
+                          int64_t seg_begin, int64_t seg_end, const int64_t* slot_base, int32_t* s_code, T* s_pay, int cls) {
+    const int64_t t = seg_begin + (int64_t)blockIdx.x * 64 + ((int)threadIdx.x & 63);
+    if (t >= seg_end) return;
     const int64_t p = seg_first[t];
     const int32_t dst = dest_sorted[p];
-    if (!generic_only) {
-        if (dst < g.n_vars) {
-            const int D = g.dom_size[dst], deg = g.var_rowptr[dst + 1] - g.var_rowptr[dst];
-            if (deg <= 64 && D >= 2 && D <= 4) {
-                if (D == 2) chain_variable<T, 2>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
-                else if (D == 3) chain_variable<T, 3>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
-                else chain_variable<T, 4>(g, dst, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
-                return;
-            }
-        } else {
-            const int f = dst - g.n_vars, e0 = g.factor_rowptr[f];
-            if (g.factor_rowptr[f + 1] - e0 == 2 && g.dom_size[g.edge_var[e0]] <= 4 && g.dom_size[g.edge_var[e0 + 1]] <= 4) {
-                if ((threadIdx.x & 63) == 0)
-                    chain_factor2<T>(g, f, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
-                return;
-            }
-        }
+    if (cls == CLS_FACTOR2) {
+        chain_factor2<T>(g, dst - g.n_vars, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+        return;
     }
-    if ((threadIdx.x & 63) != 0) return;
     for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {  // its messages, in FIFO order
         const int64_t i = order[r];
         const bool last = r + 1 >= n || dest_sorted[r + 1] != dst;
@@ -646,12 +704,29 @@ __global__ void k_seg_starts(const int32_t* head, const int64_t* idx, int64_t n,
     if (p < n && head[p]) seg_pos[idx[p]] = (int32_t)p;
 }
 
-// key = ~length: an ascending sort runs the longest queues first
-__global__ void k_seg_keys(const int32_t* seg_pos, int64_t n_seg, int64_t n, uint32_t* key) {
+// key = class << 32 | ~length: an ascending sort groups the classes and runs the longest queues of
+// each class first
+template <typename T>
+__global__ void k_seg_keys(Dev<T> g, const int32_t* dest_sorted, const int32_t* seg_pos, int64_t n_seg, int64_t n,
+                           int generic_only, uint64_t* key) {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_seg) return;
     const int64_t end = t + 1 < n_seg ? seg_pos[t + 1] : n;
-    key[t] = ~(uint32_t)(end - seg_pos[t]);
+    const int cls = generic_only ? CLS_GENERIC : class_of(g, dest_sorted[seg_pos[t]]);
+    key[t] = ((uint64_t)cls << 32) | (uint32_t)~(uint32_t)(end - seg_pos[t]);
+}
+
+// first[c] = number of sorted keys below class c (c = 0 .. N_CLS)
+__global__ void k_class_bounds(const uint64_t* key_sorted, int64_t n_seg, int64_t* first) {
+    const int c = threadIdx.x;
+    if (c > N_CLS) return;
+    int64_t lo = 0, hi = n_seg;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) / 2;
+        if ((key_sorted[mid] >> 32) < (uint64_t)c) lo = mid + 1;
+        else hi = mid;
+    }
+    first[c] = lo;
 }
 
 template <typename T>
@@ -711,7 +786,8 @@ struct Engine : Base {
     Buf<T> q_pay, q_pay2, s_pay;
     Buf<int64_t> slot_base, flag, pos, cap64, head_idx;
     Buf<int32_t> head, seg_pos, seg_first;
-    Buf<uint32_t> seg_key, seg_key_sorted;
+    Buf<uint64_t> seg_key, seg_key_sorted;
+    Buf<int64_t> cls_first;
     Buf<uint8_t> temp;
     int64_t nm = 0;
 
@@ -909,21 +985,37 @@ struct Engine : Base {
             AMX_TRY(seg_key_sorted.reserve(n_seg));
             hipLaunchKernelGGL(k_seg_starts, dim3(grid(n)), dim3(TPB), 0, 0, head.p, head_idx.p, n, seg_pos.p);
             AMX_TRY(hipGetLastError());
-            hipLaunchKernelGGL(k_seg_keys, dim3(grid(n_seg)), dim3(TPB), 0, 0, seg_pos.p, n_seg, n, seg_key.p);
+            const char* env = std::getenv("MAXSUM_AMAXSUM_GENERIC");  // =1: the per-message handler only (A/B, tests)
+            hipLaunchKernelGGL((k_seg_keys<T>), dim3(grid(n_seg)), dim3(TPB), 0, 0, g, dest_sorted.p, seg_pos.p, n_seg, n,
+                               (env && env[0] == '1') ? 1 : 0, seg_key.p);
             AMX_TRY(hipGetLastError());
             size_t bytes = 0;
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg, 0, 35));
             AMX_TRY(temp.reserve(bytes));
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg, 0, 35));
+            AMX_TRY(cls_first.reserve(N_CLS + 1));
+            hipLaunchKernelGGL(k_class_bounds, dim3(1), dim3(64), 0, 0, seg_key_sorted.p, n_seg, cls_first.p);
+            AMX_TRY(hipGetLastError());
         }
+        int64_t h_first[N_CLS + 1];
+        AMX_TRY(hipMemcpy(h_first, cls_first.p, sizeof(h_first), hipMemcpyDeviceToHost));
         AMX_TRY(s_code.reserve(n_slots + 1));
         AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
         AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
         AMX_TRY(hipMemset(s_pay.p, 0, sizeof(T) * (n_slots + 1) * g.dmax));
-        const char* env = std::getenv("MAXSUM_AMAXSUM_GENERIC");  // =1: the per-message handler only (A/B, tests)
-        hipLaunchKernelGGL((k_process<T>), dim3((unsigned)n_seg), dim3(64), 0, 0, g, q_code.p, q_pay.p, dest_sorted.p,
-                           order.p, n, seg_first.p, n_seg, slot_base.p, s_code.p, s_pay.p, (env && env[0] == '1') ? 1 : 0);
-        AMX_TRY(hipGetLastError());
+        for (int cls = 0; cls < N_CLS; ++cls) {
+            const int64_t b = h_first[cls], e = h_first[cls + 1];
+            if (e <= b) continue;
+            const int per_wave = cls == CLS_VAR8 ? 8 : (cls == CLS_VAR16 ? 4 : (cls == CLS_VAR64 ? 1 : 64));
+            const dim3 gr((unsigned)((e - b + per_wave - 1) / per_wave)), bl(64);
+#define AMX_ARGS g, q_code.p, q_pay.p, dest_sorted.p, order.p, n, seg_first.p, b, e, slot_base.p, s_code.p, s_pay.p
+            if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, 0, AMX_ARGS);
+            else if (cls == CLS_VAR16) hipLaunchKernelGGL((k_process_vars<T, 16>), gr, bl, 0, 0, AMX_ARGS);
+            else if (cls == CLS_VAR64) hipLaunchKernelGGL((k_process_vars<T, 64>), gr, bl, 0, 0, AMX_ARGS);
+            else hipLaunchKernelGGL((k_process_lanes<T>), gr, bl, 0, 0, AMX_ARGS, cls);
+#undef AMX_ARGS
+            AMX_TRY(hipGetLastError());
+        }
         // compaction of the filled slots, slot order = FIFO order of the next generation
         int64_t n_next = 0;
         if (n_slots > 0) {
