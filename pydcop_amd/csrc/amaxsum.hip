@@ -878,6 +878,15 @@ struct Engine : Base {
         return reset();
     }
 
+    // A few bytes back to the host between the phases of a step.  The device is drained FIRST with
+    // hipDeviceSynchronize (an active wait): a blocking hipMemcpy behind a long kernel was measured
+    // to return milliseconds late (16 generations at 100k variables: 0.40 s of wall time for 0.05 s of
+    // kernels; 0.12 s with the explicit synchronisation).
+    hipError_t read_back(void* dst, const void* src, size_t bytes) {
+        hipError_t e = hipDeviceSynchronize();
+        return e != hipSuccess ? e : hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost);
+    }
+
     // exclusive prefix sum of int32 counts into int64 (hipCUB), total read back
     int scan32(const int32_t* in, int64_t* out, int64_t n, int64_t* total) {
         *total = 0;
@@ -889,8 +898,8 @@ struct Engine : Base {
         AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, it, out, (int)n));
         int64_t last_off = 0;
         int32_t last_cnt = 0;
-        AMX_TRY(hipMemcpy(&last_off, out + n - 1, 8, hipMemcpyDeviceToHost));
-        AMX_TRY(hipMemcpy(&last_cnt, in + n - 1, 4, hipMemcpyDeviceToHost));
+        AMX_TRY(read_back(&last_off, out + n - 1, 8));
+        AMX_TRY(read_back(&last_cnt, in + n - 1, 4));
         *total = last_off + last_cnt;
         return MXS_OK;
     }
@@ -998,7 +1007,7 @@ struct Engine : Base {
             AMX_TRY(hipGetLastError());
         }
         int64_t h_first[N_CLS + 1];
-        AMX_TRY(hipMemcpy(h_first, cls_first.p, sizeof(h_first), hipMemcpyDeviceToHost));
+        AMX_TRY(read_back(h_first, cls_first.p, sizeof(h_first)));
         AMX_TRY(s_code.reserve(n_slots + 1));
         AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
         AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
@@ -1028,8 +1037,8 @@ struct Engine : Base {
             AMX_TRY(temp.reserve(bytes));
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, flag.p, pos.p, (int)n_slots));
             int64_t last_pos = 0, last_flag = 0;
-            AMX_TRY(hipMemcpy(&last_pos, pos.p + n_slots - 1, 8, hipMemcpyDeviceToHost));
-            AMX_TRY(hipMemcpy(&last_flag, flag.p + n_slots - 1, 8, hipMemcpyDeviceToHost));
+            AMX_TRY(read_back(&last_pos, pos.p + n_slots - 1, 8));
+            AMX_TRY(read_back(&last_flag, flag.p + n_slots - 1, 8));
             n_next = last_pos + last_flag;
             AMX_TRY(q_code2.reserve(n_next + 1));
             AMX_TRY(q_pay2.reserve((n_next + 1) * g.dmax));
