@@ -49,6 +49,26 @@ def with_init(g, seed):
     return g
 
 
+def star_coloring(n_leaves, n_extra, seed, n_colors=3):
+    """A hub (variable 0) with `n_leaves` binary constraints + a few random ones among the leaves:
+    degrees above 64 leave the wave-per-variable kernels for the per-message handler."""
+    from pydcop_amd.generators import _finish
+    rng = np.random.default_rng(seed)
+    n_vars = n_leaves + 1
+    pairs = [(0, i) if rng.random() < 0.5 else (i, 0) for i in range(1, n_vars)]
+    seen = set()
+    while len(seen) < n_extra:
+        a, b = (int(x) for x in rng.integers(1, n_vars, 2))
+        if a != b and (min(a, b), max(a, b)) not in seen:
+            seen.add((min(a, b), max(a, b)))
+    pairs += sorted(seen)
+    nf, D = len(pairs), n_colors
+    tables = rng.integers(0, 10, size=(nf, D, D)).astype(np.float64)
+    return _finish(np.full(n_vars, D, dtype=np.int32), rng.uniform(0.0, 0.01, size=n_vars * D),
+                   np.arange(0, 2 * nf + 1, 2, dtype=np.int32), np.array(pairs, dtype=np.int32).reshape(-1),
+                   tables.reshape(-1), np.arange(0, (nf + 1) * D * D, D * D, dtype=np.int64))
+
+
 def amaxsum_cases(k=1):
     """k > 1: graphs k times smaller (the emulated engine of the CPU tests is slow)."""
     return [
@@ -67,6 +87,7 @@ def amaxsum_cases(k=1):
          {"start_messages": "leafs_vars", "stability": 0.3}),
         ("d4_deg20_hub", lambda: G.random_coloring(40, avg_degree=20 if k == 1 else 14, n_colors=4, seed=10),
          {"start_messages": "leafs_vars", "stability": 0.5}),
+        ("hub_deg70", lambda: star_coloring(70, 12, seed=11), {"start_messages": "leafs_vars", "stability": 0.3}),
     ]
 
 
