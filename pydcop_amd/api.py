@@ -1,4 +1,6 @@
-"""Direct API: solve a pyDCOP `DCOP` object (or a YAML file) on the GPU without agents.
+"""Direct API: solve a pyDCOP `DCOP` object (or a YAML file, or an .npz instance) on the GPU
+without agents -- synchronous Max-Sum by default, `algo=` "amaxsum", "dsa" or "mgm" for the other
+engines of the library.
 
 `pydcop.infrastructure.run.solve` (pydcop/infrastructure/run.py:49) deploys one
 computation per node on agent threads and lets an orchestrator collect the values;
@@ -16,14 +18,48 @@ from .compile import assignment_to_values, compile_nodes
 from .graph import FlatGraph, Params
 
 
-def _engine_for(graph: FlatGraph, params: Params, device: int, devices: int, lib_path):
-    """One engine on `device`, or -- devices > 1 -- the graph partitioned over GPUs 0..devices-1
-    of this node (pydcop_amd.sharded.LocalShardedMaxSum: same surface, same result)."""
+ALGOS = ("maxsum", "amaxsum", "dsa", "mgm")
+
+
+def _engine_for(graph: FlatGraph, params: Params, device: int, devices: int, lib_path, algo: str = "maxsum",
+                algo_kw: Optional[dict] = None):
+    """One engine on `device`, or -- Max-Sum with devices > 1 -- the graph partitioned over GPUs
+    0..devices-1 of this node (pydcop_amd.sharded.LocalShardedMaxSum: same surface, same result).
+    Every engine has run / assignment / eval_cost / close."""
+    algo_kw = algo_kw or {}
+    if algo not in ALGOS:
+        raise ValueError(f"algo must be one of {ALGOS}")
+    if algo != "maxsum":
+        if devices and int(devices) > 1:
+            raise ValueError("devices > 1: synchronous Max-Sum only")
+        if algo == "amaxsum":
+            from .amaxsum import AMaxSumEngine
+            return AMaxSumEngine(graph, params, device=device, lib_path=lib_path)
+        if algo == "dsa":
+            from .dsa import DsaEngine
+            return DsaEngine(graph, params, device=device, lib_path=lib_path, **algo_kw)
+        from .mgm import MgmEngine
+        return MgmEngine(graph, params, device=device, lib_path=lib_path)
     from .engine import MaxSumEngine
     if devices and int(devices) > 1:
         from .sharded import LocalShardedMaxSum
         return LocalShardedMaxSum(graph, params, list(range(int(devices))), lib_path=lib_path)
     return MaxSumEngine(graph, params, device=device, lib_path=lib_path)
+
+
+def _run_and_trace(eng, algo: str, cycles: int, cost_every: int, infinity: float):
+    """`cycles` cycles (amaxsum: generations of messages, its run() counts from the start), the
+    cost evaluated on the device every `cost_every` of them."""
+    curve: List[Tuple[int, float, int]] = []
+    done = 0
+    while done < cycles:
+        n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
+        eng.run(done + n if algo == "amaxsum" else n)
+        done += n
+        if cost_every > 0:
+            c, v = eng.eval_cost(infinity=infinity)
+            curve.append((done, c, v))
+    return curve
 
 
 def compile_dcop(dcop, noise: float = 0.0, seed: int = 0) -> FlatGraph:
@@ -41,30 +77,26 @@ def compile_dcop(dcop, noise: float = 0.0, seed: int = 0) -> FlatGraph:
 def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: str = "both",
                stability: float = 0.1, noise: float = 0.01, start_messages: str = "leafs",
                precision: str = "f64", seed: int = 0, infinity: float = 10000, device: int = 0,
-               cost_every: int = 0, lib_path: Optional[str] = None, devices: int = 1) -> Dict:
+               cost_every: int = 0, lib_path: Optional[str] = None, devices: int = 1, algo: str = "maxsum",
+               variant: str = "B", probability: float = 0.7, p_mode: str = "fixed") -> Dict:
     """Synchronous Max-Sum for exactly `cycles` cycles; parameters and defaults are those
     of `pydcop.algorithms.maxsum` (maxsum.py:212-220), `infinity` that of
-    `pydcop.infrastructure.run.solve` (run.py:49).
+    `pydcop.infrastructure.run.solve` (run.py:49).  `algo`: "amaxsum" (`cycles` = generations of
+    messages under FIFO delivery, same parameters), "dsa" (`variant`, `probability`, `p_mode` of
+    pydcop.algorithms.dsa, dsa.py:119-125; `seed` keys its draws) or "mgm"; the local-search
+    algorithms take no noise (their variable costs enter as the reference's do).
 
     Returns {"assignment", "cost", "violation", "cycle", "cost_curve"}: the first three
     as `DCOP.solution_cost` computes them for the selected values; `cost_curve` (when
     `cost_every` > 0) = [(cycle, cost, violations)] evaluated on the device every
     `cost_every` cycles (the reference's `--collect_on cycle_change`,
     pydcop/commands/solve.py:356-376, without leaving the GPU)."""
-    from .engine import MaxSumEngine
-    graph = compile_dcop(dcop, noise=noise, seed=seed)
+    graph = compile_dcop(dcop, noise=noise if algo in ("maxsum", "amaxsum") else 0.0, seed=seed)
     params = Params(mode=dcop.objective, damping=damping, damping_nodes=damping_nodes,
                     stability=stability, start_messages=start_messages, dtype=precision)
-    curve: List[Tuple[int, float, int]] = []
-    with _engine_for(graph, params, device, devices, lib_path) as eng:
-        done = 0
-        while done < cycles:
-            n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
-            eng.run(n)
-            done += n
-            if cost_every > 0:
-                c, v = eng.eval_cost(infinity=infinity)
-                curve.append((done, c, v))
+    algo_kw = dict(variant=variant, probability=probability, p_mode=p_mode, seed=seed) if algo == "dsa" else None
+    with _engine_for(graph, params, device, devices, lib_path, algo, algo_kw) as eng:
+        curve = _run_and_trace(eng, algo, cycles, cost_every, infinity)
         idx, _ = eng.assignment()
     assignment = assignment_to_values(graph, idx)
     violation, cost = dcop.solution_cost(assignment, infinity)
@@ -75,24 +107,17 @@ def solve_dcop(dcop, cycles: int = 30, *, damping: float = 0.5, damping_nodes: s
 def solve_flat(graph: FlatGraph, objective: str = "min", cycles: int = 30, *, damping: float = 0.5,
                damping_nodes: str = "both", stability: float = 0.1, start_messages: str = "leafs",
                precision: str = "f64", infinity: float = 10000, device: int = 0, cost_every: int = 0,
-               lib_path: Optional[str] = None, devices: int = 1) -> Dict:
+               lib_path: Optional[str] = None, devices: int = 1, algo: str = "maxsum", variant: str = "B",
+               probability: float = 0.7, p_mode: str = "fixed", seed: int = 0) -> Dict:
     """`solve_dcop` for an already compiled instance (`FlatGraph`, e.g. loaded from the
     .npz instance format): no pyDCOP import at all.  Cost and violations come from the
     device (`mxs_eval_cost` = DCOP.solution_cost, pydcop/dcop/dcop.py:308-367); noise, if
     wanted, is already folded into `graph.var_cost` by whoever compiled the instance."""
-    from .engine import MaxSumEngine
     params = Params(mode=objective, damping=damping, damping_nodes=damping_nodes,
                     stability=stability, start_messages=start_messages, dtype=precision)
-    curve: List[Tuple[int, float, int]] = []
-    with _engine_for(graph, params, device, devices, lib_path) as eng:
-        done = 0
-        while done < cycles:
-            n = min(cost_every, cycles - done) if cost_every > 0 else cycles - done
-            eng.run(n)
-            done += n
-            if cost_every > 0:
-                c, v = eng.eval_cost(infinity=infinity)
-                curve.append((done, c, v))
+    algo_kw = dict(variant=variant, probability=probability, p_mode=p_mode, seed=seed) if algo == "dsa" else None
+    with _engine_for(graph, params, device, devices, lib_path, algo, algo_kw) as eng:
+        curve = _run_and_trace(eng, algo, cycles, cost_every, infinity)
         idx, _ = eng.assignment()
         cost, violation = eng.eval_cost(infinity=infinity)
     if graph.var_names is not None and graph.domains is not None:
@@ -126,6 +151,7 @@ def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m pydcop_amd.api")
     ap.add_argument("dcop_files", nargs="+")
     ap.add_argument("-c", "--cycles", type=int, default=30)
+    ap.add_argument("-a", "--algo", default="maxsum", choices=ALGOS)
     ap.add_argument("-p", "--algo_params", action="append", default=[],
                     help="name:value, e.g. damping:0.7 noise:0 precision:f32 (maxsum.py:212-220)")
     ap.add_argument("--infinity", type=float, default=float("inf"))   # pydcop/commands/solve.py:316-324
@@ -134,7 +160,8 @@ def main(argv=None):
                     help="compile the YAML DCOP (noise folded in) and write it as an instance file")
     args = ap.parse_args(argv)
     kinds = {"damping": float, "stability": float, "noise": float, "seed": int,
-             "damping_nodes": str, "start_messages": str, "precision": str, "devices": int}
+             "damping_nodes": str, "start_messages": str, "precision": str, "devices": int,
+             "variant": str, "probability": float, "p_mode": str}
     kw = {}
     for item in args.algo_params:
         name, _, value = item.partition(":")
@@ -154,13 +181,14 @@ def main(argv=None):
         return
     if len(args.dcop_files) == 1 and args.dcop_files[0].endswith(".npz"):
         graph, header = FlatGraph.load(args.dcop_files[0])
-        for k in ("noise", "seed"):  # folded into the instance when it was compiled
-            kw.pop(k, None)
+        kw.pop("noise", None)  # folded into the instance when it was compiled
+        if args.algo != "dsa":
+            kw.pop("seed", None)
         res = solve_flat(graph, header.get("objective", "min"), args.cycles, infinity=args.infinity,
-                         cost_every=args.cost_every, **kw)
+                         cost_every=args.cost_every, algo=args.algo, **kw)
     else:
         res = solve_yaml(args.dcop_files, args.cycles, infinity=args.infinity,
-                         cost_every=args.cost_every, **kw)
+                         cost_every=args.cost_every, algo=args.algo, **kw)
     out = {"assignment": res["assignment"], "cost": res["cost"], "violation": res["violation"],
            "cycle": res["cycle"], "status": "FINISHED", "time": time.perf_counter() - t0,
            "msg_count": 0, "msg_size": 0, "agt_metrics": {}}

@@ -223,3 +223,44 @@ def test_plugin_uses_fast_graph_when_asked(pydcop_ready):
         assert hasattr(gm, "build_computation_graph")
     finally:
         mod.GRAPH_TYPE = old
+
+
+@pytest.mark.parametrize("name", ["graph_coloring1.yaml", "graph_coloring_3agts_10vars.yaml", "secp_simple1.yaml"])
+def test_direct_api_local_search_equals_the_reference(pydcop_ready, name):
+    """`solve_yaml(algo="mgm" / "dsa")` = the reference's own MgmComputation / DsaComputation objects
+    after the same number of rounds (DSA: both sides on the keyed generator, indexed by the compiled
+    graph's variable order)."""
+    from emu.build_emu import build
+    from oracle import ref_harness
+    from pydcop_amd import api
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    path = os.path.join(INST, name)
+    dcop = load_dcop_from_file([path])
+    values, _, _ = ref_harness.run_reference_mgm(dcop, 6)
+    res = api.solve_yaml(path, cycles=6, algo="mgm", lib_path=build(), infinity=float("inf"))
+    assert res["assignment"] == values
+    graph = api.compile_dcop(dcop, noise=0.0)
+    index = {n: i for i, n in enumerate(graph.var_names)}
+    for variant in ("A", "C"):
+        dcop = load_dcop_from_file([path])
+        try:
+            values, _, _ = ref_harness.run_reference_dsa(dcop, 7, variant=variant, probability=0.6, seed=5, var_index=index)
+        except ZeroDivisionError:   # p_mode / arity corner of the reference on variables without binary constraint
+            continue
+        res = api.solve_yaml(path, cycles=7, algo="dsa", variant=variant, probability=0.6, seed=5,
+                             lib_path=build(), infinity=float("inf"))
+        assert res["assignment"] == values, variant
+
+
+@pytest.mark.parametrize("name", ["graph_coloring1.yaml", "graph_coloring_tuto.yaml", "secp_simple1.yaml"])
+def test_direct_api_amaxsum_equals_the_reference(pydcop_ready, name):
+    """`solve_yaml(algo="amaxsum")` = the reference's amaxsum computations under FIFO delivery after
+    the same number of generations."""
+    from emu.build_emu import build
+    from oracle import ref_harness
+    from pydcop_amd import api
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    path = os.path.join(INST, name)
+    values, _, info = ref_harness.run_reference_amaxsum(load_dcop_from_file([path]), 8)
+    res = api.solve_yaml(path, cycles=8, algo="amaxsum", noise=0, lib_path=build(), infinity=float("inf"))
+    assert res["assignment"] == values

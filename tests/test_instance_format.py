@@ -87,3 +87,45 @@ def g_cost(g, idx):
             lin = lin * g.dom_size[g.edge_var[e]] + idx[g.edge_var[e]]
         cost += float(g.tables[g.table_off[f] + lin])
     return cost
+
+
+@pytest.mark.parametrize("algo", ["amaxsum", "dsa", "mgm"])
+def test_solve_flat_other_algorithms(algo, emu_lib, tmp_path):
+    """`solve_flat(algo=...)` and `python -m pydcop_amd.api -a ...` = the engine of that algorithm used
+    directly (amaxsum: generations under FIFO delivery; dsa: variant / probability / seed passed on)."""
+    from pydcop_amd.amaxsum import AMaxSumEngine
+    from pydcop_amd.api import solve_flat
+    from pydcop_amd.dsa import DsaEngine
+    from pydcop_amd.graph import Params
+    from pydcop_amd.mgm import MgmEngine
+    g = G.random_coloring(120, seed=4)
+    kw = dict(variant="C", probability=0.6, seed=9) if algo == "dsa" else {}
+    res = solve_flat(g, "min", 9, lib_path=emu_lib, cost_every=4, algo=algo, start_messages="leafs_vars", **kw)
+    make = {"amaxsum": lambda: AMaxSumEngine(g, Params(start_messages="leafs_vars"), lib_path=emu_lib),
+            "dsa": lambda: DsaEngine(g, Params(), lib_path=emu_lib, **kw),
+            "mgm": lambda: MgmEngine(g, Params(), lib_path=emu_lib)}[algo]
+    with make() as e:
+        e.run(9)
+        idx = e.assignment()[0]
+        cost, viol = e.eval_cost(infinity=10000)
+    assert res["cost"] == cost and res["violation"] == viol
+    assert [c[0] for c in res["cost_curve"]] == [4, 8, 9]
+    assert res["assignment"] == {n: g.domains[i][int(idx[i])] for i, n in enumerate(g.var_names)}
+    with pytest.raises(ValueError):
+        solve_flat(g, "min", 3, lib_path=emu_lib, algo=algo, devices=2)
+    path = str(tmp_path / "col.npz")
+    g.save(path, objective="min")
+    extra = ["-p", "variant:C", "-p", "probability:0.6", "-p", "seed:9"] if algo == "dsa" else []
+    code = ("import sys, runpy; sys.argv = ['api', '-c', '9', '-a', %r, '-p', 'start_messages:leafs_vars'] + %r + [%r]; "
+            "from pydcop_amd import engine; engine.register_test_engine(%r, make_default=True); "
+            "runpy.run_module('pydcop_amd.api', run_name='__main__')" % (algo, extra, path, emu_lib))
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout)
+    assert out["violation"] == viol and abs(out["cost"] - cost) < 1e-9 * max(1.0, abs(cost))
+
+
+def test_solve_flat_rejects_unknown_algorithm(emu_lib):
+    from pydcop_amd.api import solve_flat
+    with pytest.raises(ValueError, match="algo must be one of"):
+        solve_flat(G.random_coloring(10, seed=0), "min", 1, lib_path=emu_lib, algo="dpop")
