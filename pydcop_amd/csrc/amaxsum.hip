@@ -132,6 +132,84 @@ __device__ T factor_value(const Dev<T>& g, int f, int pos, int d, int64_t others
     return best;
 }
 
+// The whole message of factor f (arity A as a template: positions, strides and "heard from" flags in
+// registers, static indexing only) to its scope position p: out[d] = factor_value(g, f, p, d, .) for
+// every d, the other variables' assignments walked like an odometer (last position fastest = the order
+// of the reference's generator) instead of one 64-bit division per position and entry.
+template <typename T, int A>
+__device__ void factor_message(const Dev<T>& g, int f, int p, T* out) {
+    const int e0 = g.factor_rowptr[f];
+    int Dm[A], stride[A];
+    int64_t moff[A];
+    bool has[A];
+    int st = 1;
+#pragma unroll
+    for (int i = A - 1; i >= 0; --i) {
+        Dm[i] = g.dom_size[g.edge_var[e0 + i]];
+        stride[i] = st;
+        st *= Dm[i];
+        moff[i] = g.msg_off[e0 + i];
+        has[i] = g.f_has[e0 + i] != 0;
+    }
+    int Dp = 1, sp = 0;
+    int64_t others = 1;
+#pragma unroll
+    for (int i = 0; i < A; ++i) {
+        if (i == p) {
+            Dp = Dm[i];
+            sp = stride[i];
+        } else {
+            others *= Dm[i];
+        }
+    }
+    const T* tab = g.tables + g.table_off[f];
+    for (int d = 0; d < Dp; ++d) {
+        T best = g.is_max ? -(T)INFINITY : (T)INFINITY;
+        int dig[A];
+#pragma unroll
+        for (int i = 0; i < A; ++i) dig[i] = 0;
+        for (int64_t lin = 0; lin < others; ++lin) {
+            int t = d * sp;
+            T sum_cost = (T)0;
+#pragma unroll
+            for (int i = 0; i < A; ++i)
+                if (i != p) {
+                    t += dig[i] * stride[i];
+                    if (has[i]) sum_cost += g.f_cost[moff[i] + dig[i]];
+                }
+            const T cur = tab[t] + sum_cost;
+            if (g.is_max ? best < cur : best > cur) best = cur;
+            bool carry = true;  // next assignment of the others
+#pragma unroll
+            for (int i = A - 1; i >= 0; --i)
+                if (i != p && carry) {
+                    dig[i] += 1;
+                    carry = dig[i] == Dm[i];
+                    if (carry) dig[i] = 0;
+                }
+        }
+        out[d] = best;
+    }
+}
+
+// out[0 .. D_p) for any arity
+template <typename T>
+__device__ void factor_message_any(const Dev<T>& g, int f, int p, T* out) {
+    const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
+    switch (ar) {
+        case 1: factor_message<T, 1>(g, f, p, out); return;
+        case 2: factor_message<T, 2>(g, f, p, out); return;
+        case 3: factor_message<T, 3>(g, f, p, out); return;
+        case 4: factor_message<T, 4>(g, f, p, out); return;
+        default: break;
+    }
+    int64_t others = 1;
+    for (int q = 0; q < ar; ++q)
+        if (q != p) others *= g.dom_size[g.edge_var[e0 + q]];
+    const int D = g.dom_size[g.edge_var[e0 + p]];
+    for (int d = 0; d < D; ++d) out[d] = factor_value(g, f, p, d, others);
+}
+
 // apply_damping + the send rule (amaxsum.py:213-244 / 386-424) on the message sitting in `msg`
 // (D values, global memory).  Returns true if it is sent (prev / count updated).
 template <typename T>
@@ -233,11 +311,7 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, int32_t* q_code, T* 
         if (!sends) return;
         for (int p = 0; p < ar; ++p) {
             const int64_t at = (int64_t)base[i] + p;
-            int64_t others = 1;
-            for (int q = 0; q < ar; ++q)
-                if (q != p) others *= g.dom_size[g.edge_var[e0 + q]];
-            const int D = g.dom_size[g.edge_var[e0 + p]];
-            for (int d = 0; d < D; ++d) q_pay[at * g.dmax + d] = factor_value(g, f, p, d, others);
+            factor_message_any(g, f, p, q_pay + at * g.dmax);
             q_code[at] = (e0 + p) * 2 + 1;
         }
     }
@@ -278,11 +352,8 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
             const int e2 = e0 + p;
             if (e2 == e) continue;  // not back to the sender
             const int D2 = g.dom_size[g.edge_var[e2]];
-            int64_t others = 1;
-            for (int q = 0; q < ar; ++q)
-                if (q != p) others *= g.dom_size[g.edge_var[e0 + q]];
             T* out = s_pay + (int64_t)slot * g.dmax;
-            for (int d = 0; d < D2; ++d) out[d] = factor_value(g, f, p, d, others);
+            factor_message_any(g, f, p, out);
             if (damp_and_decide(g, out, g.f_prev + g.msg_off[e2], &g.f_cnt[e2], D2, g.damp_f != 0))
                 s_code[slot] = e2 * 2 + 1;
             ++slot;
