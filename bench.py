@@ -14,9 +14,9 @@ is quoted on -- random 3-colouring, 100k variables, average degree 4, reference 
 other BASELINE.json configuration that runs on one GPU (coloring_10k, ising_1024,
 coloring_1m_deg6, meeting_50k; f64 and f32) with its own cycle time, roofline fraction and the
 id of the `-m gpu` test that compares it bit for bit with the oracle at that size, and under
-"cpu_baseline" the C port of the reference algorithm timed on this box's host cores plus the
-recorded timing of the reference's own thread-agent runtime (profiles/, build container --
-the reference cannot travel to the GPU box).
+"cpu_baseline" the reference's own thread-agent runtime (run_local_thread_dcop) timed on this
+box's host cores on a bounded sample -- the reference travels to the GPU box as the git-ignored
+archive oracle/_ref/ -- with the C port of the reference algorithm as a labelled extra.
 
 N > 1 (the driver launches one rank per GPU through torch.distributed.run): STRONG scaling of
 ONE instance -- by default BASELINE.json configs[3], the 1M-variable degree-6 colouring that
@@ -93,10 +93,68 @@ def make_workload(name, scale=1, per_gpu=100_000):
     raise SystemExit(f"unknown workload {name}")
 
 
-def cpu_baseline(graph, mode, dtype, budget_s=12.0):
-    """The oracle (plain-C port of the reference algorithm) timed on the host cores on a
-    bounded number of cycles of the same workload.  The thread count is the fastest of a few
-    candidates (a 100k-variable cycle is too short to feed every core of a big host)."""
+def reference_thread_agents(graph, budget_s=25.0, n_vars=1000):
+    """The REFERENCE's own runtime on THIS box's host cores: pydcop.infrastructure.run.
+    run_local_thread_dcop (run.py:145) -- thread agents, orchestrator, maxsum with default
+    parameters -- on a 1 000-variable instance of the metric's family (same generator, seed,
+    degree, domain), k in {1, nproc} agents, `budget_s` seconds of orchestrator time each
+    (tools/reference_cpu_baseline.py in a child process with a hard time limit; the reference
+    comes from oracle/stage_reference.locate(): /root/reference in the build container, the
+    git-ignored archive oracle/_ref/ on the GPU box).  The metric's 100k-variable instance
+    itself is out of reach (its computations need ~60 s per cycle in a single-thread FIFO harness;
+    deploying 30 000 computations through the orchestrator alone takes minutes), so `value` is
+    the measured edge-messages/s converted to iterations/s of the 100k instance; the rate per
+    message does not improve with size (profiles/reference_thread_agents.json: 1.2e4/s at 1k,
+    4e3/s at 10k variables), so this flatters the reference.  -> dict or None."""
+    import subprocess
+    from oracle import stage_reference
+    if not stage_reference.locate():
+        return None
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    ks = sorted({1, avail})
+    cmd = [sys.executable, os.path.join(ROOT, "tools", "reference_cpu_baseline.py"), "--mode", "threads",
+           "--timeout", str(budget_s), "--n-vars", str(n_vars), "--agents"] + [str(k) for k in ks]
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=len(ks) * (3 * budget_s + 60), cwd=ROOT)
+        text = out.stdout
+    except subprocess.TimeoutExpired as e:
+        text = e.stdout.decode() if isinstance(e.stdout, bytes) else (e.stdout or "")
+    runs = []
+    for line in text.splitlines():
+        if line.startswith("{"):
+            try:
+                runs.append(json.loads(line))
+            except ValueError:
+                pass
+    runs = [r for r in runs if r.get("edge_messages_per_s")]
+    if not runs:
+        return None
+    best = max(runs, key=lambda r: r["edge_messages_per_s"])
+    per_iter = 2 * graph.n_edges
+    keep = ("n_vars", "n_edges", "agents", "timeout_s", "time_s", "cycle_median", "cycle_min", "cycle_max",
+            "iterations_per_s", "edge_messages_per_s", "run_wall_s")
+    return {"value": best["edge_messages_per_s"] / per_iter, "unit": "iterations/s", "cores": int(best["agents"]),
+            "kind": "reference",
+            "sample": f"pydcop run_local_thread_dcop (thread agents + orchestrator, maxsum defaults) on a {n_vars}-variable "
+                      f"instance of the same family for {budget_s:.0f} s per agent count k in {ks}: best k = {best['agents']}, "
+                      f"{best['iterations_per_s']} iterations/s of THAT instance = {best['edge_messages_per_s']:.0f} "
+                      f"edge-messages/s, / {per_iter} edge-messages per iteration of this instance; CPython, GIL-bound "
+                      f"(about one core busy whatever k); {best.get('host', '')}",
+            "measured_here": True, "edge_messages_per_s": best["edge_messages_per_s"],
+            "thread_agents": [{k: r.get(k) for k in keep} for r in runs]}
+
+
+def cpu_baseline(graph, mode, dtype, budget_s=12.0, reference_budget_s=25.0):
+    """`cpu_baseline` of the JSON line.  Leads with the REFERENCE's own thread-agent runtime
+    timed on this box (kind "reference", see reference_thread_agents) when the reference is on
+    the machine; the oracle (plain-C port of the reference algorithm, OpenMP) timed on the host
+    cores on a bounded number of cycles of the same workload is the labelled extra `port` (and
+    the headline, kind "port", where there is no reference).  The port's thread count is the
+    fastest of a few candidates (a 100k-variable cycle is too short to feed every core of a big
+    host)."""
     from oracle.maxsum_oracle import OracleMaxSum, build
     from pydcop_amd.graph import Params
     build()
@@ -122,18 +180,20 @@ def cpu_baseline(graph, mode, dtype, budget_s=12.0):
     ora.run(n)
     dt = time.perf_counter() - t0
     ora.close()
-    out = {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
-           "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c (OpenMP, best of "
-                     f"1..{avail} threads = {cores}; host has {os.cpu_count()} logical cpus)"}
-    # The reference's OWN runtime (pydcop.infrastructure.run.run_local_thread_dcop, thread
-    # agents) cannot run on the GPU box (/root/reference does not travel): its timing is a
-    # recorded profile made in the build container by tools/reference_cpu_baseline.py.
+    port = {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
+            "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c (OpenMP, best of "
+                      f"1..{avail} threads = {cores}; host has {os.cpu_count()} logical cpus)"}
+    ref = reference_thread_agents(graph, reference_budget_s) if reference_budget_s > 0 else None
+    if ref is None:
+        return port
+    ref["port"] = port
+    # recorded runs at 10k variables (minutes of wall time each; not repeated in every bench run)
     try:
         with open(REFERENCE_BASELINE_FILE) as f:
-            out["reference"] = json.load(f)
+            ref["recorded"] = json.load(f)
     except (OSError, ValueError):
         pass
-    return out
+    return ref
 
 
 def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None, graph=None, storage=None):
@@ -329,6 +389,9 @@ def main():
     ap.add_argument("--layout-flags", type=int, default=0)
     ap.add_argument("--graph-chunk", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reference-budget", type=float, default=25.0,
+                    help="seconds of orchestrator time per agent count for the reference's thread-agent "
+                         "runtime in cpu_baseline (0: C port only)")
     ap.add_argument("--configs", default="all", choices=["all", "main"],
                     help="N = 1: all = also time the other BASELINE.json configurations (default); "
                          "N > 1: all = also run the 100k instance strong- and weak-scaled")
@@ -390,7 +453,7 @@ def main():
                                     graph, storage),
         })
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype)
+            out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype, reference_budget_s=args.reference_budget)
         if args.configs == "all" and args.workload is None:
             del graph
             out["configs"] = extra_configs(skip={(workload, args.dtype)})

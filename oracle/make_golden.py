@@ -4,8 +4,9 @@ container only; needs /root/reference).  TEST INFRASTRUCTURE.
 Each fixture holds a compiled FlatGraph, the algorithm parameters, a cycle
 count T and what the reference's own MaxSum computations
 (pydcop/algorithms/maxsum.py) hold after exactly T cycles -- selected value
-index + cost per variable -- plus DCOP.solution_cost of that assignment
-(pydcop/dcop/dcop.py:308-367).
+index + cost per variable, every sender's `_prev_messages` (last sent message
+and count) and every receiver's `_costs` (ref_harness.reference_message_state)
+-- plus DCOP.solution_cost of that assignment (pydcop/dcop/dcop.py:308-367).
 
     python -m oracle.make_golden
 """
@@ -19,16 +20,22 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 from oracle.ref_harness import (REFERENCE_ROOT, flat_to_dcop, install_shims,  # noqa: E402
-                                run_reference_maxsum)
+                                reference_message_state, run_reference_maxsum)
 from pydcop_amd import generators as G  # noqa: E402
 from pydcop_amd.compile import compile_computation_graph  # noqa: E402
 
-OUT = os.path.join(ROOT, "tests", "golden")
+OUT = os.environ.get("GOLDEN_OUT", os.path.join(ROOT, "tests", "golden"))
 GRAPH_FIELDS = ("dom_size", "var_cost", "factor_rowptr", "edge_var", "table_off",
                 "tables", "var_rowptr", "var_edges")
 
 
-def save(name, graph, mode, params, T, vals, costs, sol):
+def run(dcop, T, params, cg):
+    """-> (values, costs, message state of the reference's computations after T cycles)"""
+    vals, costs, comps = run_reference_maxsum(dcop, T, params, cg=cg, return_comps=True)
+    return vals, costs, comps
+
+
+def save(name, graph, mode, params, T, vals, costs, sol, comps=None):
     idx = np.array([graph.domains[i].index(vals[n]) for i, n in enumerate(graph.var_names)],
                    dtype=np.int32)
     cost = np.array([np.nan if costs[n] is None else costs[n] for n in graph.var_names])
@@ -39,6 +46,9 @@ def save(name, graph, mode, params, T, vals, costs, sol):
     arrays = {k: getattr(graph, k) for k in GRAPH_FIELDS}
     if graph.init_idx is not None:
         arrays["init_idx"] = graph.init_idx
+    if comps is not None:
+        for k, a in reference_message_state(comps, graph).items():
+            arrays["ref_" + k] = a
     np.savez_compressed(os.path.join(OUT, name + ".npz"), ref_idx=idx, ref_cost=cost,
                         meta=np.frombuffer(json.dumps(meta).encode(), dtype=np.uint8), **arrays)
     print(f"{name}: V={graph.n_vars} F={graph.n_factors} E={graph.n_edges} T={T} "
@@ -59,10 +69,10 @@ def yaml_cases():
         cg = factor_graph.build_computation_graph(dcop)
         graph = compile_computation_graph(cg)
         for T in Ts:
-            vals, costs = run_reference_maxsum(dcop, T, cg=cg)
+            vals, costs, comps = run(dcop, T, None, cg)
             sol = dcop.solution_cost(vals, float("inf"))
             save(f"yaml_{fname.split('.')[0].replace('.', '_')}_T{T}", graph, dcop.objective,
-                 {}, T, vals, costs, sol)
+                 {}, T, vals, costs, sol, comps)
 
 
 def synthetic_cases():
@@ -86,9 +96,9 @@ def synthetic_cases():
     for name, graph, mode, params, Ts in cases:
         dcop, cg = flat_to_dcop(graph, mode)
         for T in Ts:
-            vals, costs = run_reference_maxsum(dcop, T, params, cg=cg)
+            vals, costs, comps = run(dcop, T, params, cg)
             sol = dcop.solution_cost(vals, float("inf"))
-            save(f"syn_{name}_T{T}", graph, mode, params, T, vals, costs, sol)
+            save(f"syn_{name}_T{T}", graph, mode, params, T, vals, costs, sol, comps)
 
 
 def generator_cases():
@@ -107,9 +117,9 @@ def generator_cases():
         cg = factor_graph.build_computation_graph(dcop)
         graph = compile_computation_graph(cg)
         for T in Ts:
-            vals, costs = run_reference_maxsum(dcop, T, params or {}, cg=cg)
+            vals, costs, comps = run(dcop, T, params or {}, cg)
             sol = dcop.solution_cost(vals, float("inf"))
-            save(f"gen_{name}_T{T}", graph, dcop.objective, params or {}, T, vals, costs, sol)
+            save(f"gen_{name}_T{T}", graph, dcop.objective, params or {}, T, vals, costs, sol, comps)
 
     random.seed(20260923)
     # pydcop generate ising --row_count 5 --col_count 4 [--intentional]   (ising.py:274-331)

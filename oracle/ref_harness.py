@@ -9,8 +9,10 @@ number of cycles, without agents, threads or the orchestrator.  Used to
   * generate the committed golden vectors under `tests/golden/`
     (`oracle/make_golden.py`).
 
-`/root/reference` does not exist on the GPU box: everything that travels is the
-C restatement + the golden fixtures.
+`/root/reference` does not exist on the GPU box; what travels there is the C
+restatement, the golden fixtures and -- git-ignored, packed by
+`oracle/stage_reference.py` at build time -- an archive of the reference itself
+(`oracle/_ref/`), which `stage_reference.locate()` unpacks outside the repository.
 
 Shims (reference untouched, all in-process):
   1. `collections.Iterable/Mapping/...` aliases (pydcop/dcop/yamldcop.py:32,
@@ -26,7 +28,12 @@ import sys
 import types
 from collections import deque
 
-REFERENCE_ROOT = os.environ.get("PYDCOP_REFERENCE", "/root/reference")
+try:
+    from oracle import stage_reference as _stage
+except ImportError:  # run as a script from inside oracle/
+    import stage_reference as _stage
+
+REFERENCE_ROOT = _stage.locate() or "/root/reference"
 
 
 def reference_available() -> bool:
@@ -46,6 +53,7 @@ class _Permissive(types.ModuleType):
 
 def install_shims():
     """Make `import pydcop` work on python 3.10 / numpy 2 without touching it."""
+    sys.dont_write_bytecode = True  # never write __pycache__ into the (read-only) reference tree
     for n in ("Iterable", "Mapping", "Sequence", "Callable", "Sized",
               "MutableMapping", "Hashable", "Set"):
         if not hasattr(collections, n):
@@ -138,6 +146,53 @@ def run_reference_maxsum(dcop, cycles, params=None, cg=None, return_comps=False)
     if return_comps:
         return values, costs, comps
     return values, costs
+
+
+def reference_message_state(comps, graph):
+    """What the reference's synchronous computations HOLD, laid out like the flat message
+    buffers (graph.msg_off per factor-major edge), after `run_reference_maxsum(...,
+    return_comps=True)`:
+
+      sent_f2v / count_f2v   the factor's `_prev_messages[variable]` = (last SENT message, count)
+                             (maxsum.py:303, 343-377)
+      sent_v2f / count_v2f   the variable's `_prev_messages[factor]` (maxsum.py:474, 529-564)
+      held_v2f               the factor's `_costs[variable]`: what it last RECEIVED (maxsum.py:294, 342)
+      held_f2v               the variable's `costs[factor]` (maxsum.py:466, 528)
+
+    NaN = nothing there (no message sent / received yet)."""
+    import numpy as np
+    g = graph
+    nm, ne = int(g.msg_off[-1]), g.n_edges
+    names = g.var_names
+    fnames = g.factor_names or [f"c{i}" for i in range(g.n_factors)]
+    out = {k: np.full(nm, np.nan) for k in ("sent_f2v", "sent_v2f", "held_v2f", "held_f2v")}
+    out["count_f2v"] = np.zeros(ne, dtype=np.uint8)
+    out["count_v2f"] = np.zeros(ne, dtype=np.uint8)
+
+    def put(key, e, costs, domain):
+        o = int(g.msg_off[e])
+        for d, val in enumerate(domain):
+            out[key][o + d] = costs[val]
+
+    for f in range(g.n_factors):
+        fc = comps[fnames[f]]
+        for e in range(int(g.factor_rowptr[f]), int(g.factor_rowptr[f + 1])):
+            v = int(g.edge_var[e])
+            vc = comps[names[v]]
+            domain = list(vc.variable.domain)
+            msg, cnt = fc._prev_messages[names[v]]
+            out["count_f2v"][e] = cnt
+            if msg is not None:
+                put("sent_f2v", e, msg, domain)
+            if names[v] in fc._costs:
+                put("held_v2f", e, fc._costs[names[v]], domain)
+            msg, cnt = vc._prev_messages[fnames[f]]
+            out["count_v2f"][e] = cnt
+            if msg is not None:
+                put("sent_v2f", e, msg, domain)
+            if fnames[f] in vc.costs:
+                put("held_f2v", e, vc.costs[fnames[f]], domain)
+    return out
 
 
 def run_reference_amaxsum(dcop, max_generations=-1, params=None, cg=None, max_messages=None):

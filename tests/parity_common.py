@@ -42,12 +42,46 @@ def compare_with_oracle(oracle_mod, graph, params: Params, T, lib_path=None, exa
     ora.close()
 
 
+def assert_messages_equal_reference(ref, at_T, before_T):
+    """`ref`: oracle/ref_harness.reference_message_state after T calls of on_new_cycle (live, or
+    stored in a golden fixture); `at_T` / `before_T`: (v2f, f2v, count_v2f, count_f2v) of the
+    flat engine (oracle or HIP) after T and T - 1 cycles.  Bit-exact: every expression of
+    factor_costs_for_var / costs_for_factor / apply_damping runs in a deterministic order in the
+    reference (dimensions / factors order).
+
+    * what a sender last SENT + its counter (`_prev_messages`, maxsum.py:303, 474) == the
+      buffer + counter after T cycles;
+    * what a receiver HOLDS (`_costs`, maxsum.py:294, 466: stored at the top of on_new_cycle, so
+      the messages of cycle T - 1, start messages included) == the buffer after T - 1 cycles; an
+      edge nothing travelled on yet is all zeros there ("zero == not received")."""
+    v2f, f2v, cv, cf = at_T
+    np.testing.assert_array_equal(cf, ref["count_f2v"])
+    np.testing.assert_array_equal(cv, ref["count_v2f"])
+    for buf, key in ((f2v, "sent_f2v"), (v2f, "sent_v2f")):
+        sent = ~np.isnan(ref[key])
+        assert sent.all()          # after one cycle every edge has sent (approx_match(None) is False)
+        np.testing.assert_array_equal(buf[sent], ref[key][sent], err_msg=key)
+    pv2f, pf2v, _, _ = before_T
+    for buf, key in ((pv2f, "held_v2f"), (pf2v, "held_f2v")):
+        held = ~np.isnan(ref[key])
+        np.testing.assert_array_equal(buf[held], ref[key][held], err_msg=key)
+        assert not buf[~held].any(), key
+
+
 def check_golden(graph, params_kw, meta, ref_idx, ref_cost, lib_path=None, **extra):
     """Engine against the reference's own result stored in a golden fixture:
-    final assignment identical, costs within 1e-5 (the north-star tolerance)."""
+    final assignment identical, costs within 1e-5 (the north-star tolerance); in f64 every
+    message the reference's computations sent / hold and every send counter bit for bit."""
     p = Params(**{**params_kw, **extra})
     eng = MaxSumEngine(graph, p, lib_path=lib_path)
-    eng.run(meta["T"])
+    ref_msgs = meta.get("ref_messages") if p.dtype == "f64" and meta["T"] >= 1 else None
+    if ref_msgs is not None:
+        eng.run(meta["T"] - 1)
+        before = eng.messages()
+        eng.run(1)
+        assert_messages_equal_reference(ref_msgs, eng.messages(), before)
+    else:
+        eng.run(meta["T"])
     idx, belief = eng.assignment()
     np.testing.assert_array_equal(idx, ref_idx)
     ok = ~np.isnan(ref_cost)

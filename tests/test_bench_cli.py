@@ -66,7 +66,7 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     with roofline + traffic source + the parity test id."""
     from emu.build_emu import build
     code = (
-        "import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400']\n"
+        "import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400', '--reference-budget', '4']\n"
         f"from pydcop_amd import engine; engine.register_test_engine({build()!r}, make_default=True)\n"
         "import pydcop_amd.generators as G\n"
         "_ising, _meet, _col = G.ising_grid, G.meeting_like, G.random_coloring\n"
@@ -81,7 +81,14 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["config"]["workload"] == "coloring_100k" and out["dtype"] == "f64"
-    assert out["cpu_baseline"]["kind"] == "port" and out["cpu_baseline"]["value"] > 0
+    from oracle.stage_reference import locate
+    cb = out["cpu_baseline"]
+    if locate():   # the reference's own thread-agent runtime, timed in this run, leads; the C port is an extra
+        assert cb["kind"] == "reference" and cb["measured_here"] and cb["value"] > 0 and cb["cores"] >= 1
+        assert cb["port"]["kind"] == "port" and cb["port"]["value"] > 0
+        assert all(r["n_vars"] == 1000 for r in cb["thread_agents"])
+    else:
+        assert cb["kind"] == "port" and cb["value"] > 0
     assert out["roofline"]["traffic_source"] is None or "static" in out["roofline"]["traffic_source"]
     got = {(c["workload"], c["dtype"]) for c in out["configs"]}
     assert got == {("coloring_100k", "f32"), ("coloring_10k", "f64"), ("coloring_10k", "f32"),

@@ -10,7 +10,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF = os.environ.get("PYDCOP_REFERENCE", "/root/reference")
+from oracle.stage_reference import locate as _locate_reference  # noqa: E402
+REF = _locate_reference() or "/root/reference"
 INST = os.path.join(REF, "tests", "instances")
 
 pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "pydcop")),

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import golden_files, load_golden
+from parity_common import assert_messages_equal_reference
 from pydcop_amd.graph import Params
 
 
@@ -14,7 +15,11 @@ from pydcop_amd.graph import Params
 def test_oracle_matches_reference_golden(path, oracle_built):
     g, params, meta, ref_idx, ref_cost = load_golden(path)
     o = oracle_built.OracleMaxSum(g, Params(**params))
-    o.run(meta["T"])
+    o.run(meta["T"] - 1)
+    before = o.messages()
+    o.run(1)
+    # every message the reference's computations sent / hold + every send counter, bit for bit
+    assert_messages_equal_reference(meta["ref_messages"], o.messages(), before)
     idx, belief = o.assignment()
     assert o.cycle_count == meta["T"]
     np.testing.assert_array_equal(idx, ref_idx)

@@ -7,6 +7,7 @@ import pytest
 from oracle import ref_harness
 from pydcop_amd import generators as G
 from pydcop_amd.graph import Params
+from parity_common import assert_messages_equal_reference
 
 pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
                                 reason="reference tree not present")
@@ -38,6 +39,22 @@ def test_oracle_equals_reference(name, make, mode, params, T, oracle_built):
     viol, cost = dcop.solution_cost(vals, float("inf"))
     ocost, oviol = o.eval_cost()
     assert oviol == viol and ocost == pytest.approx(cost, rel=1e-12, abs=1e-9)
+
+
+@pytest.mark.parametrize("name,make,mode,params", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("T", [1, 2, 7, 25])
+def test_oracle_messages_and_counters_equal_reference(name, make, mode, params, T, oracle_built):
+    """Message-level pin of the synchronous oracle: every receiver's `_costs` and every
+    sender's `_prev_messages` (message AND count) of the reference's own computations."""
+    g = make()
+    dcop, cg = ref_harness.flat_to_dcop(g, mode)
+    _, _, comps = ref_harness.run_reference_maxsum(dcop, T, params, cg=cg, return_comps=True)
+    ref = ref_harness.reference_message_state(comps, g)
+    o = oracle_built.OracleMaxSum(g, Params(mode=mode, **params))
+    o.run(T - 1)
+    before = o.messages()
+    o.run(1)
+    assert_messages_equal_reference(ref, o.messages(), before)
 
 
 def test_reference_unit_pins(oracle_built):

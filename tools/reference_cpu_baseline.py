@@ -1,5 +1,8 @@
-"""The reference's own Max-Sum timed on the host CPU (needs the reference checkout: build
-container only -- /root/reference does not travel to the GPU box).
+"""The reference's own Max-Sum timed on the host CPU of whatever box this runs on (build
+container: /root/reference; GPU box: the git-ignored archive oracle/_ref/ that build() packs,
+see oracle/stage_reference.py).  bench.py's cpu_baseline leg calls `--mode threads` on a
+1 000-variable instance; 10 000 variables cost minutes of wall time per run (the orchestrator
+deploys 30 000 computations one message at a time) and are run on request only.
 
 Two ways, both on instances of the benchmark family built by our O(E) generator and converted
 to pyDCOP objects (oracle/ref_harness.flat_to_dcop):
@@ -15,7 +18,7 @@ to pyDCOP objects (oracle/ref_harness.flat_to_dcop):
                    orchestrator.
 
 usage: python tools/reference_cpu_baseline.py [--mode threads|fifo] [--timeout T] [--agents k ...]
-                                               [--out profiles/x.jsonl] [n_vars ...]
+                                               [--out profiles/x.jsonl] [--n-vars n ...]
 """
 import argparse
 import json
@@ -38,7 +41,7 @@ def host_info():
                 break
     except OSError:
         pass
-    return {"host": f"build container: {os.cpu_count()} logical cpus, {model}; python {platform.python_version()}",
+    return {"host": f"{platform.node()}: {os.cpu_count()} logical cpus, {model}; python {platform.python_version()}",
             "cores": len(os.sched_getaffinity(0))}
 
 
@@ -133,13 +136,14 @@ def main():
     ap.add_argument("--timeout", type=float, default=30.0)
     ap.add_argument("--agents", type=int, nargs="*", default=None)
     ap.add_argument("--out", default=None)
-    ap.add_argument("n_vars", type=int, nargs="*")
+    ap.add_argument("--n-vars", type=int, nargs="*", default=None,
+                    help="instance sizes (default 1000; 10000 takes 6-20 minutes of wall time per run)")
     args = ap.parse_args()
     if not R.reference_available():
         raise SystemExit("the pyDCOP reference checkout is not on this machine")
     R.install_shims()
     info = host_info()
-    sizes = args.n_vars or [1000, 10000]
+    sizes = args.n_vars or [1000]
     out = open(args.out, "a") if args.out else None
     for n in sizes:
         if args.mode == "fifo":
