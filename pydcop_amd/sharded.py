@@ -299,6 +299,9 @@ class ShardedMaxSum:
         self.engine.close()
 
 
+_LEAKED = []   # engines whose rank thread never came back from a C-ABI call (see _each)
+
+
 class LocalShardedMaxSum:
     """The sharded path driven from ONE process: k shards on k GPUs, one thread per GPU.
 
@@ -324,30 +327,49 @@ class LocalShardedMaxSum:
         self.part = partition_variables(graph, k) if part is None else np.asarray(part, dtype=np.int32)
         self.shards = [build_shard(graph, self.part, r, k) for r in range(k)]
         self.engines = [None] * k
+        self._stuck = set()
         self.collective = "rccl" if k > 1 else "none"
         uid = comm_unique_id(lib_path, rccl) if k > 1 else None
 
-        def boot(r):
+        # Two phases with a join in between: ncclCommInitRank blocks until ALL k ranks have
+        # called it, so a rank must not enter it before every rank is known to get there (an
+        # engine that failed to build -- out of memory, bad device, bad halo lists -- would
+        # leave the other k - 1 threads waiting for it forever, with the plug-in's session lock
+        # held).  The multi-process driver all-gathers an ok flag for the same reason.
+        def make(r):
             s = self.shards[r]
             e = MaxSumEngine(s.graph, self.params, device=self.devices[r], lib_path=lib_path)
             self.engines[r] = e
             if k > 1:
                 e.halo_setup(s.send_edges, s.recv_edges)
-                e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=rccl)
-                e.comm_exchange()  # the start messages of cycle 0
-                e.step_unpack()
+            e.sync()
+
+        def connect(r):
+            s, e = self.shards[r], self.engines[r]
+            e.comm_init(r, k, uid, s.send_counts, s.recv_counts, rccl=rccl)
+            e.comm_exchange()  # the start messages of cycle 0
+            e.step_unpack()
             e.sync()
         try:
-            self._each(boot)
+            self._each(make)
+            if k > 1:
+                self._each(connect, timeout=self.COMM_TIMEOUT_S)
         except Exception:
             self.close()
             raise
 
-    def _each(self, fn):
-        """fn(rank) on one thread per rank; the first exception is re-raised here."""
+    # how long the ranks may take to meet in the communicator before the caller gets an error
+    # instead of a hang (a wedged rank's thread is a daemon: it does not keep the process alive)
+    COMM_TIMEOUT_S = 300.0
+
+    def _each(self, fn, timeout=None):
+        """fn(rank) on one thread per rank; the first exception is re-raised here.  With a
+        `timeout` (seconds, all ranks together) a rank that has not returned raises
+        MaxSumGpuError in the caller instead of blocking it."""
         if self.world == 1:
             return [fn(0)]
         import threading
+        import time
         out, errors = [None] * self.world, []
 
         def work(r):
@@ -355,11 +377,22 @@ class LocalShardedMaxSum:
                 out[r] = fn(r)
             except Exception as e:  # surfaced in the calling thread
                 errors.append((r, e))
-        threads = [threading.Thread(target=work, args=(r,), name=f"maxsum-gpu-rank{r}") for r in range(self.world)]
+        threads = [threading.Thread(target=work, args=(r,), name=f"maxsum-gpu-rank{r}", daemon=True)
+                   for r in range(self.world)]
         for t in threads:
             t.start()
+        deadline = None if timeout is None else time.monotonic() + timeout
         for t in threads:
-            t.join()
+            t.join(None if deadline is None else max(0.0, deadline - time.monotonic()))
+        stuck = [r for r, t in enumerate(threads) if t.is_alive()]
+        if stuck:
+            # their threads are still inside a C-ABI call on their engines: those handles are
+            # leaked on purpose (close() skips them) -- destroying one under a running call
+            # would be a use after free
+            self._stuck.update(stuck)
+            first = f"; rank {errors[0][0]} failed first: {errors[0][1]}" if errors else ""
+            raise MaxSumGpuError(f"ranks {stuck} (devices {[self.devices[r] for r in stuck]}) did not return within "
+                                 f"{timeout:.0f} s{first}")
         if errors:
             r, e = errors[0]
             raise MaxSumGpuError(f"rank {r} (device {self.devices[r]}): {e}") from e
@@ -421,8 +454,12 @@ class LocalShardedMaxSum:
         self.graph.tables[lo:hi] = t
 
     def close(self):
-        for e in self.engines:
-            if e is not None:
+        for r, e in enumerate(self.engines):
+            if e is None:
+                continue
+            if r in self._stuck:
+                _LEAKED.append(e)   # keeps __del__ from destroying it under the running call
+            else:
                 e.close()
         self.engines = [None] * self.world
 

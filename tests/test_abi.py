@@ -124,3 +124,63 @@ def test_no_kernel_of_the_other_engines_uses_scratch(source, at_least):
     assert len(ks) >= at_least, ks
     bad = [(n, s) for n, s in ks if s != 0]
     assert not bad, f"kernels using scratch: {bad}"
+
+
+def _c_layout(tmp_path):
+    """sizeof / offsetof of the three structs of include/maxsum_gpu.h, as gcc lays them out."""
+    import subprocess
+    fields = {
+        "mxs_graph": ["n_vars", "n_factors", "n_edges", "dom_size", "var_cost", "init_idx", "factor_rowptr", "edge_var",
+                      "table_off", "tables", "var_rowptr", "var_edges", "var_owned", "factor_owned", "eval_var_cost"],
+        "mxs_params": ["mode", "damping_nodes", "start_messages", "dtype", "damping", "stability", "graph_chunk",
+                       "layout_flags"],
+        "mxs_peer_info": ["qualifies", "rank", "ghost_len", "recv_at", "recv_len", "ghost_handle", "flag_handle", "pid",
+                          "ghost_ptr", "flag_ptr"],
+    }
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "maxsum_gpu.h"', 'int main(void) {']
+    for st, names in fields.items():
+        src.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for n in names:
+            src.append(f'  printf("{st}.{n} %zu\\n", offsetof({st}, {n}));')
+    src += ['  return 0;', '}']
+    c, exe = tmp_path / "layout.c", tmp_path / "layout"
+    c.write_text("\n".join(src))
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(c), "-o", str(exe)])
+    out = subprocess.check_output([str(exe)], text=True)
+    return fields, {k: int(v) for k, v in (line.split() for line in out.splitlines())}
+
+
+def test_struct_layouts_of_header_ctypes_and_documented_stub_agree(tmp_path):
+    """A C program compiled against include/maxsum_gpu.h, the ctypes mirrors the binding uses
+    (pydcop_amd/graph.py CGraph / CParams, engine.py PeerInfo) and the stub INTEGRATION.md shows
+    a maintainer must describe the same bytes: same fields, same order, same offsets, same size.
+    (Round 2 shipped a stub that stopped one pointer short of `eval_var_cost`.)"""
+    import ctypes as C
+    from pydcop_amd.engine import PeerInfo
+    from pydcop_amd.graph import CGraph, CParams
+    fields, c = _c_layout(tmp_path)
+    for st, cls in (("mxs_graph", CGraph), ("mxs_params", CParams), ("mxs_peer_info", PeerInfo)):
+        assert [n for n, _ in cls._fields_] == fields[st]
+        assert C.sizeof(cls) == c[st], st
+        for n in fields[st]:
+            assert getattr(cls, n).offset == c[f"{st}.{n}"], f"{st}.{n}"
+    # every member the header declares is in the list above (a new member must be added here,
+    # to the ctypes mirror and to the stub)
+    header = open(os.path.join(ROOT, "include", "maxsum_gpu.h")).read()
+    for st in fields:
+        body = header[header.index(f"typedef struct {st} {{"):header.index(f"}} {st};")]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        declared = [m for decl in body.split("{", 1)[1].split(";")
+                    for m in re.findall(r"\b([a-z_]+)\s*(?:\[[A-Z_]+\])?\s*(?:,|$)", decl.strip())]
+        assert declared == fields[st], (st, declared)
+    # the stub of INTEGRATION.md section 2, executed as written (minus the CDLL lines)
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class mxs_graph(C.Structure):"):doc.index('C.CDLL("libamdhip64.so"')]
+    ns = {"C": C}
+    exec(block, ns)
+    for st, mine in (("mxs_graph", CGraph), ("mxs_params", CParams)):
+        stub = ns[st]
+        assert [n for n, _ in stub._fields_] == fields[st]
+        assert C.sizeof(stub) == C.sizeof(mine) == c[st]
+        for n in fields[st]:
+            assert getattr(stub, n).offset == c[f"{st}.{n}"]

@@ -516,3 +516,34 @@ def test_local_sharded_one_process_equals_single_engine(case, k, emu_lib, fake_r
     with pytest.raises(ValueError):
         LocalShardedMaxSum(g, p, [0, 0], lib_path=emu_lib, rccl=fake_rccl)
     one.close()
+
+
+def test_local_sharded_boot_fails_instead_of_hanging(emu_lib, fake_rccl, tmp_path, monkeypatch):
+    """One rank failing BEFORE the communicator (engine creation on a device that does not
+    exist) must surface as an error in the caller, not leave the other ranks blocked in
+    ncclCommInitRank; a rank that never reaches the communicator must end in a timeout error."""
+    import time
+    from pydcop_amd.engine import MaxSumGpuError
+    from pydcop_amd import sharded
+    monkeypatch.setenv("FAKE_RCCL_DIR", str(tmp_path))
+    monkeypatch.setenv("EMU_HIP_DEVICES", "2")
+    g, kw = make_case("coloring")
+    t0 = time.monotonic()
+    with pytest.raises(MaxSumGpuError, match="rank 1"):
+        sharded.LocalShardedMaxSum(g, Params(**kw), [0, 7], lib_path=emu_lib, rccl=fake_rccl)   # device 7: absent
+    assert time.monotonic() - t0 < 60
+    # a wedged communicator: rank 1 never calls comm_init
+    real = MaxSumEngine.comm_init
+
+    def comm_init(self, rank, *a, **k):
+        if rank == 1:
+            time.sleep(30)
+            raise RuntimeError("late")
+        return real(self, rank, *a, **k)
+    monkeypatch.setattr(MaxSumEngine, "comm_init", comm_init)
+    monkeypatch.setattr(sharded.LocalShardedMaxSum, "COMM_TIMEOUT_S", 3.0)
+    monkeypatch.setenv("FAKE_RCCL_TIMEOUT_S", "5")
+    t0 = time.monotonic()
+    with pytest.raises(MaxSumGpuError, match="did not return within|rank 0"):
+        sharded.LocalShardedMaxSum(g, Params(**kw), [0, 1], lib_path=emu_lib, rccl=fake_rccl)
+    assert time.monotonic() - t0 < 25
