@@ -1,4 +1,4 @@
-"""CPU twin of tests/test_gpu_plugin.py: the same test functions (plug-in proxies + session driven
+"""CPU twin of tests/test_gpu_plugin.py: the same cases (tests/plugin_standin_cases.py: (plug-in proxies + session driven
 through the pyDCOP stand-in of tests/standin) on the emulated engine, in a subprocess so that the
 stand-in never shadows the real pyDCOP of the other tests."""
 import os
@@ -12,14 +12,8 @@ import os, sys
 sys.path.insert(0, os.path.join(%(root)r, "tests")); sys.path.insert(0, %(root)r)
 from emu.run_emulated import enable
 enable()
-sys.path.insert(0, os.path.join(%(root)r, "tests", "standin"))
-import pydcop
-assert pydcop.STANDIN
-import test_gpu_plugin as T
-from pydcop_amd import plugin
-plugin.install()
-from pydcop.algorithms import load_algorithm_module
-mod = load_algorithm_module("maxsum_gpu")
+import plugin_standin_cases as T
+mod = T.load_plugin()
 from oracle import maxsum_oracle
 maxsum_oracle.build()
 T.test_graph_coloring1_through_the_proxies(mod, "f64")
