@@ -208,6 +208,7 @@ struct Engine : EngineBase {
     bool fused = false;          // sharded cycles use the fused launch
     uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
     DevBuf<NaryDesc> ndesc;
+    DevBuf<WideBlock> wide_blocks;
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -401,11 +402,9 @@ struct Engine : EngineBase {
         if (phase == 3) {  // everything of the cycle; the cut factor blocks wait inside the sweep
             int rc = launch_sweep(a, L.n_blocks_fused);
             if (rc) return rc;
-            for (int c : L.wide_classes) {
-                const ClassInfo& ci = L.classes[c];
-                const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
-                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, stream, a, ci);
-                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, stream, a, ci);
+            if (!L.wide_blocks.empty()) {
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(BLOCK), 0, stream, a,
+                                   (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }
             return launch_nary(a, 0);
@@ -421,11 +420,9 @@ struct Engine : EngineBase {
                 HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
                 ws = side;
             }
-            for (int c : L.wide_classes) {
-                const ClassInfo& ci = L.classes[c];
-                const dim3 grid((unsigned)((ci.count + ci.per_block - 1) / ci.per_block)), block(BLOCK);
-                if (ci.D == 0) hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_SMALL>), grid, block, 0, ws, a, ci);
-                else hipLaunchKernelGGL((k_variable_wide<T, WIDE_CAP_LARGE>), grid, block, 0, ws, a, ci);
+            if (!L.wide_blocks.empty()) {
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(BLOCK), 0, ws, a,
+                                   (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }
             if (fork) HIP_TRY(hipEventRecord(ev_join, side));
@@ -616,6 +613,7 @@ struct Engine : EngineBase {
         HIP_TRY(sched.upload(L.sched, stream));
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
+        HIP_TRY(wide_blocks.upload(L.wide_blocks, stream));
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
         HIP_TRY(edge_var_int.upload(L.edge_var_int, stream));

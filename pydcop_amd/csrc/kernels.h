@@ -30,6 +30,8 @@
 #include <cmath>
 #include <cstdint>
 #include <cstring>
+#include <type_traits>
+#include <utility>
 
 #include "layout.h"
 
@@ -1371,22 +1373,25 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 }
 
 // ---------------------------------------------------------------------------
-// Variable side, wide class: ONE WAVE PER VARIABLE, for domains too large for the
-// packed class (5 <= D <= 256) or degrees above 64, as long as deg * D <= 1024, deg <= 256.
-// The incoming F->V messages are staged in LDS with one round of parallel loads;
-// lanes then run over d (beliefs, outgoing messages) or over the outgoing edges
-// (the `sum_cost` chains).  Arithmetic order is the reference's, op for op:
+// Variable side, wide class: domains too large for the packed class (5 <= D <= 256) or degrees
+// above 64, as long as deg * D <= 1024, deg <= 256.  ONE WORKGROUP PER RUN OF VARIABLES of one
+// domain size (layout.h WideBlock; e.g. 32 variables of D = 24 and degree 3), every phase with
+// all lanes busy:
+//   1. stage: lane <-> (edge, d) element of the incoming F->V messages, all of a thread's
+//      gathers in flight together; own costs and send counters likewise;
+//   2. lane <-> outgoing edge: the serial `sum_cost` chain of costs_for_factor (ONE accumulator
+//      runs through all (d, f != target) in d-major order, maxsum.py:651-665) walked in LDS --
+//      the chains of ALL the block's edges side by side; lane <-> variable: belief + selection;
+//   3. lane <-> (outgoing edge, d) element: the new message, damped, against the one sent last;
+//   4. the send rule per edge (the elements of an edge agree through an LDS flag), stores as
+//      one contiguous stream (the V->F records of consecutive variables are adjacent).
+// (Round 2 ran a wave per variable with lanes over d and a serial loop over the outgoing edges:
+// D = 24 used 24 of 64 lanes, the chains 3 -- 171 us per cycle on meeting_50k, 7 % of the HBM
+// peak.)  Arithmetic order is the reference's, op for op:
 //   select_value      maxsum.py:584-620   b[d] = c[d] + in_0[d] + in_1[d] + ...
-//   costs_for_factor  maxsum.py:623-676   ONE accumulator `sum_cost` runs through all
-//                     (d, f != target) in d-major order, so that chain stays serial:
-//                     one lane per outgoing edge walks it in LDS
+//   costs_for_factor  maxsum.py:623-676
 // Own launch (its LDS must not cap the occupancy of the register classes).
 // ---------------------------------------------------------------------------
-constexpr int WIDE_MAX_D = 256;       // <= 4 domain values per lane
-constexpr int WIDE_VARS = BLOCK / 64;
-// Two instantiations: CAP = staged elements per variable (deg * D <= CAP, deg <= CAP / 4).
-constexpr int WIDE_CAP_SMALL = 128;   // 5 KB of LDS per block: full occupancy
-constexpr int WIDE_CAP_LARGE = 1024;  // 40 KB per block
 
 // sum over t of in[..] in (d major, k minor) order, skipping edge `ko`: the serial
 // `sum_cost` chain of costs_for_factor.  Reads are issued four at a time, the adds stay
@@ -1443,124 +1448,148 @@ __device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, in
     return acc;
 }
 
-template <typename T, int CAP>
-__global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, ClassInfo ci) {
-    // the small footprint also stages the previous outgoing messages (one more round of
-    // parallel loads instead of a dependent load per outgoing edge)
-    constexpr bool STAGE_PREV = CAP <= WIDE_CAP_SMALL;
-    __shared__ T s_in[WIDE_VARS][CAP];
-    __shared__ T s_prev[WIDE_VARS][STAGE_PREV ? CAP : 1];
-    __shared__ T s_c[WIDE_VARS][WIDE_MAX_D];   // the variable's own costs
-    __shared__ T s_avg[WIDE_VARS][CAP / 4];
-    __shared__ int s_vo[WIDE_VARS][CAP / 4];   // per outgoing edge: V2F offset,
-    __shared__ int s_cn[WIDE_VARS][CAP / 4];   // send counter
-    const int w = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    // wave-uniform: the variable's record comes through scalar loads
-    const int j = __builtin_amdgcn_readfirstlane((int)blockIdx.x * WIDE_VARS + w);
-    if (j >= ci.count) return;  // whole waves; only wave-level synchronisation below
-    const int v = ci.first + j;
-    const int D = a.vdom[v];
-    const int k0 = a.vrowptr[v], deg = a.vrowptr[v + 1] - k0;
-    const T* c = a.var_cost + a.vcost_off[v];
-    T* in = s_in[w];
-    // stage what this variable holds: every load of a round is in flight together
-    // (no per-lane arrays anywhere below: everything indexed lives in LDS)
-    for (int d = lane; d < D; d += 64) s_c[w][d] = c[d];
-    for (int idx = lane; idx < deg * D; idx += 64) {
-        const int k = idx / D, d = idx - k * D;
-        in[idx] = a.f2v_old[a.vslot_f2v[k0 + k] + d];
-        if (STAGE_PREV) s_prev[w][idx] = a.start ? (T)0 : a.v2f_old[a.vslot_v2f[k0 + k] + d];
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a
+// compile-time constant in every copy of the body, so that per-thread arrays indexed by it are
+// registers from the start (a `#pragma unroll` loop around bodies with inner run-time loops left
+// them in scratch memory).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const WideBlock* blocks) {
+    constexpr int R = WIDE_CAPB / BLOCK;  // elements per thread
+    static_assert(WIDE_CAPB % BLOCK == 0, "");
+    __shared__ T s_in[WIDE_CAPB];               // staged F->V messages: [slot][d]
+    __shared__ T s_c[WIDE_MAX_COSTS];           // own costs: [variable][d]
+    __shared__ T s_avg[WIDE_MAX_SLOTS];         // per outgoing edge: sum_cost / D
+    __shared__ uint8_t s_svar[WIDE_MAX_SLOTS];  // ... its variable (local index)
+    __shared__ uint8_t s_cnt[WIDE_MAX_SLOTS];   // ... its send counter
+    __shared__ uint8_t s_nom[WIDE_MAX_SLOTS];   // ... 1: some element differs from the message sent last
+    __shared__ int s_vk0[WIDE_MAX_VARS];        // per variable: its first (local) slot
+    __shared__ int s_vdeg[WIDE_MAX_VARS];
+    const WideBlock wb = blocks[blockIdx.x];    // block-uniform: one scalar load
+    const int tid = (int)threadIdx.x;
+    const int D = wb.D, ns = wb.n_slots, ne = ns * D;
+    // ---- 1. stage ------------------------------------------------------------------------
+    int sl[R], dd[R];  // a thread's elements: local slot and d (idx = tid + r * BLOCK)
+    T x[R];
+    static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const int idx = tid + r * BLOCK;
+        const int s = D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);  // idx / D
+        sl[r] = s;
+        dd[r] = idx - s * D;
+        x[r] = (T)0;
+        if (idx < ne) x[r] = a.f2v_old[a.vslot_f2v[wb.slot0 + s] + dd[r]];
+    });
+    for (int j = tid; j < wb.n_vars; j += BLOCK) {
+        const int v = wb.first_var + j;
+        const int k0 = a.vrowptr[v] - wb.slot0, deg = a.vrowptr[v + 1] - a.vrowptr[v];
+        s_vk0[j] = k0;
+        s_vdeg[j] = deg;
+        for (int k = 0; k < deg; ++k) s_svar[k0 + k] = (uint8_t)j;
     }
-    for (int k = lane; k < deg; k += 64) {
-        s_vo[w][k] = a.vslot_v2f[k0 + k];
-        s_cn[w][k] = a.start ? 0 : (int)a.cV[k0 + k];
+    for (int i = tid; i < wb.n_vars * D; i += BLOCK) s_c[i] = a.var_cost[a.vcost_off[wb.first_var] + i];
+    for (int s = tid; s < ns; s += BLOCK) {
+        s_cnt[s] = a.start ? (uint8_t)0 : a.cV[wb.slot0 + s];
+        s_nom[s] = 0;
     }
-    __builtin_amdgcn_wave_barrier();
-    // belief and selection: first index attaining the minimum
-    T bb = pos_inf<T>();
-    int bi = 0x7fffffff;
-    for (int d = lane; d < D; d += 64) {
-        const T b = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, -1);
-        if (bi == 0x7fffffff || b < bb) {
-            bb = b;
-            bi = d;
-        }
-    }
-#pragma unroll
-    for (int sft = 32; sft > 0; sft >>= 1) {
-        const T y = __shfl(bb, lane ^ sft, 64);
-        const int yi = __shfl(bi, lane ^ sft, 64);
-        if (yi != 0x7fffffff && (bi == 0x7fffffff || y < bb || (y == bb && yi < bi))) {
-            bb = y;
-            bi = yi;
-        }
-    }
-    if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
-        bi = a.init_idx[v];
-        bb = (T)0;
-    }
-    if (lane == 0) {
-        a.sel[v] = bi;
-        a.belief[v] = bb;
-    }
-    // the mean of each outgoing message: one lane per target walks its serial chain
-    for (int ko = lane; ko < deg; ko += 64) s_avg[w][ko] = wide_sum_cost<T>(in, D, deg, ko) / (T)D;
-    __builtin_amdgcn_wave_barrier();
-    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
-                             a.start_mode != MXS_START_LEAFS;
-    const bool single = D <= 64;  // one domain value per lane: the new message stays in a register
-    for (int ko = 0; ko < deg; ++ko) {
-        const T avg = s_avg[w][ko];
-        const int cnt = s_cn[w][ko];
-        const int vo = s_vo[w][ko];
-        const bool damp = cnt > 0 && a.damp_v;
-        // pass 1: the new message, damped, against the one sent last
-        bool nomatch = false;
-        T m_keep = (T)0, p_keep = (T)0;
-        for (int d = lane; d < D; d += 64) {
-            T m = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, ko) - avg;
-            T p = (T)0;
-            if (a.start) {
-                m = start_sends ? m : (T)0;
-            } else {
-                p = STAGE_PREV ? s_prev[w][ko * D + d] : a.v2f_old[vo + d];
-                if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
-                if (!comp_match(m, p, a.stability)) nomatch = true;
-            }
-            m_keep = m;
-            p_keep = p;
-        }
-        const bool any_nomatch = __ballot(nomatch ? 1 : 0) != 0;  // over the wave
-        int out = 1;
-        bool keep_old = false;
-        if (a.start) {
-            out = 0;
-        } else if (cnt > 0 && !any_nomatch) {
-            if (cnt < SAME_COUNT) {
-                out = cnt + 1;
-            } else {
-                out = cnt;
-                keep_old = true;  // not sent: the receiver keeps the old message
-            }
-        }
-        // pass 2: write what the receiver holds after this cycle (wider domains recompute
-        // the element: same expression, same bits)
-        T* wout = a.v2f_new + vo;
-        for (int d = lane; d < D; d += 64) {
-            T m = m_keep, p = p_keep;
-            if (!single) {
-                m = wide_sum_edges<T>(s_c[w][d], in, D, deg, d, ko) - avg;
-                if (a.start) {
-                    m = start_sends ? m : (T)0;
-                } else {
-                    p = STAGE_PREV ? s_prev[w][ko * D + d] : a.v2f_old[vo + d];
-                    if (damp) m = a.damping * p + ((T)1 - a.damping) * m;
+    static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if (tid + r * BLOCK < ne) s_in[tid + r * BLOCK] = x[r];
+    });
+    __syncthreads();
+    // ---- 2. chains and beliefs --------------------------------------------------------------
+    for (int t = tid; t < ns + wb.n_vars; t += BLOCK) {
+        if (t < ns) {  // the mean of an outgoing message: its serial chain
+            const int j = s_svar[t], k0 = s_vk0[j];
+            s_avg[t] = wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
+        } else {       // belief and selection: first index attaining the minimum
+            const int j = t - ns, v = wb.first_var + j;
+            const T* in = s_in + s_vk0[j] * D;
+            const int deg = s_vdeg[j];
+            T bb = (T)0;
+            int bi = 0;
+            for (int d = 0; d < D; ++d) {
+                const T b = wide_sum_edges<T>(s_c[j * D + d], in, D, deg, d, -1);
+                if (d == 0 || b < bb) {
+                    bb = b;
+                    bi = d;
                 }
             }
-            wout[d] = keep_old ? p : m;
+            if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+                bi = a.init_idx[v];
+                bb = (T)0;
+            }
+            a.sel[v] = bi;
+            a.belief[v] = bb;
         }
-        if (lane == 0) a.cV[k0 + ko] = (uint8_t)out;
     }
+    // the messages sent last: requested before the barrier, used behind it
+    int vo[R];
+    T p[R], m[R];
+    static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        vo[r] = 0;
+        p[r] = (T)0;
+        if (tid + r * BLOCK < ne) {
+            vo[r] = a.vslot_v2f[wb.slot0 + sl[r]] + dd[r];
+            if (!a.start) p[r] = a.v2f_old[vo[r]];
+        }
+    });
+    __syncthreads();
+    // ---- 3. the new messages, damped, against the ones sent last ---------------------------------
+    static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        m[r] = (T)0;
+        if (tid + r * BLOCK < ne) {
+            const int s = sl[r], j = s_svar[s], k0 = s_vk0[j], deg = s_vdeg[j];
+            T mm = wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
+            if (a.start) {
+                const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                                         a.start_mode != MXS_START_LEAFS;
+                mm = start_sends ? mm : (T)0;
+            } else {
+                if (s_cnt[s] > 0 && a.damp_v) mm = a.damping * p[r] + ((T)1 - a.damping) * mm;
+                if (!comp_match(mm, p[r], a.stability)) s_nom[s] = 1;  // same value from all writers
+            }
+            m[r] = mm;
+        }
+    });
+    __syncthreads();
+    // ---- 4. send / send again / stay silent (the receiver keeps the old message) -------------------
+    static_for<R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        if (tid + r * BLOCK < ne) {
+            const int s = sl[r];
+            const int cnt = s_cnt[s];
+            int out = 1;
+            bool keep_old = false;
+            if (a.start) {
+                out = 0;
+            } else if (cnt > 0 && !s_nom[s]) {
+                if (cnt < SAME_COUNT) {
+                    out = cnt + 1;
+                } else {
+                    out = cnt;
+                    keep_old = true;
+                }
+            }
+            // (not `keep_old ? p[r] : m[r]`: the optimiser turns that into a select of the two
+            // arrays' ADDRESSES, which keeps both in scratch memory; the second read of the
+            // record is a cache hit)
+            T val = m[r];
+            if (keep_old) val = a.v2f_old[vo[r]];
+            a.v2f_new[vo[r]] = val;
+            if (dd[r] == 0) a.cV[wb.slot0 + s] = (uint8_t)out;
+        }
+    });
 }
 
 // ---------------------------------------------------------------------------

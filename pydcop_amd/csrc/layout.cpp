@@ -166,13 +166,14 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
             kind = K_V_PACK; sub = D;
         } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
-            kind = K_V_WIDE;  // wave per variable, messages staged in LDS; two LDS footprints
-            sub = ((int64_t)deg * D <= 128 && deg <= 32) ? 0 : 1;
+            kind = K_V_WIDE;  // workgroup per run of variables of one D, messages staged in LDS
+            sub = 0;
         } else { kind = K_V_GEN; sub = 0; }
         // sort key: class, then degree (the packed class needs equal degrees side
-        // by side; bit3 of layout_flags keeps the caller's order elsewhere)
+        // by side; bit3 of layout_flags keeps the caller's order elsewhere).  The wide class
+        // is ordered by domain size instead: its workgroups take runs of ONE D (WideBlock).
         const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
-        vsort[v] = (kind * 1024 + sub) * 4096 + (by_deg ? std::min(deg, 4095) : 0);
+        vsort[v] = (kind * 1024 + sub) * 4096 + (kind == K_V_WIDE ? D : by_deg ? std::min(deg, 4095) : 0);
     }
     L.var_i2e.resize(nV);
     std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);
@@ -510,7 +511,21 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.kind = K_V_GEN;
         } else if (kind == K_V_WIDE) {
             ci.kind = K_V_WIDE;
-            ci.D = sub;  // 0: small LDS footprint, 1: large
+            // its workgroups: runs of one D that fit the kernel's LDS arrays
+            for (int w = vi; w < vj;) {
+                const int D = L.vdom[w];
+                WideBlock wb{w, 0, D, L.vrowptr[w], 0, (uint32_t)((((uint64_t)1 << 32) + D - 1) / D)};
+                while (w < vj && L.vdom[w] == D) {
+                    const int deg = L.vrowptr[w + 1] - L.vrowptr[w];
+                    if (wb.n_vars > 0 && ((int64_t)(wb.n_slots + deg) * D > WIDE_CAPB || wb.n_slots + deg > WIDE_MAX_SLOTS ||
+                                          wb.n_vars + 1 > WIDE_MAX_VARS || (int64_t)(wb.n_vars + 1) * D > WIDE_MAX_COSTS))
+                        break;
+                    wb.n_vars += 1;
+                    wb.n_slots += deg;
+                    ++w;
+                }
+                L.wide_blocks.push_back(wb);
+            }
         } else if (kind == 80) {
             ci.kind = K_V_GEN;
             ci.start_only = 1;
@@ -566,7 +581,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             const int cls = (int)L.classes.size();
             L.classes.push_back(ci);
             if (ci.kind == K_V_WIDE) {
-                L.classes[cls].per_block = BLOCK / 64;  // one wave per variable
+                L.classes[cls].per_block = 1;  // (its grid is wide_blocks.size())
                 L.wide_classes.push_back(cls);
             } else {
                 sweep_class(cls, BLOCK);

@@ -53,8 +53,8 @@ enum Kind : int32_t {
                     // variables of a wave have the same degree and are packed side
                     // by side (64/deg per wave), cross-lane sums
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
-    K_V_WIDE = 7,   // 5 <= D <= 256 or deg > 64, deg * D <= 1024: wave per variable, messages
-                    // staged in LDS (own launch)
+    K_V_WIDE = 7,   // 5 <= D <= 256 or deg > 64, deg * D <= 1024: a workgroup per run of variables
+                    // of one domain size (WideBlock), messages staged in LDS (own launch)
 };
 
 #ifndef MXS_BLOCK
@@ -145,6 +145,23 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
     int32_t f2v_off[4];  // F2V offsets of the outgoing messages
 };
 
+// One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME
+// domain size D, cut so that the staged F->V elements (slots * D), the outgoing edges (slots)
+// and the own costs (variables * D) fit the kernel's LDS arrays.  Read with ONE scalar load.
+constexpr int WIDE_CAPB = 2304;       // staged F->V elements per block: 9 per thread
+constexpr int WIDE_MAX_SLOTS = 768;   // outgoing edges (CSR slots) per block
+constexpr int WIDE_MAX_VARS = 256;    // variables per block (their local index fits a byte)
+constexpr int WIDE_MAX_COSTS = 1024;  // variables * D per block
+struct WideBlock {
+    int32_t first_var;   // internal id of the first variable
+    int32_t n_vars;
+    int32_t D;
+    int32_t slot0;       // CSR slot of its first edge (vrowptr[first_var])
+    int32_t n_slots;
+    uint32_t magic;      // ceil(2^32 / D): idx / D == (idx * magic) >> 32 for idx < WIDE_CAPB (D >= 2;
+                         // D = 1 does not fit and is handled apart)
+};
+
 struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY factors
     int32_t arity, nj;   // nj = ceil(R / BLOCK), R = product of the dimensions after the first
     int32_t threads;     // block size: ceil(R / nj) rounded up to whole waves -- when R allows
@@ -217,7 +234,8 @@ struct Layout {
     bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)
     std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)
     std::vector<NaryLaunch> nary_launches;
-    std::vector<int32_t> wide_classes;    // K_V_WIDE classes: one launch each
+    std::vector<int32_t> wide_classes;    // K_V_WIDE classes (at most one: every wide variable, sorted by D)
+    std::vector<WideBlock> wide_blocks;   // the workgroups of the K_V_WIDE launch
 
     // per internal edge (factor-major)
     std::vector<int32_t> f2v_off;    // element offset of the edge's F->V message
