@@ -148,6 +148,84 @@ def run_reference_maxsum(dcop, cycles, params=None, cg=None, return_comps=False)
     return values, costs
 
 
+class ReferenceMaxSumRun:
+    """The reference's synchronous Max-Sum computations under the FIFO harness of
+    `run_reference_maxsum`, RESUMABLE: `run_to(T)` delivers every queued message whose cycle_id
+    is below T (each computation then has executed exactly T calls of on_new_cycle) and parks the
+    rest, so that something can happen to the computations between two cycles -- what
+    pydcop/algorithms/maxsum_dynamic.py does to a factor:
+
+      change_factor_function(name, relation)
+          runs the reference's OWN `DynamicFunctionFactorComputation.change_factor_function`
+          (maxsum_dynamic.py:80-104: the two dimension checks, then `self.factor = fn`; the
+          re-emission of messages is commented out there, "FIXME") on the factor's computation.
+          The reference defines that class over the ASYNCHRONOUS factor computation (`from
+          pydcop.algorithms.amaxsum import MaxSumFactorComputation`, maxsum_dynamic.py:35); the
+          method body touches nothing but `self.factor`, which the synchronous computation reads
+          in the same way (maxsum.py:345: `factor_costs_for_var(self.factor, ...)`), so it is
+          applied to the synchronous computation object unchanged.
+      slice_external(relation, values)
+          `relation.slice(values)` (relations.py:760-810) -- what
+          FactorWithReadOnlyVariableComputation._on_new_var_value_msg (maxsum_dynamic.py:159-176)
+          computes before it calls change_factor_function.  (That class itself cannot be
+          constructed: its __init__ calls `super().__init__(relation, name=..., msg_sender=...)`
+          on a parent that takes a single comp_def, maxsum_dynamic.py:124-143 -- a TypeError,
+          checked by tests/test_dynamic_vs_reference.py.)"""
+
+    def __init__(self, dcop, params=None, cg=None):
+        install_shims()
+        from pydcop.algorithms import AlgorithmDef, ComputationDef, load_algorithm_module
+        from pydcop.computations_graph import factor_graph
+        import logging
+        p = {"noise": 0}
+        p.update(params or {})
+        algo = AlgorithmDef.build_with_default_param("maxsum", p, mode=dcop.objective)
+        self.dcop = dcop
+        self.cg = cg if cg is not None else factor_graph.build_computation_graph(dcop)
+        module = load_algorithm_module("maxsum")
+        self.q = deque()
+        self.comps = {}
+        logging.disable(logging.CRITICAL)
+        try:
+            for node in self.cg.nodes:
+                c = module.build_computation(ComputationDef(node, algo))
+                c.message_sender = lambda src, dest, msg, prio=None, on_error=None: self.q.append((src, dest, msg))
+                self.comps[node.name] = c
+            for c in self.comps.values():
+                c.start()
+        finally:
+            logging.disable(logging.NOTSET)
+        self.cycles = 0
+
+    def run_to(self, T):
+        import logging
+        logging.disable(logging.CRITICAL)
+        try:
+            parked = deque()
+            while self.q:
+                s, d, m = self.q.popleft()
+                if m.cycle_id < T:
+                    self.comps[d].on_message(s, m, 0.0)
+                else:
+                    parked.append((s, d, m))
+            self.q = parked
+        finally:
+            logging.disable(logging.NOTSET)
+        self.cycles = T
+
+    def change_factor_function(self, name, relation):
+        from pydcop.algorithms.maxsum_dynamic import DynamicFunctionFactorComputation
+        DynamicFunctionFactorComputation.change_factor_function(self.comps[name], relation)
+
+    @staticmethod
+    def slice_external(relation, values):
+        return relation.slice(values)
+
+    def values(self):
+        return ({v: self.comps[v].current_value for v in self.dcop.variables},
+                {v: self.comps[v].current_cost for v in self.dcop.variables})
+
+
 def reference_message_state(comps, graph):
     """What the reference's synchronous computations HOLD, laid out like the flat message
     buffers (graph.msg_off per factor-major edge), after `run_reference_maxsum(...,

@@ -219,6 +219,7 @@ struct Engine : EngineBase {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false, capturing = false;
+    bool streaming = false;  // non-temporal stores / index loads in the sweep (cycle larger than the Infinity Cache)
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
     bool halo_pending = false;
@@ -349,6 +350,13 @@ struct Engine : EngineBase {
                 case 3: hipLaunchKernelGGL((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
                 case 4: hipLaunchKernelGGL((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
                 default: hipLaunchKernelGGL((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
+            }
+        } else if (streaming) {  // the cycle does not fit the Infinity Cache: see kernels.h, NT_STREAMING
+            switch (L.dsel) {
+                case 2: hipLaunchKernelGGL((k_sweep<T, 2, NT_STREAMING>), grid, block, 0, stream, a); break;
+                case 3: hipLaunchKernelGGL((k_sweep<T, 3, NT_STREAMING>), grid, block, 0, stream, a); break;
+                case 4: hipLaunchKernelGGL((k_sweep<T, 4, NT_STREAMING>), grid, block, 0, stream, a); break;
+                default: hipLaunchKernelGGL((k_sweep<T, 0, NT_STREAMING>), grid, block, 0, stream, a); break;
             }
         } else {
             switch (L.dsel) {
@@ -535,6 +543,12 @@ struct Engine : EngineBase {
         // 1M-variable colouring 434 vs 370 us, meeting_50k 1351 vs 1176 us per cycle).
         // Default (graph_chunk < 0): graphs of 32 cycles below 4 MB per cycle, eager above.
         if (params.graph_chunk < 0) params.graph_chunk = L.algorithmic_bytes < (4 << 20) ? 32 : 0;
+        {   // cache policy of the sweep: streaming (nt stores, nt index loads) once a cycle moves more
+            // than the 256-MB Infinity Cache holds; MAXSUM_STREAMING=0/1 forces it (A/B runs)
+            streaming = L.algorithmic_bytes > ((int64_t)256 << 20);
+            const char* env = getenv("MAXSUM_STREAMING");
+            if (env && (env[0] == '0' || env[0] == '1')) streaming = env[0] == '1';
+        }
         int count = 0;
         if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
             return fail(MXS_E_NODEVICE, "no HIP device visible: the Max-Sum engine has no CPU fallback");

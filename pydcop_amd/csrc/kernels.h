@@ -42,6 +42,30 @@ constexpr int SAME_COUNT = 4;  // maxsum.py:106
 #define SWEEP_MIN_WAVES 4
 #endif
 
+// Cache policy experiments (build variants only; the default build is MXS_NT = 0).  Non-temporal
+// accesses on  bit0 (1): the single-use index / table streams,  bit1 (2): a side's own previous
+// records,  bit2 (4): the gathers,  bit3 (8): the stores.  tools/bw_sweep.hip: a streaming read
+// of 1 GB runs at 7.2 TB/s with nt loads against 6.2 with the default policy.
+#ifndef MXS_NT
+#define MXS_NT 0
+#endif
+// The policy is a template parameter NT of the sweep: the engine runs k_sweep<.., NT_STREAMING>
+// on instances whose cycle does not fit the 256-MB Infinity Cache (measured, profiles/
+// r03_cache_policy_ab_v1.txt: nt stores 1M-variable colouring 279 -> 264 us, Ising 113 -> 106;
+// on the cache-resident 100k instance every nt variant is SLOWER, 19.9 -> 21.5 us with nt stores:
+// the next cycle finds its input in the cache only if the stores left it there).
+constexpr int NT_STREAMING = 9;  // nt on the index / table streams and on the stores
+#define MXS_NT_FLAGS(NT)                                                                        \
+    constexpr bool NT_IDX = ((NT) & 1) != 0, NT_PREV = ((NT) & 2) != 0, NT_GATHER = ((NT) & 4) != 0; \
+    (void)NT_IDX, (void)NT_PREV, (void)NT_GATHER
+template <bool NT, typename U>
+__device__ __forceinline__ U ldp(const U* p) {
+#if defined(__HIPCC__)
+    if constexpr (NT) return __builtin_nontemporal_load(p);
+#endif
+    return *p;
+}
+
 // A wave hands its outgoing messages over through LDS so that every store instruction of
 // the wave writes 1 KB of contiguous bytes (16 per lane) instead of 16-byte pieces at the
 // stride of a message record: measured 1.5 % (cache-resident) to 4 % (HBM-resident) faster.
@@ -55,8 +79,9 @@ struct Piece16 {  // 16 bytes, moved with one instruction
 
 // Every lane of the wave holds ELEMS contiguous elements of `arr`, lane l at element
 // wave_base + l * ELEMS.  ELEMS * sizeof(T) is a multiple of 16.  All 64 lanes take part.
-template <typename T, int ELEMS>
+template <typename T, int ELEMS, int NT = MXS_NT>
 __device__ __forceinline__ void wave_store_linear(T* arr, int64_t wave_base, const T (&vals)[ELEMS]) {
+    constexpr bool NT_STORE = (NT & 8) != 0;
     static_assert(ELEMS * sizeof(T) % 16 == 0 && 64 * ELEMS * sizeof(T) <= STAGE_BYTES_PER_WAVE, "");
     const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
     char* so = (char*)g_stage[w];
@@ -67,9 +92,18 @@ __device__ __forceinline__ void wave_store_linear(T* arr, int64_t wave_base, con
     char* out = (char*)(arr + wave_base);
     constexpr int PIECES = ELEMS * (int)sizeof(T) / 16;
 #pragma unroll
-    for (int k = 0; k < PIECES; ++k)
+    for (int k = 0; k < PIECES; ++k) {
+#if defined(__HIPCC__)
+        if constexpr (NT_STORE) {
+            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+            __builtin_nontemporal_store(*(const v4u*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16),
+                                        (v4u*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16));
+            continue;
+        }
+#endif
         *(Piece16*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16) =
             *(const Piece16*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16);
+    }
 }
 
 template <typename T>
@@ -190,10 +224,11 @@ template <typename T, int D>
 struct Msg {
     static constexpr int H = half_stride(D, (int)sizeof(T));
     static constexpr int ALIGN = H * (int)sizeof(T) >= 16 ? 16 : 8;
+    template <bool NT = false>
     static __device__ __forceinline__ void load(const T* p, T (&m)[D]) {
         const T* q = (const T*)__builtin_assume_aligned(p, ALIGN);
 #pragma unroll
-        for (int d = 0; d < D; ++d) m[d] = q[d];
+        for (int d = 0; d < D; ++d) m[d] = ldp<NT>(q + d);
     }
     // stores the padding too: full-sector, fully coalesced writes
     static __device__ __forceinline__ void store(T* p, const T (&m)[D]) {
@@ -214,11 +249,12 @@ struct Msg {
     // edge.  The other side gathers only the D values.  Records without padding use the
     // counter arrays cF / cV.
     static constexpr bool CNT_IN_MSG = H > D;
+    template <bool NT = false>
     static __device__ __forceinline__ uint8_t load_c(const T* p, T (&m)[D]) {
         const T* q = (const T*)__builtin_assume_aligned(p, ALIGN);
 #pragma unroll
-        for (int d = 0; d < D; ++d) m[d] = q[d];
-        return (uint8_t)(int)q[D < H ? D : 0];
+        for (int d = 0; d < D; ++d) m[d] = ldp<NT>(q + d);
+        return (uint8_t)(int)ldp<NT>(q + (D < H ? D : 0));
     }
     static __device__ __forceinline__ T padded(const T (&m)[D], uint8_t cnt, int d) {
         return d < D ? m[d < D ? d : 0] : (d == D ? (T)(int)cnt : (T)0);
@@ -235,11 +271,12 @@ struct Msg {
 // back-to-back narrow entries per factor, read with whole-dword vector loads (consecutive lanes
 // read consecutive records) and widened here -- every value is exactly what the full-width
 // image holds, including the sign of a negated zero.
-template <typename T, int N>
+template <typename T, int N, int NT = MXS_NT>
 __device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInfo& ci, int j, T (&tab)[N]) {
+    MXS_NT_FLAGS(NT);
     if (ci.tab_type == TAB_FULL) {
 #pragma unroll
-        for (int k = 0; k < N; ++k) tab[k] = a.tables[ci.tab_base + (int64_t)k * ci.count + j];
+        for (int k = 0; k < N; ++k) tab[k] = ldp<NT_IDX>(a.tables + ci.tab_base + (int64_t)k * ci.count + j);
         return;
     }
     if (ci.tab_type == TAB_I8) {
@@ -248,7 +285,7 @@ __device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInf
         const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
             a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
 #pragma unroll
-        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+        for (int i = 0; i < REC / 4; ++i) w[i] = ldp<NT_IDX>(p + i);
 #pragma unroll
         for (int k = 0; k < N; ++k) tab[k] = (T)(int)(int8_t)(uint8_t)(w[k >> 2] >> (8 * (k & 3)));
     } else if (ci.tab_type == TAB_I16) {
@@ -257,7 +294,7 @@ __device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInf
         const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
             a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
 #pragma unroll
-        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+        for (int i = 0; i < REC / 4; ++i) w[i] = ldp<NT_IDX>(p + i);
 #pragma unroll
         for (int k = 0; k < N; ++k) tab[k] = (T)(int)(int16_t)(uint16_t)(w[k >> 1] >> (16 * (k & 1)));
     } else {  // TAB_F32
@@ -266,7 +303,7 @@ __device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInf
         const uint32_t* p = (const uint32_t*)__builtin_assume_aligned(
             a.ctables + ci.ctab_base + (int64_t)j * REC, REC >= 16 ? 16 : REC);
 #pragma unroll
-        for (int i = 0; i < REC / 4; ++i) w[i] = p[i];
+        for (int i = 0; i < REC / 4; ++i) w[i] = ldp<NT_IDX>(p + i);
 #pragma unroll
         for (int k = 0; k < N; ++k) {
             float f;
@@ -285,20 +322,21 @@ __device__ __forceinline__ void load_table(const SweepArgs<T>& a, const ClassInf
 // factor_costs_for_var, maxsum.py:382-447:  out_i[d] = min over the other
 // variables' values of  table[..] + sum of their messages.
 // ---------------------------------------------------------------------------
-template <typename T, int D>
+template <typename T, int D, int NT = MXS_NT>
 __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    MXS_NT_FLAGS(NT);
     constexpr int H = Msg<T, D>::H;
     const int64_t fo = ci.f2v_base + (int64_t)j * H;
     const int e = ci.edge_base + j;
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     T out[D], prev[D], tab[D];
     uint8_t cn;
-    if constexpr (CIM) cn = Msg<T, D>::load_c(a.f2v_old + fo, prev);
+    if constexpr (CIM) cn = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo, prev);
     else {
-        Msg<T, D>::load(a.f2v_old + fo, prev);
+        Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo, prev);
         cn = a.cF[e];
     }
-    load_table<T, D>(a, ci, j, tab);
+    load_table<T, D, NT>(a, ci, j, tab);
 #pragma unroll
     for (int d = 0; d < D; ++d)  // a single assignment of "the others": f_val + sum_cost with sum_cost = 0
         out[d] = tab[d] + (T)0;
@@ -313,27 +351,28 @@ __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassI
     }
 }
 
-template <typename T, int D, bool P2P = false>
+template <typename T, int D, bool P2P = false, int NT = MXS_NT>
 __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
+    MXS_NT_FLAGS(NT);
     constexpr int H = Msg<T, D>::H;
     const int e = ci.edge_base + 2 * j;
     // the class's records are split by scope position: two dense streams
     const int64_t fo0 = ci.f2v_base + (int64_t)j * H, fo1 = ci.f2v_base1 + (int64_t)j * H;
     // everything addressed by j: coalesced
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
-    const int v0 = a.edge_v2f[e], v1 = a.edge_v2f[e + 1];
+    const int v0 = ldp<NT_IDX>(a.edge_v2f + e), v1 = ldp<NT_IDX>(a.edge_v2f + e + 1);
     uint8_t cn0, cn1;
     T m0[D], p0[D], m1[D], p1[D], tab[D * D];
     if constexpr (CIM) {
-        cn0 = Msg<T, D>::load_c(a.f2v_old + fo0, p0);  // F->V message last sent to variable 0
-        cn1 = Msg<T, D>::load_c(a.f2v_old + fo1, p1);  // (+ its send counter)
+        cn0 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo0, p0);  // F->V message last sent to variable 0
+        cn1 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo1, p1);  // (+ its send counter)
     } else {
         cn0 = a.cF[e];
         cn1 = a.cF[e + 1];
-        Msg<T, D>::load(a.f2v_old + fo0, p0);
-        Msg<T, D>::load(a.f2v_old + fo1, p1);
+        Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo0, p0);
+        Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo1, p1);
     }
-    load_table<T, D * D>(a, ci, j, tab);
+    load_table<T, D * D, NT>(a, ci, j, tab);
     // the two gathers
     // (peer-store mode: the message of a ghost variable lives in the ghost region)
     if constexpr (P2P) {
@@ -343,8 +382,8 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         if (v1 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v1 - a.ghost_lo), m1);
         else Msg<T, D>::load(a.v2f_old + v1, m1);
     } else {
-        Msg<T, D>::load(a.v2f_old + v0, m0);      // V->F message of scope variable 0
-        Msg<T, D>::load(a.v2f_old + v1, m1);
+        Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v0, m0);      // V->F message of scope variable 0
+        Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v1, m1);
     }
     T o0[D], o1[D];
 #pragma unroll
@@ -378,10 +417,10 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
             T full[H];
 #pragma unroll
             for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
-            wave_store_linear<T, H>(a.f2v_new, fo0 - (int64_t)lw * H, full);
+            wave_store_linear<T, H, NT>(a.f2v_new, fo0 - (int64_t)lw * H, full);
 #pragma unroll
             for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
-            wave_store_linear<T, H>(a.f2v_new, fo1 - (int64_t)lw * H, full);
+            wave_store_linear<T, H, NT>(a.f2v_new, fo1 - (int64_t)lw * H, full);
         } else {
             Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
             Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
@@ -478,8 +517,9 @@ __device__ __forceinline__ void factor_generic(const SweepArgs<T>& a, const Clas
 //   select_value      maxsum.py:584-620
 //   costs_for_factor  maxsum.py:623-676  (the mean excludes the own cost)
 // ---------------------------------------------------------------------------
-template <typename T, int D, bool P2P = false>
+template <typename T, int D, bool P2P = false, int NT = MXS_NT>
 __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
+    MXS_NT_FLAGS(NT);
     constexpr int H = Msg<T, D>::H;
     const int lane_id = item + (int)threadIdx.x;
     if (lane_id >= ci.count) return;  // whole waves (count is a multiple of 64)
@@ -493,18 +533,18 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
     const int k = l - var * deg;                              // edge position in the variable
     const bool has = var < nv;
     const int v = wm.first_var + (has ? var : 0);
-    const int32_t slot = a.vell[pos];
+    const int32_t slot = ldp<NT_IDX>(a.vell + pos);
     const int32_t send_at = a.send_slot != nullptr ? a.send_slot[pos] : -1;
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
     T pv[D], in[D], c[D], b[D], m[D];
     const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
     uint8_t cnt;
-    if constexpr (CIM) cnt = Msg<T, D>::load_c(a.v2f_old + vo, pv);  // V->F message last sent on
+    if constexpr (CIM) cnt = Msg<T, D>::template load_c<NT_PREV>(a.v2f_old + vo, pv);  // V->F message last sent on
     else {                                                            // this edge (+ its counter)
         cnt = a.cV[ci.cv_base + lane_id];
-        Msg<T, D>::load(a.v2f_old + vo, pv);
+        Msg<T, D>::template load<NT_PREV>(a.v2f_old + vo, pv);
     }
-    Msg<T, D>::load(a.f2v_old + (has ? slot : a.null_f2v), in);  // F->V held from this factor
+    Msg<T, D>::template load<NT_GATHER>(a.f2v_old + (has ? slot : a.null_f2v), in);  // F->V held from this factor
 #pragma unroll
     for (int d = 0; d < D; ++d) c[d] = a.var_cost[ci.cost_base + (int64_t)(v - ci.first) * D + d];
     int init = -1;
@@ -579,7 +619,7 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
         T full[H];
 #pragma unroll
         for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(m, CIM ? co : 0, d);
-        wave_store_linear<T, H>(a.v2f_new, vo - (int64_t)l * H, full);
+        wave_store_linear<T, H, NT>(a.v2f_new, vo - (int64_t)l * H, full);
     } else {
         Msg<T, D>::store(a.v2f_new + vo, m);
     }
@@ -661,16 +701,16 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // size only (the engine picks it when the graph has a single D), which keeps the
 // kernel's register allocation -- the maximum over all paths -- small.
 // ---------------------------------------------------------------------------
-template <typename T, int D, bool P2P = false>
+template <typename T, int D, bool P2P = false, int NT = MXS_NT>
 __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     if (ci.kind == K_V_PACK) {  // one lane per edge
-        variable_pack<T, D, P2P>(a, ci, item);
+        variable_pack<T, D, P2P, NT>(a, ci, item);
         return;
     }
     const int j = item + (int)threadIdx.x;
     if (j >= ci.count) return;
-    if (ci.kind == K_F_BIN) factor_binary<T, D, P2P>(a, ci, j);
-    else if (ci.kind == K_F_UNARY) factor_unary<T, D>(a, ci, j);
+    if (ci.kind == K_F_BIN) factor_binary<T, D, P2P, NT>(a, ci, j);
+    else if (ci.kind == K_F_UNARY) factor_unary<T, D, NT>(a, ci, j);
 }
 
 // A block of a cut factor class in the fused sharded launch: the ghost V->F messages it
@@ -720,7 +760,7 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
     }
 }
 
-template <typename T, int DSEL, bool P2P = false>
+template <typename T, int DSEL, bool P2P = false, int NT = MXS_NT>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0, blk = -1;
     if (a.sched != nullptr) {
@@ -742,12 +782,12 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
         return ci.kind;
     }
     if (DSEL != 0) {
-        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P>(a, ci, item);
+        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
     } else {
         switch (ci.D) {
-            case 2: sweep_d<T, 2, P2P>(a, ci, item); break;
-            case 3: sweep_d<T, 3, P2P>(a, ci, item); break;
-            case 4: sweep_d<T, 4, P2P>(a, ci, item); break;
+            case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
+            case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
+            case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
             default: break;
         }
     }
@@ -757,10 +797,10 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
 // At most 80 SGPRs: a CU admits 8 workgroups of 256 threads only up to that count (6 at the
 // 98 the compiler would otherwise use -- MI355X_MICROARCH.md, "Residency"; seen as 1536
 // instead of 2048 resident blocks in the per-block timeline).
-template <typename T, int DSEL>
+template <typename T, int DSEL, int NT = MXS_NT>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep(SweepArgs<T> a) {
-    sweep_block<T, DSEL>(a);
+    sweep_block<T, DSEL, false, NT>(a);
 }
 
 // The sweep of a shard in peer-store mode (engine.hip, p2p): same blocks, plus the stores of
@@ -1394,41 +1434,50 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // ---------------------------------------------------------------------------
 
 // sum over t of in[..] in (d major, k minor) order, skipping edge `ko`: the serial
-// `sum_cost` chain of costs_for_factor.  Reads are issued four at a time, the adds stay
-// in order.
+// `sum_cost` chain of costs_for_factor.  Reads are issued four at a time and one group ahead of
+// the adds, which stay in order.
 template <typename T>
 __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
-    T sc = (T)0;
     const int n = D * deg;
-    int d = 0, k = 0, t = 0;
-    for (; t + 4 <= n; t += 4) {
-        T x[4];
-        bool use[4];
+    T sc = (T)0;
+    int d = 0, k = 0;
+    T cur[4], nxt[4];
+    bool cuse[4], nuse[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x[u] = in[k * D + d];
-            use[u] = k != ko;
-            if (++k == deg) {
+    for (int u = 0; u < 4; ++u) {
+        const bool ok = u < n;
+        cur[u] = in[ok ? k * D + d : 0];
+        cuse[u] = ok && k != ko;
+        if (ok && ++k == deg) {
+            k = 0;
+            ++d;
+        }
+    }
+    for (int t = 0; t < n; t += 4) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {  // the next group (past the end: a harmless read of in[0])
+            const bool ok = t + 4 + u < n;
+            nxt[u] = in[ok ? k * D + d : 0];
+            nuse[u] = ok && k != ko;
+            if (ok && ++k == deg) {
                 k = 0;
                 ++d;
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (use[u]) sc += x[u];
-    }
-    for (; t < n; ++t) {
-        const T x = in[k * D + d];
-        if (k != ko) sc += x;
-        if (++k == deg) {
-            k = 0;
-            ++d;
+            if (cuse[u]) sc += cur[u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            cur[u] = nxt[u];
+            cuse[u] = nuse[u];
         }
     }
     return sc;
 }
 
-// c + in_0[d] + in_1[d] + ... in order, skipping edge `skip` (-1: none); reads four at a time
+// c + in_0[d] + in_1[d] + ... in order, skipping edge `skip` (-1: none); reads four at a time,
+// the last one to three together as well
 template <typename T>
 __device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, int d, int skip) {
     T acc = c;
@@ -1441,9 +1490,14 @@ __device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, in
         for (int u = 0; u < 4; ++u)
             if (k + u != skip) acc += x[u];
     }
-    for (; k < deg; ++k) {
-        const T x = in[k * D + d];
-        if (k != skip) acc += x;
+    const int rem = deg - k;
+    if (rem > 0) {
+        const T x0 = in[k * D + d];
+        const T x1 = in[(rem > 1 ? k + 1 : k) * D + d];
+        const T x2 = in[(rem > 2 ? k + 2 : k) * D + d];
+        if (k != skip) acc += x0;
+        if (rem > 1 && k + 1 != skip) acc += x1;
+        if (rem > 2 && k + 2 != skip) acc += x2;
     }
     return acc;
 }
@@ -1467,6 +1521,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     static_assert(WIDE_CAPB % BLOCK == 0, "");
     __shared__ T s_in[WIDE_CAPB];               // staged F->V messages: [slot][d]
     __shared__ T s_c[WIDE_MAX_COSTS];           // own costs: [variable][d]
+    __shared__ T s_b[WIDE_MAX_COSTS];           // beliefs: [variable][d]
     __shared__ T s_avg[WIDE_MAX_SLOTS];         // per outgoing edge: sum_cost / D
     __shared__ uint8_t s_svar[WIDE_MAX_SLOTS];  // ... its variable (local index)
     __shared__ uint8_t s_cnt[WIDE_MAX_SLOTS];   // ... its send counter
@@ -1506,30 +1561,13 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     });
     __syncthreads();
     // ---- 2. chains and beliefs --------------------------------------------------------------
-    for (int t = tid; t < ns + wb.n_vars; t += BLOCK) {
-        if (t < ns) {  // the mean of an outgoing message: its serial chain
-            const int j = s_svar[t], k0 = s_vk0[j];
-            s_avg[t] = wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
-        } else {       // belief and selection: first index attaining the minimum
-            const int j = t - ns, v = wb.first_var + j;
-            const T* in = s_in + s_vk0[j] * D;
-            const int deg = s_vdeg[j];
-            T bb = (T)0;
-            int bi = 0;
-            for (int d = 0; d < D; ++d) {
-                const T b = wide_sum_edges<T>(s_c[j * D + d], in, D, deg, d, -1);
-                if (d == 0 || b < bb) {
-                    bb = b;
-                    bi = d;
-                }
-            }
-            if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
-                bi = a.init_idx[v];
-                bb = (T)0;
-            }
-            a.sel[v] = bi;
-            a.belief[v] = bb;
-        }
+    for (int t = tid; t < ns; t += BLOCK) {  // the mean of an outgoing message: its serial chain
+        const int j = s_svar[t], k0 = s_vk0[j];
+        s_avg[t] = wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
+    }
+    for (int i = tid; i < wb.n_vars * D; i += BLOCK) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
+        const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
+        s_b[i] = wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
     }
     // the messages sent last: requested before the barrier, used behind it
     int vo[R];
@@ -1544,6 +1582,24 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
         }
     });
     __syncthreads();
+    for (int j = tid; j < wb.n_vars; j += BLOCK) {  // selection: first index attaining the minimum
+        const int v = wb.first_var + j;
+        T bb = s_b[j * D];
+        int bi = 0;
+        for (int d = 1; d < D; ++d) {
+            const T b = s_b[j * D + d];
+            if (b < bb) {
+                bb = b;
+                bi = d;
+            }
+        }
+        if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+            bi = a.init_idx[v];
+            bb = (T)0;
+        }
+        a.sel[v] = bi;
+        a.belief[v] = bb;
+    }
     // ---- 3. the new messages, damped, against the ones sent last ---------------------------------
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;

@@ -148,10 +148,11 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
 // One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME
 // domain size D, cut so that the staged F->V elements (slots * D), the outgoing edges (slots)
 // and the own costs (variables * D) fit the kernel's LDS arrays.  Read with ONE scalar load.
-constexpr int WIDE_CAPB = 2304;       // staged F->V elements per block: 9 per thread
-constexpr int WIDE_MAX_SLOTS = 768;   // outgoing edges (CSR slots) per block
+constexpr int WIDE_CAPB = 2048;       // staged F->V elements per block: 8 per thread
+constexpr int WIDE_MAX_SLOTS = 512;   // outgoing edges (CSR slots) per block
 constexpr int WIDE_MAX_VARS = 256;    // variables per block (their local index fits a byte)
-constexpr int WIDE_MAX_COSTS = 1024;  // variables * D per block
+constexpr int WIDE_MAX_COSTS = 768;   // variables * D per block
+// (f64: 36 KB of LDS per block, four blocks per CU)
 struct WideBlock {
     int32_t first_var;   // internal id of the first variable
     int32_t n_vars;

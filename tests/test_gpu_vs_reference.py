@@ -52,3 +52,13 @@ def test_hip_engine_equals_the_reference(name, make, mode, params, T):
         viol, cost = dcop.solution_cost(vals, float("inf"))
         ecost, eviol = eng.eval_cost()
         assert eviol == viol and ecost == pytest.approx(cost, rel=1e-12, abs=1e-9)
+
+
+def test_dynamic_changes_on_the_hip_engine_equal_the_reference(oracle_built):
+    """SURVEY 8(f).3 on hardware: the reference's own change_factor_function (same scope, permuted
+    dimension order) and relation.slice against mxs_update_factor_table / mxs_slice_factor of the
+    HIP library -- the cases of tests/test_dynamic_vs_reference.py with lib_path=None."""
+    import test_dynamic_vs_reference as D
+    for _, make, mode, params in D.CASES:
+        D.check_change_factor_function(make, mode, params, oracle_built, None)
+    D.check_external_slice(oracle_built, None)
