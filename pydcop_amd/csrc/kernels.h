@@ -772,23 +772,27 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
         for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
     }
     const ClassInfo ci = a.classes[c];
-    const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
+    const int item0 = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
     if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
-    if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
-        const int j = item + (int)threadIdx.x;
-        if (j >= ci.count) return ci.kind;
-        if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
-        else variable_generic<T>(a, ci, j);
-        return ci.kind;
-    }
-    if (DSEL != 0) {
-        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
-    } else {
-        switch (ci.D) {
-            case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
-            case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
-            case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
-            default: break;
+    // a workgroup works on MXS_TILES consecutive tiles of BLOCK items (layout.h; 1 by default)
+#pragma unroll
+    for (int t = 0; t < MXS_TILES; ++t) {
+        const int item = item0 + t * BLOCK;
+        if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
+            const int j = item + (int)threadIdx.x;
+            if (j < ci.count) {
+                if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
+                else variable_generic<T>(a, ci, j);
+            }
+        } else if (DSEL != 0) {
+            sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
+        } else {
+            switch (ci.D) {
+                case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
+                case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
+                case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
+                default: break;
+            }
         }
     }
     return ci.kind;
@@ -1433,46 +1437,45 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // Own launch (its LDS must not cap the occupancy of the register classes).
 // ---------------------------------------------------------------------------
 
-// sum over t of in[..] in (d major, k minor) order, skipping edge `ko`: the serial
-// `sum_cost` chain of costs_for_factor.  Reads are issued four at a time and one group ahead of
-// the adds, which stay in order.
+// sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of
+// costs_for_factor (ONE accumulator, maxsum.py:651-665).  Straight-line body -- clamped
+// addresses and selects, no branch -- with the reads of the next d requested before the adds
+// of this one, so that only the additions are serial.  (A version that walked (k, d) with a
+// wrap-around counter compiled to a branch and a wait per element: 45 of the kernel's 95 us on
+// meeting_50k, profiles/r03_wide_phases_v1.txt.)
 template <typename T>
 __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
-    const int n = D * deg;
     T sc = (T)0;
-    int d = 0, k = 0;
-    T cur[4], nxt[4];
-    bool cuse[4], nuse[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        const bool ok = u < n;
-        cur[u] = in[ok ? k * D + d : 0];
-        cuse[u] = ok && k != ko;
-        if (ok && ++k == deg) {
-            k = 0;
-            ++d;
+    if (deg <= 4) {  // the whole chain as ONE loop over d, the (up to four) edges side by side
+        const bool u0 = 0 != ko, u1 = 1 < deg && 1 != ko, u2 = 2 < deg && 2 != ko, u3 = 3 < deg && 3 != ko;
+        const T* r0 = in;
+        const T* r1 = in + (1 < deg ? 1 : 0) * D;
+        const T* r2 = in + (2 < deg ? 2 : 0) * D;
+        const T* r3 = in + (3 < deg ? 3 : 0) * D;
+        T x0 = r0[0], x1 = r1[0], x2 = r2[0], x3 = r3[0];
+        for (int d = 0; d < D; ++d) {
+            const int dn = d + 1 < D ? d + 1 : d;
+            const T y0 = r0[dn], y1 = r1[dn], y2 = r2[dn], y3 = r3[dn];
+            sc = u0 ? sc + x0 : sc;
+            sc = u1 ? sc + x1 : sc;
+            sc = u2 ? sc + x2 : sc;
+            sc = u3 ? sc + x3 : sc;
+            x0 = y0, x1 = y1, x2 = y2, x3 = y3;
         }
+        return sc;
     }
-    for (int t = 0; t < n; t += 4) {
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {  // the next group (past the end: a harmless read of in[0])
-            const bool ok = t + 4 + u < n;
-            nxt[u] = in[ok ? k * D + d : 0];
-            nuse[u] = ok && k != ko;
-            if (ok && ++k == deg) {
-                k = 0;
-                ++d;
-            }
+    // degrees above 4: d outer, the edges four at a time
+    for (int d = 0; d < D; ++d)
+        for (int k = 0; k < deg; k += 4) {
+            const T x0 = in[k * D + d];
+            const T x1 = in[(k + 1 < deg ? k + 1 : k) * D + d];
+            const T x2 = in[(k + 2 < deg ? k + 2 : k) * D + d];
+            const T x3 = in[(k + 3 < deg ? k + 3 : k) * D + d];
+            sc = k != ko ? sc + x0 : sc;
+            sc = (k + 1 < deg && k + 1 != ko) ? sc + x1 : sc;
+            sc = (k + 2 < deg && k + 2 != ko) ? sc + x2 : sc;
+            sc = (k + 3 < deg && k + 3 != ko) ? sc + x3 : sc;
         }
-#pragma unroll
-        for (int u = 0; u < 4; ++u)
-            if (cuse[u]) sc += cur[u];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            cur[u] = nxt[u];
-            cuse[u] = nuse[u];
-        }
-    }
     return sc;
 }
 
@@ -1515,6 +1518,9 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+#ifndef MXS_WIDE_SKIP
+#define MXS_WIDE_SKIP 0  // timing experiments only (results wrong): 1 no chains, 2 no message arithmetic,
+#endif                   // 4 no beliefs, 8 no gathers, 16 no stores
 template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const WideBlock* blocks) {
     constexpr int R = WIDE_CAPB / BLOCK;  // elements per thread
@@ -1541,7 +1547,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
         sl[r] = s;
         dd[r] = idx - s * D;
         x[r] = (T)0;
-        if (idx < ne) x[r] = a.f2v_old[a.vslot_f2v[wb.slot0 + s] + dd[r]];
+        if (idx < ne && !(MXS_WIDE_SKIP & 8)) x[r] = a.f2v_old[a.vslot_f2v[wb.slot0 + s] + dd[r]];
     });
     for (int j = tid; j < wb.n_vars; j += BLOCK) {
         const int v = wb.first_var + j;
@@ -1563,11 +1569,11 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     // ---- 2. chains and beliefs --------------------------------------------------------------
     for (int t = tid; t < ns; t += BLOCK) {  // the mean of an outgoing message: its serial chain
         const int j = s_svar[t], k0 = s_vk0[j];
-        s_avg[t] = wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
+        s_avg[t] = (MXS_WIDE_SKIP & 1) ? (T)0 : wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
     }
     for (int i = tid; i < wb.n_vars * D; i += BLOCK) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
         const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
-        s_b[i] = wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
+        s_b[i] = (MXS_WIDE_SKIP & 4) ? s_c[i] : wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
     }
     // the messages sent last: requested before the barrier, used behind it
     int vo[R];
@@ -1606,7 +1612,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
         m[r] = (T)0;
         if (tid + r * BLOCK < ne) {
             const int s = sl[r], j = s_svar[s], k0 = s_vk0[j], deg = s_vdeg[j];
-            T mm = wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
+            T mm = (MXS_WIDE_SKIP & 2) ? s_avg[s] : wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
             if (a.start) {
                 const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
                                          a.start_mode != MXS_START_LEAFS;
@@ -1642,7 +1648,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
             // record is a cache hit)
             T val = m[r];
             if (keep_old) val = a.v2f_old[vo[r]];
-            a.v2f_new[vo[r]] = val;
+            if (!(MXS_WIDE_SKIP & 16)) a.v2f_new[vo[r]] = val;
             if (dd[r] == 0) a.cV[wb.slot0 + s] = (uint8_t)out;
         }
     });

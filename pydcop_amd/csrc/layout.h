@@ -61,6 +61,9 @@ enum Kind : int32_t {
 #define MXS_BLOCK 256  // threads per workgroup of the sweep (other values: experiments only)
 #endif
 constexpr int BLOCK = MXS_BLOCK;
+#ifndef MXS_TILES
+#define MXS_TILES 1  // consecutive tiles of BLOCK items a workgroup of the sweep works on (experiments: 2..4)
+#endif
 #ifndef MXS_FACTORS_SECOND_DEFAULT
 #define MXS_FACTORS_SECOND_DEFAULT 0  // layout_flags bit9 forces it on, bit10 off
 #endif
@@ -148,11 +151,12 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
 // One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME
 // domain size D, cut so that the staged F->V elements (slots * D), the outgoing edges (slots)
 // and the own costs (variables * D) fit the kernel's LDS arrays.  Read with ONE scalar load.
-constexpr int WIDE_CAPB = 2048;       // staged F->V elements per block: 8 per thread
-constexpr int WIDE_MAX_SLOTS = 512;   // outgoing edges (CSR slots) per block
-constexpr int WIDE_MAX_VARS = 256;    // variables per block (their local index fits a byte)
-constexpr int WIDE_MAX_COSTS = 768;   // variables * D per block
-// (f64: 36 KB of LDS per block, four blocks per CU)
+constexpr int WIDE_CAPB = 1024;       // staged F->V elements per block: 4 per thread
+constexpr int WIDE_MAX_SLOTS = 256;   // outgoing edges (CSR slots) per block
+constexpr int WIDE_MAX_VARS = 128;    // variables per block (their local index fits a byte)
+constexpr int WIDE_MAX_COSTS = 384;   // variables * D per block
+// (f64: 18 KB of LDS per block, eight blocks per CU: the phases of a block are chains of
+// dependent loads, what hides them is the number of blocks in flight)
 struct WideBlock {
     int32_t first_var;   // internal id of the first variable
     int32_t n_vars;

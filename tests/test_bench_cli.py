@@ -106,6 +106,11 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     assert algos[0]["messages"] > 0 and algos[0]["messages_per_s"] > 0
     for a in algos[1:]:
         assert a["cycles_per_s"] > 0 and a["cost_now"] <= a["cost_at_start"]
+    for a in algos:   # every widened row with bytes by a stated formula and a fraction of the peak
+        assert a["roofline"]["achieved"] > 0 and 0 < a["roofline"]["frac"] and "formula" in a["roofline"]
+    for c in out["configs"]:  # no fraction of the peak above 1 at the top level of a roofline object
+        if c["roofline"]["bytes_basis"] == "stored":
+            assert c["roofline"]["frac"] == c["roofline"]["frac_of_stored_bytes"] and "frac_algorithmic" in c["roofline"]
     for a in algos:
         assert a["parity_test"].startswith("tests/test_gpu_") and os.path.exists(
             os.path.join(ROOT, a["parity_test"].split("::")[0]))
