@@ -772,27 +772,27 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
         for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
     }
     const ClassInfo ci = a.classes[c];
-    const int item0 = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
+    const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
     if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
-    // a workgroup works on MXS_TILES consecutive tiles of BLOCK items (layout.h; 1 by default)
-#pragma unroll
-    for (int t = 0; t < MXS_TILES; ++t) {
-        const int item = item0 + t * BLOCK;
-        if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
-            const int j = item + (int)threadIdx.x;
-            if (j < ci.count) {
-                if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
-                else variable_generic<T>(a, ci, j);
-            }
-        } else if (DSEL != 0) {
-            sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
-        } else {
-            switch (ci.D) {
-                case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
-                case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
-                case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
-                default: break;
-            }
+    if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
+        const int j = item + (int)threadIdx.x;
+        if (j >= ci.count) return ci.kind;
+        if (ci.kind == K_F_GEN) factor_generic<T>(a, ci, j);
+        else variable_generic<T>(a, ci, j);
+        return ci.kind;
+    }
+    // (Several consecutive tiles per workgroup -- fewer, longer blocks, one generation of them on
+    // the 100k instance -- measured slower everywhere: 2 / 3 / 4 tiles 24.4 / 23.9 / 26.1 us against
+    // 20.5 on coloring_100k, 274 / 277 / 284 against 259 on the 1M instance, 10.3 / 13.6 / 16.5 against
+    // 6.4 on the 10k one: profiles/r03_tiles_ab_v1.txt.)
+    if (DSEL != 0) {
+        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
+    } else {
+        switch (ci.D) {
+            case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
+            case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
+            case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
+            default: break;
         }
     }
     return ci.kind;
@@ -1446,21 +1446,31 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 template <typename T>
 __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
     T sc = (T)0;
-    if (deg <= 4) {  // the whole chain as ONE loop over d, the (up to four) edges side by side
+    if (deg <= 4) {  // the (up to four) edges side by side, FOUR values of d per pass: sixteen reads
+                     // requested together, then the sixteen additions in (d, k) order
         const bool u0 = 0 != ko, u1 = 1 < deg && 1 != ko, u2 = 2 < deg && 2 != ko, u3 = 3 < deg && 3 != ko;
         const T* r0 = in;
         const T* r1 = in + (1 < deg ? 1 : 0) * D;
         const T* r2 = in + (2 < deg ? 2 : 0) * D;
         const T* r3 = in + (3 < deg ? 3 : 0) * D;
-        T x0 = r0[0], x1 = r1[0], x2 = r2[0], x3 = r3[0];
-        for (int d = 0; d < D; ++d) {
-            const int dn = d + 1 < D ? d + 1 : d;
-            const T y0 = r0[dn], y1 = r1[dn], y2 = r2[dn], y3 = r3[dn];
-            sc = u0 ? sc + x0 : sc;
-            sc = u1 ? sc + x1 : sc;
-            sc = u2 ? sc + x2 : sc;
-            sc = u3 ? sc + x3 : sc;
-            x0 = y0, x1 = y1, x2 = y2, x3 = y3;
+        for (int d = 0; d < D; d += 4) {
+            T x[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int di = d + i < D ? d + i : D - 1;
+                x[i][0] = r0[di];
+                x[i][1] = r1[di];
+                x[i][2] = r2[di];
+                x[i][3] = r3[di];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool in_range = d + i < D;
+                sc = (in_range && u0) ? sc + x[i][0] : sc;
+                sc = (in_range && u1) ? sc + x[i][1] : sc;
+                sc = (in_range && u2) ? sc + x[i][2] : sc;
+                sc = (in_range && u3) ? sc + x[i][3] : sc;
+            }
         }
         return sc;
     }

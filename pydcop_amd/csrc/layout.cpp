@@ -423,7 +423,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             }
             for (int j = 0; j < n; ++j) L.f_class[fi + j] = cls;
             L.classes.push_back(ci);
-            sweep_class(cls, BLOCK * MXS_TILES, key.cut || second);
+            sweep_class(cls, BLOCK, key.cut || second);
         } else {
             const int gen_base = (int)L.fgen.size();
             for (int j = 0; j < n; ++j) {
@@ -440,7 +440,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (key.kind == K_F_GEN) {
                 ci.count = L.frowptr[fj] - L.frowptr[fi];  // thread per edge
                 L.classes.push_back(ci);
-                sweep_class(cls, BLOCK * MXS_TILES, key.cut || second);
+                sweep_class(cls, BLOCK, key.cut || second);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
                 const int code = key.D / 4, t = key.D % 4;
                 NaryLaunch nl{code / 256, (code / 16) % 16, (code % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut, t};
@@ -584,7 +584,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.classes[cls].per_block = 1;  // (its grid is wide_blocks.size())
                 L.wide_classes.push_back(cls);
             } else {
-                sweep_class(cls, BLOCK * MXS_TILES);
+                sweep_class(cls, BLOCK);
             }
         }
         vi = vj;

@@ -61,9 +61,7 @@ enum Kind : int32_t {
 #define MXS_BLOCK 256  // threads per workgroup of the sweep (other values: experiments only)
 #endif
 constexpr int BLOCK = MXS_BLOCK;
-#ifndef MXS_TILES
-#define MXS_TILES 1  // consecutive tiles of BLOCK items a workgroup of the sweep works on (experiments: 2..4)
-#endif
+
 #ifndef MXS_FACTORS_SECOND_DEFAULT
 #define MXS_FACTORS_SECOND_DEFAULT 0  // layout_flags bit9 forces it on, bit10 off
 #endif

@@ -101,8 +101,13 @@ def _kernel_scratch(source):
     assert out.returncode == 0, out.stderr[-2000:]
     names = re.findall(r"Function Name: (\S+)", out.stderr)
     scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out.stderr)]
-    assert len(names) == len(scratch)
+    vgprs = [int(x) for x in re.findall(r" VGPRs: (\d+)", out.stderr)]
+    assert len(names) == len(scratch) == len(vgprs)
+    _VGPRS[source] = dict(zip(names, vgprs))
     return list(zip(names, scratch))
+
+
+_VGPRS = {}
 
 
 def test_no_kernel_uses_scratch():
@@ -114,6 +119,11 @@ def test_no_kernel_uses_scratch():
     assert len(ks) >= 20
     bad = [(n, s) for n, s in ks if s != 0]
     assert not bad, f"kernels using scratch: {bad}"
+    # the sweep's register budget: 7 waves per SIMD (<= 72 VGPRs) for the metric's
+    # instantiation, both cache policies (a restructured block loop once cost 12 registers and
+    # 3 % of the metric without anything else noticing)
+    sweep = {n: v for n, v in _VGPRS["engine.hip"].items() if "7k_sweepIdLi3ELi" in n}   # <double, D = 3, policy>
+    assert len(sweep) == 2 and max(sweep.values()) <= 72, sweep
 
 
 @pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6)])
