@@ -82,7 +82,29 @@ struct Piece16 {  // 16 bytes, moved with one instruction
 template <typename T, int ELEMS, int NT = MXS_NT>
 __device__ __forceinline__ void wave_store_linear(T* arr, int64_t wave_base, const T (&vals)[ELEMS]) {
     constexpr bool NT_STORE = (NT & 8) != 0;
-    static_assert(ELEMS * sizeof(T) % 16 == 0 && 64 * ELEMS * sizeof(T) <= STAGE_BYTES_PER_WAVE, "");
+    static_assert(64 * ELEMS * sizeof(T) % 16 == 0 && 64 * ELEMS * sizeof(T) <= STAGE_BYTES_PER_WAVE, "");
+    if constexpr (ELEMS * sizeof(T) % 16 != 0) {
+        // records that are no multiple of 16 bytes (unpadded D = 3: 24 / 12 bytes): the wave's 64
+        // records are still ONE contiguous run of 64 * ELEMS * sizeof(T) bytes (the wave base is
+        // 16-byte aligned: a class starts on 32 bytes and 64 records are a multiple of 16); 16-byte
+        // pieces, the last instruction with part of the lanes
+        const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
+        char* so = (char*)g_stage[w];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int d = 0; d < ELEMS; ++d) ((T*)so)[l * ELEMS + d] = vals[d];
+        __builtin_amdgcn_wave_barrier();
+        char* out = (char*)(arr + wave_base);
+        constexpr int BYTES = 64 * ELEMS * (int)sizeof(T), FULL = BYTES / 1024, REST = (BYTES % 1024) / 16;
+#pragma unroll
+        for (int k = 0; k < FULL; ++k)
+            *(Piece16*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16) =
+                *(const Piece16*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16);
+        if (REST > 0 && l < REST)
+            *(Piece16*)__builtin_assume_aligned(out + FULL * 1024 + l * 16, 16) =
+                *(const Piece16*)__builtin_assume_aligned(so + FULL * 1024 + l * 16, 16);
+        return;
+    }
     const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
     char* so = (char*)g_stage[w];
     __builtin_amdgcn_wave_barrier();  // the previous use of the staging area is over
@@ -223,7 +245,7 @@ __device__ __forceinline__ uint8_t damp_and_filter(T (&m)[D], const T (&prev)[D]
 template <typename T, int D>
 struct Msg {
     static constexpr int H = half_stride(D, (int)sizeof(T));
-    static constexpr int ALIGN = H * (int)sizeof(T) >= 16 ? 16 : 8;
+    static constexpr int ALIGN = (H * (int)sizeof(T)) % 16 == 0 ? 16 : ((H * (int)sizeof(T)) % 8 == 0 ? 8 : 4);
     template <bool NT = false>
     static __device__ __forceinline__ void load(const T* p, T (&m)[D]) {
         const T* q = (const T*)__builtin_assume_aligned(p, ALIGN);
@@ -412,7 +434,7 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
         c1 = damp_and_filter<T, D>(o1, p1, cn1, a.damp_f != 0, a.damping, a.stability);
     }
     const int lw = (int)threadIdx.x & 63;
-    if constexpr ((H * sizeof(T)) % 16 == 0) {
+    if constexpr ((64 * H * sizeof(T)) % 16 == 0) {
         if ((j - lw + 63) < ci.count) {  // wave-uniform: a whole wave of factors
             T full[H];
 #pragma unroll
@@ -615,7 +637,7 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
         }
         Msg<T, D>::store_c(dst, m, CIM ? co : 0);
     }
-    if constexpr ((H * sizeof(T)) % 16 == 0) {  // the whole wave is here (count is a multiple of 64)
+    if constexpr ((64 * H * sizeof(T)) % 16 == 0) {  // the whole wave is here (count is a multiple of 64)
         T full[H];
 #pragma unroll
         for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(m, CIM ? co : 0, d);
@@ -1438,54 +1460,33 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // ---------------------------------------------------------------------------
 
 // sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of
-// costs_for_factor (ONE accumulator, maxsum.py:651-665).  Straight-line body -- clamped
-// addresses and selects, no branch -- with the reads of the next d requested before the adds
-// of this one, so that only the additions are serial.  (A version that walked (k, d) with a
-// wrap-around counter compiled to a branch and a wait per element: 45 of the kernel's 95 us on
-// meeting_50k, profiles/r03_wide_phases_v1.txt.)
+// costs_for_factor (ONE accumulator, maxsum.py:651-665).  The D * deg terms are walked as one
+// sequence, SIXTEEN per pass: their addresses with select arithmetic (no branch, the same code for
+// every degree -- the lanes of a wave hold chains of different degrees), sixteen reads requested
+// together, then the sixteen additions in order.  (Versions that branched on the degree or on
+// the wrap-around of k cost 24 to 45 of the kernel's 65 to 95 us on meeting_50k: one wave per block
+// walks the chains while the others wait, so the SLOWEST lane's path is what a block pays;
+// profiles/r03_wide_phases_v*.txt.)
 template <typename T>
 __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
+    const int n = D * deg;
     T sc = (T)0;
-    if (deg <= 4) {  // the (up to four) edges side by side, FOUR values of d per pass: sixteen reads
-                     // requested together, then the sixteen additions in (d, k) order
-        const bool u0 = 0 != ko, u1 = 1 < deg && 1 != ko, u2 = 2 < deg && 2 != ko, u3 = 3 < deg && 3 != ko;
-        const T* r0 = in;
-        const T* r1 = in + (1 < deg ? 1 : 0) * D;
-        const T* r2 = in + (2 < deg ? 2 : 0) * D;
-        const T* r3 = in + (3 < deg ? 3 : 0) * D;
-        for (int d = 0; d < D; d += 4) {
-            T x[4][4];
+    int d = 0, k = 0;
+    for (int t = 0; t < n; t += 16) {
+        T x[16];
+        bool use[16];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int di = d + i < D ? d + i : D - 1;
-                x[i][0] = r0[di];
-                x[i][1] = r1[di];
-                x[i][2] = r2[di];
-                x[i][3] = r3[di];
-            }
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool in_range = d + i < D;
-                sc = (in_range && u0) ? sc + x[i][0] : sc;
-                sc = (in_range && u1) ? sc + x[i][1] : sc;
-                sc = (in_range && u2) ? sc + x[i][2] : sc;
-                sc = (in_range && u3) ? sc + x[i][3] : sc;
-            }
+        for (int u = 0; u < 16; ++u) {
+            const bool ok = t + u < n;
+            x[u] = in[ok ? k * D + d : 0];
+            use[u] = ok && k != ko;
+            const bool wrap = k + 1 == deg;
+            k = wrap ? 0 : k + 1;
+            d += wrap ? 1 : 0;
         }
-        return sc;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) sc = use[u] ? sc + x[u] : sc;
     }
-    // degrees above 4: d outer, the edges four at a time
-    for (int d = 0; d < D; ++d)
-        for (int k = 0; k < deg; k += 4) {
-            const T x0 = in[k * D + d];
-            const T x1 = in[(k + 1 < deg ? k + 1 : k) * D + d];
-            const T x2 = in[(k + 2 < deg ? k + 2 : k) * D + d];
-            const T x3 = in[(k + 3 < deg ? k + 3 : k) * D + d];
-            sc = k != ko ? sc + x0 : sc;
-            sc = (k + 1 < deg && k + 1 != ko) ? sc + x1 : sc;
-            sc = (k + 2 < deg && k + 2 != ko) ? sc + x2 : sc;
-            sc = (k + 3 < deg && k + 3 != ko) ? sc + x3 : sc;
-        }
     return sc;
 }
 
