@@ -88,6 +88,10 @@ struct Dev {
     int32_t* cur_out;
     T* cost;
     lsearch::Slots slots;
+    lsearch::Pack pack;          // the packed view (local_search.h): lane per (variable, constraint)
+    const T* pack_fopt;          // [lanes] optimum of the lane's constraint (variant B)
+    const int32_t* var_list;     // the variables a thread-per-variable launch works on (NULL: all)
+    int32_t n_list;
 };
 
 template <typename T>
@@ -112,8 +116,9 @@ __device__ T assignment_cost(const Dev<T>& g, int v, int x) {
 // evaluate_cycle, dsa.py:319-359 + variant_a/b/c :361-409 + probabilistic_change :411-419
 template <typename T>
 __global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
     const int mine = g.cur[v];
     int out = mine;
     if (g.n_neigh[v] != 0) {
@@ -173,8 +178,9 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
 // variable's constraints instead of 2D+1 CSR walks; domains of at most MAXD values
 template <typename T, int MAXD>
 __global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
     const int mine = g.cur[v];
     int out = mine;
     if (g.n_neigh[v] != 0) {
@@ -236,6 +242,85 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
     g.cur_out[v] = out;
 }
 
+// the same cycle on the PACKED view (local_search.h): one lane per (variable, constraint), the
+// constraint's entries for the neighbour's current value from the lane's private transposed
+// record, the D costs by cross-lane sums in slot order; every lane of a variable then takes the
+// same decision, lane k = 0 writes it.  TT = int8_t (records of small integers) or T.
+constexpr int PACK_TPB = 256;
+template <typename T, typename TT>
+__global__ void __launch_bounds__(PACK_TPB) k_dsa_cycle_pack(Dev<T> g) {
+    constexpr int MAXD = lsearch::PACK_D;
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= g.pack.n_lanes) return;  // whole waves (n_lanes is a multiple of 64)
+    const lsearch::PackWave wm = g.pack.waves[__builtin_amdgcn_readfirstlane((int)(pos >> 6))];
+    const uint32_t dn = (uint32_t)wm.deg_nv;
+    const int deg = (int)(dn & 255u), nv = (int)((dn >> 8) & 255u);
+    const int l = (int)threadIdx.x & 63;
+    const int var = (int)(((uint32_t)l * (dn >> 16)) >> 15);  // l / deg (exact for l < 64)
+    const int k = l - var * deg;
+    const bool has = var < nv;
+    const int v = g.pack.vars[wm.first + (has ? var : 0)];
+    const int seg = l - k;
+    const int mine = g.cur[v];
+    const int D = g.dom_size[v];
+    T t[MAXD], c[MAXD];
+    lsearch::pack_costs<T, TT>(g.pack, g.cur, pos, deg, seg, true, t, c);
+    T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;   // find_optimal, relations.py:1622-1638
+    int n_best = 0, first_best = -1;
+    bool has_cur = false;
+#pragma unroll
+    for (int x = 0; x < MAXD; ++x)
+        if (x < D) {
+            if (c[x] == best_cost) {
+                n_best += 1;
+                if (x == mine) has_cur = true;
+            } else if ((!g.is_max && c[x] < best_cost) || (g.is_max && c[x] > best_cost)) {
+                best_cost = c[x];
+                n_best = 1;
+                first_best = x;
+                has_cur = x == mine;
+            }
+        }
+    const T diff = lsearch::pick<T, MAXD>(c, mine) - best_cost;
+    const T delta = diff < (T)0 ? -diff : diff;
+    // variant B (dsa.py:421-433): some constraint of the variable is not at its optimum -- the
+    // lanes of the variable vote (a padding lane has no constraint)
+    bool off_opt = false;
+    if (g.variant == 1 && has) off_opt = lsearch::pick<T, MAXD>(t, mine) != g.pack_fopt[pos];
+    const unsigned long long votes = __ballot(off_opt ? 1 : 0);
+    const unsigned long long mine_mask = (deg >= 64 ? ~0ull : ((1ull << deg) - 1ull)) << seg;
+    bool attempt = false, drop_cur = false;
+    if (delta > (T)0) {
+        attempt = true;
+    } else if (delta == (T)0) {
+        if (g.variant == 1) attempt = (votes & mine_mask) != 0ull;
+        else if (g.variant == 2) attempt = true;
+        if (attempt && n_best > 1 && has_cur) drop_cur = true;  // best_values.remove(current_value)
+    }
+    int out = mine;
+    bool moved = false;
+    if (attempt && g.prob[v] > uniform(g.seed, v, g.cycle + 1, 1)) {
+        const int n = n_best - (drop_cur ? 1 : 0);
+        int j = (int)(uniform(g.seed, v, g.cycle + 1, 2) * n);
+        int pick = first_best;
+        bool done = false;
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x)
+            if (x < D && !done && c[x] == best_cost && !(drop_cur && x == mine)) {
+                if (j-- == 0) {
+                    pick = x;
+                    done = true;
+                }
+            }
+        out = pick;
+        moved = true;
+    }
+    if (has && k == 0) {
+        g.cur_out[v] = out;
+        if (moved) g.cost[v] = best_cost;  // value_selection(choice, best_cost)
+    }
+}
+
 struct Base {
     virtual ~Base() {}
     virtual int init(const mxs_graph& G, const mxs_params& p, int variant, double probability, int arity_mode,
@@ -264,6 +349,12 @@ struct Engine : Base {
     Buf<double> prob;
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
+    Buf<lsearch::PackWave> pk_waves;
+    Buf<int32_t> pk_vars, pk_nb, pk_slot, pk_rest;
+    Buf<int8_t> pk_rec8;
+    Buf<T> pk_recT, pk_fopt;
+    bool pack_int8 = false;
+    int n_rest = 0;
     int max_dom = 0;
 
     ~Engine() override {
@@ -330,6 +421,34 @@ struct Engine : Base {
         if (!bad.empty()) return fail(MXS_E_INVALID, bad);
         max_dom = 0;
         for (int v = 0; v < nV; ++v) max_dom = h_dom[v] > max_dom ? h_dom[v] : max_dom;
+        {   // the packed view of the variables it can take (local_search.h); the others -- constraints of
+            // arity > 2, larger domains, degrees above 64 -- stay on the thread-per-variable kernel
+            lsearch::HostPack hp;
+            hp.build(nV, h_dom, vrow, h_nn, hs, h_tables);
+            std::vector<T> fopt_lane(hp.slot.size(), (T)0);
+            for (size_t i = 0; i < hp.slot.size(); ++i)
+                if (hp.slot[i] >= 0) fopt_lane[i] = fo[efac[vedges[hp.slot[i]]]];
+            pack_int8 = hp.int8_exact;
+            if (pack_int8) {
+                std::vector<int8_t> r8(hp.rec.size());
+                for (size_t i = 0; i < r8.size(); ++i) r8[i] = (int8_t)hp.rec[i];
+                DSA_TRY(pk_rec8.upload(r8, stream));
+            } else {
+                std::vector<T> rt(hp.rec.size());
+                for (size_t i = 0; i < rt.size(); ++i) rt[i] = (T)hp.rec[i];
+                DSA_TRY(pk_recT.upload(rt, stream));
+            }
+            DSA_TRY(pk_waves.upload(hp.waves, stream));
+            DSA_TRY(pk_vars.upload(hp.vars, stream));
+            DSA_TRY(pk_nb.upload(hp.nb, stream));
+            DSA_TRY(pk_slot.upload(hp.slot, stream));
+            DSA_TRY(pk_rest.upload(hp.rest, stream));
+            DSA_TRY(pk_fopt.upload(fopt_lane, stream));
+            n_rest = (int)hp.rest.size();
+            g.pack = lsearch::Pack{pk_waves.p, pk_vars.p, pk_nb.p, pk_slot.p,
+                                   pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
+            g.pack_fopt = pk_fopt.p;
+        }
         DSA_TRY(sl_base.upload(hs.base, stream));
         DSA_TRY(sl_stride_v.upload(hs.stride_v, stream));
         DSA_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
@@ -386,6 +505,8 @@ struct Engine : Base {
         which = 0;
         if (nV) {
             DSA_TRY(hipMemcpyAsync(cur[0].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
+            // (both buffers: the packed launch writes only the variables that have neighbours)
+            DSA_TRY(hipMemcpyAsync(cur[1].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
             DSA_TRY(hipMemcpyAsync(cost.p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
             DSA_TRY(hipStreamSynchronize(stream));
         }
@@ -400,19 +521,32 @@ struct Engine : Base {
             cycles += n > 0 ? n : 0;
             return MXS_OK;
         }
-        const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
-        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernel (A/B, tests)
-        const bool generic = env && env[0] == '1';
+        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernel, =2: the slot
+        const bool generic = env && env[0] == '1';                     // kernel for every variable (A/B, tests)
+        const bool packed = !generic && !(env && env[0] == '2') && g.pack.n_lanes > 0;
         for (int32_t r = 0; r < n; ++r) {
             g.cur = cur[which].p;
             g.cur_out = cur[which ^ 1].p;
             g.cycle = cycles;
-            if (generic || max_dom > 32) hipLaunchKernelGGL((k_dsa_cycle<T>), grid, block, 0, stream, g);
-            else if (max_dom <= 4) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 4>), grid, block, 0, stream, g);
-            else if (max_dom <= 8) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 8>), grid, block, 0, stream, g);
-            else if (max_dom <= 16) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 16>), grid, block, 0, stream, g);
-            else hipLaunchKernelGGL((k_dsa_cycle_slots<T, 32>), grid, block, 0, stream, g);
-            DSA_TRY(hipGetLastError());
+            g.var_list = nullptr;
+            g.n_list = nV;
+            if (packed) {
+                const dim3 pgrid((unsigned)((g.pack.n_lanes + PACK_TPB - 1) / PACK_TPB)), pblock(PACK_TPB);
+                if (pack_int8) hipLaunchKernelGGL((k_dsa_cycle_pack<T, int8_t>), pgrid, pblock, 0, stream, g);
+                else hipLaunchKernelGGL((k_dsa_cycle_pack<T, T>), pgrid, pblock, 0, stream, g);
+                DSA_TRY(hipGetLastError());
+                g.var_list = pk_rest.p;
+                g.n_list = n_rest;
+            }
+            if (g.n_list > 0) {
+                const dim3 grid((unsigned)((g.n_list + TPB - 1) / TPB)), block(TPB);
+                if (generic || max_dom > 32) hipLaunchKernelGGL((k_dsa_cycle<T>), grid, block, 0, stream, g);
+                else if (max_dom <= 4) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 4>), grid, block, 0, stream, g);
+                else if (max_dom <= 8) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 8>), grid, block, 0, stream, g);
+                else if (max_dom <= 16) hipLaunchKernelGGL((k_dsa_cycle_slots<T, 16>), grid, block, 0, stream, g);
+                else hipLaunchKernelGGL((k_dsa_cycle_slots<T, 32>), grid, block, 0, stream, g);
+                DSA_TRY(hipGetLastError());
+            }
             which ^= 1;
             cycles += 1;
         }

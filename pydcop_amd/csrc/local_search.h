@@ -14,6 +14,7 @@
 #pragma once
 #include <algorithm>
 #include <climits>
+#include <cmath>
 #include <cstdint>
 #include <string>
 #include <vector>
@@ -138,6 +139,119 @@ __device__ inline void costs_of_values(const Slots& sl, const T* __restrict__ ta
 #pragma unroll
                 for (int x = 0; x < MAXD; ++x) c[x] = first ? t[i][x] : c[x] + t[i][x];
             }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The PACKED view: one LANE per (variable, constraint) slot, for variables whose every constraint
+// is unary or binary over domains of at most PACK_D values (graph colouring, Ising, most
+// benchmark families).  Like the packed variable class of the Max-Sum sweep (kernels.h,
+// variable_pack): the variables are grouped by degree, a wave holds floor(64 / deg) of them side
+// by side (lane = var_in_wave * deg + k), and everything a lane needs is laid out in LANE order:
+//   * nb[lane]      the other variable of the lane's constraint (-1: none),
+//   * a PRIVATE, TRANSPOSED copy of the constraint's table, rec[lane][y][x] = the entry for the
+//     neighbour's value y and the own value x -- the PACK_D entries the lane needs for the
+//     neighbour's current value are ONE aligned row (4 bytes when every entry of every table is a
+//     small integer and the records are int8, else PACK_D elements of T), inside a record that the
+//     wave's neighbouring lanes stream through anyway.
+// The thread-per-variable kernels gather, per constraint, a slot record, the neighbour's value and
+// D table entries at a stride -- three to five random 64-byte requests; here the only random access
+// left is the neighbour's value (an array of 4 bytes per variable: L2-resident).  Sums over a
+// variable's constraints are cross-lane reads in slot order: the reference's order, bit for bit.
+constexpr int PACK_D = 4;
+struct PackWave {
+    int32_t first;    // index of the wave's first variable in Pack::vars
+    int32_t deg_nv;   // deg | nv << 8 | ceil(2^15 / deg) << 16
+};
+struct Pack {  // device pointers
+    const PackWave* waves;
+    const int32_t* vars;   // the packed variables, wave after wave
+    const int32_t* nb;     // [lanes]
+    const int32_t* slot;   // [lanes] CSR slot of the lane, -1 = padding lane
+    const void* rec;       // [lanes][PACK_D][PACK_D] int8 or T
+    int32_t n_lanes;
+};
+struct HostPack {
+    std::vector<PackWave> waves;
+    std::vector<int32_t> vars, nb, slot, rest;  // rest: variables with neighbours the pack cannot take
+    std::vector<double> rec;                    // [lanes * 16], as doubles; narrowed at upload
+    bool int8_exact = true;
+
+    void build(int nV, const std::vector<int32_t>& dom, const std::vector<int32_t>& vrow, const std::vector<int32_t>& n_neigh,
+               const HostSlots& hs, const std::vector<double>& tables) {
+        std::vector<std::vector<int>> by_deg(65);
+        for (int v = 0; v < nV; ++v) {
+            if (n_neigh[v] == 0) continue;  // never moves (dsa.py:278-289, mgm.py:335): no work
+            const int deg = vrow[v + 1] - vrow[v];
+            bool ok = dom[v] <= PACK_D && deg >= 1 && deg <= 64;
+            for (int s = vrow[v]; ok && s < vrow[v + 1]; ++s) {
+                const int n_nb = hs.nb_rowptr[s + 1] - hs.nb_rowptr[s];
+                if (n_nb > 1 || (n_nb == 1 && dom[hs.nb0_var[s]] > PACK_D)) ok = false;
+            }
+            if (ok) by_deg[deg].push_back(v);
+            else rest.push_back(v);
+        }
+        for (int deg = 1; deg <= 64; ++deg) {
+            const std::vector<int>& vs = by_deg[deg];
+            const int per_wave = 64 / deg;
+            for (size_t x = 0; x < vs.size(); x += per_wave) {
+                const int nv = (int)std::min<size_t>(per_wave, vs.size() - x);
+                waves.push_back(PackWave{(int32_t)vars.size(), (int32_t)((uint32_t)deg | ((uint32_t)nv << 8) |
+                                                                          ((uint32_t)((32768 + deg - 1) / deg) << 16))});
+                for (int i = 0; i < nv; ++i) vars.push_back(vs[x + i]);
+                for (int lane = 0; lane < 64; ++lane) {
+                    const int var = lane / deg, k = lane % deg;
+                    if (var >= nv) {
+                        nb.push_back(-1);
+                        slot.push_back(-1);
+                        rec.insert(rec.end(), PACK_D * PACK_D, 0.0);
+                        continue;
+                    }
+                    const int v = vs[x + var], s = vrow[v] + k;
+                    const bool has_nb = hs.nb_rowptr[s + 1] > hs.nb_rowptr[s];
+                    const int u = has_nb ? hs.nb0_var[s] : -1;
+                    nb.push_back(u);
+                    slot.push_back(s);
+                    for (int y = 0; y < PACK_D; ++y)
+                        for (int xx = 0; xx < PACK_D; ++xx) {
+                            double e = 0.0;
+                            if (xx < dom[v] && y < (has_nb ? dom[u] : 1))
+                                e = tables[hs.base[s] + (int64_t)xx * hs.stride_v[s] + (has_nb ? (int64_t)y * hs.nb0_stride[s] : 0)];
+                            rec.push_back(e);
+                            if (!(e >= -128.0 && e <= 127.0 && e == (double)(int)e) || (e == 0.0 && std::signbit(e)))
+                                int8_exact = false;
+                        }
+                }
+            }
+        }
+    }
+};
+
+// The PACK_D costs of the lane's variable, c[x] = sum over its constraints in slot order of the
+// entry at (x, neighbour's current value); `from_zero` as in costs_of_values.  t[] = the lane's own
+// row (what its constraint contributes).  All 64 lanes take part (padding lanes read record zeros).
+template <typename T, typename TT>
+__device__ inline void pack_costs(const Pack& pk, const int32_t* __restrict__ cur, int64_t pos, int deg, int seg,
+                                  bool from_zero, T (&t)[PACK_D], T (&c)[PACK_D]) {
+    const int u = pk.nb[pos];
+    const int y = u >= 0 ? cur[u] : 0;
+    if constexpr (sizeof(TT) == 1) {
+        const uint32_t w = *(const uint32_t*)((const uint8_t*)pk.rec + pos * (PACK_D * PACK_D) + y * PACK_D);
+#pragma unroll
+        for (int x = 0; x < PACK_D; ++x) t[x] = (T)(int)(int8_t)(uint8_t)(w >> (8 * x));
+    } else {
+        const T* r = (const T*)pk.rec + pos * (PACK_D * PACK_D) + y * PACK_D;
+#pragma unroll
+        for (int x = 0; x < PACK_D; ++x) t[x] = r[x];
+    }
+#pragma unroll
+    for (int x = 0; x < PACK_D; ++x) {
+        T acc = (T)0;
+        for (int kk = 0; kk < deg; ++kk) {
+            const T e = __shfl(t[x], seg + kk, 64);
+            acc = (!from_zero && kk == 0) ? e : acc + e;
+        }
+        c[x] = acc;
     }
 }
 

@@ -24,3 +24,14 @@ def test_dsa_emu_csr_walk_kernel(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
     name, make, kw, dsa_kw = case
     compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw, lib_path=build(), steps=(0, 1, 3, 6))
+
+
+@pytest.mark.parametrize("case", dsa_cases(k=4)[:6], ids=lambda c: c[0])
+def test_dsa_emu_slot_kernel_everywhere(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=2: the thread-per-variable slot kernel also for the variables the
+    packed (lane per constraint) kernel takes by default."""
+    from emu.build_emu import build
+    from oracle.dsa_oracle import OracleDsa
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
+    name, make, kw, dsa_kw = case
+    compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw, lib_path=build(), steps=(0, 1, 3, 6))

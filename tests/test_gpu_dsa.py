@@ -38,3 +38,13 @@ def test_dsa_csr_walk_kernel(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
     name, make, kw, dsa_kw = case
     compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw)
+
+
+@pytest.mark.parametrize("case", dsa_cases()[:6], ids=lambda c: c[0])
+def test_dsa_slot_kernel_everywhere(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=2: the thread-per-variable slot kernel also for the variables the
+    packed (lane per constraint) kernel takes by default."""
+    from oracle.dsa_oracle import OracleDsa
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
+    name, make, kw, dsa_kw = case
+    compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw)
