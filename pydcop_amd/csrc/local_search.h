@@ -174,6 +174,7 @@ struct Pack {  // device pointers
 struct HostPack {
     std::vector<PackWave> waves;
     std::vector<int32_t> vars, nb, slot, rest;  // rest: variables with neighbours the pack cannot take
+    std::vector<int32_t> lane_var, lane_k, lane_deg;  // [lanes] the lane's variable (-1: padding), position, degree
     std::vector<double> rec;                    // [lanes * 16], as doubles; narrowed at upload
     bool int8_exact = true;
 
@@ -201,6 +202,9 @@ struct HostPack {
                 for (int i = 0; i < nv; ++i) vars.push_back(vs[x + i]);
                 for (int lane = 0; lane < 64; ++lane) {
                     const int var = lane / deg, k = lane % deg;
+                    lane_var.push_back(var < nv ? vs[x + var] : -1);
+                    lane_k.push_back(k);
+                    lane_deg.push_back(deg);
                     if (var >= nv) {
                         nb.push_back(-1);
                         slot.push_back(-1);

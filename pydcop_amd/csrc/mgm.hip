@@ -75,6 +75,11 @@ struct Dev {
     T* gain;
     int32_t* newv;
     lsearch::Slots slots;
+    lsearch::Pack pack;          // the packed view (local_search.h): lane per (variable, constraint)
+    const int32_t* pack_conc;    // [lanes] element k of the variable's concerned-variables list, -1 = none
+    const int32_t* pack_conc_x;  // [lanes] lane k = 0: element `deg` of that list (it has at most deg + 1), else -1
+    const int32_t* var_list;     // the variables a thread-per-variable launch works on (NULL: all)
+    int32_t n_list;
 };
 
 // c.slice(neighbours' values)(x): the table entry with v at x, every other scope variable at its value
@@ -124,8 +129,10 @@ __device__ T add_concerned_costs(const Dev<T>& g, int v, T acc) {
 
 template <typename T>
 __global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars || g.n_neigh[v] == 0) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
+    if (g.n_neigh[v] == 0) return;
     T cost = cost_rw[v];
     if (!g.has_cost[v]) {  // first round: the cost of the current value (mgm.py:349-372)
         cost = add_concerned_costs(g, v, utilities_at(g, v, g.cur[v]));
@@ -149,8 +156,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
 
 template <typename T>
 __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
     int cur = g.cur[v];
     T cost = g.cost[v];
     if (g.n_neigh[v] != 0) {
@@ -198,8 +206,10 @@ __device__ T add_concerned_costs_listed(const Dev<T>& g, int v, T acc) {
 
 template <typename T, int MAXD>
 __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars || g.n_neigh[v] == 0) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
+    if (g.n_neigh[v] == 0) return;
     const int D = g.dom_size[v];
     T c[MAXD];
     lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, g.var_rowptr[v], g.var_rowptr[v + 1], D, false, c);
@@ -225,8 +235,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
 
 template <typename T>
 __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
-    const int v = blockIdx.x * blockDim.x + threadIdx.x;
-    if (v >= g.n_vars) return;
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= g.n_list) return;
+    const int v = g.var_list ? g.var_list[tid] : tid;
     int cur = g.cur[v];
     T cost = g.cost[v];
     if (g.n_neigh[v] != 0) {
@@ -257,6 +268,135 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
     g.cost_out[v] = cost;
 }
 
+// ---- the same two kernels on the PACKED view (local_search.h): one lane per (variable, constraint) ----
+// What a lane holds of its variable's concerned-variables list (ascending, the variable included; at most
+// deg + 1 entries): element k, and on lane k = 0 also element deg.
+constexpr int PACK_TPB = 256;
+struct PackLane {
+    int deg, nv, var, k, seg, v;
+    bool has;
+};
+template <typename T>
+__device__ inline PackLane pack_lane(const Dev<T>& g, int64_t pos) {
+    const lsearch::PackWave wm = g.pack.waves[__builtin_amdgcn_readfirstlane((int)(pos >> 6))];
+    const uint32_t dn = (uint32_t)wm.deg_nv;
+    PackLane p;
+    p.deg = (int)(dn & 255u);
+    p.nv = (int)((dn >> 8) & 255u);
+    const int l = (int)threadIdx.x & 63;
+    p.var = (int)(((uint32_t)l * (dn >> 16)) >> 15);
+    p.k = l - p.var * p.deg;
+    p.has = p.var < p.nv;
+    p.seg = l - p.k;
+    p.v = g.pack.vars[wm.first + (p.has ? p.var : 0)];
+    return p;
+}
+
+// acc + cost_for_val of every concerned variable at its current value, in list order: each lane
+// fetches ITS element (the fetches of a variable's lanes are in flight together), the additions
+// then run in order through cross-lane reads -- every lane of the variable ends with the same sum
+template <typename T>
+__device__ inline T pack_add_concerned(const Dev<T>& g, const PackLane& p, int64_t pos, T acc) {
+    const int u = g.pack_conc[pos], ux = g.pack_conc_x[pos];
+    T w = (T)0, wx = (T)0;
+    if (u >= 0) w = g.var_cost[g.cost_off[u] + g.cur[u]];
+    if (ux >= 0) wx = g.var_cost[g.cost_off[ux] + g.cur[ux]];
+    for (int i = 0; i < p.deg; ++i) {
+        const T e = __shfl(w, p.seg + i, 64);
+        const int ui = __shfl(u, p.seg + i, 64);
+        if (ui >= 0) acc += e;
+    }
+    const T ex = __shfl(wx, p.seg, 64);
+    const int uxi = __shfl(ux, p.seg, 64);
+    if (uxi >= 0) acc += ex;
+    return acc;
+}
+
+template <typename T, typename TT>
+__global__ void __launch_bounds__(PACK_TPB) k_mgm_gain_pack(Dev<T> g, T* cost_rw) {
+    constexpr int MAXD = lsearch::PACK_D;
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= g.pack.n_lanes) return;  // whole waves
+    const PackLane p = pack_lane(g, pos);
+    const int v = p.v, D = g.dom_size[v], mine = g.cur[v];
+    T t[MAXD], c[MAXD];
+    lsearch::pack_costs<T, TT>(g.pack, g.cur, pos, p.deg, p.seg, false, t, c);
+    T cost = cost_rw[v];
+    const bool first_round = !g.has_cost[v];
+    // (wave-uniform in practice: every variable gets its cost in the first round)
+    if (__ballot(first_round ? 1 : 0) != 0ull) {
+        const T c0 = pack_add_concerned(g, p, pos, lsearch::pick<T, MAXD>(c, mine));
+        if (first_round) cost = c0;
+    }
+    T best = c[0];
+    int best_x = 0;
+#pragma unroll
+    for (int x = 1; x < MAXD; ++x)
+        if (x < D && (g.is_max ? best < c[x] : best > c[x])) {
+            best = c[x];
+            best_x = x;
+        }
+    const T val_cost = pack_add_concerned(g, p, pos, best);  // own cost at the CURRENT value (mgm.py:449-450)
+    const T gain = cost - val_cost;
+    if (p.has && p.k == 0) {
+        if (first_round) {
+            cost_rw[v] = cost;
+            g.has_cost[v] = 1;
+        }
+        g.gain[v] = gain;
+        g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : mine;
+    }
+}
+
+template <typename T>
+__global__ void __launch_bounds__(PACK_TPB) k_mgm_move_pack(Dev<T> g) {
+    const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (pos >= g.pack.n_lanes) return;
+    const PackLane p = pack_lane(g, pos);
+    const int v = p.v, my_rank = g.name_rank[v];
+    // the largest gain among the OTHER concerned variables and whether a lower name holds it
+    // (max() also in max mode, mgm.py:513; lexic ties :566-588): order-independent
+    const int u = g.pack_conc[pos], ux = g.pack_conc_x[pos];
+    T gu = (T)0, gx = (T)0;
+    bool lu = false, lx = false;
+    const bool on = u >= 0 && u != v, onx = ux >= 0 && ux != v;
+    if (on) {
+        gu = g.gain[u];
+        lu = g.name_rank[u] < my_rank;
+    }
+    if (onx) {
+        gx = g.gain[ux];
+        lx = g.name_rank[ux] < my_rank;
+    }
+    T max_n = (T)0;
+    bool first = true, wins_tie = true;
+    for (int i = 0; i <= p.deg; ++i) {  // element deg = the extra one of lane k = 0
+        const int src = i < p.deg ? p.seg + i : p.seg;
+        const T e = i < p.deg ? __shfl(gu, src, 64) : __shfl(gx, src, 64);
+        const int live = i < p.deg ? __shfl(on ? 1 : 0, src, 64) : __shfl(onx ? 1 : 0, src, 64);
+        const int lower = i < p.deg ? __shfl(lu ? 1 : 0, src, 64) : __shfl(lx ? 1 : 0, src, 64);
+        if (!live) continue;
+        if (first || e > max_n) {
+            max_n = e;
+            wins_tie = !lower;
+        } else if (e == max_n && lower) {
+            wins_tie = false;
+        }
+        first = false;
+    }
+    if (p.has && p.k == 0) {
+        int cur = g.cur[v];
+        T cost = g.cost[v];
+        const T gain = g.gain[v];
+        if (gain > max_n || (gain == max_n && wins_tie)) {  // :514-525
+            cur = g.newv[v];
+            cost = cost - gain;
+        }
+        g.cur_out[v] = cur;
+        g.cost_out[v] = cost;
+    }
+}
+
 struct Base {
     virtual ~Base() {}
     virtual int init(const mxs_graph& G, const mxs_params& p, const int32_t* rank, int device) = 0;
@@ -285,6 +425,12 @@ struct Engine : Base {
     Buf<uint8_t> has_cost;
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
+    Buf<lsearch::PackWave> pk_waves;
+    Buf<int32_t> pk_vars, pk_nb, pk_slot, pk_rest, pk_conc, pk_conc_x;
+    Buf<int8_t> pk_rec8;
+    Buf<T> pk_recT;
+    bool pack_int8 = false;
+    int n_rest = 0;
     int max_dom = 0;
 
     ~Engine() override {
@@ -351,6 +497,41 @@ struct Engine : Base {
         MGM_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
         MGM_TRY(sl_nb0_var.upload(hs.nb0_var, stream));
         MGM_TRY(sl_nb0_stride.upload(hs.nb0_stride, stream));
+        {   // the packed view of the variables it can take (local_search.h)
+            lsearch::HostPack hp;
+            hp.build(nV, h_dom, vrow, h_nn, hs, h_tables);
+            std::vector<int32_t> conc(hp.nb.size(), -1), conc_x(hp.nb.size(), -1);
+            for (size_t i = 0; i < hp.nb.size(); ++i) {
+                const int v = hp.lane_var[i];
+                if (v < 0) continue;
+                const int c0 = hs.conc_rowptr[v], n_conc = hs.conc_rowptr[v + 1] - c0, k = hp.lane_k[i], deg = hp.lane_deg[i];
+                if (n_conc > deg + 1) return fail(MXS_E_STATE, "concerned-variables list longer than the degree + 1");
+                if (k < n_conc) conc[i] = hs.conc_var[c0 + k];
+                if (k == 0 && n_conc > deg) conc_x[i] = hs.conc_var[c0 + deg];
+            }
+            pack_int8 = hp.int8_exact;
+            if (pack_int8) {
+                std::vector<int8_t> r8(hp.rec.size());
+                for (size_t i = 0; i < r8.size(); ++i) r8[i] = (int8_t)hp.rec[i];
+                MGM_TRY(pk_rec8.upload(r8, stream));
+            } else {
+                std::vector<T> rt(hp.rec.size());
+                for (size_t i = 0; i < rt.size(); ++i) rt[i] = (T)hp.rec[i];
+                MGM_TRY(pk_recT.upload(rt, stream));
+            }
+            MGM_TRY(pk_waves.upload(hp.waves, stream));
+            MGM_TRY(pk_vars.upload(hp.vars, stream));
+            MGM_TRY(pk_nb.upload(hp.nb, stream));
+            MGM_TRY(pk_slot.upload(hp.slot, stream));
+            MGM_TRY(pk_rest.upload(hp.rest, stream));
+            MGM_TRY(pk_conc.upload(conc, stream));
+            MGM_TRY(pk_conc_x.upload(conc_x, stream));
+            n_rest = (int)hp.rest.size();
+            g.pack = lsearch::Pack{pk_waves.p, pk_vars.p, pk_nb.p, pk_slot.p,
+                                   pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
+            g.pack_conc = pk_conc.p;
+            g.pack_conc_x = pk_conc_x.p;
+        }
         MGM_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
         MGM_TRY(sl_conc_var.upload(hs.conc_var, stream));
         g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
@@ -406,8 +587,10 @@ struct Engine : Base {
         }
         which = 0;
         if (nV) {
-            MGM_TRY(hipMemcpyAsync(cur[0].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
-            MGM_TRY(hipMemcpyAsync(cost[0].p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+            for (int b = 0; b < 2; ++b) {  // both buffers: the packed launches write only the variables with neighbours
+                MGM_TRY(hipMemcpyAsync(cur[b].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
+                MGM_TRY(hipMemcpyAsync(cost[b].p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+            }
             MGM_TRY(hipMemcpyAsync(has_cost.p, h0.data(), nV, hipMemcpyHostToDevice, stream));
             MGM_TRY(hipMemcpyAsync(newv.p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
             MGM_TRY(hipMemsetAsync(gain.p, 0, sizeof(T) * nV, stream));
@@ -424,24 +607,41 @@ struct Engine : Base {
             rounds += n > 0 ? n : 0;
             return MXS_OK;
         }
-        const dim3 grid((unsigned)((nV + TPB - 1) / TPB)), block(TPB);
-        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernels (A/B, tests)
-        const bool generic = env && env[0] == '1';
+        const char* env = std::getenv("MAXSUM_LOCAL_SEARCH_GENERIC");  // =1: the CSR-walk kernels, =2: the slot
+        const bool generic = env && env[0] == '1';                     // kernels for every variable (A/B, tests)
+        const bool packed = !generic && !(env && env[0] == '2') && g.pack.n_lanes > 0;
+        const dim3 pgrid((unsigned)((g.pack.n_lanes + PACK_TPB - 1) / PACK_TPB)), pblock(PACK_TPB);
         for (int32_t r = 0; r < n; ++r) {
             g.cur = cur[which].p;
             g.cost = cost[which].p;
             g.cur_out = cur[which ^ 1].p;
             g.cost_out = cost[which ^ 1].p;
             T* const cw = cost[which].p;
-            if (generic || max_dom > 32) hipLaunchKernelGGL((k_mgm_gain<T>), grid, block, 0, stream, g, cw);
-            else if (max_dom <= 4) hipLaunchKernelGGL((k_mgm_gain_slots<T, 4>), grid, block, 0, stream, g, cw);
-            else if (max_dom <= 8) hipLaunchKernelGGL((k_mgm_gain_slots<T, 8>), grid, block, 0, stream, g, cw);
-            else if (max_dom <= 16) hipLaunchKernelGGL((k_mgm_gain_slots<T, 16>), grid, block, 0, stream, g, cw);
-            else hipLaunchKernelGGL((k_mgm_gain_slots<T, 32>), grid, block, 0, stream, g, cw);
-            MGM_TRY(hipGetLastError());
-            if (generic) hipLaunchKernelGGL((k_mgm_move<T>), grid, block, 0, stream, g);
-            else hipLaunchKernelGGL((k_mgm_move_listed<T>), grid, block, 0, stream, g);
-            MGM_TRY(hipGetLastError());
+            g.var_list = packed ? pk_rest.p : nullptr;
+            g.n_list = packed ? n_rest : nV;
+            const dim3 grid((unsigned)((g.n_list + TPB - 1) / TPB)), block(TPB);
+            if (packed) {
+                if (pack_int8) hipLaunchKernelGGL((k_mgm_gain_pack<T, int8_t>), pgrid, pblock, 0, stream, g, cw);
+                else hipLaunchKernelGGL((k_mgm_gain_pack<T, T>), pgrid, pblock, 0, stream, g, cw);
+                MGM_TRY(hipGetLastError());
+            }
+            if (g.n_list > 0) {
+                if (generic || max_dom > 32) hipLaunchKernelGGL((k_mgm_gain<T>), grid, block, 0, stream, g, cw);
+                else if (max_dom <= 4) hipLaunchKernelGGL((k_mgm_gain_slots<T, 4>), grid, block, 0, stream, g, cw);
+                else if (max_dom <= 8) hipLaunchKernelGGL((k_mgm_gain_slots<T, 8>), grid, block, 0, stream, g, cw);
+                else if (max_dom <= 16) hipLaunchKernelGGL((k_mgm_gain_slots<T, 16>), grid, block, 0, stream, g, cw);
+                else hipLaunchKernelGGL((k_mgm_gain_slots<T, 32>), grid, block, 0, stream, g, cw);
+                MGM_TRY(hipGetLastError());
+            }
+            if (packed) {
+                hipLaunchKernelGGL((k_mgm_move_pack<T>), pgrid, pblock, 0, stream, g);
+                MGM_TRY(hipGetLastError());
+            }
+            if (g.n_list > 0) {
+                if (generic) hipLaunchKernelGGL((k_mgm_move<T>), grid, block, 0, stream, g);
+                else hipLaunchKernelGGL((k_mgm_move_listed<T>), grid, block, 0, stream, g);
+                MGM_TRY(hipGetLastError());
+            }
             which ^= 1;
             rounds += 1;
         }

@@ -39,3 +39,13 @@ def test_mgm_csr_walk_kernels(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "1")
     name, make, kw = case
     compare_mgm(OracleMgm, make(), Params(**kw))
+
+
+@pytest.mark.parametrize("case", mgm_cases()[:6], ids=lambda c: c[0])
+def test_mgm_slot_kernels_everywhere(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_GENERIC=2: the thread-per-variable slot kernels also for the variables
+    the packed (lane per constraint) kernels take by default."""
+    from oracle.mgm_oracle import OracleMgm
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(**kw))
