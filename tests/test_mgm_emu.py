@@ -26,7 +26,7 @@ def test_mgm_emu_csr_walk_kernels(case, oracle_built, monkeypatch):
     compare_mgm(OracleMgm, make(), Params(**kw), lib_path=build(), steps=(0, 1, 3, 6))
 
 
-@pytest.mark.parametrize("case", mgm_cases(k=4)[:6], ids=lambda c: c[0])
+@pytest.mark.parametrize("case", mgm_cases()[:6], ids=lambda c: c[0])
 def test_mgm_emu_slot_kernels_everywhere(case, oracle_built, monkeypatch):
     """MAXSUM_LOCAL_SEARCH_GENERIC=2: the thread-per-variable slot kernels also for the variables
     the packed (lane per constraint) kernels take by default."""
