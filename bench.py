@@ -277,21 +277,47 @@ def extra_configs(skip=()):
 
 
 def local_search_bytes(g, word, mgm):
-    """Algorithmic bytes of one DSA cycle / MGM round on the slot view (csrc/local_search.h), every
-    array touched once: per (variable, constraint) slot its record (base 8, own stride 4, two row
-    pointers 8, first neighbour + its stride 8), the neighbour's current value (4) and the D table
-    entries at it (D * w); per variable row pointers, domain size, current value in / out, the
-    move probability (DSA) or gain + best value out (MGM) = 32; MGM's second launch reads the gain
-    of every variable it shares a constraint with (4 + w each, itself included) and writes the
-    value (4 + w)."""
+    """-> (algorithmic bytes of one DSA cycle / MGM round, which data layout they are counted on).
+
+    "packed" (csrc/local_search.h, Pack: every variable with neighbours has unary / binary
+    constraints over domains of at most 4 values -- what the engines then run): per (variable,
+    constraint) lane the neighbour's index (4), its current value (4) and ONE row of the lane's
+    private transposed record (4 entries: 4 bytes when every table entry is a small integer, else
+    4 * w); per variable its value in / out, domain size, move probability and the wave record
+    (24); MGM adds per lane the concerned variable's index, cost offset, value and cost (4 + 8 + 4 + w,
+    first launch), its gain and name rank (w + 4, second launch) and per variable gain, new value,
+    cost in / out (2 * w + 8).
+    "slots" (the thread-per-variable kernels): per (variable, constraint) slot its record (base 8,
+    own stride 4, two row pointers 8, first neighbour + its stride 8), the neighbour's current
+    value (4) and the D table entries at it (D * w); per variable 32; MGM's second launch reads the
+    gain of every concerned variable (4 + w each) and writes the value (4 + w)."""
     import numpy as np
     deg = np.diff(g.var_rowptr)
     D = g.dom_size.astype(np.int64)
+    arity = np.diff(g.factor_rowptr)
+    edge_arity = np.repeat(arity, arity)
+    var_max_arity = np.zeros(g.n_vars, dtype=np.int64)
+    np.maximum.at(var_max_arity, g.edge_var, edge_arity)
+    nb_dom_ok = True
+    if (arity == 2).any():
+        f2 = np.flatnonzero(arity == 2)
+        nb_dom_ok = bool((D[g.edge_var[g.factor_rowptr[f2]]] <= 4).all() and (D[g.edge_var[g.factor_rowptr[f2] + 1]] <= 4).all())
+    has_nb = var_max_arity >= 2
+    packed = bool(nb_dom_ok and (var_max_arity[has_nb] <= 2).all() and (D[has_nb] <= 4).all() and (deg[has_nb] <= 64).all())
+    if packed:
+        t = g.tables
+        small = bool(((t == np.round(t)) & (np.abs(t) <= 127)).all())
+        lanes = int(deg[has_nb].sum())
+        n = int(has_nb.sum())
+        total = lanes * (4 + 4 + (4 if small else 4 * word)) + 24 * n
+        if mgm:
+            total += lanes * (4 + 8 + 4 + word) + lanes * (word + 4) + n * (2 * word + 8)
+        return total, "packed"
     slots = int((deg * (28 + 4 + D * word)).sum())
     per_var = 32 * g.n_vars
     if not mgm:
-        return slots + per_var
-    return slots + per_var + int(((deg + 1) * (4 + word)).sum()) + (4 + word) * g.n_vars
+        return slots + per_var, "slots"
+    return slots + per_var + int(((deg + 1) * (4 + word)).sum()) + (4 + word) * g.n_vars, "slots"
 
 
 def other_algorithms(n_vars, device=0):
@@ -337,7 +363,7 @@ def other_algorithms(n_vars, device=0):
             t0 = time.perf_counter()
             eng.run(cycles)
             dt = time.perf_counter() - t0
-            nbytes = local_search_bytes(g, 8, mgm)
+            nbytes, layout = local_search_bytes(g, 8, mgm)
             out.append({"algo": name, "workload": "coloring_100k", "n_vars": g.n_vars, "dtype": "f64", "cycles": cycles,
                         "cycles_per_s": cycles / max(dt, 1e-12), "us_per_cycle": 1e6 * dt / cycles,
                         "cost_at_start": start, "cost_now": eng.eval_cost()[0],
@@ -345,9 +371,11 @@ def other_algorithms(n_vars, device=0):
                                      "achieved": nbytes * cycles / max(dt, 1e-12) / 1e9,
                                      "frac": nbytes * cycles / max(dt, 1e-12) / 1e9 / HBM_PEAK_GBPS,
                                      "algorithmic_bytes_per_cycle": nbytes,
-                                     "formula": "bench.py local_search_bytes: slot records + neighbour values + D table "
-                                                "entries per (variable, constraint), 32 B per variable"
-                                                + ("; + the neighbours' gains and the move (second launch)" if mgm else ""),
+                                     "layout": layout,
+                                     "formula": "bench.py local_search_bytes (docstring): per (variable, constraint) lane / "
+                                                "slot its index data, the neighbour's value and the table entries read; "
+                                                "per variable its state"
+                                                + ("; + the concerned variables' costs and gains (MGM)" if mgm else ""),
                                      "launches_per_cycle": 2 if mgm else 1},
                         "parity_test": test})
     return out

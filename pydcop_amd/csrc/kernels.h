@@ -1460,17 +1460,54 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // ---------------------------------------------------------------------------
 
 // sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of
-// costs_for_factor (ONE accumulator, maxsum.py:651-665).  The D * deg terms are walked as one
-// sequence, SIXTEEN per pass: their addresses with select arithmetic (no branch, the same code for
-// every degree -- the lanes of a wave hold chains of different degrees), sixteen reads requested
-// together, then the sixteen additions in order.  (Versions that branched on the degree or on
-// the wrap-around of k cost 24 to 45 of the kernel's 65 to 95 us on meeting_50k: one wave per block
-// walks the chains while the others wait, so the SLOWEST lane's path is what a block pays;
+// costs_for_factor (ONE accumulator, maxsum.py:651-665).  One wave of a block walks the chains of
+// the block's edges while the others wait, so what a block pays is the instruction count of the
+// SLOWEST lane's path:
+//   * degrees <= 4 (the variables of the class are sorted by domain size, then by degree in steps of
+//     four, so a wave is rarely mixed): the (up to four) edges side by side, four values of d per
+//     pass -- sixteen reads at constant offsets from four row pointers, then sixteen additions under
+//     masks computed once: three instructions per term;
+//   * any degree: the D * deg terms as one sequence, sixteen per pass, addresses by select
+//     arithmetic (no branch on the wrap-around of k).
+// (Versions that branched per element cost 24 to 45 of the kernel's 65 to 95 us on meeting_50k:
 // profiles/r03_wide_phases_v*.txt.)
 template <typename T>
 __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
-    const int n = D * deg;
     T sc = (T)0;
+    if (deg <= 4) {
+        const bool u0 = 0 != ko, u1 = 1 < deg && 1 != ko, u2 = 2 < deg && 2 != ko, u3 = 3 < deg && 3 != ko;
+        const T* r0 = in;
+        const T* r1 = in + (1 < deg ? 1 : 0) * D;
+        const T* r2 = in + (2 < deg ? 2 : 0) * D;
+        const T* r3 = in + (3 < deg ? 3 : 0) * D;
+        int d = 0;
+        for (; d + 4 <= D; d += 4) {
+            T x[4][4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                x[i][0] = r0[d + i];
+                x[i][1] = r1[d + i];
+                x[i][2] = r2[d + i];
+                x[i][3] = r3[d + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                sc = u0 ? sc + x[i][0] : sc;
+                sc = u1 ? sc + x[i][1] : sc;
+                sc = u2 ? sc + x[i][2] : sc;
+                sc = u3 ? sc + x[i][3] : sc;
+            }
+        }
+        for (; d < D; ++d) {
+            const T x0 = r0[d], x1 = r1[d], x2 = r2[d], x3 = r3[d];
+            sc = u0 ? sc + x0 : sc;
+            sc = u1 ? sc + x1 : sc;
+            sc = u2 ? sc + x2 : sc;
+            sc = u3 ? sc + x3 : sc;
+        }
+        return sc;
+    }
+    const int n = D * deg;
     int d = 0, k = 0;
     for (int t = 0; t < n; t += 16) {
         T x[16];

@@ -173,7 +173,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         // by side; bit3 of layout_flags keeps the caller's order elsewhere).  The wide class
         // is ordered by domain size instead: its workgroups take runs of ONE D (WideBlock).
         const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
-        vsort[v] = (kind * 1024 + sub) * 4096 + (kind == K_V_WIDE ? D : by_deg ? std::min(deg, 4095) : 0);
+        // (wide class: by domain size, then by degree in steps of four -- the chains of a wave then
+        // take the same path through wide_sum_cost, kernels.h)
+        vsort[v] = (kind * 1024 + sub) * 4096 +
+                   (kind == K_V_WIDE ? D * 8 + std::min((deg + 3) / 4, 7) : by_deg ? std::min(deg, 4095) : 0);
     }
     L.var_i2e.resize(nV);
     std::iota(L.var_i2e.begin(), L.var_i2e.end(), 0);

@@ -3,8 +3,10 @@
 
     python tools/local_search_bench.py [--cycles 500]
 
-One JSON line per (algorithm, instance, kernels); "kernels": "slots" = the register-array kernels
-on the slot view (local_search.h), "csr_walk" = the generic kernels (MAXSUM_LOCAL_SEARCH_GENERIC=1).
+One JSON line per (algorithm, instance, kernels); "kernels": "packed" = the default (lane per
+constraint where the instance allows it, local_search.h), "slots" = the thread-per-variable
+register-array kernels on the slot view (MAXSUM_LOCAL_SEARCH_GENERIC=2), "csr_walk" = the generic
+kernels (=1).
 """
 import argparse
 import json
@@ -28,8 +30,8 @@ def main():
     instances = [("coloring_100k", G.random_coloring(100_000, seed=0, names=False), Params()),
                  ("meeting_50k", G.meeting_like(50_000, dom=24, seed=0, names=False), Params(mode="max"))]
     for inst, g, p in instances:
-        for kernels in ("slots", "csr_walk"):
-            os.environ["MAXSUM_LOCAL_SEARCH_GENERIC"] = "1" if kernels == "csr_walk" else "0"
+        for kernels in ("packed", "slots", "csr_walk"):
+            os.environ["MAXSUM_LOCAL_SEARCH_GENERIC"] = {"packed": "0", "slots": "2", "csr_walk": "1"}[kernels]
             for name, make in (("dsa_B", lambda: DsaEngine(g, p, variant="B", seed=1, lib_path=a.lib)),
                                ("mgm", lambda: MgmEngine(g, p, lib_path=a.lib))):
                 eng = make()
