@@ -25,6 +25,15 @@
  * hasattr(variable, "cost_for_value") -- the attribute is cost_for_val -- relations.py:1630);
  * Variable.initial_value is ignored (dsa.py:291); the cost a computation holds is 0 until its first
  * move (value_selection's default, computations.py:1057), then the best cost of that move.
+
+ * Deliberate deviations in corners no comparison reaches (round-2 ADVICE), on BOTH sides of every
+ * test (oracle, engines): (1) a variable WITHOUT neighbours starts at the optimum of its own costs;
+ * the reference's optimal_cost_value takes min / max over (cost, value) tuples, i.e. ties break on
+ * the domain VALUE (smallest for min, largest for max) -- here on the domain INDEX (first for min,
+ * last for max), the same thing for domains written in ascending order, as every instance of the
+ * tests is; (2) such a variable without cost function gets random.choice and cost None in the
+ * reference, index 0 and cost 0 here; (3) p_mode "arity" with a variable whose constraints are all
+ * unary divides by zero in the reference (dsa.py:256-259), here it falls back to `probability`.
  */
 #include <math.h>
 #include <stdint.h>

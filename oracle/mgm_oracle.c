@@ -25,6 +25,14 @@
  * Quirks restated as they are (each cited below): the cost a variable holds is only updated when
  * the variable itself moves; the candidate evaluation adds the variable's own cost at its CURRENT
  * value; the winner of a neighbourhood is the LARGEST gain also in max mode.
+
+ * Deliberate deviations in corners no comparison reaches (round-2 ADVICE), on BOTH sides of every
+ * test (oracle, engines): (1) a variable WITHOUT neighbours starts at the optimum of its own costs;
+ * the reference's optimal_cost_value takes min / max over (cost, value) tuples, i.e. ties break on
+ * the domain VALUE (smallest for min, largest for max) -- here on the domain INDEX (first for min,
+ * last for max), the same thing for domains written in ascending order, as every instance of the
+ * tests is; (2) such a variable without cost function gets random.choice and cost None in the
+ * reference, index 0 and cost 0 here.
  */
 #include <math.h>
 #include <stdint.h>

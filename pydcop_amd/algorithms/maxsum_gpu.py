@@ -191,6 +191,13 @@ class _Session:
                     self._fetch()
                     self.done = True
                 elif getattr(self.engine, "quiescent", False):
+                    # amaxsum_gpu with nothing to deliver at all (e.g. `start_messages: leafs` on a graph
+                    # without leaves): the run ends FINISHED with the initial values, where the
+                    # reference sits until its TIMEOUT -- say so, it is not a converged run
+                    import logging
+                    logging.getLogger("pydcop.algo.amaxsum_gpu").warning(
+                        "amaxsum_gpu: no start message (start_messages=%s): finished with the initial values, "
+                        "0 generations", next(iter(self.comp_defs.values())).algo.params.get("start_messages"))
                     self.done = True
                 return
             if self.stop_cycle == 0:

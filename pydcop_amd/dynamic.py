@@ -50,7 +50,13 @@ def rescope_factor(graph: FlatGraph, state: Dict, factor: int, new_scope: Sequen
     -> (new FlatGraph, new state) with the semantics of the module docstring: surviving edges
     keep their messages and send counters; an added edge starts with an all-zero V->F message,
     no previous message on either side, and the F->V message the factor sends with ADD; a
-    variable that lost the factor has no previous message on any of its remaining edges."""
+    variable that lost the factor has no previous message on any of its remaining edges.
+
+    Cost: the carry-over walks the edges and variables in Python and `DynamicMaxSum` then builds a
+    fresh engine (layout + upload) -- seconds of host time at 100k..1M variables, paid under the
+    plug-in's session lock.  A change of scope is a rare event in the reference's model (a rule
+    rewritten, maxsum_dynamic.py:234-271); same-scope changes and external-value moves -- the frequent
+    ones -- are device-side kernels and cost microseconds."""
     g = graph
     f = int(factor)
     new_scope = [int(v) for v in new_scope]

@@ -29,9 +29,9 @@ def register_test_engine(path: str, make_default: bool = False):
     is deliberately no environment variable or parameter that does this: the product path
     cannot be pointed at a CPU build from outside."""
     global DEFAULT_LIB
-    _TEST_ENGINES.add(os.path.abspath(path))
+    _TEST_ENGINES.add(os.path.realpath(path))
     if make_default:
-        DEFAULT_LIB = os.path.abspath(path)
+        DEFAULT_LIB = os.path.realpath(path)
 
 # every symbol include/maxsum_gpu.h declares
 ABI_SYMBOLS = (
@@ -112,7 +112,7 @@ def _load_hip_runtime():
 
 def load_library(path: Optional[str] = None) -> C.CDLL:
     """Load the engine library and declare the prototypes of its C-ABI."""
-    path = os.path.abspath(path or DEFAULT_LIB)
+    path = os.path.realpath(path or DEFAULT_LIB)  # (symlinks and relative paths name the same library)
     if path in _libs:
         return _libs[path]
     if not os.path.exists(path):
