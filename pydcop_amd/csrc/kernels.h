@@ -1464,10 +1464,10 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // the block's edges while the others wait, so what a block pays is the instruction count of the
 // SLOWEST lane's path:
 //   * degrees <= 4 (the variables of the class are sorted by domain size, then by degree in steps of
-//     four, so a wave is rarely mixed): the (up to four) edges side by side, four values of d per
-//     pass -- sixteen reads at constant offsets from four row pointers, then sixteen additions under
+//     four, so a wave is rarely mixed): the (up to four) edges side by side, two values of d per
+//     pass -- eight reads at constant offsets from four row pointers, then eight additions under
 //     masks computed once: three instructions per term;
-//   * any degree: the D * deg terms as one sequence, sixteen per pass, addresses by select
+//   * any degree: the D * deg terms as one sequence, eight per pass, addresses by select
 //     arithmetic (no branch on the wrap-around of k).
 // (Versions that branched per element cost 24 to 45 of the kernel's 65 to 95 us on meeting_50k:
 // profiles/r03_wide_phases_v*.txt.)
@@ -1481,17 +1481,17 @@ __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) 
         const T* r2 = in + (2 < deg ? 2 : 0) * D;
         const T* r3 = in + (3 < deg ? 3 : 0) * D;
         int d = 0;
-        for (; d + 4 <= D; d += 4) {
-            T x[4][4];
+        for (; d + 2 <= D; d += 2) {
+            T x[2][4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 x[i][0] = r0[d + i];
                 x[i][1] = r1[d + i];
                 x[i][2] = r2[d + i];
                 x[i][3] = r3[d + i];
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < 2; ++i) {
                 sc = u0 ? sc + x[i][0] : sc;
                 sc = u1 ? sc + x[i][1] : sc;
                 sc = u2 ? sc + x[i][2] : sc;
@@ -1509,11 +1509,11 @@ __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) 
     }
     const int n = D * deg;
     int d = 0, k = 0;
-    for (int t = 0; t < n; t += 16) {
-        T x[16];
-        bool use[16];
+    for (int t = 0; t < n; t += 8) {
+        T x[8];
+        bool use[8];
 #pragma unroll
-        for (int u = 0; u < 16; ++u) {
+        for (int u = 0; u < 8; ++u) {
             const bool ok = t + u < n;
             x[u] = in[ok ? k * D + d : 0];
             use[u] = ok && k != ko;
@@ -1522,7 +1522,7 @@ __device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) 
             d += wrap ? 1 : 0;
         }
 #pragma unroll
-        for (int u = 0; u < 16; ++u) sc = use[u] ? sc + x[u] : sc;
+        for (int u = 0; u < 8; ++u) sc = use[u] ? sc + x[u] : sc;
     }
     return sc;
 }
@@ -1586,8 +1586,8 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     const int tid = (int)threadIdx.x;
     const int D = wb.D, ns = wb.n_slots, ne = ns * D;
     // ---- 1. stage ------------------------------------------------------------------------
-    int sl[R], dd[R];  // a thread's elements: local slot and d (idx = tid + r * BLOCK)
-    T x[R];
+    int sl[R], dd[R], vo[R];  // a thread's elements: local slot, d, V2F offset (idx = tid + r * BLOCK)
+    T x[R], p[R], m[R];
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         const int idx = tid + r * BLOCK;
@@ -1595,7 +1595,14 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
         sl[r] = s;
         dd[r] = idx - s * D;
         x[r] = (T)0;
-        if (idx < ne && !(MXS_WIDE_SKIP & 8)) x[r] = a.f2v_old[a.vslot_f2v[wb.slot0 + s] + dd[r]];
+        vo[r] = 0;
+        p[r] = (T)0;
+        if (idx < ne) {  // both index loads, then both record loads, of all R elements: in flight together
+            const int fo = a.vslot_f2v[wb.slot0 + s];
+            vo[r] = a.vslot_v2f[wb.slot0 + s] + dd[r];
+            if (!(MXS_WIDE_SKIP & 8)) x[r] = a.f2v_old[fo + dd[r]];
+            if (!a.start) p[r] = a.v2f_old[vo[r]];  // the message sent last on this edge
+        }
     });
     for (int j = tid; j < wb.n_vars; j += BLOCK) {
         const int v = wb.first_var + j;
@@ -1623,18 +1630,6 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
         const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
         s_b[i] = (MXS_WIDE_SKIP & 4) ? s_c[i] : wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
     }
-    // the messages sent last: requested before the barrier, used behind it
-    int vo[R];
-    T p[R], m[R];
-    static_for<R>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        vo[r] = 0;
-        p[r] = (T)0;
-        if (tid + r * BLOCK < ne) {
-            vo[r] = a.vslot_v2f[wb.slot0 + sl[r]] + dd[r];
-            if (!a.start) p[r] = a.v2f_old[vo[r]];
-        }
-    });
     __syncthreads();
     for (int j = tid; j < wb.n_vars; j += BLOCK) {  // selection: first index attaining the minimum
         const int v = wb.first_var + j;
