@@ -823,6 +823,8 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
 // At most 80 SGPRs: a CU admits 8 workgroups of 256 threads only up to that count (6 at the
 // 98 the compiler would otherwise use -- MI355X_MICROARCH.md, "Residency"; seen as 1536
 // instead of 2048 resident blocks in the per-block timeline).
+// (Forcing the D = 2 / 3 instantiations to 64 VGPRs -- 8 waves per SIMD, 2 048 resident workgroups instead of
+// 1 792 -- changes nothing measurable: profiles/r03_sweep_waves_ab_v1.txt.)
 template <typename T, int DSEL, int NT = MXS_NT>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
 k_sweep(SweepArgs<T> a) {
