@@ -367,6 +367,12 @@ int mxs_amaxsum_get_assignment(mxs_amaxsum *e, int32_t *idx, double *belief);
 int mxs_amaxsum_get_messages(mxs_amaxsum *e, double *f_cost, double *v_cost, double *f_prev, double *v_prev,
                              uint8_t *f_has, uint8_t *v_has, uint8_t *f_cnt, uint8_t *v_cnt);
 int mxs_amaxsum_eval_cost(mxs_amaxsum *e, const int32_t *idx, double infinity, double *cost, int64_t *violations);
+/* DynamicFunctionFactorComputation.change_factor_function with the same scope
+ * (pydcop/algorithms/maxsum_dynamic.py:80-104 -- the reference defines it over the ASYNCHRONOUS
+ * factor computation): `self.factor = fn`, nothing is sent; the new table (row-major in the
+ * factor's own dimension order, n_entries = its size) is what the deliveries from now on are
+ * computed with, held costs and last-sent messages carry on. */
+int mxs_amaxsum_update_factor_table(mxs_amaxsum *e, int32_t factor, const double *table, int64_t n_entries);
 int mxs_amaxsum_destroy(mxs_amaxsum *e);
 
 /* ---- MGM (pydcop/algorithms/mgm.py) on the same flat arrays ------------------------------------

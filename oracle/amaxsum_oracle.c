@@ -438,6 +438,17 @@ void amso_eval_cost(const amso_state *s, const int32_t *idx, double infinity, do
     *violations = hard;
 }
 
+/* change_factor_function with the same scope (maxsum_dynamic.py:80-104: `self.factor = fn`, nothing
+ * is sent): the factor's table is replaced between two deliveries, held costs and last-sent
+ * messages carry on.  `table`: row-major in the factor's own dimension order. */
+void amso_update_table(amso_state *s, int32_t factor, const double *table) {
+    const int64_t lo = s->table_off[factor], hi = s->table_off[factor + 1];
+    for (int64_t i = lo; i < hi; ++i) {
+        s->tables64[i] = table[i - lo];
+        s->tables[i] = (real)table[i - lo];
+    }
+}
+
 void amso_destroy(amso_state *s) {
     if (!s) return;
     free(s->dom_size); free(s->init_idx); free(s->factor_rowptr); free(s->edge_var); free(s->var_rowptr);

@@ -35,6 +35,7 @@ def _lib(dtype):
         lib.amso_get_assignment.argtypes = [vp, vp, vp]
         lib.amso_get_messages.argtypes = [vp] + [vp] * 8
         lib.amso_eval_cost.argtypes = [vp, vp, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int64)]
+        lib.amso_update_table.argtypes = [vp, C.c_int32, vp]
         lib.amso_destroy.argtypes = [vp]
         _LIBS[dtype] = lib
     return _LIBS[dtype]
@@ -52,6 +53,12 @@ class OracleAMaxSum:
 
     def reset(self):
         self._lib.amso_reset(self._h)
+
+    def update_factor_table(self, factor: int, table):
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
+        assert t.shape[0] == hi - lo
+        self._lib.amso_update_table(self._h, int(factor), t.ctypes.data)
 
     def run(self, max_generations: int = -1, max_messages: int = -1) -> int:
         """Deliver the queued messages of generations < max_generations (all: -1)."""

@@ -81,6 +81,15 @@ class AMaxSumEngine:
                                                     "f_has", "v_has", "f_cnt", "v_cnt")]))
         return out
 
+    def update_factor_table(self, factor: int, table):
+        """`change_factor_function` with the same scope (pydcop/algorithms/maxsum_dynamic.py:80-104):
+        a new table (in the factor's own dimension order) between two generations."""
+        t = np.ascontiguousarray(table, dtype=np.float64).reshape(-1)
+        self._check(self._lib.mxs_amaxsum_update_factor_table(self._h, int(factor), t.ctypes.data, t.shape[0]))
+        lo, hi = int(self.graph.table_off[factor]), int(self.graph.table_off[factor + 1])
+        if t.shape[0] == hi - lo:
+            self.graph.tables[lo:hi] = t
+
     def eval_cost(self, idx=None, infinity: float = float("inf")) -> Tuple[float, int]:
         cost, viol = C.c_double(0), C.c_int64(0)
         p = None

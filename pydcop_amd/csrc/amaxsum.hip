@@ -824,6 +824,7 @@ struct Base {
     virtual int get_messages(double* fc, double* vc, double* fp, double* vp, uint8_t* fh, uint8_t* vh, uint8_t* fn,
                              uint8_t* vn) = 0;
     virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
+    virtual int update_table(int32_t factor, const double* table, int64_t n) = 0;
     int32_t next_generation = 0;
     int64_t pending = 0, delivered_total = 0;
     std::vector<int64_t> gen_sizes;
@@ -1182,6 +1183,23 @@ struct Engine : Base {
         return MXS_OK;
     }
 
+    // change_factor_function, same scope (maxsum_dynamic.py:80-104): the factor's table replaced in place
+    int update_table(int32_t factor, const double* table, int64_t n) override {
+        const int nF = (int)h_toff.size() - 1;
+        if (factor < 0 || factor >= nF) return fail(MXS_E_INVALID, "factor out of range");
+        const int64_t lo = h_toff[factor], hi = h_toff[factor + 1];
+        if (!table || n != hi - lo) return fail(MXS_E_INVALID, "table size differs from the factor's");
+        std::vector<T> tt((size_t)n);
+        for (int64_t i = 0; i < n; ++i) {
+            h_tables[lo + i] = table[i];
+            tt[i] = (T)table[i];
+        }
+        AMX_TRY(hipSetDevice(device));
+        AMX_TRY(hipDeviceSynchronize());  // no delivery is in flight between two run() calls; be sure
+        AMX_TRY(hipMemcpy(tables.p + lo, tt.data(), sizeof(T) * (size_t)n, hipMemcpyHostToDevice));
+        return MXS_OK;
+    }
+
     // DCOP.solution_cost (dcop.py:308-367) of the selection: reporting, evaluated on the host
     int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) override {
         std::vector<int32_t> cur;
@@ -1241,6 +1259,14 @@ int mxs_amaxsum_create(const mxs_graph* g, const mxs_params* p, int32_t device, 
     }
 }
 int mxs_amaxsum_reset(mxs_amaxsum* e) { return e ? e->impl->reset() : amx::fail(MXS_E_INVALID, "null handle"); }
+int mxs_amaxsum_update_factor_table(mxs_amaxsum* e, int32_t factor, const double* table, int64_t n_entries) {
+    if (!e) return amx::fail(MXS_E_INVALID, "null handle");
+    try {
+        return e->impl->update_table(factor, table, n_entries);
+    } catch (const std::exception& ex) {
+        return amx::fail(MXS_E_NOMEM, ex.what());
+    }
+}
 int mxs_amaxsum_run(mxs_amaxsum* e, int32_t max_generations, int64_t* delivered) {
     if (!e) return amx::fail(MXS_E_INVALID, "null handle");
     try {

@@ -46,7 +46,7 @@ ABI_SYMBOLS = (
     "mxs_table_storage",
     "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
     "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
-    "mxs_amaxsum_eval_cost", "mxs_amaxsum_destroy",
+    "mxs_amaxsum_eval_cost", "mxs_amaxsum_update_factor_table", "mxs_amaxsum_destroy",
     "mxs_mgm_create", "mxs_mgm_reset", "mxs_mgm_run", "mxs_mgm_rounds", "mxs_mgm_get_state",
     "mxs_mgm_eval_cost", "mxs_mgm_destroy",
     "mxs_dsa_create", "mxs_dsa_reset", "mxs_dsa_run", "mxs_dsa_cycles", "mxs_dsa_get_state",
@@ -150,6 +150,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_table_storage": ([vp, vp, C.POINTER(i64)], C.c_int),
         "mxs_amaxsum_create": ([C.POINTER(CGraph), C.POINTER(CParams), i32, C.POINTER(vp)], C.c_int),
         "mxs_amaxsum_reset": ([vp], C.c_int),
+        "mxs_amaxsum_update_factor_table": ([vp, i32, vp, i64], C.c_int),
         "mxs_amaxsum_run": ([vp, i32, C.POINTER(i64)], C.c_int),
         "mxs_amaxsum_status": ([vp, C.POINTER(i32), C.POINTER(i64), C.POINTER(i64)], C.c_int),
         "mxs_amaxsum_generation_sizes": ([vp, vp, i32, C.POINTER(i32)], C.c_int),

@@ -188,3 +188,78 @@ def test_which_reference_classes_cannot_be_constructed():
         md.DynamicFactorComputation(rel, name="r")
     with pytest.raises(TypeError):
         md.DynamicFactorVariableComputation(x, ["r"])
+
+
+def check_reference_dynamic_class_under_amaxsum(make, mode, params, emu_lib):
+    """The reference's `change_factor_function` (maxsum_dynamic.py:80-104) where the reference defines
+    it: on the ASYNCHRONOUS factor computation (the parent class of DynamicFunctionFactorComputation,
+    maxsum_dynamic.py:35), FIFO delivery, called between two generations (same scope, then the same
+    variables in another dimension order) -- against `mxs_amaxsum_update_factor_table` of the engine
+    and the asynchronous oracle: values, costs and every held / last-sent message, bit for bit, after
+    every change."""
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    from pydcop_amd.amaxsum import AMaxSumEngine
+    from test_amaxsum_oracle_vs_reference import _held
+    g = make()
+    dcop, cg = ref_harness.flat_to_dcop(g, mode)
+    ref = ref_harness.ReferenceDynamicAMaxSumRun(dcop, params, cg=cg)
+    p = Params(mode=mode, **params)
+    ora, eng = OracleAMaxSum(g, p), AMaxSumEngine(g, p, lib_path=emu_lib)
+    rng = np.random.default_rng(11)
+    arity = np.diff(g.factor_rowptr)
+
+    def advance(gens, what):
+        n = ref.run(gens)
+        assert ora.run(gens) + 0 >= 0 and eng.run(gens) >= 0
+        assert ora.delivered == eng.delivered == n, what
+        held = _held(ref.comps, g, None)
+        for k, want in held.items():
+            np.testing.assert_array_equal(ora.messages()[k], want, err_msg=f"{k} {what}")
+            np.testing.assert_array_equal(eng.messages()[k], want, err_msg=f"{k} {what}")
+        vals, costs = ref.values()
+        idx = np.array([g.domains[i].index(vals[nm]) for i, nm in enumerate(g.var_names)])
+        for e in (ora, eng):
+            np.testing.assert_array_equal(e.assignment()[0], idx, err_msg=what)
+            np.testing.assert_array_equal(e.assignment()[1], [0.0 if costs[nm] is None else costs[nm] for nm in g.var_names],
+                                          err_msg=what)
+
+    advance(3, "before any change")
+    gens = 3
+    for ar, order_of in ((2, lambda a: list(range(a))), (3, lambda a: list(range(a))),
+                         (2, lambda a: list(range(a))[::-1]), (3, lambda a: [1, 2, 0])):
+        fs = np.flatnonzero(arity == ar)
+        if not len(fs):
+            continue
+        f = int(fs[gens % len(fs)])
+        scope = [int(v) for v in g.edge_var[g.factor_rowptr[f]:g.factor_rowptr[f + 1]]]
+        order = order_of(ar)
+        t = rng.integers(-6, 10, [int(g.dom_size[scope[i]]) for i in order]).astype(float) + 0.5
+        ref.change_factor_function(g.factor_names[f], _relation(dcop, g, f, order, t))
+        own = np.ascontiguousarray(np.transpose(t, np.argsort(order)))   # back in the factor's own dimension order
+        ora.update_factor_table(f, own), eng.update_factor_table(f, own)
+        gens += 3
+        advance(gens, f"arity {ar}, order {order}")
+    ora.close(), eng.close()
+
+
+ACASES = [("mixed_lv", lambda: G.random_mixed(20, 30, seed=51, max_arity=3, dom_choices=(2, 3, 4)), "min", {"start_messages": "leafs_vars"}),
+          ("mixed_max_all", lambda: G.random_mixed(16, 24, seed=52, max_arity=3, dom_choices=(2, 3)), "max", {"start_messages": "all"}),
+          ("coloring_lv", lambda: G.random_coloring(24, seed=53), "min", {"start_messages": "leafs_vars", "damping_nodes": "vars"})]
+
+
+@pytest.mark.parametrize("name,make,mode,params", ACASES, ids=[c[0] for c in ACASES])
+def test_reference_dynamic_class_under_amaxsum(name, make, mode, params, oracle_built, emu):
+    check_reference_dynamic_class_under_amaxsum(make, mode, params, emu)
+
+
+def test_the_reference_dynamic_class_itself_cannot_handle_a_message():
+    """Why `change_factor_function` is exercised on the parent class's objects: a
+    DynamicFunctionFactorComputation constructs, but its handler table lacks the parent's
+    `max_sum` handler -- the first message raises KeyError (computations.py:509; the class
+    docstring says so: "does not work since the refactoring", maxsum_dynamic.py:60)."""
+    g = G.random_coloring(12, seed=3)
+    dcop, cg = ref_harness.flat_to_dcop(g, "min")
+    run = ref_harness.ReferenceDynamicAMaxSumRun(dcop, {"start_messages": "leafs_vars"}, cg=cg, dynamic_class=True)
+    assert run.q          # the variables' start messages are waiting for the factors
+    with pytest.raises(KeyError):
+        run.run(1)

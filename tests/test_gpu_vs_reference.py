@@ -62,3 +62,5 @@ def test_dynamic_changes_on_the_hip_engine_equal_the_reference(oracle_built):
     for _, make, mode, params in D.CASES:
         D.check_change_factor_function(make, mode, params, oracle_built, None)
     D.check_external_slice(oracle_built, None)
+    for _, make, mode, params in D.ACASES:   # the method where the reference defines it: asynchronous Max-Sum
+        D.check_reference_dynamic_class_under_amaxsum(make, mode, params, None)
