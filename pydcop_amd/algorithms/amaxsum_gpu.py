@@ -48,6 +48,9 @@ class _GenerationEngine:
     def quiescent(self) -> bool:
         return self._e.pending == 0
 
+    def update_factor_table(self, factor: int, table):
+        self._e.update_factor_table(factor, table)
+
     def close(self):
         self._e.close()
 
@@ -58,8 +61,10 @@ class _AsyncSession(_base._Session):
     def _make_engine(self, params, p):
         return _GenerationEngine(self.graph, params)
 
-    def update_factor(self, name, old, fn):
-        raise ValueError("amaxsum_gpu: change_factor_function is a maxsum_gpu feature")
+    # change_factor_function: the base session's path for engines without re-layout -- the same
+    # variables (any dimension order) swap the table in place between two generations
+    # (mxs_amaxsum_update_factor_table; DynamicFunctionFactorComputation.change_factor_function,
+    # maxsum_dynamic.py:80-104, allows nothing else); other variables raise ValueError there too.
 
 
 _base.SESSION_CLASSES["amaxsum_gpu"] = _AsyncSession

@@ -527,7 +527,7 @@ struct Engine : EngineBase {
             graph_tried = false;
         }
         HIP_TRY(ndesc.upload(L.ndesc, stream));
-        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
+        launches_per_cycle = ((L.n_blocks_sweep > 0 && L.sweep_regular) ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
                              (int)L.nary_launches.size() + (int)L.wide_classes.size();
         return MXS_OK;
     }
@@ -637,7 +637,7 @@ struct Engine : EngineBase {
         HIP_TRY(eval_idx.alloc((size_t)L.n_vars));
         HIP_TRY(part_cost.alloc(EVAL_BLOCKS));
         HIP_TRY(part_viol.alloc(EVAL_BLOCKS));
-        launches_per_cycle = (L.n_blocks_sweep > 0 ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
+        launches_per_cycle = ((L.n_blocks_sweep > 0 && L.sweep_regular) ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
                              (int)L.nary_launches.size() + (int)L.wide_classes.size();
         return reset();
     }
