@@ -956,6 +956,28 @@ __device__ __forceinline__ T wave_min_to_lane63(T x) {
     x = min2(x, dpp_mov<0x143, 0xc>(x));  // row_bcast31 -> rows 2, 3
     return x;
 }
+// The two registers a permlane swap of (x, x) leaves behind, per 32-bit half of T.
+typedef unsigned int swap2u __attribute__((ext_vector_type(2)));
+template <bool W32, bool SECOND>
+__device__ __forceinline__ unsigned int swap_word(unsigned int w) {
+    const swap2u r = W32 ? __builtin_amdgcn_permlane32_swap(w, w, false, false)
+                         : __builtin_amdgcn_permlane16_swap(w, w, false, false);
+    return SECOND ? r.y : r.x;
+}
+template <bool W32, bool SECOND>
+__device__ __forceinline__ double swap_val(double x) {
+    const unsigned int lo = swap_word<W32, SECOND>((unsigned int)__double2loint(x));
+    const unsigned int hi = swap_word<W32, SECOND>((unsigned int)__double2hiint(x));
+    return __hiloint2double((int)hi, (int)lo);
+}
+template <bool W32, bool SECOND>
+__device__ __forceinline__ float swap_val(float x) {
+    return __int_as_float((int)swap_word<W32, SECOND>((unsigned int)__float_as_int(x)));
+}
+template <typename T> __device__ __forceinline__ T swap16_lo(T x) { return swap_val<false, false>(x); }
+template <typename T> __device__ __forceinline__ T swap16_hi(T x) { return swap_val<false, true>(x); }
+template <typename T> __device__ __forceinline__ T swap32_lo(T x) { return swap_val<true, false>(x); }
+template <typename T> __device__ __forceinline__ T swap32_hi(T x) { return swap_val<true, true>(x); }
 // FOUR wavefront minima at once, for less than the price of two: lanes trade values before they
 // reduce them.  Step A (partner l^1): even lanes keep b[0], b[1], odd lanes b[2], b[3], each gets
 // the partner's copies of what it keeps; step B (partner l^2): one value per lane is left --
@@ -978,8 +1000,12 @@ __device__ __forceinline__ T wave_min4(const T (&b)[4]) {
     k = min2(k, dpp_mov<0x4E, 0xf>(s));
     k = min2(k, dpp_mov<0x124, 0xf>(k));  // row_ror:4
     k = min2(k, dpp_mov<0x128, 0xf>(k));  // row_ror:8
-    k = min2(k, __shfl(k, l ^ 16, 64));
-    k = min2(k, __shfl(k, l ^ 32, 64));
+    // lanes l ^ 16 and l ^ 32: gfx950's permlane swaps (VALU, no trip through the LDS crossbar that
+    // ds_bpermute takes).  With the same value in both operands, v_permlane16_swap leaves rows {0,0,2,2}
+    // in one register and {1,1,3,3} in the other, v_permlane32_swap the low half in both halves of one
+    // and the high half in the other: their minimum is min(k[l], k[l ^ 16]) resp. min(k[l], k[l ^ 32]).
+    k = min2(swap16_lo(k), swap16_hi(k));
+    k = min2(swap32_lo(k), swap32_hi(k));
     return k;
 }
 #endif
@@ -1045,20 +1071,28 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
     }
 }
 
+// x / D and x % D for a block-uniform D with the host's magic number (NaryDesc::magic): a multiply-high
+// and a multiply instead of the ~25 instructions of an emulated integer division (x < 2^16).
+__device__ __forceinline__ void nary_divmod(int x, int D, uint32_t magic, int& q, int& r) {
+    q = D == 1 ? x : (int)(((uint64_t)(uint32_t)x * magic) >> 32);
+    r = x - q * D;
+}
+
 // dig[j][1..A-1] = the mixed-radix digits (dimensions 1..A-1, last fastest) of q_j = tid + j * NT,
 // those of R - 1 where q_j is past the table.  Divisions for q_0 and for the block-uniform stride
 // NT only; q_j = q_(j-1) + NT is a digit-wise addition with carry.
 template <int A, int NJ>
-__device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A], const bool (&live)[NJ],
-                                            int (&dig)[NJ][A]) {
+__device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A], const uint32_t (&mg)[A],
+                                            const bool (&live)[NJ], int (&dig)[NJ][A]) {
     int step[A];
     int rem = tid, rs = NT;
 #pragma unroll
     for (int i = A - 1; i >= 1; --i) {
-        dig[0][i] = rem % Dm[i];
-        rem /= Dm[i];
-        step[i] = rs % Dm[i];
-        rs /= Dm[i];
+        int q;
+        nary_divmod(rem, Dm[i], mg[i], q, dig[0][i]);
+        rem = q;
+        nary_divmod(rs, Dm[i], mg[i], q, step[i]);
+        rs = q;
     }
 #pragma unroll
     for (int j = 1; j < NJ; ++j) {
@@ -1090,10 +1124,12 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     int Dm[A], off[A];
+    uint32_t mg[A];
     int sumd = 0;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         Dm[i] = fd.dom[i];
+        mg[i] = fd.magic[i];
         off[i] = sumd;
         sumd += Dm[i];
     }
@@ -1133,7 +1169,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // per owned q: its digits' messages and the running minima for p >= 1
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
-    nary_digits<A, NJ>(tid, NT, Dm, live, dig);
+    nary_digits<A, NJ>(tid, NT, Dm, mg, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -1288,10 +1324,12 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
     const NaryDesc fd = descs[blockIdx.x];
     const int tid = (int)threadIdx.x, NT = (int)blockDim.x;
     int Dm[A], off[A];
+    uint32_t mg[A];
     int sumd = 0;
 #pragma unroll
     for (int i = 0; i < A; ++i) {
         Dm[i] = fd.dom[i];
+        mg[i] = fd.magic[i];
         off[i] = sumd;
         sumd += Dm[i];
     }
@@ -1332,7 +1370,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
     __syncthreads();
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
-    nary_digits<A, NJ>(tid, NT, Dm, live, dig);
+    nary_digits<A, NJ>(tid, NT, Dm, mg, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll

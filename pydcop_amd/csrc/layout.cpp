@@ -458,6 +458,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.dom[i] = in ? L.edge_dom[d.edge_base + i] : 1;
                         d.f2v_off[i] = in ? L.f2v_off[d.edge_base + i] : 0;
                         d.v2f_off[i] = 0;  // filled in once the variable side is laid out
+                        d.magic[i] = d.dom[i] > 1 ? (uint32_t)((((uint64_t)1 << 32) + d.dom[i] - 1) / d.dom[i]) : 0u;
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
                     if (t != TAB_FULL) {  // lane-packed narrow image (layout.h, nary_packed_pos)

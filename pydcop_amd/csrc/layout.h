@@ -152,6 +152,8 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
     int32_t dom[4];      // domain sizes in dimensions order (1 beyond the arity)
     int32_t v2f_off[4];  // V2F offsets of the incoming messages
     int32_t f2v_off[4];  // F2V offsets of the outgoing messages
+    uint32_t magic[4];   // ceil(2^32 / dom[i]) (0 for dom[i] = 1): x / dom[i] == (x * magic[i]) >> 32 for the
+                         // x < 2^16 the kernel divides (a lane's index into the table rows)
 };
 
 // One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME
