@@ -370,14 +370,35 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    // Is the block size of the launch group a multiple of the LAST dimension of every factor in it
+    // (kernels.h, nary_batch: LS)?  Looked at once per group (the groups change only in widen_factor).
+    std::vector<int8_t> nary_ls_cache;
+    bool nary_last_same(const NaryLaunch& nl) {
+        const size_t idx = (size_t)(&nl - L.nary_launches.data());
+        if (nary_ls_cache.size() != L.nary_launches.size()) nary_ls_cache.assign(L.nary_launches.size(), -1);
+        if (nary_ls_cache[idx] < 0) {
+            int8_t ok = 1;
+            for (int j = 0; j < nl.count && ok; ++j) {
+                const NaryDesc& d = L.ndesc[nl.first + j];
+                if (nl.threads % d.dom[(d.arity & 255) - 1] != 0) ok = 0;
+            }
+            nary_ls_cache[idx] = ok;
+        }
+        return nary_ls_cache[idx] == 1;
+    }
+
     int launch_nary(const SweepArgs<T>& a, int cut) {
         for (const NaryLaunch& nl : L.nary_launches) {
             if (nl.cut != cut) continue;
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
+            const bool ls = nary_last_same(nl);
 #define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
     do {                                                                                                    \
-        if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, 0, stream, a, d);  \
+        if (AR == 3 && ls) {  /* kernels.h, nary_batch: LS */                                               \
+            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, 0, stream, a, d);  \
+            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, 0, stream, a, d);           \
+        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, 0, stream, a, d);  \
         else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, 0, stream, a, d);           \
     } while (0)
 #define MXS_NARY_CASE(AR, NJ)                                                                              \
@@ -511,6 +532,7 @@ struct Engine : EngineBase {
         });
         L.ndesc.clear();
         L.nary_launches.clear();
+        nary_ls_cache.clear();
         for (size_t i = 0; i < items.size(); ++i) {
             const Item& it = items[i];
             if (i == 0 || it.cut != items[i - 1].cut || it.code != items[i - 1].code || it.type != items[i - 1].type)

@@ -1015,7 +1015,11 @@ constexpr int NARY_UNR = 4;  // values of d0 per batch: UNR * NJ table loads per
 
 // One batch of d0 values: `tv[u][j]` = table[d0 + u][q_j].  Every entry feeds all A outputs.
 // MASKED: some (u, j) are out of range (tail batch / q >= R) and must not count.
-template <typename T, int A, int NJ, bool MASKED>
+// LS ("last digit the same", arity 3): the block size is a multiple of the last dimension, so a lane's NJ
+// entries of a table row differ in the digit of dimension 1 only -- the message of dimension 2 they add is
+// ONE value, and the sum (0 + m0) + m2 for the output to variable 1 is computed once per d0, not once per
+// entry (24^3 tables on 192 lanes: 8 of the 96 f64 operations of a batch).  Same values, same bits.
+template <typename T, int A, int NJ, bool MASKED, bool LS = false>
 __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, int D0, const T* s_m0,
                                            const T (&ms)[NJ][A], const T (&s0)[NJ], const bool (&live)[NJ],
                                            T (&acc)[NJ][A], typename OrdKey<T>::U* s_key0) {
@@ -1025,6 +1029,7 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
         const T m0 = s_m0[(!MASKED || d0 + u < D0) ? d0 + u : 0];
         const T a0 = (T)0 + m0;
         T b0 = pos_inf<T>();
+        const T sp1_shared = (LS && A == 3) ? a0 + ms[0][A - 1] : (T)0;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             T t = tv[u][j];
@@ -1034,9 +1039,13 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
 #pragma unroll
             for (int p = 1; p < A; ++p) {
                 T sp = a0;
+                if (LS && A == 3 && p == 1) {
+                    sp = sp1_shared;
+                } else {
 #pragma unroll
-                for (int i = 1; i < A; ++i)
-                    if (i != p) sp += ms[j][i];
+                    for (int i = 1; i < A; ++i)
+                        if (i != p) sp += ms[j][i];
+                }
                 acc[j][p] = min2(acc[j][p], t + sp);
             }
         }
@@ -1310,7 +1319,7 @@ __device__ __forceinline__ T nary_slot_entry(const uint32_t* w, int j) {
 
 // NEG (max mode: narrow images hold un-negated values) is a template parameter: the negation then
 // folds into the first use of the entry as an operand modifier instead of a 64-bit select per entry.
-template <typename T, int A, int NJ, typename TT, bool NEG>
+template <typename T, int A, int NJ, typename TT, bool NEG, bool LS = false>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
@@ -1406,9 +1415,9 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
                 }
                 const int d0 = b * UNR;
                 if (all_live && d0 + UNR <= D0)
-                    nary_batch<T, A, NJ, false>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+                    nary_batch<T, A, NJ, false, LS>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
                 else
-                    nary_batch<T, A, NJ, true>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+                    nary_batch<T, A, NJ, true, LS>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
             }
         }
     }
