@@ -351,20 +351,34 @@ struct Engine : EngineBase {
                 case 4: hipLaunchKernelGGL((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
                 default: hipLaunchKernelGGL((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
             }
-        } else if (streaming) {  // the cycle does not fit the Infinity Cache: see kernels.h, NT_STREAMING
-            switch (L.dsel) {
-                case 2: hipLaunchKernelGGL((k_sweep<T, 2, NT_STREAMING>), grid, block, 0, stream, a); break;
-                case 3: hipLaunchKernelGGL((k_sweep<T, 3, NT_STREAMING>), grid, block, 0, stream, a); break;
-                case 4: hipLaunchKernelGGL((k_sweep<T, 4, NT_STREAMING>), grid, block, 0, stream, a); break;
-                default: hipLaunchKernelGGL((k_sweep<T, 0, NT_STREAMING>), grid, block, 0, stream, a); break;
-            }
         } else {
+            // <.., policy, schedule>: NT_STREAMING when the cycle does not fit the Infinity Cache (kernels.h);
+            // the lean instantiation when the launch has a block schedule
+#define MXS_SWEEP(DS)                                                                                          \
+    do {                                                                                                        \
+        if (streaming) {                                                                                        \
+            if (a.sched) hipLaunchKernelGGL((k_sweep<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);   \
+            else hipLaunchKernelGGL((k_sweep<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);          \
+        } else {                                                                                                \
+            if (a.sched) hipLaunchKernelGGL((k_sweep<T, DS, MXS_NT, true>), grid, block, 0, stream, a);         \
+            else hipLaunchKernelGGL((k_sweep<T, DS, MXS_NT, false>), grid, block, 0, stream, a);                \
+        }                                                                                                       \
+    } while (0)
             switch (L.dsel) {
-                case 2: hipLaunchKernelGGL((k_sweep<T, 2>), grid, block, 0, stream, a); break;
-                case 3: hipLaunchKernelGGL((k_sweep<T, 3>), grid, block, 0, stream, a); break;
-                case 4: hipLaunchKernelGGL((k_sweep<T, 4>), grid, block, 0, stream, a); break;
-                default: hipLaunchKernelGGL((k_sweep<T, 0>), grid, block, 0, stream, a); break;
+                case 2:  // its own kernel (SGPR budget, kernels.h)
+                    if (streaming) {
+                        if (a.sched) hipLaunchKernelGGL((k_sweep_d2<T, NT_STREAMING, true>), grid, block, 0, stream, a);
+                        else hipLaunchKernelGGL((k_sweep_d2<T, NT_STREAMING, false>), grid, block, 0, stream, a);
+                    } else {
+                        if (a.sched) hipLaunchKernelGGL((k_sweep_d2<T, MXS_NT, true>), grid, block, 0, stream, a);
+                        else hipLaunchKernelGGL((k_sweep_d2<T, MXS_NT, false>), grid, block, 0, stream, a);
+                    }
+                    break;
+                case 3: MXS_SWEEP(3); break;
+                case 4: MXS_SWEEP(4); break;
+                default: MXS_SWEEP(0); break;
             }
+#undef MXS_SWEEP
         }
         HIP_TRY(hipGetLastError());
         return MXS_OK;

@@ -782,10 +782,14 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
     }
 }
 
-template <typename T, int DSEL, bool P2P = false, int NT = MXS_NT>
+// SCHED: the launch has a block schedule (launch 0 of every cycle: a.sched != NULL) -- the instantiation
+// then carries neither the compare chain on block_base[] nor the halo wait of the cut classes (which run
+// in launches without schedule), and its prologue is two dependent scalar loads (schedule word, class
+// record) instead of a chain of argument pieces.
+template <typename T, int DSEL, bool P2P = false, int NT = MXS_NT, bool SCHED = false>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0, blk = -1;
-    if (a.sched != nullptr) {
+    if (SCHED || a.sched != nullptr) {
         const uint32_t s = a.sched[blockIdx.x];
         c = (int)(s >> 24);
         blk = (int)(s & 0xffffffu);
@@ -795,7 +799,7 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     }
     const ClassInfo ci = a.classes[c];
     const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
-    if (ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
+    if (!SCHED && ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;
         if (j >= ci.count) return ci.kind;
@@ -825,10 +829,24 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
 // instead of 2048 resident blocks in the per-block timeline).
 // (Forcing the D = 2 / 3 instantiations to 64 VGPRs -- 8 waves per SIMD, 2 048 resident workgroups instead of
 // 1 792 -- changes nothing measurable: profiles/r03_sweep_waves_ab_v1.txt.)
-template <typename T, int DSEL, int NT = MXS_NT>
-__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+// SGPR budget per instantiation: what keeps the occupancy the VGPRs allow.  D = 2 (53-56 VGPRs, 8 waves per
+// SIMD) must stay within 80 SGPRs -- 8 workgroups per CU; D = 3 runs 7 waves per SIMD on its 69 VGPRs
+// anyway, and with 104 SGPRs its prologue (kernel arguments, class record) holds what it loaded instead of
+// spilling and reloading it: coloring_100k 18.75 -> 18.15 us, 10k 6.5 -> 5.9, the 1M instance 244 -> 234;
+// Ising (D = 2) with 104: 99 -> 101 us, f32 71.5 -> 78.5 (`profiles/r03_sweep_sgpr_ab_v1.txt`).
+#ifndef SWEEP_SGPRS
+#define SWEEP_SGPRS 104
+#endif
+template <typename T, int DSEL, int NT = MXS_NT, bool SCHED = false>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(SWEEP_SGPRS)))
 k_sweep(SweepArgs<T> a) {
-    sweep_block<T, DSEL, false, NT>(a);
+    sweep_block<T, DSEL, false, NT, SCHED>(a);
+}
+// (the attribute takes no template-dependent value: the D = 2 instantiations are a kernel of their own)
+template <typename T, int NT = MXS_NT, bool SCHED = false>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) __attribute__((amdgpu_num_sgpr(80)))
+k_sweep_d2(SweepArgs<T> a) {
+    sweep_block<T, 2, false, NT, SCHED>(a);
 }
 
 // The sweep of a shard in peer-store mode (engine.hip, p2p): same blocks, plus the stores of

@@ -122,8 +122,8 @@ def test_no_kernel_uses_scratch():
     # the sweep's register budget: 7 waves per SIMD (<= 72 VGPRs) for the metric's
     # instantiation, both cache policies (a restructured block loop once cost 12 registers and
     # 3 % of the metric without anything else noticing)
-    sweep = {n: v for n, v in _VGPRS["engine.hip"].items() if "7k_sweepIdLi3ELi" in n}   # <double, D = 3, policy>
-    assert len(sweep) == 2 and max(sweep.values()) <= 72, sweep
+    sweep = {n: v for n, v in _VGPRS["engine.hip"].items() if "7k_sweepIdLi3ELi" in n}   # <double, D = 3, policy, schedule>
+    assert len(sweep) >= 2 and max(sweep.values()) <= 72, sweep
 
 
 @pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6)])
