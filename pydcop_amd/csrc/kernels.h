@@ -798,6 +798,8 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
         for (int i = 1; i < MAX_CLASSES; ++i) c += ((int)blockIdx.x >= a.block_base[i]) ? 1 : 0;
     }
     const ClassInfo ci = a.classes[c];
+    // (Forcing the whole class record into SGPRs in one round of scalar loads -- two dependent rounds fewer
+    // before the first vector load -- measured no gain: profiles/r03_class_preload_ab_v1.txt.)
     const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
     if (!SCHED && ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
