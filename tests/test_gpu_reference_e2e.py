@@ -18,7 +18,9 @@ import pytest
 
 from oracle.stage_reference import locate
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(locate() is None,
+                                 reason="no reference: oracle/_ref/pydcop_reference.tar.gz was not staged by build()")]
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = locate()
