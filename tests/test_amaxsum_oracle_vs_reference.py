@@ -1,8 +1,8 @@
 """Pins oracle/amaxsum_oracle.c against the REAL reference: the reference's own amaxsum
 computations (pydcop/algorithms/amaxsum.py) driven first-in-first-out by
 oracle/ref_harness.run_reference_amaxsum -- values, costs, the number of messages of every
-generation, and every message a computation holds / last sent.  Only where /root/reference
-exists (build container); tests/golden/amaxsum_*.npz stand in on the GPU box."""
+generation, and every message a computation holds / last sent.  Where the reference is on the
+machine (oracle/stage_reference.locate()); tests/golden/amaxsum/*.npz carry the same pins everywhere."""
 import numpy as np
 import pytest
 

@@ -2,7 +2,7 @@
 (pydcop/algorithms/dsa.py, variants A / B / C, both p_modes) run for exactly n cycles by
 oracle/ref_harness.run_reference_dsa, their draws from the unseeded `random` module replaced on
 BOTH sides by one counter-based generator (dsa_uniform) -- selected values and held costs, bit for
-bit.  Only where /root/reference exists (build container)."""
+bit.  Where the reference is on the machine (oracle/stage_reference.locate())."""
 import numpy as np
 import pytest
 

@@ -2,7 +2,7 @@
 (pydcop/algorithms/mgm.py) run for exactly R rounds by oracle/ref_harness.run_reference_mgm --
 selected values and held costs, bit for bit.  Variable costs sit on a binary grid so that the one
 order the reference leaves to PYTHONHASHSEED (its `concerned_vars` set) cannot change a sum.
-Only where /root/reference exists (build container)."""
+Where the reference is on the machine (oracle/stage_reference.locate())."""
 import numpy as np
 import pytest
 

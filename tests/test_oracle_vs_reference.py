@@ -1,6 +1,7 @@
 """Pins the C oracle against the REAL reference, run live through
-oracle/ref_harness.py.  Only possible where /root/reference exists (the build
-container); skipped on the GPU box, where tests/golden/ stands in."""
+oracle/ref_harness.py.  Where the reference is on the machine
+(oracle/stage_reference.locate()); tests/golden/ carries the same pins everywhere, and
+tests/test_gpu_vs_reference.py compares the HIP engine with the reference directly on the GPU box."""
 import numpy as np
 import pytest
 
