@@ -38,6 +38,9 @@
 namespace mxs {
 
 constexpr int SAME_COUNT = 4;  // maxsum.py:106
+#ifndef MXS_ASM_MIN
+#define MXS_ASM_MIN 1
+#endif
 #ifndef SWEEP_MIN_WAVES
 #define SWEEP_MIN_WAVES 4
 #endif
@@ -942,7 +945,18 @@ __device__ __forceinline__ T wave_min(T x) {  // all 64 lanes get the minimum
 
 // min(a, b) as one instruction.  Equal to the reference's `if (best > cur) best = cur`
 // scan for every value but the sign of a zero minimum, which nothing downstream observes.
-__device__ __forceinline__ double min2(double x, double y) { return __builtin_fmin(x, y); }
+// (f64: the instruction itself.  Through __builtin_fmin the compiler first canonicalises every operand it
+// cannot prove canonical -- a `v_max_f64 x, x, x` per value that came out of a lane exchange or a conversion,
+// 120 of the ~1 000 f64 instructions of the n-ary kernel -- to quiet signalling NaNs, which no cost is.)
+__device__ __forceinline__ double min2(double x, double y) {
+#if defined(__HIP_DEVICE_COMPILE__) && MXS_ASM_MIN
+    double r;
+    asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+#else
+    return __builtin_fmin(x, y);
+#endif
+}
 __device__ __forceinline__ float min2(float x, float y) { return __builtin_fminf(x, y); }
 
 // Wavefront minimum with DPP moves instead of ds_bpermute shuffles: quad swaps, row half mirror,
