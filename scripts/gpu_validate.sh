@@ -10,6 +10,6 @@ echo "== bench default"
 ( time timeout 900 python bench.py ) 2>&1 | tail -5 | tee $OUT/bench_default.json
 echo "== rocprofv3 kernel trace of the metric's configuration"
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python $R/bench.py --no-cpu-baseline --configs main --steps 500 --warmup 50 > $OUT/prof.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python $R/bench.py --no-cpu-baseline --configs main --steps 2000 --warmup 200 > $OUT/prof.log 2>&1
 f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_coloring100k.csv && cut -c1-200 $OUT/kernel_stats_coloring100k.csv | head -6; rm -rf $OUT/p
 tail -1 $OUT/prof.log | cut -c1-300
