@@ -966,7 +966,7 @@ __device__ __forceinline__ float min2(float x, float y) { return __builtin_fminf
 #ifndef MXS_NARY_DPP
 #define MXS_NARY_DPP 1  // measured: meeting_50k 1168 -> 1099 us (f32 681 -> 655), parity green
 #endif
-#if defined(__HIPCC__) && MXS_NARY_DPP
+#if MXS_NARY_DPP  // (the emulated build of the CPU tests provides the same lane-selection rules: tests/emu/hip)
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_mov(double x) {
     int lo = __double2loint(x), hi = __double2hiint(x);
@@ -991,7 +991,11 @@ __device__ __forceinline__ T wave_min_to_lane63(T x) {
     return x;
 }
 // The two registers a permlane swap of (x, x) leaves behind, per 32-bit half of T.
+#if defined(__HIPCC__)
 typedef unsigned int swap2u __attribute__((ext_vector_type(2)));
+#else
+typedef hipemu_swap2 swap2u;
+#endif
 template <bool W32, bool SECOND>
 __device__ __forceinline__ unsigned int swap_word(unsigned int w) {
     const swap2u r = W32 ? __builtin_amdgcn_permlane32_swap(w, w, false, false)
@@ -1085,7 +1089,7 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
         }
         best0[u] = b0;
     }
-#if defined(__HIPCC__) && MXS_NARY_DPP && MXS_NARY_REDUCE4
+#if MXS_NARY_DPP && MXS_NARY_REDUCE4
     static_assert(NARY_UNR == 4, "wave_min4 reduces four values");
     {
         const T m = wave_min4(best0);
@@ -1094,7 +1098,7 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
         if (l < 4 && (!MASKED || d0 + u < D0)) atomicMin(&s_key0[d0 + u], OrdKey<T>::enc(m));
     }
     if (false) {
-#elif defined(__HIPCC__) && MXS_NARY_DPP
+#elif MXS_NARY_DPP
 #pragma unroll
     for (int u = 0; u < NARY_UNR; ++u) best0[u] = wave_min_to_lane63(best0[u]);
     if ((threadIdx.x & 63) == 63) {

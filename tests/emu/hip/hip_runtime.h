@@ -235,6 +235,58 @@ inline V __shfl(V var, int src_lane, int width = 64) {
     return out;
 }
 
+// DPP moves and the gfx950 permlane swaps the wave reductions of kernels.h use (wave_min_to_lane63,
+// wave_min4): the lane-selection rules of the ISA, so that the CPU suite runs the product's reduction and
+// not a stand-in.  old == what a lane keeps when its row is masked off or the control gives it no source.
+inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool bound_ctrl) {
+    (void)bank_mask;
+    (void)bound_ctrl;
+    const unsigned t = threadIdx.x, lane = t % 64, base = t - lane, row = lane / 16, i = lane % 16;
+    hipemu::g_xchg[t] = (unsigned long long)(unsigned)src;
+    hipemu::yield_barrier();
+    int from = -1;
+    if (ctrl < 0x100) from = (int)((lane & ~3u) + (((unsigned)ctrl >> (2 * (lane & 3))) & 3u));  // quad_perm
+    else if (ctrl == 0x140) from = (int)(row * 16 + 15 - i);                                        // row_mirror
+    else if (ctrl == 0x141) from = (int)((lane & ~7u) + 7 - (lane & 7));                            // row_half_mirror
+    else if (ctrl == 0x142) from = row > 0 ? (int)(row * 16 - 1) : -1;     // row_bcast15: lane 15 of the previous row
+    else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;                     // row_bcast31: lane 31 to rows 2, 3
+    else if (ctrl > 0x120 && ctrl < 0x130) from = (int)(row * 16 + ((i + 16 - (unsigned)(ctrl - 0x120)) & 15));  // row_ror:n
+    else abort();
+    int out = old;
+    if (from >= 0 && ((row_mask >> row) & 1)) out = (int)(unsigned)hipemu::g_xchg[base + (unsigned)from];
+    hipemu::yield_barrier();
+    return out;
+}
+struct hipemu_swap2 {
+    unsigned int x, y;
+};
+// v_permlane16_swap: the odd rows (16 lanes each) of the first operand trade places with the even rows of
+// the second; v_permlane32_swap: the upper half of the first with the lower half of the second.
+inline hipemu_swap2 hipemu_permlane_swap(unsigned int a, unsigned int b, bool halves) {
+    const unsigned t = threadIdx.x, lane = t % 64, base = t - lane;
+    hipemu::g_xchg[t] = ((unsigned long long)b << 32) | a;
+    hipemu::yield_barrier();
+    hipemu_swap2 r{a, b};
+    const unsigned span = halves ? 32 : 16, blk = lane / span, i = lane % span;
+    if (blk & 1) {  // odd row / upper half of the first operand <- even row / lower half of the second
+        r.x = (unsigned)(hipemu::g_xchg[base + (blk - 1) * span + i] >> 32);
+    } else {        // even row / lower half of the second operand <- odd row / upper half of the first
+        r.y = (unsigned)(hipemu::g_xchg[base + (blk + 1) * span + i] & 0xffffffffull);
+    }
+    hipemu::yield_barrier();
+    return r;
+}
+inline hipemu_swap2 __builtin_amdgcn_permlane16_swap(unsigned int a, unsigned int b, bool, bool) { return hipemu_permlane_swap(a, b, false); }
+inline hipemu_swap2 __builtin_amdgcn_permlane32_swap(unsigned int a, unsigned int b, bool, bool) { return hipemu_permlane_swap(a, b, true); }
+inline int __double2loint(double x) { unsigned long long b; std::memcpy(&b, &x, 8); return (int)(unsigned)(b & 0xffffffffull); }
+inline int __double2hiint(double x) { unsigned long long b; std::memcpy(&b, &x, 8); return (int)(unsigned)(b >> 32); }
+inline double __hiloint2double(int hi, int lo) {
+    const unsigned long long b = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
+    double x; std::memcpy(&x, &b, 8); return x;
+}
+inline int __float_as_int(float x) { int b; std::memcpy(&b, &x, 4); return b; }
+inline float __int_as_float(int b) { float x; std::memcpy(&x, &b, 4); return x; }
+
 // 64-bit mask of the lanes of the wave whose predicate is non-zero
 inline unsigned long long __ballot(int pred) {
     const unsigned t = threadIdx.x;
