@@ -1864,8 +1864,8 @@ __global__ void __launch_bounds__(BLOCK) k_table_update(T* tables, int64_t base,
 // parent[base + sum_i digit_i(k) * stride[i]].
 struct SliceDims {
     int32_t n;                 // writable dimensions
-    int32_t dom[16];           // their sizes, in scope order
-    int64_t stride[16];        // their strides in the parent table
+    int32_t dom[MAX_ARITY];    // their sizes, in scope order
+    int64_t stride[MAX_ARITY]; // their strides in the parent table
     int64_t base;              // offset contributed by the external dimensions' values
 };
 template <typename T>

@@ -66,7 +66,7 @@ std::string validate(const mxs_graph& g) {
     for (int32_t f = 0; f < g.n_factors; ++f) {
         const int32_t e0 = g.factor_rowptr[f], e1 = g.factor_rowptr[f + 1];
         if (e1 <= e0) { err << "factor " << f << " has no variable"; return err.str(); }
-        if (e1 - e0 > 16) { err << "factor " << f << ": arity > 16 not supported"; return err.str(); }
+        if (e1 - e0 > MAX_ARITY) { err << "factor " << f << ": arity > " << MAX_ARITY << " not supported"; return err.str(); }
         int64_t size = 1;
         for (int32_t e = e0; e < e1; ++e) {
             const int32_t v = g.edge_var[e];

@@ -100,6 +100,9 @@ constexpr int64_t nary_packed_pos(int64_t d0, int64_t q, int nt, int slot, int e
 }
 constexpr int NUM_XCD = 8;  // MI355X: workgroup b of a grid runs on XCD b % 8 (observed; used for speed only)
 constexpr int MAX_REG_D = 4;
+// The reference has no limit on the arity of a constraint (maxsum.py:411-421 walks any scope); a table of
+// more than 2^31 entries cannot be addressed here, so 30 binary variables is the most a factor can have.
+constexpr int MAX_ARITY = 30;
 constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
 

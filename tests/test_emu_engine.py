@@ -120,3 +120,29 @@ def _empty_graph_checks(oracle_mod, lib_path=None):
 
 def test_emu_empty_and_invalid_graphs(emu_lib, oracle_built):
     _empty_graph_checks(oracle_built, emu_lib)
+
+
+def test_emu_factor_of_arity_18(emu_lib, oracle_built):
+    """The reference has no limit on a constraint's arity (maxsum.py:411-421); the engine's is what a
+    2^31-entry table allows (30 binary variables).  An arity-18 factor over binary variables (262 144
+    entries) among ordinary ones: generic factor kernel == oracle, bit for bit."""
+    import numpy as np
+    from pydcop_amd.engine import MaxSumEngine
+    from pydcop_amd.generators import _finish
+    rng = np.random.default_rng(18)
+    n = 24
+    scopes = [list(range(18))] + [[int(a), int(b)] for a, b in zip(rng.integers(0, n, 30), rng.integers(0, n, 30)) if a != b]
+    tables = [rng.integers(0, 7, 2 ** len(sc)).astype(np.float64) for sc in scopes]
+    rowptr = np.concatenate([[0], np.cumsum([len(sc) for sc in scopes])]).astype(np.int32)
+    toff = np.concatenate([[0], np.cumsum([t.shape[0] for t in tables])]).astype(np.int64)
+    g = _finish(np.full(n, 2, dtype=np.int32), rng.uniform(0, 0.01, 2 * n), rowptr,
+                np.concatenate(scopes).astype(np.int32), np.concatenate(tables), toff).validate()
+    p = Params(start_messages="all")
+    with MaxSumEngine(g, p, lib_path=emu_lib) as eng:
+        ora = oracle_built.OracleMaxSum(g, p)
+        for k in (0, 1, 3):
+            eng.run(k), ora.run(k)
+            for x, y in zip(eng.messages(), ora.messages()):
+                np.testing.assert_array_equal(x, y)
+            np.testing.assert_array_equal(eng.assignment()[1], ora.assignment()[1])
+        ora.close()

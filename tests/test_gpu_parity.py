@@ -201,3 +201,10 @@ def test_dynamic_maxsum(dtype, oracle_built):
     for seed in (1, 2):
         check_dynamic_run(oracle_built, dtype=dtype, seed=seed)
     check_dynamic_run(oracle_built, dtype=dtype, seed=3, float_tables=False)
+
+
+def test_factor_of_arity_18(oracle_built):
+    """The reference has no arity limit (maxsum.py:411-421); the engine's is 30 (a 2^31-entry table).  An
+    arity-18 factor over binary variables among ordinary ones: generic factor kernel == oracle, bit for bit."""
+    import test_emu_engine as E
+    E.test_emu_factor_of_arity_18(None, oracle_built)
