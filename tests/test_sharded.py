@@ -191,11 +191,11 @@ def _run_ranks(world, lib, case, steps, tmp_path, timeout=600, extra_env=None):
     return np.load(out)
 
 
-@pytest.mark.parametrize("case", ["coloring", "mixed_max"])
-def test_gloo_two_ranks_equal_single_engine(case, emu_lib, tmp_path):
-    """pydcop_amd.sharded.ShardedMaxSum over torch.distributed (gloo, world 2)."""
+@pytest.mark.parametrize("case,world", [("coloring", 2), ("mixed_max", 2), ("coloring", 4)])
+def test_gloo_two_ranks_equal_single_engine(case, world, emu_lib, tmp_path):
+    """pydcop_amd.sharded.ShardedMaxSum over torch.distributed (gloo, world 2 and 4: a process per rank)."""
     steps = [1, 5, 14]
-    z = _run_ranks(2, emu_lib, case, steps, tmp_path)
+    z = _run_ranks(world, emu_lib, case, steps, tmp_path)
     g, kw = make_case(case)
     one = MaxSumEngine(g, Params(**kw), lib_path=emu_lib)
     done = 0
@@ -481,7 +481,7 @@ def test_nccl_world1_code_path(collective, tmp_path):
     np.testing.assert_array_equal(z["bel_25"], one.assignment()[1])
 
 
-@pytest.mark.parametrize("case,k", [("coloring", 2), ("ising", 3), ("mixed_max", 2), ("coloring_2k", 4)])
+@pytest.mark.parametrize("case,k", [("coloring", 2), ("ising", 3), ("mixed_max", 2), ("coloring_2k", 4), ("coloring_2k", 8)])
 def test_local_sharded_one_process_equals_single_engine(case, k, emu_lib, fake_rccl, tmp_path, monkeypatch):
     """pydcop_amd.sharded.LocalShardedMaxSum (what the plugin's `devices` parameter runs): k
     shards on k (emulated) devices driven by k threads of ONE process through the library's own
