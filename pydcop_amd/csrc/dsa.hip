@@ -259,28 +259,28 @@ __global__ void __launch_bounds__(PACK_TPB) k_dsa_cycle_pack(Dev<T> g) {
     const int var = (int)(((uint32_t)l * (dn >> 16)) >> 15);  // l / deg (exact for l < 64)
     const int k = l - var * deg;
     const bool has = var < nv;
-    const int v = g.pack.vars[wm.first + (has ? var : 0)];
+    const int v = g.pack.vars[pos];
     const int seg = l - k;
     const int mine = g.cur[v];
     const int D = g.dom_size[v];
+    const double prob = g.prob[v];  // requested with the others, used after the decision
     T t[MAXD], c[MAXD];
     lsearch::pack_costs<T, TT>(g.pack, g.cur, pos, deg, seg, true, t, c);
     T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;   // find_optimal, relations.py:1622-1638
     int n_best = 0, first_best = -1;
     bool has_cur = false;
+    // (selects, no branches: "equal" and "better" exclude each other)
 #pragma unroll
-    for (int x = 0; x < MAXD; ++x)
-        if (x < D) {
-            if (c[x] == best_cost) {
-                n_best += 1;
-                if (x == mine) has_cur = true;
-            } else if ((!g.is_max && c[x] < best_cost) || (g.is_max && c[x] > best_cost)) {
-                best_cost = c[x];
-                n_best = 1;
-                first_best = x;
-                has_cur = x == mine;
-            }
-        }
+    for (int x = 0; x < MAXD; ++x) {
+        const bool in = x < D;
+        const bool lt = c[x] < best_cost, gt = c[x] > best_cost;
+        const bool eq = in & (c[x] == best_cost);
+        const bool better = in & (g.is_max ? gt : lt);
+        n_best = better ? 1 : n_best + (eq ? 1 : 0);
+        first_best = better ? x : first_best;
+        has_cur = better ? x == mine : (has_cur || (eq && x == mine));
+        best_cost = better ? c[x] : best_cost;
+    }
     const T diff = lsearch::pick<T, MAXD>(c, mine) - best_cost;
     const T delta = diff < (T)0 ? -diff : diff;
     // variant B (dsa.py:421-433): some constraint of the variable is not at its optimum -- the
@@ -299,7 +299,7 @@ __global__ void __launch_bounds__(PACK_TPB) k_dsa_cycle_pack(Dev<T> g) {
     }
     int out = mine;
     bool moved = false;
-    if (attempt && g.prob[v] > uniform(g.seed, v, g.cycle + 1, 1)) {
+    if (attempt && prob > uniform(g.seed, v, g.cycle + 1, 1)) {
         const int n = n_best - (drop_cur ? 1 : 0);
         int j = (int)(uniform(g.seed, v, g.cycle + 1, 2) * n);
         int pick = first_best;
@@ -439,7 +439,7 @@ struct Engine : Base {
                 DSA_TRY(pk_recT.upload(rt, stream));
             }
             DSA_TRY(pk_waves.upload(hp.waves, stream));
-            DSA_TRY(pk_vars.upload(hp.vars, stream));
+            DSA_TRY(pk_vars.upload(hp.lane_v, stream));
             DSA_TRY(pk_nb.upload(hp.nb, stream));
             DSA_TRY(pk_slot.upload(hp.slot, stream));
             DSA_TRY(pk_rest.upload(hp.rest, stream));

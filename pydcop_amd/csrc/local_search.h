@@ -165,7 +165,9 @@ struct PackWave {
 };
 struct Pack {  // device pointers
     const PackWave* waves;
-    const int32_t* vars;   // the packed variables, wave after wave
+    const int32_t* vars;   // [lanes] the lane's variable (a padding lane: the wave's first one) -- addressed by the
+                           // lane's position like nb[], so that a variable's own value and its neighbour's are
+                           // requested together (through the wave record they were one dependent load later)
     const int32_t* nb;     // [lanes]
     const int32_t* slot;   // [lanes] CSR slot of the lane, -1 = padding lane
     const void* rec;       // [lanes][PACK_D][PACK_D] int8 or T
@@ -175,6 +177,7 @@ struct HostPack {
     std::vector<PackWave> waves;
     std::vector<int32_t> vars, nb, slot, rest;  // rest: variables with neighbours the pack cannot take
     std::vector<int32_t> lane_var, lane_k, lane_deg;  // [lanes] the lane's variable (-1: padding), position, degree
+    std::vector<int32_t> lane_v;                      // [lanes] = lane_var, padding lanes: the wave's first variable
     std::vector<double> rec;                    // [lanes * 16], as doubles; narrowed at upload
     bool int8_exact = true;
 
@@ -203,6 +206,7 @@ struct HostPack {
                 for (int lane = 0; lane < 64; ++lane) {
                     const int var = lane / deg, k = lane % deg;
                     lane_var.push_back(var < nv ? vs[x + var] : -1);
+                    lane_v.push_back(var < nv ? vs[x + var] : vs[x]);
                     lane_k.push_back(k);
                     lane_deg.push_back(deg);
                     if (var >= nv) {
@@ -234,28 +238,52 @@ struct HostPack {
 // The PACK_D costs of the lane's variable, c[x] = sum over its constraints in slot order of the
 // entry at (x, neighbour's current value); `from_zero` as in costs_of_values.  t[] = the lane's own
 // row (what its constraint contributes).  All 64 lanes take part (padding lanes read record zeros).
+struct alignas(16) Rec16 {
+    uint32_t x, y, z, w;
+};
 template <typename T, typename TT>
 __device__ inline void pack_costs(const Pack& pk, const int32_t* __restrict__ cur, int64_t pos, int deg, int seg,
                                   bool from_zero, T (&t)[PACK_D], T (&c)[PACK_D]) {
     const int u = pk.nb[pos];
-    const int y = u >= 0 ? cur[u] : 0;
+#pragma unroll
+    for (int x = 0; x < PACK_D; ++x) c[x] = (T)0;
     if constexpr (sizeof(TT) == 1) {
-        const uint32_t w = *(const uint32_t*)((const uint8_t*)pk.rec + pos * (PACK_D * PACK_D) + y * PACK_D);
+        // the whole 16-byte record is requested with the neighbour's index (the wave streams through these
+        // lines anyway); the row is picked in registers once the neighbour's value is in: one dependent
+        // level less than a load at rec[pos][y]
+        const Rec16 r = *(const Rec16*)((const uint8_t*)pk.rec + pos * (PACK_D * PACK_D));
+        const int y = u >= 0 ? cur[u] : 0;
+        const uint32_t w = y == 0 ? r.x : (y == 1 ? r.y : (y == 2 ? r.z : r.w));
 #pragma unroll
         for (int x = 0; x < PACK_D; ++x) t[x] = (T)(int)(int8_t)(uint8_t)(w >> (8 * x));
+        // The row travels between lanes as the one packed word it is, and the sums run in INTEGER
+        // arithmetic: every entry is an integer in [-128, 127] (int8_exact, no -0.0), at most 64 of them are
+        // added, so every partial sum of the reference's left-to-right floating-point fold is an integer far
+        // below 2^24 -- exactly representable in f32 and f64, whatever the order and whether the fold starts
+        // from 0 or from the first term: the integer sum converted once IS that fold, bit for bit.
+        int ci[PACK_D];
+#pragma unroll
+        for (int x = 0; x < PACK_D; ++x) ci[x] = 0;
+        for (int kk = 0; kk < deg; ++kk) {
+            const uint32_t wk = (uint32_t)__shfl((int)w, seg + kk, 64);
+#pragma unroll
+            for (int x = 0; x < PACK_D; ++x) ci[x] += (int)(int8_t)(uint8_t)(wk >> (8 * x));
+        }
+#pragma unroll
+        for (int x = 0; x < PACK_D; ++x) c[x] = (T)ci[x];
     } else {
+        const int y = u >= 0 ? cur[u] : 0;
         const T* r = (const T*)pk.rec + pos * (PACK_D * PACK_D) + y * PACK_D;
 #pragma unroll
         for (int x = 0; x < PACK_D; ++x) t[x] = r[x];
-    }
+        for (int kk = 0; kk < deg; ++kk) {  // the PACK_D exchanges of a step in flight together
+            T e[PACK_D];
 #pragma unroll
-    for (int x = 0; x < PACK_D; ++x) {
-        T acc = (T)0;
-        for (int kk = 0; kk < deg; ++kk) {
-            const T e = __shfl(t[x], seg + kk, 64);
-            acc = (!from_zero && kk == 0) ? e : acc + e;
+            for (int x = 0; x < PACK_D; ++x) e[x] = __shfl(t[x], seg + kk, 64);
+            const bool first = !from_zero && kk == 0;
+#pragma unroll
+            for (int x = 0; x < PACK_D; ++x) c[x] = first ? e[x] : c[x] + e[x];
         }
-        c[x] = acc;
     }
 }
 

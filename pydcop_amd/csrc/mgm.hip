@@ -62,6 +62,12 @@ struct Buf {
 };
 
 template <typename T>
+struct alignas(16) GainRec {
+    T gain;
+    int32_t newv, rank;  // rank: written once at init
+};
+
+template <typename T>
 struct Dev {
     int32_t n_vars, is_max;
     const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *init_idx, *name_rank, *n_neigh;
@@ -72,8 +78,11 @@ struct Dev {
     int32_t* cur_out;      // k_mgm_move: after the round
     T* cost_out;
     uint8_t* has_cost;
-    T* gain;
-    int32_t* newv;
+    GainRec<T>* grec;      // [n_vars] gain, new value and name rank of a variable in ONE 16-byte record: what a
+                           // neighbour's move reads of it is one random request instead of three
+    const T* vcc;          // [n_vars] var_cost at the variable's value in `cur` (kept by the move kernels):
+    T* vcc_out;            // the concerned-variable sums read one word instead of cost_off -> cur -> var_cost
+    const T* vc4;          // [n_vars][PACK_D] var_cost of the packed variables, addressed by the variable alone
     lsearch::Slots slots;
     lsearch::Pack pack;          // the packed view (local_search.h): lane per (variable, constraint)
     const int32_t* pack_conc;    // [lanes] element k of the variable's concerned-variables list, -1 = none
@@ -150,8 +159,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
     }
     const T val_cost = add_concerned_costs(g, v, best);  // own cost at the CURRENT value (:449-450)
     const T gain = cost - val_cost;
-    g.gain[v] = gain;
-    g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+    g.grec[v].gain = gain;
+    g.grec[v].newv = nvl;
 }
 
 template <typename T>
@@ -169,7 +179,7 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
             for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
                 const int u = g.edge_var[e];
                 if (u == v) continue;
-                if (first || g.gain[u] > max_n) max_n = g.gain[u];  // max() also in max mode (:513)
+                if (first || g.grec[u].gain > max_n) max_n = g.grec[u].gain;  // max() also in max mode (:513)
                 first = false;
             }
         }
@@ -178,17 +188,18 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
             const int f = g.edge_factor[g.var_edges[k]];
             for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
                 const int u = g.edge_var[e];
-                if (u != v && g.gain[u] == max_n && g.name_rank[u] < g.name_rank[v]) wins_tie = false;
+                if (u != v && g.grec[u].gain == max_n && g.name_rank[u] < g.name_rank[v]) wins_tie = false;
             }
         }
-        const T gain = g.gain[v];
+        const T gain = g.grec[v].gain;
         if (gain > max_n || (gain == max_n && wins_tie)) {  // :514-525, lexic ties :566-588
-            cur = g.newv[v];
+            cur = g.grec[v].newv;
             cost = cost - gain;
         }
     }
     g.cur_out[v] = cur;
     g.cost_out[v] = cost;
+    g.vcc_out[v] = g.var_cost[g.cost_off[v] + cur];
 }
 
 // ---- the same two kernels on the slot view (local_search.h) ---------------------------------
@@ -229,8 +240,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
         }
     const T val_cost = add_concerned_costs_listed(g, v, best);
     const T gain = cost - val_cost;
-    g.gain[v] = gain;
-    g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
+    g.grec[v].gain = gain;
+    g.grec[v].newv = nvl;
 }
 
 template <typename T>
@@ -248,7 +260,7 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
         for (int k = k0; k < k1; ++k) {  // one pass: the largest gain and whether a lower name holds it
             const int u = g.slots.conc_var[k];
             if (u == v) continue;
-            const T gu = g.gain[u];
+            const T gu = g.grec[u].gain;
             const bool lower = g.name_rank[u] < my_rank;
             if (first || gu > max_n) {
                 max_n = gu;
@@ -258,14 +270,15 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
             }
             first = false;
         }
-        const T gain = g.gain[v];
+        const T gain = g.grec[v].gain;
         if (gain > max_n || (gain == max_n && wins_tie)) {
-            cur = g.newv[v];
+            cur = g.grec[v].newv;
             cost = cost - gain;
         }
     }
     g.cur_out[v] = cur;
     g.cost_out[v] = cost;
+    g.vcc_out[v] = g.var_cost[g.cost_off[v] + cur];
 }
 
 // ---- the same two kernels on the PACKED view (local_search.h): one lane per (variable, constraint) ----
@@ -273,7 +286,7 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
 // deg + 1 entries): element k, and on lane k = 0 also element deg.
 constexpr int PACK_TPB = 256;
 struct PackLane {
-    int deg, nv, var, k, seg, v;
+    int deg, nv, var, k, seg, v, q;
     bool has;
 };
 template <typename T>
@@ -288,7 +301,8 @@ __device__ inline PackLane pack_lane(const Dev<T>& g, int64_t pos) {
     p.k = l - p.var * p.deg;
     p.has = p.var < p.nv;
     p.seg = l - p.k;
-    p.v = g.pack.vars[wm.first + (p.has ? p.var : 0)];
+    p.v = g.pack.vars[pos];
+    p.q = wm.first + (p.has ? p.var : 0);
     return p;
 }
 
@@ -299,16 +313,16 @@ template <typename T>
 __device__ inline T pack_add_concerned(const Dev<T>& g, const PackLane& p, int64_t pos, T acc) {
     const int u = g.pack_conc[pos], ux = g.pack_conc_x[pos];
     T w = (T)0, wx = (T)0;
-    if (u >= 0) w = g.var_cost[g.cost_off[u] + g.cur[u]];
-    if (ux >= 0) wx = g.var_cost[g.cost_off[ux] + g.cur[ux]];
+    if (u >= 0) w = g.vcc[u];
+    if (ux >= 0) wx = g.vcc[ux];
+    // which lanes hold an element: one ballot each instead of a lane exchange per step
+    const unsigned long long live = __ballot(u >= 0 ? 1 : 0), live_x = __ballot(ux >= 0 ? 1 : 0);
     for (int i = 0; i < p.deg; ++i) {
         const T e = __shfl(w, p.seg + i, 64);
-        const int ui = __shfl(u, p.seg + i, 64);
-        if (ui >= 0) acc += e;
+        acc = ((live >> (p.seg + i)) & 1ull) ? acc + e : acc;
     }
     const T ex = __shfl(wx, p.seg, 64);
-    const int uxi = __shfl(ux, p.seg, 64);
-    if (uxi >= 0) acc += ex;
+    acc = ((live_x >> p.seg) & 1ull) ? acc + ex : acc;
     return acc;
 }
 
@@ -331,11 +345,12 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_gain_pack(Dev<T> g, T* cost_rw
     T best = c[0];
     int best_x = 0;
 #pragma unroll
-    for (int x = 1; x < MAXD; ++x)
-        if (x < D && (g.is_max ? best < c[x] : best > c[x])) {
-            best = c[x];
-            best_x = x;
-        }
+    for (int x = 1; x < MAXD; ++x) {
+        const bool lt = best < c[x], gt = best > c[x];
+        const bool better = (x < D) & (g.is_max ? lt : gt);
+        best = better ? c[x] : best;
+        best_x = better ? x : best_x;
+    }
     const T val_cost = pack_add_concerned(g, p, pos, best);  // own cost at the CURRENT value (mgm.py:449-450)
     const T gain = cost - val_cost;
     if (p.has && p.k == 0) {
@@ -343,8 +358,9 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_gain_pack(Dev<T> g, T* cost_rw
             cost_rw[v] = cost;
             g.has_cost[v] = 1;
         }
-        g.gain[v] = gain;
-        g.newv[v] = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : mine;
+        const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : mine;
+        g.grec[v].gain = gain;
+        g.grec[v].newv = nvl;
     }
 }
 
@@ -353,47 +369,55 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_move_pack(Dev<T> g) {
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= g.pack.n_lanes) return;
     const PackLane p = pack_lane(g, pos);
-    const int v = p.v, my_rank = g.name_rank[v];
-    // the largest gain among the OTHER concerned variables and whether a lower name holds it
-    // (max() also in max mode, mgm.py:513; lexic ties :566-588): order-independent
+    const int v = p.v;
+    // The largest gain among the OTHER concerned variables and whether a lower name holds it (max() also in
+    // max mode, mgm.py:513; lexic ties :566-588).  Order-independent -- the reference's scan keeps (largest so
+    // far, "no lower name holds it") -- so the lanes of a variable reduce their elements pairwise in
+    // ceil(log2(deg)) steps instead of every lane scanning all of them; lane k = 0 ends with the result.
     const int u = g.pack_conc[pos], ux = g.pack_conc_x[pos];
-    T gu = (T)0, gx = (T)0;
-    bool lu = false, lx = false;
-    const bool on = u >= 0 && u != v, onx = ux >= 0 && ux != v;
-    if (on) {
-        gu = g.gain[u];
-        lu = g.name_rank[u] < my_rank;
+    const GainRec<T> me = g.grec[v];
+    const int cur0 = g.cur[v];
+    const T cost0 = g.cost[v];
+    const T vc0 = g.vcc[v];
+    // the own costs of the variable's values, addressed by v alone (through cost_off[v] + the new value
+    // they would be one dependent load later); the new value's is picked in registers
+    T vc[lsearch::PACK_D];
+#pragma unroll
+    for (int x = 0; x < lsearch::PACK_D; ++x) vc[x] = g.vc4[(int64_t)v * lsearch::PACK_D + x];
+    T e = (T)0, ex = (T)0;
+    unsigned fl = 0u, fx = 0u;  // bit 0: an element (a concerned variable other than v), bit 1: a lower name holds it
+    if (u >= 0 && u != v) {
+        const GainRec<T> r = g.grec[u];
+        e = r.gain;
+        fl = 1u | (r.rank < me.rank ? 2u : 0u);
     }
-    if (onx) {
-        gx = g.gain[ux];
-        lx = g.name_rank[ux] < my_rank;
+    if (ux >= 0 && ux != v) {
+        const GainRec<T> r = g.grec[ux];
+        ex = r.gain;
+        fx = 1u | (r.rank < me.rank ? 2u : 0u);
     }
-    T max_n = (T)0;
-    bool first = true, wins_tie = true;
-    for (int i = 0; i <= p.deg; ++i) {  // element deg = the extra one of lane k = 0
-        const int src = i < p.deg ? p.seg + i : p.seg;
-        const T e = i < p.deg ? __shfl(gu, src, 64) : __shfl(gx, src, 64);
-        const int live = i < p.deg ? __shfl(on ? 1 : 0, src, 64) : __shfl(onx ? 1 : 0, src, 64);
-        const int lower = i < p.deg ? __shfl(lu ? 1 : 0, src, 64) : __shfl(lx ? 1 : 0, src, 64);
-        if (!live) continue;
-        if (first || e > max_n) {
-            max_n = e;
-            wins_tie = !lower;
-        } else if (e == max_n && lower) {
-            wins_tie = false;
-        }
-        first = false;
+    auto merge = [&](T e2, unsigned f2) {  // (e, fl) <- the larger of the two; equal gains: either's lower name counts
+        const bool la = (fl & 1u) != 0u, lb = (f2 & 1u) != 0u;
+        const bool b_wins = lb & (!la | (e2 > e));
+        const bool tie = la & lb & (e2 == e);
+        fl = b_wins ? f2 : (tie ? fl | (f2 & 2u) : fl);
+        e = b_wins ? e2 : e;
+    };
+    const int l = (int)threadIdx.x & 63;
+    for (int s = 1; s < p.deg; s <<= 1) {
+        const T e2 = __shfl(e, (l + s) & 63, 64);
+        const unsigned f2 = (unsigned)__shfl((int)fl, (l + s) & 63, 64);
+        merge(e2, p.k + s < p.deg ? f2 : 0u);
     }
+    merge(ex, fx);  // element deg of the list: lane k = 0 holds it
     if (p.has && p.k == 0) {
-        int cur = g.cur[v];
-        T cost = g.cost[v];
-        const T gain = g.gain[v];
-        if (gain > max_n || (gain == max_n && wins_tie)) {  // :514-525
-            cur = g.newv[v];
-            cost = cost - gain;
-        }
-        g.cur_out[v] = cur;
-        g.cost_out[v] = cost;
+        const bool any = (fl & 1u) != 0u;
+        const T max_n = any ? e : (T)0;
+        const bool wins_tie = !any || (fl & 2u) == 0u;
+        const bool moves = me.gain > max_n || (me.gain == max_n && wins_tie);  // :514-525
+        g.cur_out[v] = moves ? me.newv : cur0;
+        g.cost_out[v] = moves ? cost0 - me.gain : cost0;
+        g.vcc_out[v] = moves ? lsearch::pick<T, lsearch::PACK_D>(vc, me.newv) : vc0;
     }
 }
 
@@ -413,15 +437,16 @@ struct Engine : Base {
     hipStream_t stream = nullptr;
     Dev<T> g{};
     int which = 0;
-    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn, h_rank;
     std::vector<int64_t> h_toff, h_coff;
     std::vector<double> h_tables, h_eval_cost, h_var_cost;
     bool has_init = false;
-    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx, name_rank, n_neigh, newv;
+    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx, name_rank, n_neigh;
     Buf<int32_t> cur[2];
     Buf<int64_t> table_off, cost_off;
-    Buf<T> tables, var_cost, gain;
-    Buf<T> cost[2];
+    Buf<T> tables, var_cost;
+    Buf<T> cost[2], vcc[2], vc4;
+    Buf<GainRec<T>> grec;
     Buf<uint8_t> has_cost;
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
@@ -520,7 +545,7 @@ struct Engine : Base {
                 MGM_TRY(pk_recT.upload(rt, stream));
             }
             MGM_TRY(pk_waves.upload(hp.waves, stream));
-            MGM_TRY(pk_vars.upload(hp.vars, stream));
+            MGM_TRY(pk_vars.upload(hp.lane_v, stream));
             MGM_TRY(pk_nb.upload(hp.nb, stream));
             MGM_TRY(pk_slot.upload(hp.slot, stream));
             MGM_TRY(pk_rest.upload(hp.rest, stream));
@@ -551,17 +576,25 @@ struct Engine : Base {
         for (int b = 0; b < 2; ++b) {
             MGM_TRY(cur[b].alloc(nV));
             MGM_TRY(cost[b].alloc(nV));
+            MGM_TRY(vcc[b].alloc(nV));
         }
+        {
+            std::vector<T> v4((size_t)nV * lsearch::PACK_D, (T)0);
+            for (int v = 0; v < nV; ++v)
+                for (int x = 0; x < h_dom[v] && x < lsearch::PACK_D; ++x) v4[(size_t)v * lsearch::PACK_D + x] = vc[h_coff[v] + x];
+            MGM_TRY(vc4.upload(v4, stream));
+            g.vc4 = vc4.p;
+        }
+        h_rank = rk;
+        MGM_TRY(grec.alloc(nV));
         MGM_TRY(has_cost.alloc(nV));
-        MGM_TRY(gain.alloc(nV));
-        MGM_TRY(newv.alloc(nV));
         g.n_vars = nV;
         g.is_max = p.mode == MXS_MODE_MAX;
         g.dom_size = dom_size.p; g.factor_rowptr = factor_rowptr.p; g.edge_var = edge_var.p;
         g.edge_factor = edge_factor.p; g.var_rowptr = var_rowptr.p; g.var_edges = var_edges.p;
         g.init_idx = nullptr; g.name_rank = name_rank.p; g.n_neigh = n_neigh.p;
         g.table_off = table_off.p; g.cost_off = cost_off.p; g.tables = tables.p; g.var_cost = var_cost.p;
-        g.has_cost = has_cost.p; g.gain = gain.p; g.newv = newv.p;
+        g.has_cost = has_cost.p; g.grec = grec.p;
         return reset();
     }
 
@@ -569,7 +602,7 @@ struct Engine : Base {
         MGM_TRY(hipSetDevice(device));
         const int nV = g.n_vars;
         std::vector<int32_t> c0(nV);
-        std::vector<T> k0(nV, (T)0);
+        std::vector<T> k0(nV, (T)0), v0(nV, (T)0);
         std::vector<uint8_t> h0(nV, 0);
         for (int v = 0; v < nV; ++v) {
             if (h_nn[v] == 0) {  // on_start without neighbours: optimal_cost_value (mgm.py:279-290)
@@ -584,16 +617,20 @@ struct Engine : Base {
             } else {  // the initial value, else the first of the domain (random.choice fixed)
                 c0[v] = h_init[v] >= 0 ? h_init[v] : 0;
             }
+            v0[v] = (T)h_var_cost[h_coff[v] + c0[v]];
         }
         which = 0;
         if (nV) {
             for (int b = 0; b < 2; ++b) {  // both buffers: the packed launches write only the variables with neighbours
                 MGM_TRY(hipMemcpyAsync(cur[b].p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
                 MGM_TRY(hipMemcpyAsync(cost[b].p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
+                MGM_TRY(hipMemcpyAsync(vcc[b].p, v0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
             }
+
             MGM_TRY(hipMemcpyAsync(has_cost.p, h0.data(), nV, hipMemcpyHostToDevice, stream));
-            MGM_TRY(hipMemcpyAsync(newv.p, c0.data(), 4 * nV, hipMemcpyHostToDevice, stream));
-            MGM_TRY(hipMemsetAsync(gain.p, 0, sizeof(T) * nV, stream));
+            std::vector<GainRec<T>> gr(nV);  // no gain yet, the "new value" is the initial one
+            for (int v = 0; v < nV; ++v) gr[v] = GainRec<T>{(T)0, c0[v], h_rank[v]};
+            MGM_TRY(hipMemcpyAsync(grec.p, gr.data(), sizeof(GainRec<T>) * nV, hipMemcpyHostToDevice, stream));
             MGM_TRY(hipStreamSynchronize(stream));
         }
         rounds = 0;
@@ -616,6 +653,8 @@ struct Engine : Base {
             g.cost = cost[which].p;
             g.cur_out = cur[which ^ 1].p;
             g.cost_out = cost[which ^ 1].p;
+            g.vcc = vcc[which].p;
+            g.vcc_out = vcc[which ^ 1].p;
             T* const cw = cost[which].p;
             g.var_list = packed ? pk_rest.p : nullptr;
             g.n_list = packed ? n_rest : nV;
@@ -653,16 +692,17 @@ struct Engine : Base {
         MGM_TRY(hipSetDevice(device));
         const int nV = g.n_vars;
         if (!nV) return MXS_OK;
-        std::vector<T> hc(nV), hg(nV);
+        std::vector<T> hc(nV);
+        std::vector<GainRec<T>> hg(nV);
         if (idx) MGM_TRY(hipMemcpyAsync(idx, cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
-        if (nv) MGM_TRY(hipMemcpyAsync(nv, newv.p, 4 * nV, hipMemcpyDeviceToHost, stream));
         if (has) MGM_TRY(hipMemcpyAsync(has, has_cost.p, nV, hipMemcpyDeviceToHost, stream));
         MGM_TRY(hipMemcpyAsync(hc.data(), cost[which].p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
-        MGM_TRY(hipMemcpyAsync(hg.data(), gain.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
+        MGM_TRY(hipMemcpyAsync(hg.data(), grec.p, sizeof(GainRec<T>) * nV, hipMemcpyDeviceToHost, stream));
         MGM_TRY(hipStreamSynchronize(stream));
         for (int v = 0; v < nV; ++v) {
             if (cst) cst[v] = (double)hc[v];
-            if (gn) gn[v] = (double)hg[v];
+            if (gn) gn[v] = (double)hg[v].gain;
+            if (nv) nv[v] = hg[v].newv;
         }
         return MXS_OK;
     }

@@ -26,11 +26,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cycles", type=int, default=500)
     ap.add_argument("--lib", default=None)
+    ap.add_argument("--instances", nargs="*", default=["coloring_100k", "meeting_50k"])
+    ap.add_argument("--kernels", nargs="*", default=["packed", "slots", "csr_walk"])
     a = ap.parse_args()
-    instances = [("coloring_100k", G.random_coloring(100_000, seed=0, names=False), Params()),
-                 ("meeting_50k", G.meeting_like(50_000, dom=24, seed=0, names=False), Params(mode="max"))]
+    instances = [("coloring_100k", lambda: G.random_coloring(100_000, seed=0, names=False), Params()),
+                 ("meeting_50k", lambda: G.meeting_like(50_000, dom=24, seed=0, names=False), Params(mode="max"))]
     for inst, g, p in instances:
-        for kernels in ("packed", "slots", "csr_walk"):
+        if inst not in a.instances:
+            continue
+        g = g()
+        for kernels in a.kernels:
             os.environ["MAXSUM_LOCAL_SEARCH_GENERIC"] = {"packed": "0", "slots": "2", "csr_walk": "1"}[kernels]
             for name, make in (("dsa_B", lambda: DsaEngine(g, p, variant="B", seed=1, lib_path=a.lib)),
                                ("mgm", lambda: MgmEngine(g, p, lib_path=a.lib))):
