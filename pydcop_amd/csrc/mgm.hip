@@ -89,6 +89,16 @@ struct Dev {
     const int32_t* pack_conc_x;  // [lanes] lane k = 0: element `deg` of that list (it has at most deg + 1), else -1
     const int32_t* var_list;     // the variables a thread-per-variable launch works on (NULL: all)
     int32_t n_list;
+    // The DYNAMIC per-variable state -- cur, cost, has_cost, grec, vcc -- is stored in PACKED ORDER:
+    // position q[v] = the variable's rank in the packed view's wave order (the other variables after them).
+    // A packed wave's variables are then q = first .. first + nv - 1: what lane k = 0 of each of them
+    // reads and writes of its own state is one line per array instead of one line per variable
+    // (scattered 8-byte stores of ~8 lanes per wave cost 0.9 us per store instruction at 100k variables,
+    // profiles/r03_local_search_kernels_v2.txt).  The packed view holds q directly (nb, conc, vars); the
+    // thread-per-variable kernels translate graph indices through q[].  Everything the semantics depends
+    // on -- sum orders, name ranks, the concerned lists' ascending order -- stays on graph indices.
+    const int32_t* q;
+    const int32_t* pack_dom;     // [packed variables] dom_size in packed order
 };
 
 // c.slice(neighbours' values)(x): the table entry with v at x, every other scope variable at its value
@@ -97,7 +107,7 @@ __device__ T constraint_at(const Dev<T>& g, int f, int v, int x) {
     int64_t lin = 0;
     for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
         const int u = g.edge_var[e];
-        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[u]);
+        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[g.q[u]]);
     }
     return g.tables[g.table_off[f] + lin];
 }
@@ -130,7 +140,7 @@ __device__ T add_concerned_costs(const Dev<T>& g, int v, T acc) {
             }
         }
         if (best == INT32_MAX) break;
-        acc += g.var_cost[g.cost_off[best] + g.cur[best]];
+        acc += g.vcc[g.q[best]];  // = var_cost[cost_off[best] + cur[best]], kept by the move kernels
         last = best;
     }
     return acc;
@@ -142,11 +152,12 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
     if (tid >= g.n_list) return;
     const int v = g.var_list ? g.var_list[tid] : tid;
     if (g.n_neigh[v] == 0) return;
-    T cost = cost_rw[v];
-    if (!g.has_cost[v]) {  // first round: the cost of the current value (mgm.py:349-372)
-        cost = add_concerned_costs(g, v, utilities_at(g, v, g.cur[v]));
-        cost_rw[v] = cost;
-        g.has_cost[v] = 1;
+    const int qv = g.q[v];
+    T cost = cost_rw[qv];
+    if (!g.has_cost[qv]) {  // first round: the cost of the current value (mgm.py:349-372)
+        cost = add_concerned_costs(g, v, utilities_at(g, v, g.cur[qv]));
+        cost_rw[qv] = cost;
+        g.has_cost[qv] = 1;
     }
     T best = (T)0;
     int best_x = -1;
@@ -159,9 +170,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain(Dev<T> g, T* cost_rw) {
     }
     const T val_cost = add_concerned_costs(g, v, best);  // own cost at the CURRENT value (:449-450)
     const T gain = cost - val_cost;
-    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
-    g.grec[v].gain = gain;
-    g.grec[v].newv = nvl;
+    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[qv];
+    g.grec[qv].gain = gain;
+    g.grec[qv].newv = nvl;
 }
 
 template <typename T>
@@ -169,8 +180,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.n_list) return;
     const int v = g.var_list ? g.var_list[tid] : tid;
-    int cur = g.cur[v];
-    T cost = g.cost[v];
+    const int qv = g.q[v];
+    int cur = g.cur[qv];
+    T cost = g.cost[qv];
     if (g.n_neigh[v] != 0) {
         T max_n = (T)0;
         bool first = true;
@@ -179,7 +191,8 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
             for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
                 const int u = g.edge_var[e];
                 if (u == v) continue;
-                if (first || g.grec[u].gain > max_n) max_n = g.grec[u].gain;  // max() also in max mode (:513)
+                const T gu = g.grec[g.q[u]].gain;
+                if (first || gu > max_n) max_n = gu;  // max() also in max mode (:513)
                 first = false;
             }
         }
@@ -188,30 +201,30 @@ __global__ void __launch_bounds__(TPB) k_mgm_move(Dev<T> g) {
             const int f = g.edge_factor[g.var_edges[k]];
             for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
                 const int u = g.edge_var[e];
-                if (u != v && g.grec[u].gain == max_n && g.name_rank[u] < g.name_rank[v]) wins_tie = false;
+                if (u != v && g.grec[g.q[u]].gain == max_n && g.name_rank[u] < g.name_rank[v]) wins_tie = false;
             }
         }
-        const T gain = g.grec[v].gain;
+        const T gain = g.grec[qv].gain;
         if (gain > max_n || (gain == max_n && wins_tie)) {  // :514-525, lexic ties :566-588
-            cur = g.grec[v].newv;
+            cur = g.grec[qv].newv;
             cost = cost - gain;
         }
     }
-    g.cur_out[v] = cur;
-    g.cost_out[v] = cost;
-    g.vcc_out[v] = g.var_cost[g.cost_off[v] + cur];
+    g.cur_out[qv] = cur;
+    g.cost_out[qv] = cost;
+    g.vcc_out[qv] = g.var_cost[g.cost_off[v] + cur];
 }
 
 // ---- the same two kernels on the slot view (local_search.h) ---------------------------------
 // the costs of the D values in registers from one pass over the variable's constraints; the
 // distinct variables of those constraints from a list sorted on the host instead of the
 // repeated minimum search of add_concerned_costs; domains of at most MAXD values
+// (the variable references of the slot view -- nb0_var, nb_var, conc_var -- are uploaded as packed
+// positions q: they index the dynamic state directly)
 template <typename T>
 __device__ T add_concerned_costs_listed(const Dev<T>& g, int v, T acc) {
-    for (int k = g.slots.conc_rowptr[v]; k < g.slots.conc_rowptr[v + 1]; ++k) {
-        const int u = g.slots.conc_var[k];
-        acc += g.var_cost[g.cost_off[u] + g.cur[u]];
-    }
+    for (int k = g.slots.conc_rowptr[v]; k < g.slots.conc_rowptr[v + 1]; ++k)
+        acc += g.vcc[g.slots.conc_var[k]];  // = var_cost[cost_off[u] + cur[u]], kept by the move kernels
     return acc;
 }
 
@@ -224,11 +237,12 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
     const int D = g.dom_size[v];
     T c[MAXD];
     lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, g.var_rowptr[v], g.var_rowptr[v + 1], D, false, c);
-    T cost = cost_rw[v];
-    if (!g.has_cost[v]) {
-        cost = add_concerned_costs_listed(g, v, lsearch::pick<T, MAXD>(c, g.cur[v]));
-        cost_rw[v] = cost;
-        g.has_cost[v] = 1;
+    const int qv = g.q[v];
+    T cost = cost_rw[qv];
+    if (!g.has_cost[qv]) {
+        cost = add_concerned_costs_listed(g, v, lsearch::pick<T, MAXD>(c, g.cur[qv]));
+        cost_rw[qv] = cost;
+        g.has_cost[qv] = 1;
     }
     T best = c[0];
     int best_x = 0;
@@ -240,9 +254,9 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
         }
     const T val_cost = add_concerned_costs_listed(g, v, best);
     const T gain = cost - val_cost;
-    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[v];
-    g.grec[v].gain = gain;
-    g.grec[v].newv = nvl;
+    const int nvl = ((!g.is_max && gain > (T)0) || (g.is_max && gain < (T)0)) ? best_x : g.cur[qv];
+    g.grec[qv].gain = gain;
+    g.grec[qv].newv = nvl;
 }
 
 template <typename T>
@@ -250,35 +264,35 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.n_list) return;
     const int v = g.var_list ? g.var_list[tid] : tid;
-    int cur = g.cur[v];
-    T cost = g.cost[v];
+    const int qv = g.q[v];
+    int cur = g.cur[qv];
+    T cost = g.cost[qv];
     if (g.n_neigh[v] != 0) {
         const int k0 = g.slots.conc_rowptr[v], k1 = g.slots.conc_rowptr[v + 1];
-        const int my_rank = g.name_rank[v];
+        const GainRec<T> me = g.grec[qv];
         T max_n = (T)0;
         bool first = true, wins_tie = true;
         for (int k = k0; k < k1; ++k) {  // one pass: the largest gain and whether a lower name holds it
-            const int u = g.slots.conc_var[k];
-            if (u == v) continue;
-            const T gu = g.grec[u].gain;
-            const bool lower = g.name_rank[u] < my_rank;
-            if (first || gu > max_n) {
-                max_n = gu;
+            const int uq = g.slots.conc_var[k];
+            if (uq == qv) continue;
+            const GainRec<T> r = g.grec[uq];
+            const bool lower = r.rank < me.rank;
+            if (first || r.gain > max_n) {
+                max_n = r.gain;
                 wins_tie = !lower;
-            } else if (gu == max_n && lower) {
+            } else if (r.gain == max_n && lower) {
                 wins_tie = false;
             }
             first = false;
         }
-        const T gain = g.grec[v].gain;
-        if (gain > max_n || (gain == max_n && wins_tie)) {
-            cur = g.grec[v].newv;
-            cost = cost - gain;
+        if (me.gain > max_n || (me.gain == max_n && wins_tie)) {
+            cur = me.newv;
+            cost = cost - me.gain;
         }
     }
-    g.cur_out[v] = cur;
-    g.cost_out[v] = cost;
-    g.vcc_out[v] = g.var_cost[g.cost_off[v] + cur];
+    g.cur_out[qv] = cur;
+    g.cost_out[qv] = cost;
+    g.vcc_out[qv] = g.var_cost[g.cost_off[v] + cur];
 }
 
 // ---- the same two kernels on the PACKED view (local_search.h): one lane per (variable, constraint) ----
@@ -286,7 +300,7 @@ __global__ void __launch_bounds__(TPB) k_mgm_move_listed(Dev<T> g) {
 // deg + 1 entries): element k, and on lane k = 0 also element deg.
 constexpr int PACK_TPB = 256;
 struct PackLane {
-    int deg, nv, var, k, seg, v, q;
+    int deg, nv, var, k, seg, q;  // q: the variable's packed position = its index into the dynamic state
     bool has;
 };
 template <typename T>
@@ -301,7 +315,6 @@ __device__ inline PackLane pack_lane(const Dev<T>& g, int64_t pos) {
     p.k = l - p.var * p.deg;
     p.has = p.var < p.nv;
     p.seg = l - p.k;
-    p.v = g.pack.vars[pos];
     p.q = wm.first + (p.has ? p.var : 0);
     return p;
 }
@@ -332,7 +345,7 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_gain_pack(Dev<T> g, T* cost_rw
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= g.pack.n_lanes) return;  // whole waves
     const PackLane p = pack_lane(g, pos);
-    const int v = p.v, D = g.dom_size[v], mine = g.cur[v];
+    const int v = p.q, D = g.pack_dom[v], mine = g.cur[v];  // (v: packed position; nb / conc hold positions too)
     T t[MAXD], c[MAXD];
     lsearch::pack_costs<T, TT>(g.pack, g.cur, pos, p.deg, p.seg, false, t, c);
     T cost = cost_rw[v];
@@ -369,7 +382,7 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_move_pack(Dev<T> g) {
     const int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (pos >= g.pack.n_lanes) return;
     const PackLane p = pack_lane(g, pos);
-    const int v = p.v;
+    const int v = p.q;  // packed position (conc / conc_x hold positions too)
     // The largest gain among the OTHER concerned variables and whether a lower name holds it (max() also in
     // max mode, mgm.py:513; lexic ties :566-588).  Order-independent -- the reference's scan keeps (largest so
     // far, "no lower name holds it") -- so the lanes of a variable reduce their elements pairwise in
@@ -379,8 +392,8 @@ __global__ void __launch_bounds__(PACK_TPB) k_mgm_move_pack(Dev<T> g) {
     const int cur0 = g.cur[v];
     const T cost0 = g.cost[v];
     const T vc0 = g.vcc[v];
-    // the own costs of the variable's values, addressed by v alone (through cost_off[v] + the new value
-    // they would be one dependent load later); the new value's is picked in registers
+    // the own costs of the variable's values in packed order (through cost_off[] + the new value they
+    // would be one dependent load later); the new value's is picked in registers
     T vc[lsearch::PACK_D];
 #pragma unroll
     for (int x = 0; x < lsearch::PACK_D; ++x) vc[x] = g.vc4[(int64_t)v * lsearch::PACK_D + x];
@@ -437,7 +450,7 @@ struct Engine : Base {
     hipStream_t stream = nullptr;
     Dev<T> g{};
     int which = 0;
-    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn, h_rank;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn, h_rank, h_q;
     std::vector<int64_t> h_toff, h_coff;
     std::vector<double> h_tables, h_eval_cost, h_var_cost;
     bool has_init = false;
@@ -451,7 +464,7 @@ struct Engine : Base {
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
     Buf<lsearch::PackWave> pk_waves;
-    Buf<int32_t> pk_vars, pk_nb, pk_slot, pk_rest, pk_conc, pk_conc_x;
+    Buf<int32_t> pk_nb, pk_slot, pk_rest, pk_conc, pk_conc_x, pk_dom, qmap;
     Buf<int8_t> pk_rec8;
     Buf<T> pk_recT;
     bool pack_int8 = false;
@@ -518,13 +531,38 @@ struct Engine : Base {
         MGM_TRY(sl_base.upload(hs.base, stream));
         MGM_TRY(sl_stride_v.upload(hs.stride_v, stream));
         MGM_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
-        MGM_TRY(sl_nb_var.upload(hs.nb_var, stream));
         MGM_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
-        MGM_TRY(sl_nb0_var.upload(hs.nb0_var, stream));
         MGM_TRY(sl_nb0_stride.upload(hs.nb0_stride, stream));
         {   // the packed view of the variables it can take (local_search.h)
             lsearch::HostPack hp;
             hp.build(nV, h_dom, vrow, h_nn, hs, h_tables);
+            // packed positions (Dev::q): the packed variables in wave order, then the others
+            h_q.assign(nV, -1);
+            int nq = 0;
+            for (int v : hp.vars) h_q[v] = nq++;
+            const int n_packed = nq;
+            for (int v = 0; v < nV; ++v)
+                if (h_q[v] < 0) h_q[v] = nq++;
+            auto to_q = [&](std::vector<int32_t> a) {
+                for (auto& x : a)
+                    if (x >= 0) x = h_q[x];
+                return a;
+            };
+            MGM_TRY(qmap.upload(h_q, stream));
+            MGM_TRY(sl_nb_var.upload(to_q(hs.nb_var), stream));
+            MGM_TRY(sl_nb0_var.upload(to_q(hs.nb0_var), stream));
+            MGM_TRY(sl_conc_var.upload(to_q(hs.conc_var), stream));
+            std::vector<int32_t> pdom(n_packed);
+            std::vector<T> v4((size_t)n_packed * lsearch::PACK_D, (T)0);
+            for (int v : hp.vars) {
+                pdom[h_q[v]] = h_dom[v];
+                for (int x = 0; x < h_dom[v]; ++x) v4[(size_t)h_q[v] * lsearch::PACK_D + x] = vc[h_coff[v] + x];
+            }
+            MGM_TRY(pk_dom.upload(pdom, stream));
+            MGM_TRY(vc4.upload(v4, stream));
+            g.q = qmap.p;
+            g.pack_dom = pk_dom.p;
+            g.vc4 = vc4.p;
             std::vector<int32_t> conc(hp.nb.size(), -1), conc_x(hp.nb.size(), -1);
             for (size_t i = 0; i < hp.nb.size(); ++i) {
                 const int v = hp.lane_var[i];
@@ -545,20 +583,18 @@ struct Engine : Base {
                 MGM_TRY(pk_recT.upload(rt, stream));
             }
             MGM_TRY(pk_waves.upload(hp.waves, stream));
-            MGM_TRY(pk_vars.upload(hp.lane_v, stream));
-            MGM_TRY(pk_nb.upload(hp.nb, stream));
+            MGM_TRY(pk_nb.upload(to_q(hp.nb), stream));
             MGM_TRY(pk_slot.upload(hp.slot, stream));
             MGM_TRY(pk_rest.upload(hp.rest, stream));
-            MGM_TRY(pk_conc.upload(conc, stream));
-            MGM_TRY(pk_conc_x.upload(conc_x, stream));
+            MGM_TRY(pk_conc.upload(to_q(conc), stream));
+            MGM_TRY(pk_conc_x.upload(to_q(conc_x), stream));
             n_rest = (int)hp.rest.size();
-            g.pack = lsearch::Pack{pk_waves.p, pk_vars.p, pk_nb.p, pk_slot.p,
+            g.pack = lsearch::Pack{pk_waves.p, nullptr, pk_nb.p, pk_slot.p,
                                    pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
             g.pack_conc = pk_conc.p;
             g.pack_conc_x = pk_conc_x.p;
         }
         MGM_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
-        MGM_TRY(sl_conc_var.upload(hs.conc_var, stream));
         g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
                                  sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p};
         MGM_TRY(dom_size.upload(h_dom, stream));
@@ -578,13 +614,6 @@ struct Engine : Base {
             MGM_TRY(cost[b].alloc(nV));
             MGM_TRY(vcc[b].alloc(nV));
         }
-        {
-            std::vector<T> v4((size_t)nV * lsearch::PACK_D, (T)0);
-            for (int v = 0; v < nV; ++v)
-                for (int x = 0; x < h_dom[v] && x < lsearch::PACK_D; ++x) v4[(size_t)v * lsearch::PACK_D + x] = vc[h_coff[v] + x];
-            MGM_TRY(vc4.upload(v4, stream));
-            g.vc4 = vc4.p;
-        }
         h_rank = rk;
         MGM_TRY(grec.alloc(nV));
         MGM_TRY(has_cost.alloc(nV));
@@ -601,23 +630,26 @@ struct Engine : Base {
     int reset() override {
         MGM_TRY(hipSetDevice(device));
         const int nV = g.n_vars;
-        std::vector<int32_t> c0(nV);
+        std::vector<int32_t> c0(nV);  // (all in packed order, Dev::q)
         std::vector<T> k0(nV, (T)0), v0(nV, (T)0);
         std::vector<uint8_t> h0(nV, 0);
+        std::vector<GainRec<T>> gr(nV);  // no gain yet, the "new value" is the initial one
         for (int v = 0; v < nV; ++v) {
+            const int qv = h_q[v];
             if (h_nn[v] == 0) {  // on_start without neighbours: optimal_cost_value (mgm.py:279-290)
                 int best = 0;
                 for (int d = 1; d < h_dom[v]; ++d) {
                     const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
                     if (g.is_max ? a >= b : a < b) best = d;
                 }
-                c0[v] = best;
-                k0[v] = (T)h_var_cost[h_coff[v] + best];
-                h0[v] = 1;
+                c0[qv] = best;
+                k0[qv] = (T)h_var_cost[h_coff[v] + best];
+                h0[qv] = 1;
             } else {  // the initial value, else the first of the domain (random.choice fixed)
-                c0[v] = h_init[v] >= 0 ? h_init[v] : 0;
+                c0[qv] = h_init[v] >= 0 ? h_init[v] : 0;
             }
-            v0[v] = (T)h_var_cost[h_coff[v] + c0[v]];
+            v0[qv] = (T)h_var_cost[h_coff[v] + c0[qv]];
+            gr[qv] = GainRec<T>{(T)0, c0[qv], h_rank[v]};
         }
         which = 0;
         if (nV) {
@@ -626,10 +658,7 @@ struct Engine : Base {
                 MGM_TRY(hipMemcpyAsync(cost[b].p, k0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
                 MGM_TRY(hipMemcpyAsync(vcc[b].p, v0.data(), sizeof(T) * nV, hipMemcpyHostToDevice, stream));
             }
-
             MGM_TRY(hipMemcpyAsync(has_cost.p, h0.data(), nV, hipMemcpyHostToDevice, stream));
-            std::vector<GainRec<T>> gr(nV);  // no gain yet, the "new value" is the initial one
-            for (int v = 0; v < nV; ++v) gr[v] = GainRec<T>{(T)0, c0[v], h_rank[v]};
             MGM_TRY(hipMemcpyAsync(grec.p, gr.data(), sizeof(GainRec<T>) * nV, hipMemcpyHostToDevice, stream));
             MGM_TRY(hipStreamSynchronize(stream));
         }
@@ -694,15 +723,20 @@ struct Engine : Base {
         if (!nV) return MXS_OK;
         std::vector<T> hc(nV);
         std::vector<GainRec<T>> hg(nV);
-        if (idx) MGM_TRY(hipMemcpyAsync(idx, cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
-        if (has) MGM_TRY(hipMemcpyAsync(has, has_cost.p, nV, hipMemcpyDeviceToHost, stream));
+        std::vector<int32_t> hi(nV);
+        std::vector<uint8_t> hh(nV);
+        MGM_TRY(hipMemcpyAsync(hi.data(), cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
+        MGM_TRY(hipMemcpyAsync(hh.data(), has_cost.p, nV, hipMemcpyDeviceToHost, stream));
         MGM_TRY(hipMemcpyAsync(hc.data(), cost[which].p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
         MGM_TRY(hipMemcpyAsync(hg.data(), grec.p, sizeof(GainRec<T>) * nV, hipMemcpyDeviceToHost, stream));
         MGM_TRY(hipStreamSynchronize(stream));
-        for (int v = 0; v < nV; ++v) {
-            if (cst) cst[v] = (double)hc[v];
-            if (gn) gn[v] = (double)hg[v].gain;
-            if (nv) nv[v] = hg[v].newv;
+        for (int v = 0; v < nV; ++v) {  // the state lives in packed order (Dev::q)
+            const int qv = h_q[v];
+            if (idx) idx[v] = hi[qv];
+            if (has) has[v] = hh[qv];
+            if (cst) cst[v] = (double)hc[qv];
+            if (gn) gn[v] = (double)hg[qv].gain;
+            if (nv) nv[v] = hg[qv].newv;
         }
         return MXS_OK;
     }
