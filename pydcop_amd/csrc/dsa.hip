@@ -92,6 +92,14 @@ struct Dev {
     const T* pack_fopt;          // [lanes] optimum of the lane's constraint (variant B)
     const int32_t* var_list;     // the variables a thread-per-variable launch works on (NULL: all)
     int32_t n_list;
+    // The dynamic state (cur, cost) is stored in PACKED ORDER, position q[v] = the variable's rank in the
+    // packed view's wave order (the others after them): a packed wave's variables are q = first ..
+    // first + nv - 1, what lane k = 0 of each reads and writes of its own state is one line per array
+    // instead of one per variable (mgm.hip, Dev::q).  The packed view holds positions (nb); the
+    // thread-per-variable kernels translate through q[]; the random draws stay keyed on graph indices.
+    const int32_t* q;
+    const int32_t *pack_dom, *pack_label;  // [packed variables] dom_size / graph index, in packed order
+    const double* pack_prob;               // [packed variables] the change probability
 };
 
 template <typename T>
@@ -99,7 +107,7 @@ __device__ T constraint_at(const Dev<T>& g, int f, int v, int x) {
     int64_t lin = 0;
     for (int e = g.factor_rowptr[f]; e < g.factor_rowptr[f + 1]; ++e) {
         const int u = g.edge_var[e];
-        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[u]);
+        lin = lin * g.dom_size[u] + (u == v ? x : g.cur[g.q[u]]);
     }
     return g.tables[g.table_off[f] + lin];
 }
@@ -119,7 +127,8 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.n_list) return;
     const int v = g.var_list ? g.var_list[tid] : tid;
-    const int mine = g.cur[v];
+    const int qv = g.q[v];
+    const int mine = g.cur[qv];
     int out = mine;
     if (g.n_neigh[v] != 0) {
         const int D = g.dom_size[v];
@@ -168,10 +177,10 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle(Dev<T> g) {
                 }
             }
             out = pick;
-            g.cost[v] = best_cost;  // value_selection(choice, best_cost)
+            g.cost[qv] = best_cost;  // value_selection(choice, best_cost)
         }
     }
-    g.cur_out[v] = out;
+    g.cur_out[qv] = out;
 }
 
 // the same cycle on the slot view (local_search.h): the D costs in registers, one pass over the
@@ -181,7 +190,8 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
     const int tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= g.n_list) return;
     const int v = g.var_list ? g.var_list[tid] : tid;
-    const int mine = g.cur[v];
+    const int qv = g.q[v];
+    const int mine = g.cur[qv];
     int out = mine;
     if (g.n_neigh[v] != 0) {
         const int D = g.dom_size[v];
@@ -236,10 +246,10 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
                     }
                 }
             out = pick;
-            g.cost[v] = best_cost;
+            g.cost[qv] = best_cost;
         }
     }
-    g.cur_out[v] = out;
+    g.cur_out[qv] = out;
 }
 
 // the same cycle on the PACKED view (local_search.h): one lane per (variable, constraint), the
@@ -259,11 +269,12 @@ __global__ void __launch_bounds__(PACK_TPB) k_dsa_cycle_pack(Dev<T> g) {
     const int var = (int)(((uint32_t)l * (dn >> 16)) >> 15);  // l / deg (exact for l < 64)
     const int k = l - var * deg;
     const bool has = var < nv;
-    const int v = g.pack.vars[pos];
+    const int qv = wm.first + (has ? var : 0);  // packed position: the index into the dynamic state
     const int seg = l - k;
-    const int mine = g.cur[v];
-    const int D = g.dom_size[v];
-    const double prob = g.prob[v];  // requested with the others, used after the decision
+    const int mine = g.cur[qv];
+    const int D = g.pack_dom[qv];
+    const int v = g.pack_label[qv];          // graph index: the key of the random draws
+    const double prob = g.pack_prob[qv];     // requested with the others, used after the decision
     T t[MAXD], c[MAXD];
     lsearch::pack_costs<T, TT>(g.pack, g.cur, pos, deg, seg, true, t, c);
     T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;   // find_optimal, relations.py:1622-1638
@@ -316,8 +327,8 @@ __global__ void __launch_bounds__(PACK_TPB) k_dsa_cycle_pack(Dev<T> g) {
         moved = true;
     }
     if (has && k == 0) {
-        g.cur_out[v] = out;
-        if (moved) g.cost[v] = best_cost;  // value_selection(choice, best_cost)
+        g.cur_out[qv] = out;
+        if (moved) g.cost[qv] = best_cost;  // value_selection(choice, best_cost)
     }
 }
 
@@ -339,7 +350,7 @@ struct Engine : Base {
     Dev<T> g{};
     int which = 0;
     uint64_t seed = 0;
-    std::vector<int32_t> h_dom, h_frow, h_evar, h_nn;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_nn, h_q;
     std::vector<int64_t> h_toff, h_coff;
     std::vector<double> h_tables, h_eval_cost, h_var_cost;
     Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, n_neigh;
@@ -350,7 +361,8 @@ struct Engine : Base {
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
     Buf<lsearch::PackWave> pk_waves;
-    Buf<int32_t> pk_vars, pk_nb, pk_slot, pk_rest;
+    Buf<int32_t> pk_nb, pk_slot, pk_rest, pk_dom, pk_label, qmap;
+    Buf<double> pk_prob;
     Buf<int8_t> pk_rec8;
     Buf<T> pk_recT, pk_fopt;
     bool pack_int8 = false;
@@ -439,22 +451,48 @@ struct Engine : Base {
                 DSA_TRY(pk_recT.upload(rt, stream));
             }
             DSA_TRY(pk_waves.upload(hp.waves, stream));
-            DSA_TRY(pk_vars.upload(hp.lane_v, stream));
-            DSA_TRY(pk_nb.upload(hp.nb, stream));
+            // packed positions (Dev::q): the packed variables in wave order, then the others
+            h_q.assign(nV, -1);
+            int nq = 0;
+            for (int v : hp.vars) h_q[v] = nq++;
+            const int n_packed = nq;
+            for (int v = 0; v < nV; ++v)
+                if (h_q[v] < 0) h_q[v] = nq++;
+            auto to_q = [&](std::vector<int32_t> a) {
+                for (auto& x : a)
+                    if (x >= 0) x = h_q[x];
+                return a;
+            };
+            std::vector<int32_t> pdom(n_packed), plabel(n_packed);
+            std::vector<double> pprob(n_packed);
+            for (int v : hp.vars) {
+                pdom[h_q[v]] = h_dom[v];
+                plabel[h_q[v]] = v;
+                pprob[h_q[v]] = pr[v];
+            }
+            DSA_TRY(qmap.upload(h_q, stream));
+            DSA_TRY(pk_dom.upload(pdom, stream));
+            DSA_TRY(pk_label.upload(plabel, stream));
+            DSA_TRY(pk_prob.upload(pprob, stream));
+            DSA_TRY(sl_nb_var.upload(to_q(hs.nb_var), stream));
+            DSA_TRY(sl_nb0_var.upload(to_q(hs.nb0_var), stream));
+            g.q = qmap.p;
+            g.pack_dom = pk_dom.p;
+            g.pack_label = pk_label.p;
+            g.pack_prob = pk_prob.p;
+            DSA_TRY(pk_nb.upload(to_q(hp.nb), stream));
             DSA_TRY(pk_slot.upload(hp.slot, stream));
             DSA_TRY(pk_rest.upload(hp.rest, stream));
             DSA_TRY(pk_fopt.upload(fopt_lane, stream));
             n_rest = (int)hp.rest.size();
-            g.pack = lsearch::Pack{pk_waves.p, pk_vars.p, pk_nb.p, pk_slot.p,
+            g.pack = lsearch::Pack{pk_waves.p, pk_nb.p, pk_slot.p,
                                    pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
             g.pack_fopt = pk_fopt.p;
         }
         DSA_TRY(sl_base.upload(hs.base, stream));
         DSA_TRY(sl_stride_v.upload(hs.stride_v, stream));
         DSA_TRY(sl_nb_rowptr.upload(hs.nb_rowptr, stream));
-        DSA_TRY(sl_nb_var.upload(hs.nb_var, stream));
         DSA_TRY(sl_nb_stride.upload(hs.nb_stride, stream));
-        DSA_TRY(sl_nb0_var.upload(hs.nb0_var, stream));
         DSA_TRY(sl_nb0_stride.upload(hs.nb0_stride, stream));
         DSA_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
         DSA_TRY(sl_conc_var.upload(hs.conc_var, stream));
@@ -496,10 +534,10 @@ struct Engine : Base {
                     const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
                     if (g.is_max ? a >= b : a < b) best = d;
                 }
-                c0[v] = best;
-                k0[v] = (T)h_var_cost[h_coff[v] + best];
+                c0[h_q[v]] = best;  // (the state lives in packed order, Dev::q)
+                k0[h_q[v]] = (T)h_var_cost[h_coff[v] + best];
             } else {  // random_value_selection (dsa.py:291): draw 0 of cycle 0
-                c0[v] = (int32_t)(uniform(seed, v, 0, 0) * h_dom[v]);
+                c0[h_q[v]] = (int32_t)(uniform(seed, v, 0, 0) * h_dom[v]);
             }
         }
         which = 0;
@@ -559,11 +597,14 @@ struct Engine : Base {
         const int nV = g.n_vars;
         if (!nV) return MXS_OK;
         std::vector<T> hc(nV);
-        if (idx) DSA_TRY(hipMemcpyAsync(idx, cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
+        std::vector<int32_t> hi(nV);
+        DSA_TRY(hipMemcpyAsync(hi.data(), cur[which].p, 4 * nV, hipMemcpyDeviceToHost, stream));
         DSA_TRY(hipMemcpyAsync(hc.data(), cost.p, sizeof(T) * nV, hipMemcpyDeviceToHost, stream));
         DSA_TRY(hipStreamSynchronize(stream));
-        if (cst)
-            for (int v = 0; v < nV; ++v) cst[v] = (double)hc[v];
+        for (int v = 0; v < nV; ++v) {  // the state lives in packed order (Dev::q)
+            if (idx) idx[v] = hi[h_q[v]];
+            if (cst) cst[v] = (double)hc[h_q[v]];
+        }
         return MXS_OK;
     }
 

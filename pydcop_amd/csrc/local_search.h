@@ -160,15 +160,13 @@ __device__ inline void costs_of_values(const Slots& sl, const T* __restrict__ ta
 // variable's constraints are cross-lane reads in slot order: the reference's order, bit for bit.
 constexpr int PACK_D = 4;
 struct PackWave {
-    int32_t first;    // index of the wave's first variable in Pack::vars
+    int32_t first;    // index of the wave's first variable in HostPack::vars = its position in the engines' state arrays
     int32_t deg_nv;   // deg | nv << 8 | ceil(2^15 / deg) << 16
 };
 struct Pack {  // device pointers
     const PackWave* waves;
-    const int32_t* vars;   // [lanes] the lane's variable (a padding lane: the wave's first one) -- addressed by the
-                           // lane's position like nb[], so that a variable's own value and its neighbour's are
-                           // requested together (through the wave record they were one dependent load later)
-    const int32_t* nb;     // [lanes]
+    const int32_t* nb;     // [lanes] the other variable's index INTO THE STATE ARRAYS (the engines store their dynamic
+                           // state in packed order -- position = index into HostPack::vars -- and upload nb so)
     const int32_t* slot;   // [lanes] CSR slot of the lane, -1 = padding lane
     const void* rec;       // [lanes][PACK_D][PACK_D] int8 or T
     int32_t n_lanes;
@@ -177,7 +175,6 @@ struct HostPack {
     std::vector<PackWave> waves;
     std::vector<int32_t> vars, nb, slot, rest;  // rest: variables with neighbours the pack cannot take
     std::vector<int32_t> lane_var, lane_k, lane_deg;  // [lanes] the lane's variable (-1: padding), position, degree
-    std::vector<int32_t> lane_v;                      // [lanes] = lane_var, padding lanes: the wave's first variable
     std::vector<double> rec;                    // [lanes * 16], as doubles; narrowed at upload
     bool int8_exact = true;
 
@@ -206,7 +203,6 @@ struct HostPack {
                 for (int lane = 0; lane < 64; ++lane) {
                     const int var = lane / deg, k = lane % deg;
                     lane_var.push_back(var < nv ? vs[x + var] : -1);
-                    lane_v.push_back(var < nv ? vs[x + var] : vs[x]);
                     lane_k.push_back(k);
                     lane_deg.push_back(deg);
                     if (var >= nv) {

@@ -589,7 +589,7 @@ struct Engine : Base {
             MGM_TRY(pk_conc.upload(to_q(conc), stream));
             MGM_TRY(pk_conc_x.upload(to_q(conc_x), stream));
             n_rest = (int)hp.rest.size();
-            g.pack = lsearch::Pack{pk_waves.p, nullptr, pk_nb.p, pk_slot.p,
+            g.pack = lsearch::Pack{pk_waves.p, pk_nb.p, pk_slot.p,
                                    pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
             g.pack_conc = pk_conc.p;
             g.pack_conc_x = pk_conc_x.p;
