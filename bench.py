@@ -283,10 +283,13 @@ def local_search_bytes(g, word, mgm):
     constraints over domains of at most 4 values -- what the engines then run): per (variable,
     constraint) lane the neighbour's index (4), its current value (4) and ONE row of the lane's
     private transposed record (4 entries: 4 bytes when every table entry is a small integer, else
-    4 * w); per variable its value in / out, domain size, move probability and the wave record
-    (24); MGM adds per lane the concerned variable's index, cost offset, value and cost (4 + 8 + 4 + w,
-    first launch), its gain and name rank (w + 4, second launch) and per variable gain, new value,
-    cost in / out (2 * w + 8).
+    4 * w); per variable its value in / out, domain size, move probability, graph index (24).
+    MGM (round 3 layout: state in packed order, one 16-byte gain record per variable, the own cost at
+    the current value kept per variable): per lane the concerned variable's position and kept cost
+    (4 + w, first launch), its position, gain and name rank (4 + w + 4, second launch); per variable,
+    first launch: value, domain size, cost, cost flag in, gain + new value out (13 + 2 * w); second
+    launch: gain, new value, name rank, value, cost, kept cost and the new value's own cost in, value,
+    cost, kept cost out (20 + 6 * w).
     "slots" (the thread-per-variable kernels): per (variable, constraint) slot its record (base 8,
     own stride 4, two row pointers 8, first neighbour + its stride 8), the neighbour's current
     value (4) and the D table entries at it (D * w); per variable 32; MGM's second launch reads the
@@ -309,9 +312,11 @@ def local_search_bytes(g, word, mgm):
         small = bool(((t == np.round(t)) & (np.abs(t) <= 127)).all())
         lanes = int(deg[has_nb].sum())
         n = int(has_nb.sum())
-        total = lanes * (4 + 4 + (4 if small else 4 * word)) + 24 * n
+        total = lanes * (4 + 4 + (4 if small else 4 * word))
         if mgm:
-            total += lanes * (4 + 8 + 4 + word) + lanes * (word + 4) + n * (2 * word + 8)
+            total += lanes * (4 + word) + lanes * (8 + word) + n * (33 + 8 * word)
+        else:
+            total += 24 * n
         return total, "packed"
     slots = int((deg * (28 + 4 + D * word)).sum())
     per_var = 32 * g.n_vars
