@@ -52,11 +52,13 @@ def rescope_factor(graph: FlatGraph, state: Dict, factor: int, new_scope: Sequen
     no previous message on either side, and the F->V message the factor sends with ADD; a
     variable that lost the factor has no previous message on any of its remaining edges.
 
-    Cost: the carry-over walks the edges and variables in Python and `DynamicMaxSum` then builds a
-    fresh engine (layout + upload) -- seconds of host time at 100k..1M variables, paid under the
-    plug-in's session lock.  A change of scope is a rare event in the reference's model (a rule
-    rewritten, maxsum_dynamic.py:234-271); same-scope changes and external-value moves -- the frequent
-    ones -- are device-side kernels and cost microseconds."""
+    Cost: array operations over the whole graph (one stable sort of the variable-side links, copies of
+    the message and table arrays: 4.5 s on the 1M-variable, 6M-edge instance in the build container;
+    round 2 walked every edge and variable in Python), after which `DynamicMaxSum` builds a fresh engine
+    (layout + upload) -- seconds of host time at that size, paid under the plug-in's session lock.  A
+    change of scope is a rare event in the reference's model (a rule rewritten,
+    maxsum_dynamic.py:234-271); same-scope changes and external-value moves -- the frequent ones -- are
+    device-side kernels and cost microseconds."""
     g = graph
     f = int(factor)
     new_scope = [int(v) for v in new_scope]
@@ -94,17 +96,19 @@ def rescope_factor(graph: FlatGraph, state: Dict, factor: int, new_scope: Sequen
     table_off[f + 1:] += new_table.size - (t1 - t0)
 
     # ---- variable side: links order kept, removed edges dropped, added edges appended ------
-    var_lists = []
-    for v in range(g.n_vars):
-        k0, k1 = int(g.var_rowptr[v]), int(g.var_rowptr[v + 1])
-        lst = [int(old_to_new[e]) for e in g.var_edges[k0:k1] if old_to_new[e] >= 0]
-        var_lists.append(lst)
-    for i, v in enumerate(new_scope):
-        if v in added:
-            var_lists[v].append(e0 + i)                        # `self._factors.append(factor_name)`
+    # (array operations over the whole graph: one stable sort; a scope change on a 1M-variable instance
+    # used to walk every variable and every edge in Python)
+    deg_old = np.diff(g.var_rowptr.astype(np.int64))
+    var_of_slot = np.repeat(np.arange(g.n_vars, dtype=np.int64), deg_old)
+    slot_new_edge = old_to_new[g.var_edges]
+    keep = slot_new_edge >= 0
+    add_pos = [i for i, v in enumerate(new_scope) if v in added]
+    slot_var = np.concatenate([var_of_slot[keep], np.array([new_scope[i] for i in add_pos], dtype=np.int64)])
+    slot_edge = np.concatenate([slot_new_edge[keep], np.array([e0 + i for i in add_pos], dtype=np.int64)])
+    order = np.argsort(slot_var, kind="stable")   # kept links in their order, `self._factors.append(factor_name)` last
+    var_edges = slot_edge[order].astype(np.int32)
     var_rowptr = np.zeros(g.n_vars + 1, dtype=np.int32)
-    np.cumsum([len(x) for x in var_lists], out=var_rowptr[1:])
-    var_edges = np.array([e for lst in var_lists for e in lst], dtype=np.int32)
+    np.cumsum(np.bincount(slot_var, minlength=g.n_vars), out=var_rowptr[1:])
 
     ng = FlatGraph(dom_size=g.dom_size, var_cost=g.var_cost, factor_rowptr=factor_rowptr.astype(np.int32),
                    edge_var=edge_var, table_off=table_off, tables=tables, var_rowptr=var_rowptr,
@@ -113,21 +117,32 @@ def rescope_factor(graph: FlatGraph, state: Dict, factor: int, new_scope: Sequen
 
     # ---- state ---------------------------------------------------------------------------
     old_off, new_off = g.msg_off, ng.msg_off
-    nm = int(new_off[-1])
-    v2f, f2v = np.zeros(nm), np.zeros(nm)
-    cv, cf = np.zeros(ng.n_edges, dtype=np.uint8), np.zeros(ng.n_edges, dtype=np.uint8)
-    for e_new in range(ng.n_edges):  # O(E) copies (a vectorised gather would do for big graphs)
-        e_old = int(new_edge_old[e_new])
+    # Only f's block of the factor-major edge order changes: everything before it is carried over as it
+    # is, everything after it shifted; inside, a kept variable's messages and counters move to its new
+    # position, an added variable starts from zeros.
+    m0, m1 = int(old_off[e0]), int(old_off[e1])
+    n0, n1 = int(new_off[e0]), int(new_off[e0 + len(new_scope)])
+
+    def carry(old, block):
+        return np.concatenate([old[:m0], block, old[m1:]])
+
+    bv, bf = np.zeros(n1 - n0), np.zeros(n1 - n0)
+    bcv, bcf = np.zeros(len(new_scope), dtype=np.uint8), np.zeros(len(new_scope), dtype=np.uint8)
+    for i, v in enumerate(new_scope):  # (the factor's own edges: its arity)
+        e_old = old_edge_of.get(v, -1)
         if e_old < 0:
             continue
-        D = int(new_off[e_new + 1] - new_off[e_new])
-        v2f[new_off[e_new]:new_off[e_new] + D] = state["v2f"][old_off[e_old]:old_off[e_old] + D]
-        f2v[new_off[e_new]:new_off[e_new] + D] = state["f2v"][old_off[e_old]:old_off[e_old] + D]
-        cv[e_new], cf[e_new] = state["count_v2f"][e_old], state["count_f2v"][e_old]
+        a, b = int(new_off[e0 + i]) - n0, int(new_off[e0 + i + 1]) - n0
+        bv[a:b] = state["v2f"][old_off[e_old]:old_off[e_old + 1]]
+        bf[a:b] = state["f2v"][old_off[e_old]:old_off[e_old + 1]]
+        bcv[i], bcf[i] = state["count_v2f"][e_old], state["count_f2v"][e_old]
+    v2f, f2v = carry(np.asarray(state["v2f"], dtype=np.float64), bv), carry(np.asarray(state["f2v"], dtype=np.float64), bf)
+    cv = np.concatenate([np.asarray(state["count_v2f"], dtype=np.uint8)[:e0], bcv, np.asarray(state["count_v2f"], dtype=np.uint8)[e1:]])
+    cf = np.concatenate([np.asarray(state["count_f2v"], dtype=np.uint8)[:e0], bcf, np.asarray(state["count_f2v"], dtype=np.uint8)[e1:]])
+    assert v2f.size == int(new_off[-1]) and cv.size == ng.n_edges
     # REMOVE at the variable (maxsum_dynamic.py:360-390): `self._prev_messages.clear()`
     for v in removed:
-        for e_new in var_lists[v]:
-            cv[e_new] = 0
+        cv[var_edges[var_rowptr[v]:var_rowptr[v + 1]]] = 0
     # ADD (:290-313, 392-398): the factor's costs for the new variable, from what it holds now
     # (`self._costs[v.name] = {d: 0 ...}` for the added ones); nothing was sent before
     msgs = [v2f[new_off[e0 + i]:new_off[e0 + i + 1]] for i in range(len(new_scope))]
