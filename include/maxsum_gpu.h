@@ -389,6 +389,13 @@ typedef struct mxs_mgm mxs_mgm;
 int mxs_mgm_create(const mxs_graph *g, const mxs_params *p, const int32_t *name_rank, int32_t device,
                    mxs_mgm **out);
 int mxs_mgm_reset(mxs_mgm *e);
+/* The order of every variable's domain VALUES: value_rank[cost_off(v) + d] = position of the d-th value
+   of v's domain among v's values in ascending order (cost_off = prefix sum of dom_size).  Used for ONE
+   thing: a variable without neighbours starts at the optimum of its own costs, and the reference breaks
+   cost ties there on the VALUE -- optimal_cost_value takes min / max over (cost, value) tuples
+   (pydcop/dcop/relations.py:1661-1665).  NULL or never called: the values are in ascending order as
+   written (rank = index).  Resets the engine. */
+int mxs_mgm_set_value_rank(mxs_mgm *e, const int32_t *value_rank);
 int mxs_mgm_run(mxs_mgm *e, int32_t n_rounds);
 int mxs_mgm_rounds(const mxs_mgm *e, int64_t *rounds);
 /* current value index, the cost the computation holds (has_cost = 0: still None, mgm.py:349),
@@ -411,6 +418,8 @@ typedef struct mxs_dsa mxs_dsa;
 int mxs_dsa_create(const mxs_graph *g, const mxs_params *p, int32_t variant, double probability,
                    int32_t arity_mode, uint64_t seed, int32_t device, mxs_dsa **out);
 int mxs_dsa_reset(mxs_dsa *e);
+/* as mxs_mgm_set_value_rank (dsa.py:278-289 calls the same optimal_cost_value) */
+int mxs_dsa_set_value_rank(mxs_dsa *e, const int32_t *value_rank);
 int mxs_dsa_run(mxs_dsa *e, int32_t n_cycles);
 int mxs_dsa_cycles(const mxs_dsa *e, int64_t *cycles);
 /* current value index and the cost the computation holds (0 until its first move) */

@@ -26,13 +26,14 @@
  * Variable.initial_value is ignored (dsa.py:291); the cost a computation holds is 0 until its first
  * move (value_selection's default, computations.py:1057), then the best cost of that move.
 
- * Deliberate deviations in corners no comparison reaches (round-2 ADVICE), on BOTH sides of every
- * test (oracle, engines): (1) a variable WITHOUT neighbours starts at the optimum of its own costs;
- * the reference's optimal_cost_value takes min / max over (cost, value) tuples, i.e. ties break on
- * the domain VALUE (smallest for min, largest for max) -- here on the domain INDEX (first for min,
- * last for max), the same thing for domains written in ascending order, as every instance of the
- * tests is; (2) such a variable without cost function gets random.choice and cost None in the
- * reference, index 0 and cost 0 here; (3) p_mode "arity" with a variable whose constraints are all
+ * A variable WITHOUT neighbours starts at the optimum of its own costs: optimal_cost_value takes min /
+ * max over (cost, value) tuples (relations.py:1661-1665), i.e. cost ties break on the domain VALUE
+ * (smallest for min, largest for max) -- `value_rank` carries the order of the values (round 3;
+ * NULL = written in ascending order, then first index for min, last for max), pinned against the
+ * reference with an unsorted string domain.
+ * Deliberate deviations left, on BOTH sides of every test (oracle, engines), in corners no comparison
+ * reaches: (1) such a variable without cost function gets random.choice and cost None in the
+ * reference, index 0 and cost 0 here; (2) p_mode "arity" with a variable whose constraints are all
  * unary divides by zero in the reference (dsa.py:256-259), here it falls back to `probability`.
  */
 #include <math.h>
@@ -72,6 +73,7 @@ typedef struct dsao_state {
     double probability;
     uint64_t seed;
     int32_t *cur, *n_neigh;
+    int32_t *value_rank;             /* NULL: the domains are written in ascending order */
     real *cost;
     double *prob;                    /* per variable (p_mode arity: 1.2 / sum(arity - 1)) */
     int64_t cycles;
@@ -105,9 +107,13 @@ void dsao_reset(dsao_state *s) {
     for (int32_t v = 0; v < s->n_vars; ++v) {
         if (s->n_neigh[v] == 0) { /* optimal_cost_value, dsa.py:278-289 */
             const real *c = s->var_cost + s->cost_off[v];
+            const int32_t *rk = s->value_rank ? s->value_rank + s->cost_off[v] : NULL;
             int best = 0;
-            for (int d = 1; d < s->dom_size[v]; ++d)
-                if (s->is_max ? c[d] >= c[best] : c[d] < c[best]) best = d;
+            for (int d = 1; d < s->dom_size[v]; ++d) { /* min / max over (cost, value) tuples, relations.py:1661-1665 */
+                const int rd = rk ? rk[d] : d, rb = rk ? rk[best] : best;
+                if (s->is_max ? (c[d] > c[best] || (c[d] == c[best] && rd > rb))
+                              : (c[d] < c[best] || (c[d] == c[best] && rd < rb))) best = d;
+            }
             s->cur[v] = best;
             s->cost[v] = c[best];
         } else { /* random_value_selection, dsa.py:291 */
@@ -115,6 +121,13 @@ void dsao_reset(dsao_state *s) {
             s->cost[v] = 0;
         }
     }
+}
+
+/* the order of every variable's domain values (include/maxsum_gpu.h, mxs_dsa_set_value_rank); resets */
+void dsao_set_value_rank(dsao_state *s, const int32_t *rank) {
+    free(s->value_rank);
+    s->value_rank = rank ? (int32_t *)dup_mem(rank, sizeof(int32_t) * (size_t)s->cost_off[s->n_vars]) : NULL;
+    dsao_reset(s);
 }
 
 dsao_state *dsao_create(const mxs_graph *g, const mxs_params *p, int32_t variant, double probability,
@@ -269,6 +282,6 @@ void dsao_destroy(dsao_state *s) {
     free(s->dom_size); free(s->factor_rowptr); free(s->edge_var); free(s->var_rowptr); free(s->var_edges);
     free(s->edge_factor); free(s->table_off); free(s->cost_off); free(s->var_cost); free(s->tables);
     free(s->f_opt); free(s->var_cost64); free(s->tables64); free(s->cur); free(s->n_neigh); free(s->cost);
-    free(s->prob);
+    free(s->prob); free(s->value_rank);
     free(s);
 }

@@ -23,6 +23,7 @@ def _lib(dtype):
         lib.dsao_create.restype = vp
         lib.dsao_create.argtypes = [C.POINTER(CGraph), C.POINTER(CParams), C.c_int32, C.c_double, C.c_int32, C.c_uint64]
         lib.dsao_reset.argtypes = [vp]
+        lib.dsao_set_value_rank.argtypes = [vp, vp]
         lib.dsao_run.argtypes = [vp, C.c_int32]
         lib.dsao_cycles.restype = C.c_int64
         lib.dsao_cycles.argtypes = [vp]
@@ -49,6 +50,9 @@ class OracleDsa:
         cg, cp = graph.to_c(), self.params.to_c()
         self._h = self._lib.dsao_create(C.byref(cg), C.byref(cp), VARIANTS[variant], float(probability),
                                         1 if p_mode == "arity" else 0, int(seed))
+        self._vrank = graph.value_rank()   # the order of the domain values (cost ties at the start)
+        if self._vrank is not None:
+            self._lib.dsao_set_value_rank(self._h, self._vrank.ctypes.data)
 
     def reset(self):
         self._lib.dsao_reset(self._h)

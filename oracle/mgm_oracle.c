@@ -26,12 +26,13 @@
  * the variable itself moves; the candidate evaluation adds the variable's own cost at its CURRENT
  * value; the winner of a neighbourhood is the LARGEST gain also in max mode.
 
- * Deliberate deviations in corners no comparison reaches (round-2 ADVICE), on BOTH sides of every
- * test (oracle, engines): (1) a variable WITHOUT neighbours starts at the optimum of its own costs;
- * the reference's optimal_cost_value takes min / max over (cost, value) tuples, i.e. ties break on
- * the domain VALUE (smallest for min, largest for max) -- here on the domain INDEX (first for min,
- * last for max), the same thing for domains written in ascending order, as every instance of the
- * tests is; (2) such a variable without cost function gets random.choice and cost None in the
+ * A variable WITHOUT neighbours starts at the optimum of its own costs: optimal_cost_value takes min /
+ * max over (cost, value) tuples (relations.py:1661-1665), i.e. cost ties break on the domain VALUE
+ * (smallest for min, largest for max) -- `value_rank` carries the order of the values (round 3;
+ * NULL = written in ascending order, then first index for min, last for max), pinned against the
+ * reference with an unsorted string domain.
+ * Deliberate deviations left, on BOTH sides of every test (oracle, engines), in corners no comparison
+ * reaches: (1) such a variable without cost function gets random.choice and cost None in the
  * reference, index 0 and cost 0 here.
  */
 #include <math.h>
@@ -50,6 +51,7 @@ typedef struct mgmo_state {
     int32_t n_vars, n_factors, n_edges;
     int32_t *dom_size, *init_idx, *factor_rowptr, *edge_var, *var_rowptr, *var_edges, *edge_factor;
     int32_t *name_rank;   /* [n_vars] rank of the variable's name in sorted order (lexic ties) */
+    int32_t *value_rank;  /* NULL: the domains are written in ascending order */
     int64_t *table_off, *cost_off;
     real *var_cost, *tables;
     double *var_cost64, *tables64;
@@ -177,9 +179,13 @@ void mgmo_reset(mgmo_state *s) {
         s->gain[v] = 0;
         if (s->n_neigh[v] == 0) { /* on_start without neighbours: optimal_cost_value, :279-290 */
             const real *c = s->var_cost + s->cost_off[v];
+            const int32_t *rk = s->value_rank ? s->value_rank + s->cost_off[v] : NULL;
             int best = 0;
-            for (int d = 1; d < s->dom_size[v]; ++d) /* min/max over (cost, value) tuples */
-                if (s->is_max ? c[d] >= c[best] : c[d] < c[best]) best = d;
+            for (int d = 1; d < s->dom_size[v]; ++d) { /* min / max over (cost, value) tuples, relations.py:1661-1665 */
+                const int rd = rk ? rk[d] : d, rb = rk ? rk[best] : best;
+                if (s->is_max ? (c[d] > c[best] || (c[d] == c[best] && rd > rb))
+                              : (c[d] < c[best] || (c[d] == c[best] && rd < rb))) best = d;
+            }
             s->cur[v] = best;
             s->cost[v] = c[best];
             s->has_cost[v] = 1;
@@ -188,6 +194,13 @@ void mgmo_reset(mgmo_state *s) {
         }
         s->newv[v] = s->cur[v];
     }
+}
+
+/* the order of every variable's domain values (include/maxsum_gpu.h, mxs_mgm_set_value_rank); resets */
+void mgmo_set_value_rank(mgmo_state *s, const int32_t *rank) {
+    free(s->value_rank);
+    s->value_rank = rank ? (int32_t *)dup_mem(rank, sizeof(int32_t) * (size_t)s->cost_off[s->n_vars]) : NULL;
+    mgmo_reset(s);
 }
 
 mgmo_state *mgmo_create(const mxs_graph *g, const mxs_params *p, const int32_t *name_rank) {
@@ -283,7 +296,7 @@ void mgmo_eval_cost(const mgmo_state *s, const int32_t *idx, double infinity, do
 void mgmo_destroy(mgmo_state *s) {
     if (!s) return;
     free(s->dom_size); free(s->init_idx); free(s->factor_rowptr); free(s->edge_var); free(s->var_rowptr);
-    free(s->var_edges); free(s->edge_factor); free(s->name_rank); free(s->table_off); free(s->cost_off);
+    free(s->var_edges); free(s->edge_factor); free(s->name_rank); free(s->value_rank); free(s->table_off); free(s->cost_off);
     free(s->var_cost); free(s->tables); free(s->var_cost64); free(s->tables64);
     free(s->cur); free(s->newv); free(s->n_neigh); free(s->has_cost); free(s->cost); free(s->gain);
     free(s);

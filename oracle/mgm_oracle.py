@@ -22,6 +22,7 @@ def _lib(dtype):
         lib.mgmo_create.restype = vp
         lib.mgmo_create.argtypes = [C.POINTER(CGraph), C.POINTER(CParams), vp]
         lib.mgmo_reset.argtypes = [vp]
+        lib.mgmo_set_value_rank.argtypes = [vp, vp]
         lib.mgmo_run.argtypes = [vp, C.c_int32]
         lib.mgmo_rounds.restype = C.c_int64
         lib.mgmo_rounds.argtypes = [vp]
@@ -51,6 +52,9 @@ class OracleMgm:
         self._rank = name_ranks(graph.var_names) if graph.var_names else None
         self._h = self._lib.mgmo_create(C.byref(cg), C.byref(cp),
                                         None if self._rank is None else self._rank.ctypes.data)
+        self._vrank = graph.value_rank()   # the order of the domain values (cost ties at the start)
+        if self._vrank is not None:
+            self._lib.mgmo_set_value_rank(self._h, self._vrank.ctypes.data)
 
     def reset(self):
         self._lib.mgmo_reset(self._h)

@@ -337,6 +337,7 @@ struct Base {
     virtual int init(const mxs_graph& G, const mxs_params& p, int variant, double probability, int arity_mode,
                      uint64_t seed, int device) = 0;
     virtual int reset() = 0;
+    virtual int set_value_rank(const int32_t* rank) = 0;
     virtual int run(int32_t n) = 0;
     virtual int get_state(int32_t* idx, double* cost) = 0;
     virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
@@ -350,7 +351,7 @@ struct Engine : Base {
     Dev<T> g{};
     int which = 0;
     uint64_t seed = 0;
-    std::vector<int32_t> h_dom, h_frow, h_evar, h_nn, h_q;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_nn, h_q, h_vrank;
     std::vector<int64_t> h_toff, h_coff;
     std::vector<double> h_tables, h_eval_cost, h_var_cost;
     Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, n_neigh;
@@ -522,6 +523,14 @@ struct Engine : Base {
         return reset();
     }
 
+    // the order of every variable's domain values (include/maxsum_gpu.h): cost ties of a variable without
+    // neighbours break on the value, as the reference's optimal_cost_value does
+    int set_value_rank(const int32_t* rank) override {
+        if (rank) h_vrank.assign(rank, rank + h_coff[g.n_vars]);
+        else h_vrank.clear();
+        return reset();
+    }
+
     int reset() override {
         DSA_TRY(hipSetDevice(device));
         const int nV = g.n_vars;
@@ -529,10 +538,12 @@ struct Engine : Base {
         std::vector<T> k0(nV, (T)0);
         for (int v = 0; v < nV; ++v) {
             if (h_nn[v] == 0) {  // optimal_cost_value (dsa.py:278-289)
+                const int32_t* rk = h_vrank.empty() ? nullptr : h_vrank.data() + h_coff[v];
                 int best = 0;
-                for (int d = 1; d < h_dom[v]; ++d) {
+                for (int d = 1; d < h_dom[v]; ++d) {  // min / max over (cost, value) tuples, relations.py:1661-1665
                     const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
-                    if (g.is_max ? a >= b : a < b) best = d;
+                    const int rd = rk ? rk[d] : d, rb = rk ? rk[best] : best;
+                    if (g.is_max ? (a > b || (a == b && rd > rb)) : (a < b || (a == b && rd < rb))) best = d;
                 }
                 c0[h_q[v]] = best;  // (the state lives in packed order, Dev::q)
                 k0[h_q[v]] = (T)h_var_cost[h_coff[v] + best];
@@ -665,6 +676,9 @@ int mxs_dsa_create(const mxs_graph* g, const mxs_params* p, int32_t variant, dou
     }
 }
 int mxs_dsa_reset(mxs_dsa* e) { return e ? e->impl->reset() : dsa::fail(MXS_E_INVALID, "null handle"); }
+int mxs_dsa_set_value_rank(mxs_dsa* e, const int32_t* value_rank) {
+    return e ? e->impl->set_value_rank(value_rank) : dsa::fail(MXS_E_INVALID, "null handle");
+}
 int mxs_dsa_run(mxs_dsa* e, int32_t n_cycles) {
     if (!e) return dsa::fail(MXS_E_INVALID, "null handle");
     if (n_cycles < 0) return dsa::fail(MXS_E_INVALID, "negative cycle count");

@@ -438,6 +438,7 @@ struct Base {
     virtual ~Base() {}
     virtual int init(const mxs_graph& G, const mxs_params& p, const int32_t* rank, int device) = 0;
     virtual int reset() = 0;
+    virtual int set_value_rank(const int32_t* rank) = 0;
     virtual int run(int32_t n) = 0;
     virtual int get_state(int32_t* idx, double* cost, uint8_t* has, double* gain, int32_t* newv) = 0;
     virtual int eval_cost(const int32_t* idx, double infinity, double* cost, int64_t* viol) = 0;
@@ -450,7 +451,7 @@ struct Engine : Base {
     hipStream_t stream = nullptr;
     Dev<T> g{};
     int which = 0;
-    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn, h_rank, h_q;
+    std::vector<int32_t> h_dom, h_frow, h_evar, h_init, h_nn, h_rank, h_q, h_vrank;
     std::vector<int64_t> h_toff, h_coff;
     std::vector<double> h_tables, h_eval_cost, h_var_cost;
     bool has_init = false;
@@ -627,6 +628,14 @@ struct Engine : Base {
         return reset();
     }
 
+    // the order of every variable's domain values (include/maxsum_gpu.h): cost ties of a variable without
+    // neighbours break on the value, as the reference's optimal_cost_value does
+    int set_value_rank(const int32_t* rank) override {
+        if (rank) h_vrank.assign(rank, rank + h_coff[g.n_vars]);
+        else h_vrank.clear();
+        return reset();
+    }
+
     int reset() override {
         MGM_TRY(hipSetDevice(device));
         const int nV = g.n_vars;
@@ -637,10 +646,12 @@ struct Engine : Base {
         for (int v = 0; v < nV; ++v) {
             const int qv = h_q[v];
             if (h_nn[v] == 0) {  // on_start without neighbours: optimal_cost_value (mgm.py:279-290)
+                const int32_t* rk = h_vrank.empty() ? nullptr : h_vrank.data() + h_coff[v];
                 int best = 0;
-                for (int d = 1; d < h_dom[v]; ++d) {
+                for (int d = 1; d < h_dom[v]; ++d) {  // min / max over (cost, value) tuples, relations.py:1661-1665
                     const T a = (T)h_var_cost[h_coff[v] + d], b = (T)h_var_cost[h_coff[v] + best];
-                    if (g.is_max ? a >= b : a < b) best = d;
+                    const int rd = rk ? rk[d] : d, rb = rk ? rk[best] : best;
+                    if (g.is_max ? (a > b || (a == b && rd > rb)) : (a < b || (a == b && rd < rb))) best = d;
                 }
                 c0[qv] = best;
                 k0[qv] = (T)h_var_cost[h_coff[v] + best];
@@ -797,6 +808,9 @@ int mxs_mgm_create(const mxs_graph* g, const mxs_params* p, const int32_t* name_
     }
 }
 int mxs_mgm_reset(mxs_mgm* e) { return e ? e->impl->reset() : mgm::fail(MXS_E_INVALID, "null handle"); }
+int mxs_mgm_set_value_rank(mxs_mgm* e, const int32_t* value_rank) {
+    return e ? e->impl->set_value_rank(value_rank) : mgm::fail(MXS_E_INVALID, "null handle");
+}
 int mxs_mgm_run(mxs_mgm* e, int32_t n_rounds) {
     if (!e) return mgm::fail(MXS_E_INVALID, "null handle");
     if (n_rounds < 0) return mgm::fail(MXS_E_INVALID, "negative round count");

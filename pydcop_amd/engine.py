@@ -47,9 +47,9 @@ ABI_SYMBOLS = (
     "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
     "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
     "mxs_amaxsum_eval_cost", "mxs_amaxsum_update_factor_table", "mxs_amaxsum_destroy",
-    "mxs_mgm_create", "mxs_mgm_reset", "mxs_mgm_run", "mxs_mgm_rounds", "mxs_mgm_get_state",
+    "mxs_mgm_create", "mxs_mgm_reset", "mxs_mgm_set_value_rank", "mxs_mgm_run", "mxs_mgm_rounds", "mxs_mgm_get_state",
     "mxs_mgm_eval_cost", "mxs_mgm_destroy",
-    "mxs_dsa_create", "mxs_dsa_reset", "mxs_dsa_run", "mxs_dsa_cycles", "mxs_dsa_get_state",
+    "mxs_dsa_create", "mxs_dsa_reset", "mxs_dsa_set_value_rank", "mxs_dsa_run", "mxs_dsa_cycles", "mxs_dsa_get_state",
     "mxs_dsa_eval_cost", "mxs_dsa_destroy",
 )
 
@@ -160,6 +160,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_amaxsum_destroy": ([vp], C.c_int),
         "mxs_mgm_create": ([C.POINTER(CGraph), C.POINTER(CParams), vp, i32, C.POINTER(vp)], C.c_int),
         "mxs_mgm_reset": ([vp], C.c_int),
+        "mxs_mgm_set_value_rank": ([vp, vp], C.c_int),
         "mxs_mgm_run": ([vp, i32], C.c_int),
         "mxs_mgm_rounds": ([vp, C.POINTER(i64)], C.c_int),
         "mxs_mgm_get_state": ([vp, vp, vp, vp, vp, vp], C.c_int),
@@ -168,6 +169,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_dsa_create": ([C.POINTER(CGraph), C.POINTER(CParams), i32, C.c_double, i32, C.c_uint64, i32,
                             C.POINTER(vp)], C.c_int),
         "mxs_dsa_reset": ([vp], C.c_int),
+        "mxs_dsa_set_value_rank": ([vp, vp], C.c_int),
         "mxs_dsa_run": ([vp, i32], C.c_int),
         "mxs_dsa_cycles": ([vp, C.POINTER(i64)], C.c_int),
         "mxs_dsa_get_state": ([vp, vp, vp], C.c_int),

@@ -131,6 +131,28 @@ class FlatGraph:
         np.cumsum(self.dom_size, out=off[1:])
         return off
 
+    def value_rank(self) -> Optional[np.ndarray]:
+        """rank[cost_off[v] + d] = position of the d-th value of v's domain among v's values in ascending
+        (Python) order, or None when every domain is written in ascending order / no domain values are
+        known / the values of a domain do not compare.  What the reference's `optimal_cost_value` breaks
+        cost ties on (relations.py:1661-1665: min / max over (cost, value) tuples) -- DSA and MGM start a
+        variable without neighbours there."""
+        if self.domains is None:
+            return None
+        rank = np.empty(int(self.cost_off[-1]), dtype=np.int32)
+        off, identity = 0, True
+        for values in self.domains:
+            values = list(values)
+            try:
+                order = sorted(range(len(values)), key=lambda d: values[d])
+            except TypeError:
+                return None
+            for r, d in enumerate(order):
+                rank[off + d] = r
+                identity = identity and r == d
+            off += len(values)
+        return None if identity else rank
+
     @property
     def msg_off(self) -> np.ndarray:
         """Offset of edge e's message in the message arrays returned by

@@ -38,6 +38,11 @@ class MgmEngine:
                                              None if self._rank is None else self._rank.ctypes.data,
                                              int(device), C.byref(h)))
         self._h = h
+        # cost ties of a variable without neighbours break on the domain VALUE (relations.py:1661-1665):
+        # only needed when some domain is not written in ascending order
+        self._vrank = graph.value_rank()
+        if self._vrank is not None:
+            self._check(self._lib.mxs_mgm_set_value_rank(self._h, self._vrank.ctypes.data))
 
     def _check(self, rc: int):
         if rc != 0:

@@ -6,6 +6,16 @@ from pydcop_amd.dsa import DsaEngine
 from pydcop_amd.graph import Params
 
 
+def unsorted_domains_with_ties(g, seed):
+    """Domains written in a non-ascending order and own costs on two levels: the variables without
+    neighbours start on cost ties, broken on the VALUE (FlatGraph.value_rank, relations.py:1661-1665)."""
+    rng = np.random.default_rng(seed)
+    g.domains = [["R", "G", "B"][:int(d)] for d in g.dom_size]
+    g.var_cost = rng.integers(0, 2, g.var_cost.shape[0]) / 64.0
+    assert g.value_rank() is not None
+    return g
+
+
 def dsa_cases(k=1):
     """k > 1: graphs k times smaller (the emulated engine of the CPU tests is slow)."""
     return [
@@ -16,6 +26,10 @@ def dsa_cases(k=1):
          dict(variant="B", p_mode="arity")),
         ("ising_C_always", lambda: G.ising_grid(12, 10, seed=35), {}, dict(variant="C", probability=1.0)),
         ("sparse_isolated_B", lambda: G.random_coloring(300 // k, avg_degree=1, seed=36), {"mode": "max"}, dict(variant="B")),
+        ("unsorted_domains_A", lambda: unsorted_domains_with_ties(G.random_coloring(200 // k, avg_degree=1, seed=41), 41), {},
+         dict(variant="A", probability=0.6)),
+        ("unsorted_domains_max_C", lambda: unsorted_domains_with_ties(G.random_coloring(200 // k, avg_degree=1, seed=42), 42),
+         {"mode": "max"}, dict(variant="C", probability=0.6)),
         ("meeting_d6_A", lambda: G.meeting_like(40, dom=6, seed=37), {"mode": "max"}, dict(variant="A", probability=0.9)),
         # the wider register arrays of the slot kernels (16, 32 values) and the CSR-walk kernel beyond
         ("meeting_d12_B", lambda: G.meeting_like(24, dom=12, seed=38), {"mode": "max"}, dict(variant="B", probability=0.8)),

@@ -19,6 +19,16 @@ def shuffled_names(g, seed):
     return g
 
 
+def unsorted_domains_with_ties(g, seed):
+    """Domains written in a non-ascending order and own costs on two levels: the variables without
+    neighbours start on cost ties, broken on the VALUE (FlatGraph.value_rank, relations.py:1661-1665)."""
+    rng = np.random.default_rng(seed)
+    g.domains = [["R", "G", "B"][:int(d)] for d in g.dom_size]
+    g.var_cost = rng.integers(0, 2, g.var_cost.shape[0]) / 64.0
+    assert g.value_rank() is not None
+    return g
+
+
 def mgm_cases():
     return [
         ("coloring_soft", lambda: G.random_coloring(400, seed=21), {}),
@@ -28,6 +38,8 @@ def mgm_cases():
         ("mixed_arity3_max", lambda: with_init(G.random_mixed(80, 120, seed=25, float_tables=False), 25), {"mode": "max"}),
         ("ising_unaries", lambda: G.ising_grid(12, 10, seed=26), {}),
         ("sparse_isolated", lambda: G.random_coloring(300, avg_degree=1, seed=27), {"mode": "max"}),
+        ("unsorted_domains", lambda: unsorted_domains_with_ties(G.random_coloring(200, avg_degree=1, seed=32), 32), {}),
+        ("unsorted_domains_max", lambda: unsorted_domains_with_ties(G.random_coloring(200, avg_degree=1, seed=33), 33), {"mode": "max"}),
         ("meeting_d6", lambda: G.meeting_like(40, dom=6, seed=28), {"mode": "max"}),
         # the wider register arrays of the slot kernels (16, 32 values) and the CSR-walk kernel beyond
         ("meeting_d12", lambda: G.meeting_like(24, dom=12, seed=29), {"mode": "max"}),

@@ -12,6 +12,18 @@ from pydcop_amd.graph import Params
 
 pytestmark = pytest.mark.skipif(not ref_harness.reference_available(), reason="reference tree not present")
 
+
+def unsorted_domains_with_ties(g, seed):
+    """Domains written in a NON-ascending order (['R', 'G', 'B'], sorted: B < G < R) and own costs on
+    two levels, so that the variables without neighbours have cost ties: the reference's
+    optimal_cost_value breaks them on the VALUE (min / max over (cost, value) tuples,
+    relations.py:1661-1665), not on the position in the domain."""
+    rng = np.random.default_rng(seed)
+    g.domains = [["R", "G", "B"][:int(d)] for d in g.dom_size]
+    g.var_cost = rng.integers(0, 2, g.var_cost.shape[0]) / 64.0
+    return g
+
+
 CASES = [
     ("coloring_soft", lambda: G.random_coloring(40, seed=31), "min"),
     ("coloring_hard", lambda: G.random_coloring(30, seed=32, variant="hard"), "min"),
@@ -19,6 +31,8 @@ CASES = [
     ("mixed_arity3", lambda: G.random_mixed(18, 24, seed=34), "min"),
     ("ising_unaries", lambda: G.ising_grid(4, 5, seed=35), "min"),
     ("sparse_isolated", lambda: G.random_coloring(30, avg_degree=1, seed=36), "max"),
+    ("unsorted_domains_min", lambda: unsorted_domains_with_ties(G.random_coloring(40, avg_degree=1, seed=37), 37), "min"),
+    ("unsorted_domains_max", lambda: unsorted_domains_with_ties(G.random_coloring(40, avg_degree=1, seed=38), 38), "max"),
 ]
 
 

@@ -25,6 +25,18 @@ def with_init(g, seed):
     return g
 
 
+
+def unsorted_domains_with_ties(g, seed):
+    """Domains written in a NON-ascending order (['R', 'G', 'B'], sorted: B < G < R) and own costs on
+    two levels, so that the variables without neighbours have cost ties: the reference's
+    optimal_cost_value breaks them on the VALUE (min / max over (cost, value) tuples,
+    relations.py:1661-1665), not on the position in the domain."""
+    rng = np.random.default_rng(seed)
+    g.domains = [["R", "G", "B"][:int(d)] for d in g.dom_size]
+    g.var_cost = rng.integers(0, 2, g.var_cost.shape[0]) / 64.0
+    return g
+
+
 CASES = [
     ("coloring_soft", lambda: grid_costs(G.random_coloring(40, seed=21), 21), "min"),
     ("coloring_hard_ties", lambda: grid_costs(G.random_coloring(30, seed=22, variant="hard"), 22, 2.0 ** 30), "min"),
@@ -33,6 +45,8 @@ CASES = [
     ("mixed_arity3_min", lambda: with_init(grid_costs(G.random_mixed(18, 24, seed=25, float_tables=False), 25), 25), "min"),
     ("ising_unaries", lambda: grid_costs(G.ising_grid(4, 5, seed=26), 26), "min"),
     ("sparse_isolated", lambda: grid_costs(G.random_coloring(30, avg_degree=1, seed=27), 27), "max"),
+    ("unsorted_domains_min", lambda: unsorted_domains_with_ties(G.random_coloring(40, avg_degree=1, seed=28), 28), "min"),
+    ("unsorted_domains_max", lambda: unsorted_domains_with_ties(G.random_coloring(40, avg_degree=1, seed=29), 29), "max"),
 ]
 
 
