@@ -129,3 +129,19 @@ def test_solve_flat_rejects_unknown_algorithm(emu_lib):
     from pydcop_amd.api import solve_flat
     with pytest.raises(ValueError, match="algo must be one of"):
         solve_flat(G.random_coloring(10, seed=0), "min", 1, lib_path=emu_lib, algo="dpop")
+
+
+def test_value_rank_of_the_domains():
+    """FlatGraph.value_rank: what DSA / MGM break the start-up cost ties of a variable without
+    neighbours on (the reference's optimal_cost_value compares (cost, value) tuples,
+    relations.py:1661-1665) -- None whenever the index order already is the value order."""
+    g = G.random_coloring(6, seed=0)
+    assert g.value_rank() is None                      # range(D): ascending as written
+    g.domains = None
+    assert g.value_rank() is None                      # no values known
+    g = G.random_coloring(6, seed=0)
+    g.domains = [["R", "G", "B"], ["B", "G", "R"], [2, 0, 1], [0, 1, 2], ["a", "b", "c"], [3.5, -1.0, 2.0]]
+    np.testing.assert_array_equal(g.value_rank().reshape(6, 3),
+                                  [[2, 1, 0], [0, 1, 2], [2, 0, 1], [0, 1, 2], [0, 1, 2], [2, 0, 1]])
+    g.domains[4] = ["a", 1, None]                      # values that do not compare: the reference would raise on a tie
+    assert g.value_rank() is None
