@@ -18,16 +18,21 @@ id of the `-m gpu` test that compares it bit for bit with the oracle at that siz
 box's host cores on a bounded sample -- the reference travels to the GPU box as the git-ignored
 archive oracle/_ref/ -- with the C port of the reference algorithm as a labelled extra.
 
-N > 1 (the driver launches one rank per GPU through torch.distributed.run): STRONG scaling of
-ONE instance -- by default BASELINE.json configs[3], the 1M-variable degree-6 colouring that
-north_star names for 8 GPUs -- partitioned across the ranks; boundary V->F messages cross once
+N > 1 (the driver launches one rank per GPU through torch.distributed.run): WEAK scaling of the
+metric's own instance family -- ONE instance of N x 100k variables (same generator, degree 4,
+3 colours), 100k variables per GPU, partitioned across the ranks; boundary V->F messages cross once
 per cycle (RCCL all-to-all issued by the engine itself by default; MAXSUM_COLLECTIVE=p2p|torch
-selects the peer-store / torch exchanges).  `value` = iterations/s of THAT instance; the same
-line reports what ONE GPU does on the same instance (`config.one_gpu_iterations_per_s`, measured
-on rank 0 after the timed region), the strong-scaled 100k instance and the weak-scaled
-N x 100k instance as labelled extras -- never multiplied into `value`.  After the timed region
-rank 0 re-runs the instance on a single engine: the sharded selection and beliefs must be
-bit-identical, otherwise the run exits with a non-zero status.
+selects the peer-store / torch exchanges).  `value` = N x iterations/s of that instance = the
+whole-job aggregate in the metric's unit (iterations/s per 100k variables of work): the same
+workload per GPU as the N = 1 line, so value(N) / (N * value(1)) is the weak-scaling efficiency.
+`config.iterations_per_s_of_this_instance` is the unmultiplied rate, `one_gpu_iterations_per_s`
+what ONE GPU does on the same N x 100k instance (measured on rank 0 after the timed region).
+Labelled extras, never part of `value`: BASELINE.json configs[3] -- the 1M-variable degree-6
+colouring north_star names for 8 GPUs -- and the 100k instance itself, both partitioned N ways
+(strong scaling, each with its speedup over one GPU on the same instance).  --workload NAME:
+strong scaling of that workload as `value`.  After every timed region rank 0 re-runs the instance
+on a single engine: the sharded selection and beliefs must be bit-identical, otherwise the run
+exits with a non-zero status.
 Rank 0 prints ONE JSON line.
 """
 import argparse
@@ -475,7 +480,7 @@ def main():
                          "runtime in cpu_baseline (0: C port only)")
     ap.add_argument("--configs", default="all", choices=["all", "main"],
                     help="N = 1: all = also time the other BASELINE.json configurations (default); "
-                         "N > 1: all = also run the 100k instance strong- and weak-scaled")
+                         "N > 1: all = also run configs[3] and the 100k instance strong-scaled")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: torch.distributed backend; gloo only for the CPU test of this script "
                          "(tests/test_bench_cli.py, emulated engine)")
@@ -489,7 +494,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
                          "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
-    workload = args.workload or ("coloring_100k" if args.gpus == 1 else "coloring_1m_deg6")
+    # N > 1 without --workload: WEAK scaling of the metric's own instance family -- ONE instance of
+    # N x 100k variables (same generator, degree, domain), 100k variables per GPU; `value` is the
+    # whole-job aggregate in the metric's unit, N x (iterations/s of that instance) = iterations/s per
+    # 100k variables of work, so that value(N) / (N * value(1)) is the weak-scaling efficiency.
+    # BASELINE configs[3] (the 1M-variable instance, strong scaling) and the 100k instance split N
+    # ways ride along as labelled extras.  With --workload: strong scaling of that workload.
+    weak = args.gpus > 1 and args.workload is None
+    workload = args.workload or "coloring_100k"
 
     if world > 1:
         # dmabuf IPC (hipIpc handles of the peer-store exchange, RCCL's own buffers): has to be
@@ -501,7 +513,7 @@ def main():
     from pydcop_amd.engine import MaxSumEngine
     from pydcop_amd.graph import Params
 
-    graph, mode = make_workload(workload, 1, args.vars_per_gpu)
+    graph, mode = make_workload(workload, args.gpus if weak else 1, args.vars_per_gpu)
     params = Params(mode=mode, dtype=args.dtype, layout_flags=args.layout_flags,
                     graph_chunk=args.graph_chunk)
     word = 8 if args.dtype == "f64" else 4
@@ -556,16 +568,26 @@ def main():
         elapsed = res["elapsed"]
         per_gpu = bytes_cycle / args.gpus / (elapsed / args.steps) / 1e9
         failed = failed or not res["check"]["identical_to_single_engine"]
+        its = args.steps / elapsed
+        if weak:
+            what = (f"coloring_100k x{args.gpus} (weak scaling: ONE {graph.n_vars}-variable instance of the metric's "
+                    f"family, {args.vars_per_gpu} variables per GPU; value = {args.gpus} x iterations/s of that "
+                    "instance = iterations/s per 100k variables of work, the whole-job aggregate)")
+        else:
+            what = (f"{workload} (strong scaling: ONE {graph.n_vars}-variable instance partitioned over "
+                    f"{args.gpus} GPUs; value = iterations/s of that instance)")
         out.update({
-            "value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "strong",
-            "config": {"workload": f"{workload} (strong scaling: ONE {graph.n_vars}-variable instance "
-                                   f"partitioned over {args.gpus} GPUs; value = iterations/s of that instance)",
+            "value": its * (args.gpus if weak else 1), "ms_per_step": 1e3 * elapsed / args.steps,
+            "scaling": "weak" if weak else "strong",
+            "config": {"workload": what,
                        "n_vars": graph.n_vars, "n_factors": graph.n_factors, "n_edges": graph.n_edges,
                        "domain": int(graph.dom_size.max()),
-                       "edge_messages_per_s": args.steps / elapsed * 2 * graph.n_edges,
+                       "iterations_per_s_of_this_instance": its,
+                       "edge_messages_per_s": its * 2 * graph.n_edges,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
                        "parallelism": f"graph-partition x{args.gpus}, exchange: {res['collective']}",
                        "one_gpu_iterations_per_s": res["one_gpu_iterations_per_s"],
+                       "speedup_vs_one_gpu_on_this_instance": its / res["one_gpu_iterations_per_s"],
                        "shard_rank0": res["shard_rank0"], "check": res["check"]},
             "roofline": {"bound": "hbm", "achieved": per_gpu, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": per_gpu / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
@@ -577,24 +599,25 @@ def main():
                          "avg_launch_us": 1e6 * elapsed / args.steps, "per_gpu": True},
         })
     if args.configs == "all" and args.workload is None:
-        # labelled extras: the metric's own 100k instance split N ways (strong), and ONE
-        # N x 100k-variable instance with 100k variables per GPU (weak)
+        # labelled extras: BASELINE configs[3] -- the 1M-variable degree-6 instance partitioned N ways
+        # (strong scaling; north_star's ">= 6x at 8 GPUs" is its speedup_vs_one_gpu) -- and the metric's
+        # own 100k instance split N ways (strong: it is too small to gain)
         extras = []
-        for label, scale in (("strong", 1), ("weak", args.gpus)):
-            g2, m2 = make_workload("coloring_100k", scale, args.vars_per_gpu)
+        for name in ("coloring_1m_deg6", "coloring_100k"):
+            g2, m2 = make_workload(name, 1, args.vars_per_gpu)
             steps2 = min(args.steps, 1000)
             r2 = sharded_run(g2, Params(mode=m2, dtype=args.dtype), rank, world, dev, args.backend,
                              min(args.warmup, 100), steps2, torch, dist)
             if rank == 0:
                 failed = failed or not r2["check"]["identical_to_single_engine"]
-                its = steps2 / r2["elapsed"]
-                extras.append({"workload": "coloring_100k" + (f" x{args.gpus} (one {g2.n_vars}-variable instance, "
-                                                                f"{args.vars_per_gpu} variables per GPU)" if scale > 1 else ""),
-                               "scaling": label, "n_vars": g2.n_vars, "steps": steps2,
-                               "iterations_per_s_of_this_instance": its, "ms_per_step": 1e3 * r2["elapsed"] / steps2,
-                               "edge_messages_per_s": its * 2 * g2.n_edges,
+                its2 = steps2 / r2["elapsed"]
+                extras.append({"workload": name + (" (BASELINE configs[3])" if name == "coloring_1m_deg6" else ""),
+                               "scaling": "strong", "n_vars": g2.n_vars, "steps": steps2,
+                               "iterations_per_s_of_this_instance": its2, "ms_per_step": 1e3 * r2["elapsed"] / steps2,
+                               "edge_messages_per_s": its2 * 2 * g2.n_edges,
                                "one_gpu_iterations_per_s": r2["one_gpu_iterations_per_s"],
-                               "exchange": r2["collective"], "check": r2["check"]})
+                               "speedup_vs_one_gpu": its2 / r2["one_gpu_iterations_per_s"],
+                               "exchange": r2["collective"], "shard_rank0": r2["shard_rank0"], "check": r2["check"]})
             del g2
         if rank == 0:
             out["extras"] = extras

@@ -41,23 +41,27 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "extras"):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
-    # N > 1 = STRONG scaling of BASELINE configs[3] (here scaled down 1 : 333): value is the
-    # iterations/s of that one instance, nothing multiplied in
-    assert out["scaling"] == "strong" and out["unit"] == "iterations/s" and out["dtype"] == "f64"
+    # N > 1 = WEAK scaling of the metric's own instance family (here 300 variables per GPU): value is the
+    # whole-job aggregate, N x iterations/s of the one N x 300-variable instance
+    assert out["scaling"] == "weak" and out["unit"] == "iterations/s" and out["dtype"] == "f64"
     cfg = out["config"]
-    assert cfg["workload"].startswith("coloring_1m_deg6 (strong scaling")
-    assert cfg["n_vars"] == 3000 and cfg["n_factors"] == 9000
+    assert cfg["workload"].startswith("coloring_100k x2 (weak scaling")
+    assert cfg["n_vars"] == 600 and cfg["n_factors"] == 1200
     assert f"exchange: {collective}" in cfg["parallelism"]
-    assert out["value"] > 0 and abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-6 * out["value"]
-    assert cfg["one_gpu_iterations_per_s"] > 0
+    its = cfg["iterations_per_s_of_this_instance"]
+    assert its > 0 and abs(its - 1e3 / out["ms_per_step"]) < 1e-6 * its
+    assert abs(out["value"] - 2 * its) < 1e-9 * out["value"]
+    assert cfg["one_gpu_iterations_per_s"] > 0 and cfg["speedup_vs_one_gpu_on_this_instance"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert cfg["check"] == {"cycles": 8, "identical_to_single_engine": True, "differences": 0}
-    # labelled extras: the metric's 100k instance strong- and weak-scaled
-    strong, weak = out["extras"]
-    assert strong["scaling"] == "strong" and strong["n_vars"] == 300 and strong["workload"] == "coloring_100k"
-    assert weak["scaling"] == "weak" and weak["n_vars"] == 600 and weak["workload"].startswith("coloring_100k x2")
-    for e in (strong, weak):
+    # labelled extras: BASELINE configs[3] (here scaled down 1 : 333) and the metric's instance, both split
+    # two ways (strong scaling)
+    big, small = out["extras"]
+    assert big["scaling"] == "strong" and big["n_vars"] == 3000 and big["workload"].startswith("coloring_1m_deg6")
+    assert small["scaling"] == "strong" and small["n_vars"] == 300 and small["workload"] == "coloring_100k"
+    for e in (big, small):
         assert e["check"]["identical_to_single_engine"] and e["iterations_per_s_of_this_instance"] > 0
+        assert e["speedup_vs_one_gpu"] > 0
 
 
 def test_bench_single_gpu_line_carries_every_config(tmp_path):
