@@ -1065,7 +1065,7 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
 #pragma unroll
     for (int u = 0; u < NARY_UNR; ++u) {
         const T m0 = s_m0[(!MASKED || d0 + u < D0) ? d0 + u : 0];
-        const T a0 = (T)0 + m0;
+        const T a0 = m0;  // = 0 + the message, added when it was staged
         T b0 = pos_inf<T>();
         const T sp1_shared = (LS && A == 3) ? a0 + ms[0][A - 1] : (T)0;
 #pragma unroll
@@ -1207,7 +1207,10 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     for (int i = 0; i < A; ++i) {
         const int vo = fd.v2f_off[i];
         for (int d = tid; d < Dm[i]; d += NT) {
-            s_msg[off[i] + d] = a.v2f_old[vo + d];
+            // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
+            // outputs p >= 1, maxsum.py:430-441 -- once per factor here instead of once per lane and d0)
+            const T x = a.v2f_old[vo + d];
+            s_msg[off[i] + d] = i == 0 ? (T)0 + x : x;
             s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
         }
     }
@@ -1409,7 +1412,10 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
     for (int i = 0; i < A; ++i) {
         const int vo = fd.v2f_off[i];
         for (int d = tid; d < Dm[i]; d += NT) {
-            s_msg[off[i] + d] = a.v2f_old[vo + d];
+            // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
+            // outputs p >= 1, maxsum.py:430-441 -- once per factor here instead of once per lane and d0)
+            const T x = a.v2f_old[vo + d];
+            s_msg[off[i] + d] = i == 0 ? (T)0 + x : x;
             s_key[off[i] + d] = OrdKey<T>::enc(pos_inf<T>());
         }
     }
