@@ -140,17 +140,21 @@ class FlatGraph:
         if self.domains is None:
             return None
         rank = np.empty(int(self.cost_off[-1]), dtype=np.int32)
-        off, identity = 0, True
+        off, identity, seen = 0, True, {}
         for values in self.domains:
-            values = list(values)
-            try:
-                order = sorted(range(len(values)), key=lambda d: values[d])
-            except TypeError:
-                return None
-            for r, d in enumerate(order):
-                rank[off + d] = r
-                identity = identity and r == d
-            off += len(values)
+            key = tuple(values)            # (instances share a few domains among many variables)
+            r = seen.get(key)
+            if r is None:
+                try:
+                    order = sorted(range(len(key)), key=lambda d: key[d])
+                except TypeError:
+                    return None
+                r = np.empty(len(key), dtype=np.int32)
+                r[order] = np.arange(len(key), dtype=np.int32)
+                seen[key] = r
+                identity = identity and bool((r == np.arange(len(key))).all())
+            rank[off:off + len(key)] = r
+            off += len(key)
         return None if identity else rank
 
     @property
