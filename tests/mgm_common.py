@@ -29,6 +29,30 @@ def unsorted_domains_with_ties(g, seed):
     return g
 
 
+def repeated_pairs_and_unaries(n_vars, seed):
+    """Integer tables (the int8 records of the packed view, whose lanes MGM lays out in the concerned
+    list's order), with what that order has to cope with: several constraints between the SAME pair of
+    variables (both orientations), unary constraints, variables below and above all their neighbours."""
+    from pydcop_amd.generators import _finish
+    rng = np.random.default_rng(seed)
+    g = G.random_coloring(n_vars, avg_degree=3, seed=seed)
+    D = 3
+    pairs = g.edge_var.reshape(-1, 2)
+    again = pairs[rng.random(pairs.shape[0]) < 0.35][:, ::-1]           # the same pair once more, flipped
+    thrice = again[rng.random(again.shape[0]) < 0.3][:, ::-1]
+    un = rng.choice(n_vars, size=n_vars // 3, replace=False)
+    scopes = [list(p) for p in pairs] + [list(p) for p in again] + [list(p) for p in thrice] + [[int(v)] for v in un]
+    order = rng.permutation(len(scopes))                                 # unary constraints anywhere in a variable's list
+    scopes = [scopes[i] for i in order]
+    tabs = [rng.integers(-5, 10, size=D ** len(sc)).astype(np.float64) for sc in scopes]
+    rowptr = np.zeros(len(scopes) + 1, dtype=np.int32)
+    np.cumsum([len(sc) for sc in scopes], out=rowptr[1:])
+    toff = np.zeros(len(scopes) + 1, dtype=np.int64)
+    np.cumsum([t.size for t in tabs], out=toff[1:])
+    return _finish(g.dom_size, g.var_cost, rowptr, np.array([v for sc in scopes for v in sc], dtype=np.int32),
+                   np.concatenate(tabs), toff)
+
+
 def mgm_cases():
     return [
         ("coloring_soft", lambda: G.random_coloring(400, seed=21), {}),
@@ -39,6 +63,8 @@ def mgm_cases():
         ("ising_unaries", lambda: G.ising_grid(12, 10, seed=26), {}),
         ("sparse_isolated", lambda: G.random_coloring(300, avg_degree=1, seed=27), {"mode": "max"}),
         ("unsorted_domains", lambda: unsorted_domains_with_ties(G.random_coloring(200, avg_degree=1, seed=32), 32), {}),
+        ("repeated_pairs_unaries", lambda: repeated_pairs_and_unaries(300, 34), {}),
+        ("repeated_pairs_unaries_max", lambda: with_init(repeated_pairs_and_unaries(200, 35), 35), {"mode": "max"}),
         ("unsorted_domains_max", lambda: unsorted_domains_with_ties(G.random_coloring(200, avg_degree=1, seed=33), 33), {"mode": "max"}),
         ("meeting_d6", lambda: G.meeting_like(40, dom=6, seed=28), {"mode": "max"}),
         # the wider register arrays of the slot kernels (16, 32 values) and the CSR-walk kernel beyond

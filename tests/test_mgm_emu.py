@@ -35,3 +35,4 @@ def test_mgm_emu_slot_kernels_everywhere(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
     name, make, kw = case
     compare_mgm(OracleMgm, make(), Params(**kw), lib_path=build(), steps=(0, 1, 3, 6))
+
