@@ -446,7 +446,7 @@ struct Engine : EngineBase {
             int rc = launch_sweep(a, L.n_blocks_fused);
             if (rc) return rc;
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(BLOCK), 0, stream, a,
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, stream, a,
                                    (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }
@@ -464,7 +464,7 @@ struct Engine : EngineBase {
                 ws = side;
             }
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(BLOCK), 0, ws, a,
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
                                    (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }

@@ -1663,9 +1663,9 @@ __device__ __forceinline__ void static_for(F&& f) {
 #define MXS_WIDE_SKIP 0  // timing experiments only (results wrong): 1 no chains, 2 no message arithmetic,
 #endif                   // 4 no beliefs, 8 no gathers, 16 no stores
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const WideBlock* blocks) {
-    constexpr int R = WIDE_CAPB / BLOCK;  // elements per thread
-    static_assert(WIDE_CAPB % BLOCK == 0, "");
+__global__ void __launch_bounds__(WIDE_TPB) k_variable_wide(SweepArgs<T> a, const WideBlock* blocks) {
+    constexpr int R = WIDE_CAPB / WIDE_TPB;  // elements per thread
+    static_assert(WIDE_CAPB % WIDE_TPB == 0, "");
     __shared__ T s_in[WIDE_CAPB];               // staged F->V messages: [slot][d]
     __shared__ T s_c[WIDE_MAX_COSTS];           // own costs: [variable][d]
     __shared__ T s_b[WIDE_MAX_COSTS];           // beliefs: [variable][d]
@@ -1679,11 +1679,11 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     const int tid = (int)threadIdx.x;
     const int D = wb.D, ns = wb.n_slots, ne = ns * D;
     // ---- 1. stage ------------------------------------------------------------------------
-    int sl[R], dd[R], vo[R];  // a thread's elements: local slot, d, V2F offset (idx = tid + r * BLOCK)
+    int sl[R], dd[R], vo[R];  // a thread's elements: local slot, d, V2F offset (idx = tid + r * WIDE_TPB)
     T x[R], p[R], m[R];
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        const int idx = tid + r * BLOCK;
+        const int idx = tid + r * WIDE_TPB;
         const int s = D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);  // idx / D
         sl[r] = s;
         dd[r] = idx - s * D;
@@ -1697,34 +1697,34 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
             if (!a.start) p[r] = a.v2f_old[vo[r]];  // the message sent last on this edge
         }
     });
-    for (int j = tid; j < wb.n_vars; j += BLOCK) {
+    for (int j = tid; j < wb.n_vars; j += WIDE_TPB) {
         const int v = wb.first_var + j;
         const int k0 = a.vrowptr[v] - wb.slot0, deg = a.vrowptr[v + 1] - a.vrowptr[v];
         s_vk0[j] = k0;
         s_vdeg[j] = deg;
         for (int k = 0; k < deg; ++k) s_svar[k0 + k] = (uint8_t)j;
     }
-    for (int i = tid; i < wb.n_vars * D; i += BLOCK) s_c[i] = a.var_cost[a.vcost_off[wb.first_var] + i];
-    for (int s = tid; s < ns; s += BLOCK) {
+    for (int i = tid; i < wb.n_vars * D; i += WIDE_TPB) s_c[i] = a.var_cost[a.vcost_off[wb.first_var] + i];
+    for (int s = tid; s < ns; s += WIDE_TPB) {
         s_cnt[s] = a.start ? (uint8_t)0 : a.cV[wb.slot0 + s];
         s_nom[s] = 0;
     }
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        if (tid + r * BLOCK < ne) s_in[tid + r * BLOCK] = x[r];
+        if (tid + r * WIDE_TPB < ne) s_in[tid + r * WIDE_TPB] = x[r];
     });
     __syncthreads();
     // ---- 2. chains and beliefs --------------------------------------------------------------
-    for (int t = tid; t < ns; t += BLOCK) {  // the mean of an outgoing message: its serial chain
+    for (int t = tid; t < ns; t += WIDE_TPB) {  // the mean of an outgoing message: its serial chain
         const int j = s_svar[t], k0 = s_vk0[j];
         s_avg[t] = (MXS_WIDE_SKIP & 1) ? (T)0 : wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
     }
-    for (int i = tid; i < wb.n_vars * D; i += BLOCK) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
+    for (int i = tid; i < wb.n_vars * D; i += WIDE_TPB) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
         const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
         s_b[i] = (MXS_WIDE_SKIP & 4) ? s_c[i] : wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
     }
     __syncthreads();
-    for (int j = tid; j < wb.n_vars; j += BLOCK) {  // selection: first index attaining the minimum
+    for (int j = tid; j < wb.n_vars; j += WIDE_TPB) {  // selection: first index attaining the minimum
         const int v = wb.first_var + j;
         T bb = s_b[j * D];
         int bi = 0;
@@ -1746,7 +1746,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
         m[r] = (T)0;
-        if (tid + r * BLOCK < ne) {
+        if (tid + r * WIDE_TPB < ne) {
             const int s = sl[r], j = s_svar[s], k0 = s_vk0[j], deg = s_vdeg[j];
             T mm = (MXS_WIDE_SKIP & 2) ? s_avg[s] : wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
             if (a.start) {
@@ -1764,7 +1764,7 @@ __global__ void __launch_bounds__(BLOCK) k_variable_wide(SweepArgs<T> a, const W
     // ---- 4. send / send again / stay silent (the receiver keeps the old message) -------------------
     static_for<R>([&](auto rc) __attribute__((always_inline)) {
         constexpr int r = decltype(rc)::value;
-        if (tid + r * BLOCK < ne) {
+        if (tid + r * WIDE_TPB < ne) {
             const int s = sl[r];
             const int cnt = s_cnt[s];
             int out = 1;

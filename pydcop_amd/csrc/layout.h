@@ -162,10 +162,14 @@ struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything
 // One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME
 // domain size D, cut so that the staged F->V elements (slots * D), the outgoing edges (slots)
 // and the own costs (variables * D) fit the kernel's LDS arrays.  Read with ONE scalar load.
-constexpr int WIDE_CAPB = 1024;       // staged F->V elements per block: 4 per thread
-constexpr int WIDE_MAX_SLOTS = 256;   // outgoing edges (CSR slots) per block
+#ifndef MXS_WIDE_TPB
+#define MXS_WIDE_TPB 256
+#endif
+constexpr int WIDE_TPB = MXS_WIDE_TPB;  // threads of a workgroup of the wide variable launch
+constexpr int WIDE_CAPB = 4 * WIDE_TPB; // staged F->V elements per block: 4 per thread
+constexpr int WIDE_MAX_SLOTS = WIDE_TPB;   // outgoing edges (CSR slots) per block
 constexpr int WIDE_MAX_VARS = 128;    // variables per block (their local index fits a byte)
-constexpr int WIDE_MAX_COSTS = 384;   // variables * D per block
+constexpr int WIDE_MAX_COSTS = WIDE_TPB * 3 / 2;   // variables * D per block
 // (f64: 18 KB of LDS per block, eight blocks per CU: the phases of a block are chains of
 // dependent loads, what hides them is the number of blocks in flight)
 struct WideBlock {
