@@ -2,8 +2,11 @@
 // on gfx950, on the same flat factor-graph arrays as the Max-Sum engine (SURVEY.md section
 // 8(f).4).  DSA is bulk-synchronous by construction (a computation evaluates a cycle once ALL
 // its neighbours' values of that cycle are in and parks the next ones, dsa.py:300-317): one cycle =
-// ONE launch, thread per variable, reading the neighbours' values of the previous cycle and the
-// variable's constraints' tables at them (CSR walk, integer index arithmetic + a few adds).
+// ONE launch, reading the neighbours' values of the previous cycle and the variable's constraints'
+// tables at them -- on the PACKED view (local_search.h: one lane per (variable, constraint), unary /
+// binary constraints over domains of at most four values) where the instance allows it, thread per
+// variable on the slot view or the CSR walk otherwise; bit-identical results.  The dynamic state lives
+// in packed order (Dev::q).
 //
 // The reference draws from Python's unseeded `random` module (initial value, move test, choice
 // among the best values).  Here every draw comes from a counter-based generator keyed on (seed,

@@ -7,8 +7,12 @@
 // 476-497): one round = two launches over all variables,
 //   k_mgm_gain   values in  -> the best unilateral move and its gain   (mgm.py:335-391, 428-454)
 //   k_mgm_move   gains in   -> the largest gain of a neighbourhood moves, ties by name (:499-588)
-// thread per variable; the reads are the variable's constraints' tables at the neighbours'
-// current values (CSR walk, integer index arithmetic + a handful of adds).  The reference's quirks
+// Three families of the two kernels, bit-identical results: the PACKED view (local_search.h: one lane
+// per (variable, constraint) for unary / binary constraints over domains of at most four values -- what
+// runs by default where the instance allows it), the slot view (thread per variable, register arrays
+// for domains up to 32 values) for the other variables, and the CSR walk (anything).  The dynamic
+// state lives in packed order (Dev::q); a variable's gain, new value and name rank are one 16-byte
+// record (GainRec), its own cost at the current value is kept (Dev::vcc).  The reference's quirks
 // are restated as they are and listed in oracle/mgm_oracle.c, whose arithmetic this file follows
 // expression for expression (the oracle is pinned against the reference's own MgmComputation).
 // The reference's draws from the unseeded `random` module are fixed the way the oracle fixes them:
