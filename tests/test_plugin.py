@@ -195,3 +195,74 @@ def test_cli_solve_json(emu_lib, tmp_path):
     assert res["status"] == "FINISHED"
     assert res["violation"] == 0 and abs(res["cost"] - (-0.1)) < 1e-9
     assert res["cycle"] == 20
+
+
+UNSORTED_YAML = """name: unsorted domains
+objective: {objective}
+
+domains:
+  colors:
+    values: [R, G, B]
+    type: 'color'
+
+variables:
+  v1:
+    domain: colors
+    cost_function: 0.25 if v1 == 'G' else 0.5
+  v2:
+    domain: colors
+    cost_function: 0.5 if v2 == 'R' else 0.25
+  v3:
+    domain: colors
+    cost_function: 0.125 if v3 == 'R' else 0.125
+  lonely1:
+    domain: colors
+    cost_function: 0.75 if lonely1 == 'G' else 0.5
+  lonely2:
+    domain: colors
+    cost_function: 0.5 if lonely2 == 'R' else 0.5
+  lonely3:
+    domain: colors
+    cost_function: 0.25 if lonely3 == 'B' else 0.75
+
+constraints:
+  diff_1_2:
+    type: intention
+    function: 1 if v1 == v2 else 0
+  diff_2_3:
+    type: intention
+    function: 1 if v3 == v2 else 0
+
+agents:
+  a1:
+    capacity: 1000
+  a2:
+    capacity: 1000
+"""
+
+
+@pytest.mark.parametrize("objective", ["min", "max"])
+@pytest.mark.parametrize("algo", ["mgm", "dsa"])
+def test_isolated_variables_break_cost_ties_on_the_value_like_the_reference(pydcop_ready, tmp_path, objective, algo):
+    """Domains written in a non-ascending order (R, G, B) and variables WITHOUT neighbours whose own costs
+    tie: the reference's optimal_cost_value takes min / max over (cost, value) tuples
+    (relations.py:1661-1665) -- `lonely1` ties R and B, `lonely2` all three.  The plug-ins get the order
+    of the values from the DCOP's domains (compile.py -> FlatGraph.value_rank -> mxs_*_set_value_rank)."""
+    from oracle.ref_harness import run_reference_dsa, run_reference_mgm
+    from pydcop.algorithms import AlgorithmDef
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop.infrastructure.run import solve
+    path = tmp_path / "unsorted.yaml"
+    path.write_text(UNSORTED_YAML.format(objective=objective))
+    dcop = load_dcop_from_file([str(path)])
+    params = {"stop_cycle": 6} if algo == "mgm" else {"stop_cycle": 6, "variant": "A", "seed": 3}
+    got = solve(dcop, AlgorithmDef.build_with_default_param(algo + "_gpu", params, mode=dcop.objective), "adhoc", timeout=5)
+    dcop2 = load_dcop_from_file([str(path)])
+    if algo == "mgm":
+        want, _, _ = run_reference_mgm(dcop2, 5)
+    else:
+        want, _, _ = run_reference_dsa(dcop2, 6, variant="A", seed=3)
+    assert got == want
+    # smallest / largest VALUE among the tied ones (lonely1: R and B tie at the minimum, G alone is the maximum)
+    assert got["lonely2"] == {"min": "B", "max": "R"}[objective]
+    assert got["lonely1"] == {"min": "B", "max": "G"}[objective]
