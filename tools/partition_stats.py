@@ -3,7 +3,9 @@ shards when `pydcop_amd.partition.partition_variables` (csrc/partition.cpp, the 
 METIS north_star names) cuts the instance k ways -- cut-factor fraction, halo elements per rank and
 per peer, imbalance, wall time.  profiles/partition_<workload>_k<k>.json
 
-usage: python tools/partition_stats.py [workload] [k ...]"""
+usage: python tools/partition_stats.py [workload] [k ...]
+       python tools/partition_stats.py weak [k ...]     # the N > 1 default of bench.py: ONE instance of
+                                                        # k x 100k variables of the metric's family, cut k ways"""
 import json
 import os
 import sys
@@ -18,8 +20,8 @@ from pydcop_amd.partition import build_shard, cut_statistics, partition_variable
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def stats(workload, k):
-    g, _ = make_workload(workload)
+def stats(workload, k, scale=1):
+    g, _ = make_workload(workload, scale)
     t0 = time.perf_counter()
     part = partition_variables(g, k)
     t1 = time.perf_counter()
@@ -29,7 +31,7 @@ def stats(workload, k):
     send = np.array([[int(x) for x in sh.send_counts] for sh in shards])   # elements (message entries) rank -> peer
     D = int(g.dom_size.max())
     owned = np.array([sh.n_owned for sh in shards])
-    out = {"workload": workload, "k": k, "n_vars": g.n_vars, "n_factors": g.n_factors, "n_edges": g.n_edges,
+    out = {"workload": workload + (f" x{scale} (weak scaling: {g.n_vars // scale} variables per rank)" if scale > 1 else ""), "k": k, "n_vars": g.n_vars, "n_factors": g.n_factors, "n_edges": g.n_edges,
            "partitioner": "pydcop_amd/csrc/partition.cpp (multilevel: heavy-edge matching, greedy growing, "
                           "boundary FM; METIS is not installed)",
            "partition_wall_s": round(t1 - t0, 2), "build_shards_wall_s": round(t2 - t1, 2),
@@ -51,9 +53,10 @@ def stats(workload, k):
 if __name__ == "__main__":
     workload = sys.argv[1] if len(sys.argv) > 1 else "coloring_1m_deg6"
     ks = [int(x) for x in sys.argv[2:]] or [2, 4, 8]
+    weak = workload == "weak"
     for k in ks:
-        rec = stats(workload, k)
-        path = os.path.join(ROOT, "profiles", f"partition_{workload}_k{k}.json")
+        rec = stats("coloring_100k", k, k) if weak else stats(workload, k)
+        path = os.path.join(ROOT, "profiles", f"partition_coloring_100k_x{k}_k{k}.json" if weak else f"partition_{workload}_k{k}.json")
         with open(path, "w") as f:
             json.dump(rec, f, indent=1)
         print(json.dumps(rec))
