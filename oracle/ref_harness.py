@@ -305,13 +305,16 @@ def reference_message_state(comps, graph):
       held_v2f               the factor's `_costs[variable]`: what it last RECEIVED (maxsum.py:294, 342)
       held_f2v               the variable's `costs[factor]` (maxsum.py:466, 528)
 
-    NaN = nothing there (no message sent / received yet)."""
+    NaN = nothing there (no message sent / received yet); `has_<key>` says the same as a boolean
+    mask, for instances whose messages hold real NaNs (hard constraints: inf - inf)."""
     import numpy as np
     g = graph
     nm, ne = int(g.msg_off[-1]), g.n_edges
     names = g.var_names
     fnames = g.factor_names or [f"c{i}" for i in range(g.n_factors)]
-    out = {k: np.full(nm, np.nan) for k in ("sent_f2v", "sent_v2f", "held_v2f", "held_f2v")}
+    keys = ("sent_f2v", "sent_v2f", "held_v2f", "held_f2v")
+    out = {k: np.full(nm, np.nan) for k in keys}
+    out.update({"has_" + k: np.zeros(nm, dtype=bool) for k in keys})
     out["count_f2v"] = np.zeros(ne, dtype=np.uint8)
     out["count_v2f"] = np.zeros(ne, dtype=np.uint8)
 
@@ -319,6 +322,7 @@ def reference_message_state(comps, graph):
         o = int(g.msg_off[e])
         for d, val in enumerate(domain):
             out[key][o + d] = costs[val]
+            out["has_" + key][o + d] = True
 
     for f in range(g.n_factors):
         fc = comps[fnames[f]]

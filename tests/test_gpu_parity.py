@@ -65,11 +65,14 @@ def test_ising_grid_256(oracle_built):
 # factors / variables; the order inside a message is the reference's either way): 32-bit
 # offsets, block_base[] class tables, multi-generation grids and the 24^3 launch grouping of
 # k_factor_nary only show at full size.
+# Long enough that the state machine of the send rule is compared at full size too: edges that were
+# "sent again" three times go silent (counters frozen at SAME_COUNT, the receiver keeps the old
+# message -- maxsum.py:371-377); `compare_with_oracle(expect_silent=True)` asserts that the run got there.
 _FULL = {
-    "ising_1024": (lambda: G.ising_grid(1024, 1024, seed=0, names=False), "min", [1, 5]),
+    "ising_1024": (lambda: G.ising_grid(1024, 1024, seed=0, names=False), "min", [1, 5, 34]),
     "coloring_1m_deg6": (lambda: G.random_coloring(1_000_000, avg_degree=6, n_colors=3, seed=0, names=False),
-                         "min", [1, 5]),
-    "meeting_50k": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max", [1, 3]),
+                         "min", [1, 5, 34]),
+    "meeting_50k": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max", [1, 3, 26]),
 }
 _full_cache = {}
 
@@ -86,8 +89,10 @@ def _full_graph(name):
 def test_full_size_bit_exact_vs_oracle(name, dtype, oracle_built):
     _, mode, steps = _FULL[name]
     threads = min(64, len(os.sched_getaffinity(0)))
+    # (f32 -- narrower than the reference's arithmetic, an extra -- keeps the short run)
     compare_with_oracle(oracle_built, _full_graph(name), Params(mode=mode, dtype=dtype), 0,
-                        steps=steps, threads=threads)
+                        steps=steps if dtype == "f64" else steps[:2], threads=threads,
+                        expect_silent=dtype == "f64")
     if dtype == "f32":
         _full_cache.clear()
 

@@ -18,6 +18,15 @@ pytestmark = [pytest.mark.gpu,
               pytest.mark.skipif(not ref_harness.reference_available(),
                                  reason="no reference: oracle/_ref/ was not staged by build()")]
 
+def _hard(g, seed, frac, value):
+    """Hard constraints as the reference writes them (+-inf table entries, dcop.py:352-365):
+    costs_for_factor's mean then produces inf - inf = NaN (maxsum.py:671-674) on both sides."""
+    rng = np.random.default_rng(seed)
+    t = g.tables.copy()
+    t[rng.random(t.shape[0]) < frac] = value
+    g.tables = t
+    return g
+
 CASES = [
     ("soft", lambda: G.random_coloring(60, seed=21), "min", {}),
     ("hard_all_vars", lambda: G.random_coloring(40, seed=22, variant="hard"), "min",
@@ -29,6 +38,10 @@ CASES = [
     ("meeting_d24_wide", lambda: G.meeting_like(6, dom=24, seed=25), "max", {}),
     ("ising", lambda: G.ising_grid(6, 5, seed=26), "min", {}),
     ("deg6_d4", lambda: G.random_coloring(50, avg_degree=6, n_colors=4, seed=27), "min", {"damping_nodes": "factors"}),
+    # +-inf tables -> NaN messages, through the workgroup-per-factor and wide-variable kernels
+    ("hard_inf_nary_d8", lambda: _hard(G.meeting_like(8, n_factors=5, dom=8, seed=28), 28, 0.9, -np.inf), "max", {}),
+    ("hard_inf_wide_deg30", lambda: _hard(G.random_coloring(40, avg_degree=30, n_colors=6, seed=29), 29, 0.5, np.inf),
+     "min", {"start_messages": "all"}),
 ]
 
 

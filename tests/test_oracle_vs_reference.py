@@ -13,6 +13,15 @@ from parity_common import assert_messages_equal_reference
 pytestmark = pytest.mark.skipif(not ref_harness.reference_available(),
                                 reason="reference tree not present")
 
+def _hard(g, seed, frac, value):
+    """Hard constraints as the reference writes them (+-inf table entries, dcop.py:352-365):
+    costs_for_factor's mean then produces inf - inf = NaN (maxsum.py:671-674) on both sides."""
+    rng = np.random.default_rng(seed)
+    t = g.tables.copy()
+    t[rng.random(t.shape[0]) < frac] = value
+    g.tables = t
+    return g
+
 CASES = [
     ("soft", lambda: G.random_coloring(40, seed=11), "min", {}),
     ("hard", lambda: G.random_coloring(40, seed=12, variant="hard"), "min",
@@ -21,6 +30,9 @@ CASES = [
      {"start_messages": "leafs_vars", "damping_nodes": "none"}),
     ("meeting", lambda: G.meeting_like(10, dom=4, seed=14), "max",
      {"damping_nodes": "factors", "damping": 0.3, "stability": 0.02}),
+    ("hard_inf_nary", lambda: _hard(G.meeting_like(8, n_factors=5, dom=8, seed=15), 15, 0.9, -np.inf), "max", {}),
+    ("hard_inf_binary", lambda: _hard(G.random_coloring(30, avg_degree=5, seed=16), 16, 0.3, np.inf), "min",
+     {"start_messages": "all"}),
 ]
 
 
