@@ -25,6 +25,7 @@
 
 #include "../../include/maxsum_gpu.h"
 #include "kernels.h"
+#include "nary_box.h"
 #include "layout.h"
 
 namespace mxs {
@@ -401,11 +402,23 @@ struct Engine : EngineBase {
         return nary_ls_cache[idx] == 1;
     }
 
+    // the launch group of a workgroup-per-factor factor
+    const NaryLaunch* launch_of(int fi) const {
+        for (const NaryLaunch& x : L.nary_launches)
+            if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) return &x;
+        return nullptr;
+    }
+
     int launch_nary(const SweepArgs<T>& a, int cut) {
         for (const NaryLaunch& nl : L.nary_launches) {
             if (nl.cut != cut) continue;
-            const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const NaryDesc* d = ndesc.p + nl.first;
+            if (nl.box) {  // one wave per factor, minima in registers (nary_box.h)
+                if (!launch_factor_box3<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no box kernel for this launch group");
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
+            const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const bool ls = nary_last_same(nl);
 #define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
     do {                                                                                                    \
@@ -534,10 +547,14 @@ struct Engine : EngineBase {
         std::vector<Item> items;
         for (const NaryLaunch& nl : L.nary_launches)
             for (int j = 0; j < nl.count; ++j) {
-                Item it{nl.cut, (nl.arity * 16 + nl.nj) * 16 + nl.threads / 64, nl.tab_type, fi_of[nl.first + j], L.ndesc[nl.first + j]};
-                if (it.fi == fi) {
+                Item it{nl.cut, nary_group_code(nl.box, nl.arity, nl.nj, nl.threads / 64), nl.tab_type, fi_of[nl.first + j],
+                        L.ndesc[nl.first + j]};
+                if (it.fi == fi) {  // (out of a box group: the full-width kernel's group of its size)
                     it.type = TAB_FULL;
                     it.d.tab_off = L.f_tab_base[fi];
+                    int64_t R = 1;
+                    for (int i = 1; i < nl.arity; ++i) R *= it.d.dom[i];
+                    it.code = nary_group_code(0, nl.arity, nary_classic_nj(R), nary_classic_waves(R));
                 }
                 items.push_back(it);
             }
@@ -550,8 +567,8 @@ struct Engine : EngineBase {
         for (size_t i = 0; i < items.size(); ++i) {
             const Item& it = items[i];
             if (i == 0 || it.cut != items[i - 1].cut || it.code != items[i - 1].code || it.type != items[i - 1].type)
-                L.nary_launches.push_back(NaryLaunch{it.code / 256, (it.code / 16) % 16, (it.code % 16) * 64,
-                                                     (int32_t)i, 0, it.cut, it.type});
+                L.nary_launches.push_back(NaryLaunch{(it.code / 256) % 16, (it.code / 16) % 16, (it.code % 16) * 64,
+                                                     (int32_t)i, 0, it.cut, it.type, it.code / 4096});
             L.nary_launches.back().count += 1;
             L.f_ndesc[it.fi] = (int32_t)i;
             L.ndesc.push_back(it.d);
@@ -1042,18 +1059,11 @@ struct Engine : EngineBase {
                 if (cls >= 0) {  // register class: one record of back-to-back entries
                     rec.assign((size_t)L.classes[cls].ctab_rec, 0);
                     encode_tab_record(table, (int)n, t, rec.data());
-                } else {  // workgroup-per-factor: the lane-packed image (layout.h, nary_packed_pos)
+                } else {  // workgroup-per-factor: the lane-packed / box image (layout.h, nary_place_pos)
                     const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
-                    const NaryLaunch* nl = nullptr;
-                    for (const NaryLaunch& x : L.nary_launches)
-                        if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) nl = &x;
-                    const int elem = tab_elem_bytes(t), slot = nary_slot_bytes(nl->nj, elem);
-                    const int64_t D0f = d.dom[0], Rf = n / D0f;
-                    rec.assign((size_t)(D0f * nl->threads * slot), 0);
-                    for (int64_t d0 = 0; d0 < D0f; ++d0)
-                        for (int64_t q = 0; q < Rf; ++q)
-                            encode_tab_record(table + d0 * Rf + q, 1, t,
-                                              rec.data() + nary_packed_pos(d0, q, nl->threads, slot, elem));
+                    const NaryPlace pl = nary_place(*launch_of(fi), d);
+                    rec.assign((size_t)nary_place_bytes(pl, d.dom[0]), 0);
+                    for (int64_t k = 0; k < n; ++k) encode_tab_record(table + k, 1, t, rec.data() + nary_place_pos(pl, k));
                 }
                 HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
             } else {
@@ -1136,23 +1146,14 @@ struct Engine : EngineBase {
         { int rc = sync(); if (rc) return rc; }
         const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         const int ctype = L.f_tab_type[fi];
-        int p_nt = 0, p_slot = 0;   // lane-packed narrow image of a workgroup-per-factor table
-        int64_t p_R = 1;
-        if (ctype != TAB_FULL && L.f_class[fi] < 0) {
-            const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
-            for (const NaryLaunch& x : L.nary_launches)
-                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) {
-                    p_nt = x.threads;
-                    p_slot = nary_slot_bytes(x.nj, tab_elem_bytes(ctype));
-                }
-            p_R = n / d.dom[0];
-        }
+        NaryPlace place{};   // narrow image of a workgroup-per-factor table (nt == 0 && box == 0: a register class)
+        if (ctype != TAB_FULL && L.f_class[fi] < 0) place = nary_place(*launch_of(fi), L.ndesc[L.f_ndesc[fi]]);
+        else place.elem = tab_elem_bytes(ctype);
         hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
                            tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
                            eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
                            L.is_max ? -1.0 : 1.0, n,
-                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype,
-                           p_nt, p_slot, p_R);
+                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype, place);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
@@ -1865,11 +1866,12 @@ int mxs_table_storage(const mxs_engine* e, int64_t factors[4], int64_t* table_by
         n[t] += 1;
         if (t == mxs::TAB_FULL) bytes += entries * w;
         else if (L.f_class[fi] >= 0) bytes += L.classes[L.f_class[fi]].ctab_rec;
-        else {  // lane-packed image: D0 * threads * slot
+        else {  // lane-packed image (D0 * threads * slot) or box records
             for (const mxs::NaryLaunch& x : L.nary_launches)
-                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count)
-                    bytes += (int64_t)L.ndesc[L.f_ndesc[fi]].dom[0] * x.threads *
-                             mxs::nary_slot_bytes(x.nj, mxs::tab_elem_bytes(t));
+                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) {
+                    const mxs::NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+                    bytes += mxs::nary_place_bytes(mxs::nary_place(x, d), d.dom[0]);
+                }
         }
     }
     if (factors) std::memcpy(factors, n, sizeof(n));

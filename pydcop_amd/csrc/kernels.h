@@ -1878,7 +1878,7 @@ template <typename T>
 __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_base, int64_t tab_stride,
                                                        double* eval_tables, const double* parent,
                                                        SliceDims sd, double sign, int64_t n,
-                                                       uint8_t* crec, int ctype, int nt, int slot, int64_t R) {
+                                                       uint8_t* crec, int ctype, NaryPlace place) {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= n) return;
     int64_t rem = k, lin = sd.base;
@@ -1892,8 +1892,7 @@ __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_ba
     eval_tables[k] = v;
     if (crec != nullptr) {  // the factor's narrow image too (the parent was checked to fit):
         // entry k of a register class's record, or the lane-packed place of a workgroup-per-factor table
-        const int elem = tab_elem_bytes(ctype);
-        uint8_t* at = crec + (nt > 0 ? nary_packed_pos(k / R, k % R, nt, slot, elem) : k * elem);
+        uint8_t* at = crec + ((place.nt > 0 || place.box > 0) ? nary_place_pos(place, k) : k * place.elem);
         if (ctype == TAB_I8) *(int8_t*)at = (int8_t)v;
         else if (ctype == TAB_I16) *(int16_t*)at = (int16_t)v;
         else *(float*)at = (float)v;

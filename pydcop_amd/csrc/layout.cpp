@@ -31,6 +31,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.compact_tables = MXS_COMPACT_TABLES_DEFAULT != 0;
     if (f & 16384) o.compact_tables = true;   // bit14: narrow storage of exactly-representable tables
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
+    o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
     return o;
 }
 
@@ -206,21 +207,28 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 }
                 // one launch group per (arity, R / BLOCK rounded up): compile-time loop bounds
                 if (R >= 64 && R <= 1024 && sumd <= 1024) {
-                    const int nj = (int)((R + BLOCK - 1) / BLOCK);
-                    const int waves = (int)(((R + nj - 1) / nj + 63) / 64);  // 1..4
+                    const int nj = nary_classic_nj(R);
+                    const int waves = nary_classic_waves(R);  // 1..4
                     // storage type of this factor's table (one launch group = one kernel
                     // instantiation per type): narrow + lane-packed when that is at most three
                     // quarters of the full-width bytes
-                    int t = TAB_FULL;
+                    int t = TAB_FULL, box = 0;
                     if (L.opt.compact_tables) {
                         const int64_t ne = g.table_off[f + 1] - g.table_off[f];
                         const int cand = narrowest_tab_type(g.tables + g.table_off[f], ne, L.opt.word);
                         if (cand != TAB_FULL) {
                             const int64_t packed = (int64_t)D0 * (waves * 64) * nary_slot_bytes(nj, tab_elem_bytes(cand));
                             if (4 * packed <= 3 * ne * L.opt.word) t = cand;
+                            // integer tables of arity 3 whose dimensions a box shape divides: one wave per
+                            // factor, every running minimum in registers (layout.h, nary_box.h)
+                            if (L.opt.box && ar == 3 && (cand == TAB_I8 || cand == TAB_I16)) {
+                                box = nary_box_shape(D0, g.dom_size[g.edge_var[e0 + 1]], g.dom_size[g.edge_var[e0 + 2]],
+                                                     tab_elem_bytes(cand));
+                                if (box) t = cand;
+                            }
                         }
                     }
-                    k = FKey{K_F_NARY, ((ar * 16 + nj) * 16 + waves) * 4 + t};
+                    k = FKey{K_F_NARY, (box ? nary_group_code(box, ar, 0, BOX_WAVES) : nary_group_code(0, ar, nj, waves)) * 4 + t};
                 }
             }
         }
@@ -446,7 +454,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 sweep_class(cls, BLOCK, key.cut || second);
             } else {  // K_F_NARY: one workgroup per factor, one launch per (arity, nj) group
                 const int code = key.D / 4, t = key.D % 4;
-                NaryLaunch nl{code / 256, (code / 16) % 16, (code % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut, t};
+                NaryLaunch nl{(code / 256) % 16, (code / 16) % 16, (code % 16) * 64, (int32_t)L.ndesc.size(), n, key.cut, t,
+                              code / 4096};
                 for (int j = 0; j < n; ++j) {
                     const int f2 = fi + j;
                     NaryDesc d{};
@@ -461,18 +470,14 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.magic[i] = d.dom[i] > 1 ? (uint32_t)((((uint64_t)1 << 32) + d.dom[i] - 1) / d.dom[i]) : 0u;
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
-                    if (t != TAB_FULL) {  // lane-packed narrow image (layout.h, nary_packed_pos)
-                        const int elem = tab_elem_bytes(t), slot = nary_slot_bytes(nl.nj, elem);
-                        const int64_t D0f = d.dom[0];
-                        int64_t Rf = 1;
-                        for (int i = 1; i < d.arity; ++i) Rf *= d.dom[i];
+                    if (t != TAB_FULL) {  // narrow image: lane-packed slots or a box record per lane (layout.h)
+                        const NaryPlace pl = nary_place(nl, d);
+                        const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];
                         const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
-                        L.ctables.resize((size_t)(at + D0f * nl.threads * slot), 0);
+                        L.ctables.resize((size_t)(at + nary_place_bytes(pl, d.dom[0])), 0);
                         const double* src = L.eval_tables.data() + L.eval_tab_off[f2];
-                        for (int64_t d0 = 0; d0 < D0f; ++d0)
-                            for (int64_t q = 0; q < Rf; ++q)
-                                encode_tab_record(src + d0 * Rf + q, 1, t,
-                                                  L.ctables.data() + at + nary_packed_pos(d0, q, nl.threads, slot, elem));
+                        for (int64_t k = 0; k < ne; ++k)
+                            encode_tab_record(src + k, 1, t, L.ctables.data() + at + nary_place_pos(pl, k));
                         L.f_tab_type[f2] = (uint8_t)t;
                         L.f_ctab_off[f2] = at;
                         d.tab_off = at;

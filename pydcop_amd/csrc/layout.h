@@ -98,6 +98,61 @@ constexpr int nary_slot_bytes(int nj, int elem) {
 constexpr int64_t nary_packed_pos(int64_t d0, int64_t q, int nt, int slot, int elem) {
     return (d0 * nt + q % nt) * slot + (q / nt) * elem;
 }
+// ---- box layout of a narrow arity-3 table (kernels: nary_box.h, k_factor_box3) --------------------------
+// ONE WAVE per factor; lane (l0, l1, l2) of an L0 x L1 x L2 grid (L0 * L1 * L2 = 64) owns the sub-box
+// [l0*B0, (l0+1)*B0) x [l1*B1, ..) x [l2*B2, ..) of the table: its E = B0*B1*B2 entries back to back
+// (i0 slowest) are the lane's RECORD, words = ceil(E * elem / 4) dwords that the lane keeps in registers.
+// In memory the records are interleaved in 16-byte pieces -- piece k of lane l at (k * 64 + l) * 16, the
+// last (words % 4) dwords of all lanes behind them -- so that every load instruction of the wave reads
+// one contiguous run.  Every output's running minima then live in registers (B0 + B1 + B2 of them per lane)
+// and no minimum is reduced across lanes before the factor's last entry has been read.
+constexpr int BOX_SHAPES[][3] = {{2, 2, 2}, {3, 3, 3}, {4, 4, 4}, {6, 6, 6}};  // shape id = index + 1
+constexpr int BOX_N_SHAPES = 4;
+constexpr int BOX_WAVES = 4;        // factors (waves) per workgroup
+constexpr int BOX_MAX_SUMD = 128;   // D0 + D1 + D2: two element passes of a wave in the epilogue
+constexpr int BOX_MAX_WORDS = 64;   // dwords of a lane's record
+constexpr int box_rec_words(int entries, int elem) { return (entries * elem + 3) / 4; }
+constexpr bool box_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
+// shape id (1 ..) of the box layout an arity-3 table of `elem`-byte entries can take, 0 = none
+constexpr int nary_box_shape(int d0, int d1, int d2, int elem) {
+    if (d0 + d1 + d2 > BOX_MAX_SUMD) return 0;
+    for (int s = 0; s < BOX_N_SHAPES; ++s) {
+        const int b0 = BOX_SHAPES[s][0], b1 = BOX_SHAPES[s][1], b2 = BOX_SHAPES[s][2];
+        if (d0 % b0 || d1 % b1 || d2 % b2) continue;
+        const int l0 = d0 / b0, l1 = d1 / b1, l2 = d2 / b2;
+        if (!box_pow2(l0) || !box_pow2(l1) || !box_pow2(l2) || l0 * l1 * l2 != 64) continue;
+        if (l0 > 16 || l1 > 16 || l2 > 16) continue;  // >= 4 lanes share every digit (16-byte LDS reads)
+        if (box_rec_words(b0 * b1 * b2, elem) > BOX_MAX_WORDS) continue;
+        return s + 1;
+    }
+    return 0;
+}
+// Where entry k (row-major) of a workgroup-per-factor table lives in its narrow image.
+struct NaryPlace {
+    int32_t box;          // 0: lane-packed slots (nary_packed_pos), else the box shape id
+    int32_t elem;         // bytes per entry
+    int32_t nt, slot;     // lane-packed: threads of the block, bytes of a slot
+    int32_t R;            // lane-packed: entries per value of the first variable
+    int32_t d1, d2;       // box: domain sizes of dimensions 1 and 2
+};
+constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
+    if (p.box == 0) return nary_packed_pos(k / p.R, k % p.R, p.nt, p.slot, p.elem);
+    const int b0 = BOX_SHAPES[p.box - 1][0], b1 = BOX_SHAPES[p.box - 1][1], b2 = BOX_SHAPES[p.box - 1][2];
+    const int64_t x2 = k % p.d2, x1 = (k / p.d2) % p.d1, x0 = k / ((int64_t)p.d1 * p.d2);
+    const int l1n = p.d1 / b1, l2n = p.d2 / b2;
+    const int64_t lane = ((x0 / b0) * l1n + x1 / b1) * l2n + x2 / b2;
+    const int64_t byte = (((x0 % b0) * b1 + x1 % b1) * b2 + x2 % b2) * p.elem;
+    const int words = box_rec_words(b0 * b1 * b2, p.elem), full = words / 4, rest = words % 4;
+    const int64_t piece = byte / 16;
+    return piece < full ? (piece * 64 + lane) * 16 + byte % 16
+                        : (int64_t)full * 1024 + lane * rest * 4 + byte % 16;
+}
+// bytes of the narrow image of one factor (D0 = its first domain size)
+constexpr int64_t nary_place_bytes(const NaryPlace& p, int D0) {
+    if (p.box == 0) return (int64_t)D0 * p.nt * p.slot;
+    const int* b = BOX_SHAPES[p.box - 1];
+    return (int64_t)64 * 4 * box_rec_words(b[0] * b[1] * b[2], p.elem);
+}
 constexpr int NUM_XCD = 8;  // MI355X: workgroup b of a grid runs on XCD b % 8 (observed; used for speed only)
 constexpr int MAX_REG_D = 4;
 // The reference has no limit on the arity of a constraint (maxsum.py:411-421 walks any scope); a table of
@@ -190,7 +245,28 @@ struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY fa
     int32_t count;
     int32_t cut;         // 1: factors reading ghost variables (second phase of a sharded cycle)
     int32_t tab_type;    // TabType the tables of the group are stored in (one kernel instantiation each)
+    int32_t box;         // 0: lane-packed / full-width kernels; else the box shape id (nary_box.h: one wave per
+                         // factor, BOX_WAVES factors per workgroup; nj = 0, threads = BOX_WAVES * 64)
 };
+// the image parameters of a factor of launch group `nl` (narrow types only)
+inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d) {
+    NaryPlace p{};
+    p.box = nl.box;
+    p.elem = tab_elem_bytes(nl.tab_type);
+    p.nt = nl.threads;
+    p.slot = nary_slot_bytes(nl.nj > 0 ? nl.nj : 1, p.elem);
+    int64_t R = 1;
+    for (int i = 1; i < (d.arity & 255); ++i) R *= d.dom[i];
+    p.R = (int32_t)R;
+    p.d1 = d.dom[1];
+    p.d2 = d.dom[2];
+    return p;
+}
+// Sort code of a launch group: (box, arity, nj, waves) -- one kernel instantiation each.
+constexpr int nary_group_code(int box, int arity, int nj, int waves) { return ((box * 16 + arity) * 16 + nj) * 16 + waves; }
+// the (nj, waves) of the lane-packed / full-width kernels for R entries per value of the first variable
+constexpr int nary_classic_nj(int64_t R) { return (int)((R + BLOCK - 1) / BLOCK); }
+constexpr int nary_classic_waves(int64_t R) { return (int)(((R + nary_classic_nj(R) - 1) / nary_classic_nj(R) + 63) / 64); }
 
 struct WaveMeta {  // per wave of a K_V_PACK class: read with ONE scalar load, so a lane
                    // knows its variable and edge position without per-lane tables
@@ -214,6 +290,7 @@ struct LayoutOptions {
     bool factors_second = false; // shard: all register factor classes go to the second launch
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
+    bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
 };
 
 struct Layout {

@@ -1,0 +1,235 @@
+// nary_box.h -- factor_costs_for_var (pydcop/algorithms/maxsum.py:382-447) for arity-3 factors whose
+// table is stored in a narrow integer type and whose dimensions a box shape divides (layout.h,
+// nary_box_shape): ONE WAVE PER FACTOR, every running minimum in registers.
+//
+// Why: the workgroup-per-factor kernel (kernels.h, k_factor_nary_packed) gives a lane fixed values of
+// (d1, d2) and walks d0 -- the minima towards variables 1 and 2 are register accumulators, but the one
+// towards variable 0 is a reduction ACROSS lanes for every d0: DPP / permlane moves, selects and an LDS
+// atomic per four values of d0, 18 VALU instructions per table entry where the arithmetic needs 8
+// (profiles/r03_meeting50k_pmc_kernels_v1.txt; tools/valu_bench.hip: every VALU instruction of that
+// kernel, 32- or 64-bit, costs a SIMD the same ~4.5 cycles, and an LDS atomic whose lanes share
+// addresses 100-500).  Here lane (l0, l1, l2) of an L0 x L1 x L2 lane grid owns a B0 x B1 x B2 sub-box
+// of the table -- its entries are ONE record of the image, read with 16-byte loads into registers before
+// anything else -- and keeps B0 + B1 + B2 partial minima, one per value of each of its three digits.
+// Nothing crosses lanes until the last entry has been used; then the partials go through LDS once
+// (plain stores, the 64 / L_p lanes that share a digit side by side) and the lanes of the wave -- one
+// per outgoing message element -- reduce them with 16-byte reads and run apply_damping + the send rule
+// (maxsum.py:346-377).
+//
+// Arithmetic: the reference's own expressions, op for op -- for the entry at (d0, d1, d2)
+//     to variable 0:  t + ((0 + m1[d1]) + m2[d2])
+//     to variable 1:  t + ((0 + m0[d0]) + m2[d2])
+//     to variable 2:  t + ((0 + m0[d0]) + m1[d1])         (sum_cost over the others in dimensions order,
+// maxsum.py:425-438), minima exact and order-independent: bit for bit what k_factor_nary computes.
+#pragma once
+#include "kernels.h"
+
+namespace mxs {
+
+template <typename T>
+struct alignas(4 * sizeof(T)) BoxQuad {
+    T v[4];
+};
+
+// entry e of a lane's record (narrow integers, widened exactly)
+template <typename T, typename TT>
+__device__ __forceinline__ T box_entry(const uint32_t* w, int e) {
+    if constexpr (sizeof(TT) == 1) return (T)(int)(int8_t)(uint8_t)(w[e >> 2] >> (8 * (e & 3)));
+    else return (T)(int)(int16_t)(uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+}
+
+template <typename T, typename TT, bool NEG, int B0, int B1, int B2>
+__global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, const NaryDesc* descs, int n_factors) {
+    constexpr int E = B0 * B1 * B2, NV = B0 + B1 + B2;
+    constexpr int NW = box_rec_words(E, (int)sizeof(TT)), FULL = NW / 4, REST = NW % 4;
+    static_assert(NW <= BOX_MAX_WORDS, "a lane's record lives in registers");
+    __shared__ T s_in[BOX_WAVES][BOX_MAX_SUMD];      // the incoming V->F messages of the wave's factor
+    __shared__ BoxQuad<T> s_part[BOX_WAVES][NV][16]; // partial minima: [value of a digit][lanes sharing it]
+    const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int f = __builtin_amdgcn_readfirstlane((int)blockIdx.x * BOX_WAVES + wv);
+    if (f >= n_factors) return;
+    const NaryDesc fd = descs[f];  // wave-uniform: scalar loads
+    const int D0 = fd.dom[0], D1 = fd.dom[1], D2 = fd.dom[2];
+    // the lane's record: requested before anything else
+    uint32_t w[NW];
+    {
+        const uint8_t* img = a.ctables + fd.tab_off;
+#pragma unroll
+        for (int k = 0; k < FULL; ++k) {
+            const Piece16 pc = *(const Piece16*)__builtin_assume_aligned(img + ((int64_t)k * 64 + lane) * 16, 16);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[4 * k + j] = pc.w[j];
+        }
+        if constexpr (REST > 0) {
+            const uint32_t* r = (const uint32_t*)__builtin_assume_aligned(img + (int64_t)FULL * 1024 + lane * (REST * 4), 4);
+#pragma unroll
+            for (int j = 0; j < REST; ++j) w[4 * FULL + j] = r[j];
+        }
+    }
+    // one lane per message ELEMENT (two passes cover D0 + D1 + D2 <= 128): stage the incoming message,
+    // request what the epilogue needs of the outgoing one (the message sent last, its send counter)
+    const int off1 = D0, off2 = D0 + D1, sumd = off2 + D2;
+    int el_i[2], el_d[2], el_cnt[2];
+    T el_prev[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int idx = lane + 64 * ps;
+        const int i = (idx >= off1 ? 1 : 0) + (idx >= off2 ? 1 : 0);
+        const int d = idx - (i == 0 ? 0 : i == 1 ? off1 : off2);
+        el_i[ps] = idx < sumd ? i : -1;
+        el_d[ps] = d;
+        el_prev[ps] = (T)0;
+        el_cnt[ps] = 0;
+        if (idx < sumd) {
+            const int vo = i == 0 ? fd.v2f_off[0] : i == 1 ? fd.v2f_off[1] : fd.v2f_off[2];
+            const int fo = i == 0 ? fd.f2v_off[0] : i == 1 ? fd.f2v_off[1] : fd.f2v_off[2];
+            const T x = a.v2f_old[vo + d];
+            // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
+            // outputs to variables 1 and 2, maxsum.py:430-441)
+            s_in[wv][idx] = i == 0 ? (T)0 + x : x;
+            if (!a.start) {
+                el_prev[ps] = a.f2v_old[fo + d];
+                el_cnt[ps] = a.cF[fd.edge_base + i];
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // the lane's place in the lane grid (L1, L2 powers of two, L0 * L1 * L2 = 64: layout.h)
+    const int L1 = D1 / B1, L2 = D2 / B2;
+    const int sh2 = __builtin_ctz((unsigned)L2), sh1 = __builtin_ctz((unsigned)L1);
+    const int l2 = lane & (L2 - 1), l1 = (lane >> sh2) & (L1 - 1), l0 = lane >> (sh1 + sh2);
+    T a0[B0], m1[B1], z1[B1], m2[B2], acc1[B1], acc2[B2];
+#pragma unroll
+    for (int i = 0; i < B0; ++i) a0[i] = s_in[wv][l0 * B0 + i];
+#pragma unroll
+    for (int i = 0; i < B1; ++i) {
+        m1[i] = s_in[wv][off1 + l1 * B1 + i];
+        z1[i] = (T)0 + m1[i];
+        acc1[i] = pos_inf<T>();
+    }
+#pragma unroll
+    for (int i = 0; i < B2; ++i) {
+        m2[i] = s_in[wv][off2 + l2 * B2 + i];
+        acc2[i] = pos_inf<T>();
+    }
+    // where this lane's partial minima go: the lanes that share a digit are neighbours in the row of that
+    // digit's value -- slot = digit * (64 / L) + rank among them
+    T* part = (T*)&s_part[wv][0][0];
+    const int slot0 = lane;                                              // l0 is the leading digit
+    const int slot1 = l1 * (64 >> sh1) + (l0 << sh2) + l2;
+    const int slot2 = l2 * (64 >> sh2) + (lane >> sh2);
+#pragma unroll
+    for (int i0 = 0; i0 < B0; ++i0) {
+        T sp1[B2];
+#pragma unroll
+        for (int i2 = 0; i2 < B2; ++i2) sp1[i2] = a0[i0] + m2[i2];
+        T b0 = pos_inf<T>();
+#pragma unroll
+        for (int i1 = 0; i1 < B1; ++i1) {
+            const T sp2 = a0[i0] + m1[i1];
+#pragma unroll
+            for (int i2 = 0; i2 < B2; ++i2) {
+                const T v = box_entry<T, TT>(w, (i0 * B1 + i1) * B2 + i2);
+                const T t = NEG ? -v : v;
+                b0 = min2(b0, t + (z1[i1] + m2[i2]));
+                acc1[i1] = min2(acc1[i1], t + sp1[i2]);
+                acc2[i2] = min2(acc2[i2], t + sp2);
+            }
+        }
+        part[i0 * 64 + slot0] = b0;
+    }
+#pragma unroll
+    for (int i = 0; i < B1; ++i) part[(B0 + i) * 64 + slot1] = acc1[i];
+#pragma unroll
+    for (int i = 0; i < B2; ++i) part[(B0 + B1 + i) * 64 + slot2] = acc2[i];
+    __builtin_amdgcn_wave_barrier();
+    // element lanes: the minimum over the lanes that share the digit, apply_damping, approx_match
+    T el_m[2];
+    bool el_bad[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int i = el_i[ps], d = el_d[ps];
+        T m = pos_inf<T>();
+        el_bad[ps] = false;
+        if (i >= 0) {
+            const int lp = i == 0 ? d / B0 : i == 1 ? d / B1 : d / B2;
+            const int v = i == 0 ? d - lp * B0 : i == 1 ? B0 + (d - lp * B1) : B0 + B1 + (d - lp * B2);
+            const int shp = i == 0 ? sh1 + sh2 : i == 1 ? 6 - sh1 : 6 - sh2;  // log2(64 / L_i); L0 = 64 / (L1 * L2)
+            const int n = 1 << shp;
+            const BoxQuad<T>* row = &s_part[wv][v][(lp << shp) >> 2];
+            for (int k = 0; k < (n >> 2); ++k) {
+                const BoxQuad<T> q = row[k];
+                m = min2(min2(min2(min2(m, q.v[0]), q.v[1]), q.v[2]), q.v[3]);
+            }
+            if (!a.start) {
+                const T p = el_prev[ps];
+                const int cnt = el_cnt[ps];
+                if (cnt > 0 && a.damp_f) m = a.damping * p + ((T)1 - a.damping) * m;
+                el_bad[ps] = cnt > 0 && !comp_match(m, p, a.stability);
+            }
+        }
+        el_m[ps] = m;
+    }
+    // the elements of a message agree on "changed": one ballot per edge
+    bool nomatch[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+        nomatch[i] = (__ballot((el_i[0] == i && el_bad[0]) || (el_i[1] == i && el_bad[1])) != 0ull);
+    // send / send again / stay silent (the receiver keeps the old message)
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int i = el_i[ps], d = el_d[ps];
+        if (i < 0) continue;
+        const int fo = i == 0 ? fd.f2v_off[0] : i == 1 ? fd.f2v_off[1] : fd.f2v_off[2];
+        const int e = fd.edge_base + i;
+        if (a.start) {  // only start_messages == all makes a non-unary factor send
+            a.f2v_new[fo + d] = a.start_mode == MXS_START_ALL ? el_m[ps] : (T)0;
+            if (d == 0) a.cF[e] = 0;
+            continue;
+        }
+        const int cnt = el_cnt[ps];
+        const bool match = cnt > 0 && !(i == 0 ? nomatch[0] : i == 1 ? nomatch[1] : nomatch[2]);
+        int out = 1;
+        T val = el_m[ps];
+        if (match) {
+            if (cnt < SAME_COUNT) {
+                out = cnt + 1;
+            } else {
+                out = cnt;
+                val = el_prev[ps];
+            }
+        }
+        a.f2v_new[fo + d] = val;
+        if (d == 0) a.cF[e] = (uint8_t)out;
+    }
+}
+
+// Launch of one box group (engine.hip, launch_nary).  Returns false when no instantiation exists.
+template <typename T>
+inline bool launch_factor_box3(const NaryLaunch& nl, const SweepArgs<T>& a, const NaryDesc* d, hipStream_t stream) {
+    const dim3 grid((unsigned)((nl.count + BOX_WAVES - 1) / BOX_WAVES)), block((unsigned)(BOX_WAVES * 64));
+#define MXS_BOX_LAUNCH(TT, B0, B1, B2)                                                                              \
+    do {                                                                                                             \
+        if (a.tab_neg) hipLaunchKernelGGL((k_factor_box3<T, TT, true, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);  \
+        else hipLaunchKernelGGL((k_factor_box3<T, TT, false, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);           \
+        return true;                                                                                                 \
+    } while (0)
+    if (nl.tab_type == TAB_I8) {
+        switch (nl.box) {
+            case 1: MXS_BOX_LAUNCH(int8_t, 2, 2, 2);
+            case 2: MXS_BOX_LAUNCH(int8_t, 3, 3, 3);
+            case 3: MXS_BOX_LAUNCH(int8_t, 4, 4, 4);
+            case 4: MXS_BOX_LAUNCH(int8_t, 6, 6, 6);
+        }
+    } else if (nl.tab_type == TAB_I16) {
+        switch (nl.box) {
+            case 1: MXS_BOX_LAUNCH(int16_t, 2, 2, 2);
+            case 2: MXS_BOX_LAUNCH(int16_t, 3, 3, 3);
+            case 3: MXS_BOX_LAUNCH(int16_t, 4, 4, 4);
+        }
+    }
+#undef MXS_BOX_LAUNCH
+    return false;
+}
+
+}  // namespace mxs

@@ -103,6 +103,55 @@ KERNEL(k_cndmask, int, 1, A_CNDMASK)
 KERNEL(k_swap32, int, (int)threadIdx.x, A_SWAP32)
 KERNEL(k_lshl_add, int, 1, A_LSHL_ADD)
 KERNEL(k_cmp_f64, double, 0.0, A_CMP_F64)
+// selects: the e32 form reads VCC; the e64 form any SGPR pair; a compare feeding the select
+#define A_CNDMASK_E64(i) asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(ci), "s"(smask));
+#define A_CMP_CND(i) \
+    asm volatile("v_cmp_lt_i32 vcc, %0, %1\n\tv_cndmask_b32 %0, %0, %1, vcc" : "+v"(x[i]) : "v"(ci) : "vcc");
+#define A_CMP_CND_S(i) \
+    asm volatile("v_cmp_lt_i32_e64 %2, %0, %1\n\tv_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(x[i]) : "v"(ci), "s"(smask));
+#define KERNEL_S(NAME, ASM)                                                                  \
+    __global__ void __launch_bounds__(256) NAME(int iters, long long* ticks, double* sink) {  \
+        int x[8];                                                                            \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) x[i] = i;                              \
+        const int ci = (int)threadIdx.x * 0x01010101 + 0x7f3c8912;                           \
+        unsigned long long smask = 0x5555555555555555ull * (unsigned long long)(iters | 1);  \
+        smask = __builtin_amdgcn_readfirstlane((int)smask) | ((unsigned long long)iters << 33); \
+        const long long t0 = (long long)__builtin_amdgcn_s_memtime();                        \
+        for (int it = 0; it < iters; ++it) { REP32(ASM) }                                    \
+        const long long t1 = (long long)__builtin_amdgcn_s_memtime();                        \
+        double s = 0;                                                                        \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) s += (double)x[i];                     \
+        if (s == 123.456) sink[0] = s + (double)smask;                                       \
+        if ((threadIdx.x & 63) == 0)                                                         \
+            ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;                   \
+    }
+KERNEL_S(k_cndmask_e64, A_CNDMASK_E64)
+KERNEL_S(k_cmp_cnd, A_CMP_CND)
+// what the compiler makes of a select on doubles under a lane-dependent condition
+__global__ void __launch_bounds__(256) k_select_f64(int iters, long long* ticks, double* sink) {
+    double x[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) x[i] = (double)i;
+    const bool odd = (threadIdx.x & 1) != 0;
+    const double c = 1.0 + (double)threadIdx.x * 1e-9;
+    const long long t0 = (long long)__builtin_amdgcn_s_memtime();
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                double y = odd ? x[i] : x[(i + 1) & 7];
+                asm volatile("" : "+v"(y));  // keep the select
+                x[i] = y;
+            }
+    }
+    const long long t1 = (long long)__builtin_amdgcn_s_memtime();
+    double s = c;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x[i];
+    if (s == 123.456) sink[0] = s;
+    if ((threadIdx.x & 63) == 0) ticks[(blockIdx.x * blockDim.x + threadIdx.x) >> 6] = t1 - t0;
+}
 
 // add + dependent min: the pair every table entry costs per output (2 instructions per ASM)
 __global__ void __launch_bounds__(256) k_add_min_f64x2(int iters, long long* ticks, double* sink) {
@@ -188,6 +237,9 @@ int main(int argc, char** argv) {
         {"v_mov_b32_dpp quad_perm", k_dpp_quad, 1},
         {"v_mov_b32_dpp row_ror", k_dpp_ror, 1},
         {"v_cndmask_b32", k_cndmask, 1},
+        {"v_cndmask_b32_e64 (sgpr pair)", k_cndmask_e64, 1},
+        {"v_cmp_lt_i32+v_cndmask_b32 (vcc)", k_cmp_cnd, 2},
+        {"select on f64 (compiler: 2 x v_cndmask)", k_select_f64, 2},
         {"v_permlane32_swap_b32", k_swap32, 1},
         {"ds_min_u64 64 addresses", k_lds<1, 0>, 1},
         {"ds_min_u64 4 lanes/address", k_lds<4, 0>, 1},
