@@ -210,6 +210,9 @@ struct Engine : EngineBase {
     uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
     DevBuf<NaryDesc> ndesc;
     DevBuf<WideBlock> wide_blocks;
+#ifdef MXS_WIDE_PROFILE
+    DevBuf<int64_t> wide_prof;
+#endif
     DevBuf<double> eval_tables, eval_var_cost, part_cost;
     DevBuf<unsigned long long> part_viol;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -244,6 +247,9 @@ struct Engine : EngineBase {
             if (comm) (void)hipStreamSynchronize(comm);
             (void)rccl->CommDestroy(nccl_comm);
         }
+#ifdef MXS_WIDE_PROFILE
+        wide_profile_dump();
+#endif
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
@@ -291,6 +297,9 @@ struct Engine : EngineBase {
         a.start_mode = params.start_messages;
         a.null_f2v = (int32_t)L.null_f2v;
         a.timeline = timeline_on ? timeline.p : nullptr;
+#ifdef MXS_WIDE_PROFILE  // profiling build (make variant DEFS=-DMXS_WIDE_PROFILE): phase clocks of k_variable_wide
+        if (!timeline_on) a.timeline = wide_prof.p;
+#endif
         a.halo_flags = nullptr;
         a.need_epoch = 0;
         a.send_out = direct ? send2[from ^ 1].p : nullptr;  // the parity this cycle writes
@@ -345,7 +354,7 @@ struct Engine : EngineBase {
                 case 4: hipLaunchKernelGGL((k_sweep_p2p<T, 4>), grid, block, 0, stream, a); break;
                 default: hipLaunchKernelGGL((k_sweep_p2p<T, 0>), grid, block, 0, stream, a); break;
             }
-        } else if (a.timeline != nullptr) {  // profiling twin
+        } else if (timeline_on) {  // profiling twin
             switch (L.dsel) {
                 case 2: hipLaunchKernelGGL((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
                 case 3: hipLaunchKernelGGL((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
@@ -459,8 +468,8 @@ struct Engine : EngineBase {
             int rc = launch_sweep(a, L.n_blocks_fused);
             if (rc) return rc;
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, stream, a,
-                                   (const WideBlock*)wide_blocks.p);
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)(WIDE_PERSIST ? std::min<size_t>(L.wide_blocks.size(), WIDE_GRID) : L.wide_blocks.size())),
+                                   dim3(WIDE_TPB), 0, stream, a, (const WideBlock*)wide_blocks.p, (int)L.wide_blocks.size());
                 HIP_TRY(hipGetLastError());
             }
             return launch_nary(a, 0);
@@ -477,8 +486,8 @@ struct Engine : EngineBase {
                 ws = side;
             }
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
-                                   (const WideBlock*)wide_blocks.p);
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)(WIDE_PERSIST ? std::min<size_t>(L.wide_blocks.size(), WIDE_GRID) : L.wide_blocks.size())),
+                                   dim3(WIDE_TPB), 0, ws, a, (const WideBlock*)wide_blocks.p, (int)L.wide_blocks.size());
                 HIP_TRY(hipGetLastError());
             }
             if (fork) HIP_TRY(hipEventRecord(ev_join, side));
@@ -681,6 +690,12 @@ struct Engine : EngineBase {
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         HIP_TRY(wide_blocks.upload(L.wide_blocks, stream));
+#ifdef MXS_WIDE_PROFILE
+        if (!L.wide_blocks.empty()) {
+            HIP_TRY(wide_prof.alloc(8 * L.wide_blocks.size()));
+            HIP_TRY(hipMemset(wide_prof.p, 0, sizeof(int64_t) * 8 * L.wide_blocks.size()));
+        }
+#endif
         // solution_cost data
         HIP_TRY(frowptr.upload(L.frowptr, stream));
         HIP_TRY(edge_var_int.upload(L.edge_var_int, stream));
@@ -797,6 +812,21 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+#ifdef MXS_WIDE_PROFILE
+    void wide_profile_dump() {
+        if (!wide_prof.p) return;
+        const int ng = (int)L.wide_blocks.size();
+        std::vector<int64_t> h(8 * (size_t)ng);
+        (void)hipDeviceSynchronize();
+        (void)hipMemcpy(h.data(), wide_prof.p, sizeof(int64_t) * h.size(), hipMemcpyDeviceToHost);
+        double acc[8] = {0};
+        for (int g = 0; g < ng; ++g) for (int k = 0; k < 8; ++k) acc[k] += (double)h[8 * g + k];
+        const double nb = acc[7] > 0 ? acc[7] : 1;
+        fprintf(stderr, "k_variable_wide phase clocks per block (s_memtime ticks; %d blocks timed): stage %.0f | chains+beliefs %.0f | "
+                        "selection %.0f | messages %.0f | stores %.0f | loop end %.0f | whole %.0f\n",
+                (int)acc[7], acc[0] / nb, acc[1] / nb, acc[2] / nb, acc[3] / nb, acc[4] / nb, acc[5] / nb, acc[6] / nb);
+    }
+#endif
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
         if (comm) HIP_TRY(hipStreamSynchronize(comm));

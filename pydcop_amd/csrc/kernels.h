@@ -1552,74 +1552,6 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 // Own launch (its LDS must not cap the occupancy of the register classes).
 // ---------------------------------------------------------------------------
 
-// sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of
-// costs_for_factor (ONE accumulator, maxsum.py:651-665).  One wave of a block walks the chains of
-// the block's edges while the others wait, so what a block pays is the instruction count of the
-// SLOWEST lane's path:
-//   * degrees <= 4 (the variables of the class are sorted by domain size, then by degree in steps of
-//     four, so a wave is rarely mixed): the (up to four) edges side by side, two values of d per
-//     pass -- eight reads at constant offsets from four row pointers, then eight additions under
-//     masks computed once: three instructions per term;
-//   * any degree: the D * deg terms as one sequence, eight per pass, addresses by select
-//     arithmetic (no branch on the wrap-around of k).
-// (Versions that branched per element cost 24 to 45 of the kernel's 65 to 95 us on meeting_50k:
-// profiles/r03_wide_phases_v*.txt.)
-template <typename T>
-__device__ __forceinline__ T wide_sum_cost(const T* in, int D, int deg, int ko) {
-    T sc = (T)0;
-    if (deg <= 4) {
-        const bool u0 = 0 != ko, u1 = 1 < deg && 1 != ko, u2 = 2 < deg && 2 != ko, u3 = 3 < deg && 3 != ko;
-        const T* r0 = in;
-        const T* r1 = in + (1 < deg ? 1 : 0) * D;
-        const T* r2 = in + (2 < deg ? 2 : 0) * D;
-        const T* r3 = in + (3 < deg ? 3 : 0) * D;
-        int d = 0;
-        for (; d + 2 <= D; d += 2) {
-            T x[2][4];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                x[i][0] = r0[d + i];
-                x[i][1] = r1[d + i];
-                x[i][2] = r2[d + i];
-                x[i][3] = r3[d + i];
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                sc = u0 ? sc + x[i][0] : sc;
-                sc = u1 ? sc + x[i][1] : sc;
-                sc = u2 ? sc + x[i][2] : sc;
-                sc = u3 ? sc + x[i][3] : sc;
-            }
-        }
-        for (; d < D; ++d) {
-            const T x0 = r0[d], x1 = r1[d], x2 = r2[d], x3 = r3[d];
-            sc = u0 ? sc + x0 : sc;
-            sc = u1 ? sc + x1 : sc;
-            sc = u2 ? sc + x2 : sc;
-            sc = u3 ? sc + x3 : sc;
-        }
-        return sc;
-    }
-    const int n = D * deg;
-    int d = 0, k = 0;
-    for (int t = 0; t < n; t += 8) {
-        T x[8];
-        bool use[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const bool ok = t + u < n;
-            x[u] = in[ok ? k * D + d : 0];
-            use[u] = ok && k != ko;
-            const bool wrap = k + 1 == deg;
-            k = wrap ? 0 : k + 1;
-            d += wrap ? 1 : 0;
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) sc = use[u] ? sc + x[u] : sc;
-    }
-    return sc;
-}
-
 // c + in_0[d] + in_1[d] + ... in order, skipping edge `skip` (-1: none); reads four at a time,
 // the last one to three together as well
 template <typename T>
@@ -1659,135 +1591,333 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
+// Workgroup barrier that orders the block's LDS traffic only: the global loads a wave has in flight stay
+// in flight (__syncthreads() is a fence over every address space: it drains them, vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of costs_for_factor (ONE
+// accumulator, maxsum.py:651-665).  A skipped term (k == ko, k >= deg) is read from a row of zeros: the
+// accumulator starts at +0 and can never become -0, so `sc + 0` is `sc` bit for bit -- no select on the
+// dependent chain, one add per term.  The reads of a pass (two values of d of four rows) are requested
+// before the additions of the previous pass.
+// NR row pointers in registers (deg <= NR), ND values of d per pass; the reads of a pass are requested before
+// the additions of the pass before.
+template <typename T, int NR, int ND>
+__device__ __forceinline__ T wide_chain_rows(const T* in, const T* zero, int D, int deg, int ko) {
+    const T* r[NR];
+#pragma unroll
+    for (int k = 0; k < NR; ++k) r[k] = (k < deg && k != ko) ? in + k * D : zero;
+    T q[ND][NR], sc = (T)0;
+#pragma unroll
+    for (int i = 0; i < ND; ++i)
+#pragma unroll
+        for (int k = 0; k < NR; ++k) q[i][k] = r[k][i < D ? i : 0];
+    int d = 0;
+    for (; d + ND <= D; d += ND) {
+        T n[ND][NR];
+#pragma unroll
+        for (int i = 0; i < ND; ++i) {
+            const int dn = d + ND + i < D ? d + ND + i : 0;  // (past the end: a read nobody uses)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) n[i][k] = r[k][dn];
+        }
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) sc += q[i][k];
+#pragma unroll
+        for (int i = 0; i < ND; ++i)
+#pragma unroll
+            for (int k = 0; k < NR; ++k) q[i][k] = n[i][k];
+    }
+#pragma unroll
+    for (int i = 0; i < ND - 1; ++i)  // D % ND values of d are left, already read
+        if (d + i < D) {
+#pragma unroll
+            for (int k = 0; k < NR; ++k) sc += q[i][k];
+        }
+    return sc;
+}
+template <typename T>
+__device__ __forceinline__ T wide_chain(const T* in, const T* zero, int D, int deg, int ko) {
+    // (the variables of the class are sorted by domain size, then by degree in steps of four: a wave rarely
+    // mixes the paths)
+    if (deg <= 4) return wide_chain_rows<T, 4, 2>(in, zero, D, deg, ko);
+    if (deg <= 8) return wide_chain_rows<T, 8, 1>(in, zero, D, deg, ko);
+    T sc = (T)0;
+    for (int d = 0; d < D; ++d)
+        for (int k = 0; k < deg; k += 8) {
+            T x[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[u] = (k + u < deg && k + u != ko) ? in[(k + u) * D + d] : zero[d];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) sc += x[u];
+        }
+    return sc;
+}
+
 #ifndef MXS_WIDE_SKIP
 #define MXS_WIDE_SKIP 0  // timing experiments only (results wrong): 1 no chains, 2 no message arithmetic,
 #endif                   // 4 no beliefs, 8 no gathers, 16 no stores
+// Workgroups of the wide variable launch.  0: one per block.  N > 0: N PERSISTENT workgroups, each walking blocks
+// g, g + N, ... with the next block's records and the indices of the one after in flight (registers) -- measured
+// and NOT adopted (profiles/r04_wide_persistent_v1.txt: 64.5 us with 768 workgroups against 57.4 with one per
+// block; the pipeline's registers leave 3 workgroups per CU where 8 overlap their phases by themselves).
+#ifndef MXS_WIDE_GRID
+#define MXS_WIDE_GRID 0
+#endif
+constexpr int WIDE_GRID = MXS_WIDE_GRID;
+constexpr bool WIDE_PERSIST = WIDE_GRID > 0;
+constexpr int WIDE_R = WIDE_CAPB / WIDE_TPB;                          // staged elements per thread
+constexpr int WIDE_CR = (WIDE_MAX_COSTS + WIDE_TPB - 1) / WIDE_TPB;   // own costs per thread
+
+// What a thread holds of a block between the request and the staging (registers; the loads are in flight
+// while the workgroup works on the block before).
 template <typename T>
-__global__ void __launch_bounds__(WIDE_TPB) k_variable_wide(SweepArgs<T> a, const WideBlock* blocks) {
-    constexpr int R = WIDE_CAPB / WIDE_TPB;  // elements per thread
-    static_assert(WIDE_CAPB % WIDE_TPB == 0, "");
+struct WideIdx {
+    int fo[WIDE_R], vo[WIDE_R];  // F2V / V2F offsets of the SLOTS of its elements idx = tid + r * WIDE_TPB
+};
+template <typename T>
+struct WideRec {
+    T x[WIDE_R], p[WIDE_R];      // the incoming F->V element, the V->F element sent last
+    T c[WIDE_CR];                // own costs i = tid + q * WIDE_TPB
+    int lo, hi;                  // variable j = tid: its CSR slot range
+    int cnt;                     // slot s = tid: send counter
+};
+// Every load below is unconditional (clamped indices instead of branches) and nothing is computed from a
+// loaded value: the requests of a block leave the wave back to back and nothing waits for them here.
+template <typename T>
+__device__ __forceinline__ void wide_request_idx(const SweepArgs<T>& a, const WideBlock& wb, int tid, WideIdx<T>& ix) {
+    const int ne = wb.n_slots * wb.D;
+    static_for<WIDE_R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const int idx = tid + r * WIDE_TPB;
+        const int s = wb.D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);  // idx / D
+        const int so = wb.slot0 + (idx < ne ? s : 0);
+        ix.fo[r] = a.vslot_f2v[so];
+        ix.vo[r] = a.vslot_v2f[so];
+    });
+}
+template <typename T>
+__device__ __forceinline__ void wide_request_rec(const SweepArgs<T>& a, const WideBlock& wb, int tid, const WideIdx<T>& ix,
+                                                 WideRec<T>& rc_) {
+    const int ne = wb.n_slots * wb.D;
+    static_for<WIDE_R>([&](auto rc) __attribute__((always_inline)) {
+        constexpr int r = decltype(rc)::value;
+        const int idx = tid + r * WIDE_TPB;
+        const int s = wb.D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);
+        const int dd = idx < ne ? idx - s * wb.D : 0;
+        rc_.x[r] = (MXS_WIDE_SKIP & 8) ? (T)0 : a.f2v_old[ix.fo[r] + dd];
+        rc_.p[r] = a.start ? (T)0 : a.v2f_old[ix.vo[r] + dd];  // the message sent last on this edge
+    });
+    static_for<WIDE_CR>([&](auto qc) __attribute__((always_inline)) {
+        constexpr int q = decltype(qc)::value;
+        const int i = tid + q * WIDE_TPB;
+        rc_.c[q] = a.var_cost[wb.cost_off + (i < wb.n_vars * wb.D ? i : 0)];
+    });
+    const int j = tid < wb.n_vars ? tid : 0;
+    rc_.lo = a.vrowptr[wb.first_var + j];
+    rc_.hi = a.vrowptr[wb.first_var + j + 1];
+    rc_.cnt = a.start ? 0 : (int)a.cV[wb.slot0 + (tid < wb.n_slots ? tid : 0)];
+}
+
+// PERSISTENT workgroups: workgroup g works on blocks g, g + G, g + 2G, ...  While it walks the LDS phases of
+// one block, the records of the next one and the indices of the one after are on their way (registers):
+// the launch moves its bytes while it computes instead of alternating (round 3: a block's life was
+// descriptor -> indices -> records -> three LDS phases -> stores, 56 us for 25 us worth of bytes).
+#ifndef MXS_WIDE_WAVES
+#define MXS_WIDE_WAVES 8  // register budget for that many waves per SIMD (0: the compiler's choice, 80 VGPRs in f64: 45.6 us against 42.3)
+#endif
+template <typename T>
+__global__ void __launch_bounds__(WIDE_TPB)
+#if MXS_WIDE_WAVES > 0
+__attribute__((amdgpu_waves_per_eu(MXS_WIDE_WAVES, MXS_WIDE_WAVES)))
+#endif
+k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks, int n_blocks) {
+    constexpr int R = WIDE_R;
     __shared__ T s_in[WIDE_CAPB];               // staged F->V messages: [slot][d]
     __shared__ T s_c[WIDE_MAX_COSTS];           // own costs: [variable][d]
     __shared__ T s_b[WIDE_MAX_COSTS];           // beliefs: [variable][d]
     __shared__ T s_avg[WIDE_MAX_SLOTS];         // per outgoing edge: sum_cost / D
+    __shared__ T s_zero[WIDE_MAX_D];            // a row of zeros (wide_chain)
     __shared__ uint8_t s_svar[WIDE_MAX_SLOTS];  // ... its variable (local index)
     __shared__ uint8_t s_cnt[WIDE_MAX_SLOTS];   // ... its send counter
     __shared__ uint8_t s_nom[WIDE_MAX_SLOTS];   // ... 1: some element differs from the message sent last
     __shared__ int s_vk0[WIDE_MAX_VARS];        // per variable: its first (local) slot
     __shared__ int s_vdeg[WIDE_MAX_VARS];
-    const WideBlock wb = blocks[blockIdx.x];    // block-uniform: one scalar load
-    const int tid = (int)threadIdx.x;
-    const int D = wb.D, ns = wb.n_slots, ne = ns * D;
-    // ---- 1. stage ------------------------------------------------------------------------
-    int sl[R], dd[R], vo[R];  // a thread's elements: local slot, d, V2F offset (idx = tid + r * WIDE_TPB)
-    T x[R], p[R], m[R];
-    static_for<R>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        const int idx = tid + r * WIDE_TPB;
-        const int s = D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);  // idx / D
-        sl[r] = s;
-        dd[r] = idx - s * D;
-        x[r] = (T)0;
-        vo[r] = 0;
-        p[r] = (T)0;
-        if (idx < ne) {  // both index loads, then both record loads, of all R elements: in flight together
-            const int fo = a.vslot_f2v[wb.slot0 + s];
-            vo[r] = a.vslot_v2f[wb.slot0 + s] + dd[r];
-            if (!(MXS_WIDE_SKIP & 8)) x[r] = a.f2v_old[fo + dd[r]];
-            if (!a.start) p[r] = a.v2f_old[vo[r]];  // the message sent last on this edge
+    const int tid = (int)threadIdx.x, G = (int)gridDim.x;
+    int b = (int)blockIdx.x;
+    if (b >= n_blocks) return;
+    for (int i = tid; i < WIDE_MAX_D; i += WIDE_TPB) s_zero[i] = (T)0;
+    // ---- fill the pipeline ---------------------------------------------------------------
+    auto desc = [&](int bb) { return blocks[bb < n_blocks ? bb : n_blocks - 1]; };  // block-uniform: scalar loads
+    WideBlock wA = desc(b), wB = wA, wC = wA;
+    WideIdx<T> iA, iB{};
+    WideRec<T> rA;
+    wide_request_idx(a, wA, tid, iA);
+    if constexpr (WIDE_PERSIST) {
+        wB = desc(b + G), wC = desc(b + 2 * G);
+        wide_request_idx(a, wB, tid, iB);
+    }
+    wide_request_rec(a, wA, tid, iA, rA);
+#ifdef MXS_WIDE_PROFILE
+    long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define WIDE_TICK(k) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); prof[k] += t_ - t_last; t_last = t_; } while (0)
+#else
+#define WIDE_TICK(k) ((void)0)
+#endif
+    for (;;) {
+#ifdef MXS_WIDE_PROFILE
+        long long t_last = (long long)__builtin_amdgcn_s_memtime();
+        const long long t_top = t_last;
+#endif
+        const WideBlock wb = wA;
+        const int D = wb.D, ns = wb.n_slots, ne = ns * D;
+        // ---- 1. stage block A; request the records of B and the indices of C ---------------------
+        int sl[R], dd[R];
+        static_for<R>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            const int idx = tid + r * WIDE_TPB;
+            sl[r] = D == 1 ? idx : (int)(((uint64_t)(uint32_t)idx * wb.magic) >> 32);
+            dd[r] = idx - sl[r] * D;
+            if (idx < ne) s_in[idx] = rA.x[r];
+        });
+        static_for<WIDE_CR>([&](auto qc) __attribute__((always_inline)) {
+            constexpr int q = decltype(qc)::value;
+            if (tid + q * WIDE_TPB < wb.n_vars * D) s_c[tid + q * WIDE_TPB] = rA.c[q];
+        });
+        if (tid < wb.n_vars) {
+            const int k0 = rA.lo - wb.slot0, deg = rA.hi - rA.lo;
+            s_vk0[tid] = k0;
+            s_vdeg[tid] = deg;
+            for (int k = 0; k < deg; ++k) s_svar[k0 + k] = (uint8_t)tid;
         }
-    });
-    for (int j = tid; j < wb.n_vars; j += WIDE_TPB) {
-        const int v = wb.first_var + j;
-        const int k0 = a.vrowptr[v] - wb.slot0, deg = a.vrowptr[v + 1] - a.vrowptr[v];
-        s_vk0[j] = k0;
-        s_vdeg[j] = deg;
-        for (int k = 0; k < deg; ++k) s_svar[k0 + k] = (uint8_t)j;
-    }
-    for (int i = tid; i < wb.n_vars * D; i += WIDE_TPB) s_c[i] = a.var_cost[a.vcost_off[wb.first_var] + i];
-    for (int s = tid; s < ns; s += WIDE_TPB) {
-        s_cnt[s] = a.start ? (uint8_t)0 : a.cV[wb.slot0 + s];
-        s_nom[s] = 0;
-    }
-    static_for<R>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        if (tid + r * WIDE_TPB < ne) s_in[tid + r * WIDE_TPB] = x[r];
-    });
-    __syncthreads();
-    // ---- 2. chains and beliefs --------------------------------------------------------------
-    for (int t = tid; t < ns; t += WIDE_TPB) {  // the mean of an outgoing message: its serial chain
-        const int j = s_svar[t], k0 = s_vk0[j];
-        s_avg[t] = (MXS_WIDE_SKIP & 1) ? (T)0 : wide_sum_cost<T>(s_in + k0 * D, D, s_vdeg[j], t - k0) / (T)D;
-    }
-    for (int i = tid; i < wb.n_vars * D; i += WIDE_TPB) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
-        const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
-        s_b[i] = (MXS_WIDE_SKIP & 4) ? s_c[i] : wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
-    }
-    __syncthreads();
-    for (int j = tid; j < wb.n_vars; j += WIDE_TPB) {  // selection: first index attaining the minimum
-        const int v = wb.first_var + j;
-        T bb = s_b[j * D];
-        int bi = 0;
-        for (int d = 1; d < D; ++d) {
-            const T b = s_b[j * D + d];
-            if (b < bb) {
-                bb = b;
-                bi = d;
+        if (tid < ns) {
+            s_cnt[tid] = (uint8_t)rA.cnt;
+            s_nom[tid] = 0;
+        }
+        const bool hasB = WIDE_PERSIST && b + G < n_blocks;
+        WideRec<T> rB{};
+        WideIdx<T> iC{};
+        WideBlock wD = wA;
+        if constexpr (WIDE_PERSIST) {
+            wD = desc(b + 3 * G);
+            if (hasB) wide_request_rec(a, wB, tid, iB, rB);
+            if (b + 2 * G < n_blocks) wide_request_idx(a, wC, tid, iC);
+        }
+        lds_barrier();
+        WIDE_TICK(0);
+        // ---- 2. chains and beliefs --------------------------------------------------------------
+        for (int t = tid; t < ns; t += WIDE_TPB) {  // the mean of an outgoing message: its serial chain
+            const int j = s_svar[t], k0 = s_vk0[j];
+            s_avg[t] = (MXS_WIDE_SKIP & 1) ? (T)0 : wide_chain<T>(s_in + k0 * D, s_zero, D, s_vdeg[j], t - k0) / (T)D;
+        }
+        for (int i = tid; i < wb.n_vars * D; i += WIDE_TPB) {  // b[d] = c[d] + in_0[d] + in_1[d] + ...
+            const int j = D == 1 ? i : (int)(((uint64_t)(uint32_t)i * wb.magic) >> 32);
+            s_b[i] = (MXS_WIDE_SKIP & 4) ? s_c[i] : wide_sum_edges<T>(s_c[i], s_in + s_vk0[j] * D, D, s_vdeg[j], i - j * D, -1);
+        }
+        lds_barrier();
+        WIDE_TICK(1);
+        for (int j = tid; j < wb.n_vars; j += WIDE_TPB) {  // selection: first index attaining the minimum
+            const int v = wb.first_var + j;
+            T bb = s_b[j * D];
+            int bi = 0;
+            int d = 1;
+            for (; d + 4 <= D; d += 4) {  // four reads requested together, compared in order
+                T bv[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) bv[u] = s_b[j * D + d + u];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (bv[u] < bb) {
+                        bb = bv[u];
+                        bi = d + u;
+                    }
             }
-        }
-        if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
-            bi = a.init_idx[v];
-            bb = (T)0;
-        }
-        a.sel[v] = bi;
-        a.belief[v] = bb;
-    }
-    // ---- 3. the new messages, damped, against the ones sent last ---------------------------------
-    static_for<R>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        m[r] = (T)0;
-        if (tid + r * WIDE_TPB < ne) {
-            const int s = sl[r], j = s_svar[s], k0 = s_vk0[j], deg = s_vdeg[j];
-            T mm = (MXS_WIDE_SKIP & 2) ? s_avg[s] : wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
-            if (a.start) {
-                const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
-                                         a.start_mode != MXS_START_LEAFS;
-                mm = start_sends ? mm : (T)0;
-            } else {
-                if (s_cnt[s] > 0 && a.damp_v) mm = a.damping * p[r] + ((T)1 - a.damping) * mm;
-                if (!comp_match(mm, p[r], a.stability)) s_nom[s] = 1;  // same value from all writers
-            }
-            m[r] = mm;
-        }
-    });
-    __syncthreads();
-    // ---- 4. send / send again / stay silent (the receiver keeps the old message) -------------------
-    static_for<R>([&](auto rc) __attribute__((always_inline)) {
-        constexpr int r = decltype(rc)::value;
-        if (tid + r * WIDE_TPB < ne) {
-            const int s = sl[r];
-            const int cnt = s_cnt[s];
-            int out = 1;
-            bool keep_old = false;
-            if (a.start) {
-                out = 0;
-            } else if (cnt > 0 && !s_nom[s]) {
-                if (cnt < SAME_COUNT) {
-                    out = cnt + 1;
-                } else {
-                    out = cnt;
-                    keep_old = true;
+            for (; d < D; ++d) {
+                const T bv = s_b[j * D + d];
+                if (bv < bb) {
+                    bb = bv;
+                    bi = d;
                 }
             }
-            // (not `keep_old ? p[r] : m[r]`: the optimiser turns that into a select of the two
-            // arrays' ADDRESSES, which keeps both in scratch memory; the second read of the
-            // record is a cache hit)
-            T val = m[r];
-            if (keep_old) val = a.v2f_old[vo[r]];
-            if (!(MXS_WIDE_SKIP & 16)) a.v2f_new[vo[r]] = val;
-            if (dd[r] == 0) a.cV[wb.slot0 + s] = (uint8_t)out;
+            if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+                bi = a.init_idx[v];
+                bb = (T)0;
+            }
+            a.sel[v] = bi;
+            a.belief[v] = bb;
         }
-    });
+        WIDE_TICK(2);
+        // ---- 3. the new messages, damped, against the ones sent last ---------------------------------
+        T m[R];
+        static_for<R>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            m[r] = (T)0;
+            if (tid + r * WIDE_TPB < ne) {
+                const int s = sl[r], j = s_svar[s], k0 = s_vk0[j], deg = s_vdeg[j];
+                T mm = (MXS_WIDE_SKIP & 2) ? s_avg[s] : wide_sum_edges<T>(s_c[j * D + dd[r]], s_in + k0 * D, D, deg, dd[r], s - k0) - s_avg[s];
+                if (a.start) {
+                    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) ||
+                                             a.start_mode != MXS_START_LEAFS;
+                    mm = start_sends ? mm : (T)0;
+                } else {
+                    if (s_cnt[s] > 0 && a.damp_v) mm = a.damping * rA.p[r] + ((T)1 - a.damping) * mm;
+                    if (!comp_match(mm, rA.p[r], a.stability)) s_nom[s] = 1;  // same value from all writers
+                }
+                m[r] = mm;
+            }
+        });
+        lds_barrier();
+        WIDE_TICK(3);
+        // ---- 4. send / send again / stay silent (the receiver keeps the old message) -------------------
+        static_for<R>([&](auto rc) __attribute__((always_inline)) {
+            constexpr int r = decltype(rc)::value;
+            if (tid + r * WIDE_TPB < ne) {
+                const int s = sl[r];
+                const int cnt = s_cnt[s];
+                int out = 1;
+                bool keep_old = false;
+                if (a.start) {
+                    out = 0;
+                } else if (cnt > 0 && !s_nom[s]) {
+                    if (cnt < SAME_COUNT) {
+                        out = cnt + 1;
+                    } else {
+                        out = cnt;
+                        keep_old = true;
+                    }
+                }
+                // (the old message from the registers: a second read of the record would have to wait for
+                // every load in flight, the next block's records among them)
+                const T val = keep_old ? rA.p[r] : m[r];
+                if (!(MXS_WIDE_SKIP & 16)) a.v2f_new[iA.vo[r] + dd[r]] = val;
+                if (dd[r] == 0) a.cV[wb.slot0 + s] = (uint8_t)out;
+            }
+        });
+        WIDE_TICK(4);
+#ifdef MXS_WIDE_PROFILE
+        prof[7] += 1;
+        if (!hasB) {
+            prof[6] += (long long)__builtin_amdgcn_s_memtime() - t_top;
+            if (tid == 0 && a.timeline)
+                for (int k = 0; k < 8; ++k) a.timeline[8 * blockIdx.x + k] += prof[k];
+        }
+#endif
+        if (!hasB) break;
+        lds_barrier();  // the LDS arrays are free for the next block
+        WIDE_TICK(5);
+#ifdef MXS_WIDE_PROFILE
+        prof[6] += (long long)__builtin_amdgcn_s_memtime() - t_top;
+#endif
+        b += G;
+        wA = wB, wB = wC, wC = wD;
+        iA = iB, iB = iC, rA = rB;
+    }
 }
 
 // ---------------------------------------------------------------------------

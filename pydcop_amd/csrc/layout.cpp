@@ -523,7 +523,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             // its workgroups: runs of one D that fit the kernel's LDS arrays
             for (int w = vi; w < vj;) {
                 const int D = L.vdom[w];
-                WideBlock wb{w, 0, D, L.vrowptr[w], 0, (uint32_t)((((uint64_t)1 << 32) + D - 1) / D)};
+                WideBlock wb{w, 0, D, L.vrowptr[w], 0, (uint32_t)((((uint64_t)1 << 32) + D - 1) / D), L.vcost_off[w]};
                 while (w < vj && L.vdom[w] == D) {
                     const int deg = L.vrowptr[w + 1] - L.vrowptr[w];
                     if (wb.n_vars > 0 && ((int64_t)(wb.n_slots + deg) * D > WIDE_CAPB || wb.n_slots + deg > WIDE_MAX_SLOTS ||

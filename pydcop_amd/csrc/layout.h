@@ -225,6 +225,7 @@ constexpr int WIDE_CAPB = 4 * WIDE_TPB; // staged F->V elements per block: 4 per
 constexpr int WIDE_MAX_SLOTS = WIDE_TPB;   // outgoing edges (CSR slots) per block
 constexpr int WIDE_MAX_VARS = 128;    // variables per block (their local index fits a byte)
 constexpr int WIDE_MAX_COSTS = WIDE_TPB * 3 / 2;   // variables * D per block
+constexpr int WIDE_MAX_D = 256;       // largest domain of the class (a row of zeros in LDS)
 // (f64: 18 KB of LDS per block, eight blocks per CU: the phases of a block are chains of
 // dependent loads, what hides them is the number of blocks in flight)
 struct WideBlock {
@@ -235,6 +236,7 @@ struct WideBlock {
     int32_t n_slots;
     uint32_t magic;      // ceil(2^32 / D): idx / D == (idx * magic) >> 32 for idx < WIDE_CAPB (D >= 2;
                          // D = 1 does not fit and is handled apart)
+    int64_t cost_off;    // element offset of the first variable's own costs (vcost_off[first_var])
 };
 
 struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY factors

@@ -50,7 +50,32 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
     if (f >= n_factors) return;
     const NaryDesc fd = descs[f];  // wave-uniform: scalar loads
     const int D0 = fd.dom[0], D1 = fd.dom[1], D2 = fd.dom[2];
-    // the lane's record: requested before anything else
+    // one lane per message ELEMENT (two passes cover D0 + D1 + D2 <= 128): request the incoming message
+    // element and what the epilogue needs of the outgoing one (the message sent last, its send counter) ...
+    const int off1 = D0, off2 = D0 + D1, sumd = off2 + D2;
+    int el_i[2], el_d[2], el_cnt[2];
+    T el_prev[2], el_in[2];
+#pragma unroll
+    for (int ps = 0; ps < 2; ++ps) {
+        const int idx = lane + 64 * ps;
+        const int i = (idx >= off1 ? 1 : 0) + (idx >= off2 ? 1 : 0);
+        const int d = idx - (i == 0 ? 0 : i == 1 ? off1 : off2);
+        el_i[ps] = idx < sumd ? i : -1;
+        el_d[ps] = d;
+        el_prev[ps] = el_in[ps] = (T)0;
+        el_cnt[ps] = 0;
+        if (idx < sumd) {
+            const int vo = i == 0 ? fd.v2f_off[0] : i == 1 ? fd.v2f_off[1] : fd.v2f_off[2];
+            const int fo = i == 0 ? fd.f2v_off[0] : i == 1 ? fd.f2v_off[1] : fd.f2v_off[2];
+            el_in[ps] = a.v2f_old[vo + d];
+            if (!a.start) {
+                el_prev[ps] = a.f2v_old[fo + d];
+                el_cnt[ps] = a.cF[fd.edge_base + i];
+            }
+        }
+    }
+    // ... then the lane's record (the loads return in order: the wave can stage the messages while the
+    // table is still on its way)
     uint32_t w[NW];
     {
         const uint8_t* img = a.ctables + fd.tab_off;
@@ -66,32 +91,11 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
             for (int j = 0; j < REST; ++j) w[4 * FULL + j] = r[j];
         }
     }
-    // one lane per message ELEMENT (two passes cover D0 + D1 + D2 <= 128): stage the incoming message,
-    // request what the epilogue needs of the outgoing one (the message sent last, its send counter)
-    const int off1 = D0, off2 = D0 + D1, sumd = off2 + D2;
-    int el_i[2], el_d[2], el_cnt[2];
-    T el_prev[2];
 #pragma unroll
     for (int ps = 0; ps < 2; ++ps) {
-        const int idx = lane + 64 * ps;
-        const int i = (idx >= off1 ? 1 : 0) + (idx >= off2 ? 1 : 0);
-        const int d = idx - (i == 0 ? 0 : i == 1 ? off1 : off2);
-        el_i[ps] = idx < sumd ? i : -1;
-        el_d[ps] = d;
-        el_prev[ps] = (T)0;
-        el_cnt[ps] = 0;
-        if (idx < sumd) {
-            const int vo = i == 0 ? fd.v2f_off[0] : i == 1 ? fd.v2f_off[1] : fd.v2f_off[2];
-            const int fo = i == 0 ? fd.f2v_off[0] : i == 1 ? fd.f2v_off[1] : fd.f2v_off[2];
-            const T x = a.v2f_old[vo + d];
-            // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
-            // outputs to variables 1 and 2, maxsum.py:430-441)
-            s_in[wv][idx] = i == 0 ? (T)0 + x : x;
-            if (!a.start) {
-                el_prev[ps] = a.f2v_old[fo + d];
-                el_cnt[ps] = a.cF[fd.edge_base + i];
-            }
-        }
+        // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
+        // outputs to variables 1 and 2, maxsum.py:430-441)
+        if (el_i[ps] >= 0) s_in[wv][lane + 64 * ps] = el_i[ps] == 0 ? (T)0 + el_in[ps] : el_in[ps];
     }
     __builtin_amdgcn_wave_barrier();
     // the lane's place in the lane grid (L1, L2 powers of two, L0 * L1 * L2 = 64: layout.h)

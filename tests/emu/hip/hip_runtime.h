@@ -365,7 +365,8 @@ inline U __hip_atomic_load(const U* p, int, int) { return *p; }
 template <typename U>
 inline void __hip_atomic_store(U* p, U v, int, int) { *p = v; }
 inline void __builtin_amdgcn_s_sleep(int) {}
-#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __builtin_amdgcn_fence(...) ((void)0)
+inline void __builtin_amdgcn_s_barrier() { hipemu::yield_barrier(); }
 inline void __threadfence() {}
 template <typename U>
 inline U atomicOr(U* addr, U val) { const U old = *addr; *addr = old | val; return old; }

@@ -77,6 +77,8 @@ __device__ __forceinline__ double tod(f2 x) { return (double)x.x + (double)x.y; 
 #define A_SWAP32(i) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(x[i]), "+v"(x[(i + 1) & 7]));
 #define A_ADD_MIN_F64(i) \
     asm volatile("v_add_f64 %0, %1, %2\n\tv_min_f64 %1, %1, %0" : "=&v"(t64), "+v"(x[i]) : "v"(c));
+#define A_ADD_F64_DEP(i) asm volatile("v_add_f64 %0, %0, %1" : "+v"(x[0]) : "v"(c));
+#define A_ADD_F32_DEP(i) asm volatile("v_add_f32 %0, %0, %1" : "+v"(x[0]) : "v"(cf));
 #define A_LSHL_ADD(i) asm volatile("v_lshl_add_u32 %0, %0, 1, %1" : "+v"(x[i]) : "v"(ci));
 #define A_MUL_F64(i) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(x[i]) : "v"(c));
 #define A_FMA_F64(i) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(x[i]) : "v"(c));
@@ -85,6 +87,8 @@ __device__ __forceinline__ double tod(f2 x) { return (double)x.x + (double)x.y; 
 
 KERNEL(k_add_f64, double, 0.0, A_ADD_F64)
 KERNEL(k_min_f64, double, 1e9, A_MIN_F64)
+KERNEL(k_add_f64_dep, double, 0.0, A_ADD_F64_DEP)
+KERNEL(k_add_f32_dep, float, 0.0f, A_ADD_F32_DEP)
 KERNEL(k_max_f64, double, -1e9, A_MAX_F64)
 KERNEL(k_mul_f64, double, 1.0, A_MUL_F64)
 KERNEL(k_fma_f64, double, 1.0, A_FMA_F64)
@@ -213,12 +217,14 @@ int main(int argc, char** argv) {
     const int cus = prop.multiProcessorCount;
     long long* d_ticks;
     double* d_sink;
-    const int max_waves = cus * 4 * 8;
+    const int max_waves = cus * 4 * 8 + 64;
     HIP_OK(hipMalloc(&d_ticks, sizeof(long long) * max_waves));
     HIP_OK(hipMalloc(&d_sink, 8));
     std::vector<Entry> es = {
         {"v_add_f64", k_add_f64, 1},
         {"v_min_f64", k_min_f64, 1},
+        {"v_add_f64 ONE dependent chain", k_add_f64_dep, 1},
+        {"v_add_f32 ONE dependent chain", k_add_f32_dep, 1},
         {"v_max_f64", k_max_f64, 1},
         {"v_mul_f64", k_mul_f64, 1},
         {"v_fma_f64", k_fma_f64, 1},
@@ -251,7 +257,7 @@ int main(int argc, char** argv) {
     };
     printf("{\"device\": \"%s\", \"cus\": %d, \"iters\": %d, \"clock_khz\": %d}\n", prop.name, cus, iters, prop.clockRate);
     for (const Entry& e : es) {
-        for (int W : {1, 2, 4}) {
+        for (int W : {1, 2, 4, 8}) {
             const int blocks = cus * W;  // 256 threads = 4 waves = one per SIMD of a CU
             const int waves = blocks * 4;
             HIP_OK(hipMemset(d_ticks, 0, sizeof(long long) * max_waves));
