@@ -304,6 +304,9 @@ int mxs_run_sharded(mxs_engine *e, int32_t n_cycles);
  *                     mxs_reset needs a barrier over the ranks before it (no peer may
  *                     still be running cycles of the previous run). */
 #define MXS_MAX_PEERS 8
+/* Largest arity of a factor every engine of the library accepts (a table of more than 2^31 entries
+ * cannot be addressed: 30 binary variables; the reference has no limit, maxsum.py:411-421). */
+#define MXS_MAX_ARITY 30
 #define MXS_IPC_HANDLE_BYTES 64
 typedef struct mxs_peer_info {
     int32_t qualifies;

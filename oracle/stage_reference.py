@@ -11,8 +11,10 @@ repository's tree or history:
             travels to the GPU box next to the built `.so` files -- like a compiled reference
             would (`oracle/_ref/` is where the task puts reference build outputs).
   locate()  -> the directory that holds `pydcop/` and `tests/instances/`:
-            $PYDCOP_REFERENCE, else /root/reference, else the archive unpacked ONCE into the
-            machine's temp directory (outside the repository), else None.
+            $PYDCOP_REFERENCE, else /root/reference, else the archive unpacked ONCE into a
+            directory private to the current user (~/.cache/pydcop_amd_reference/<digest of the
+            archive>, mode 0700, outside the repository; checked for ownership and a completion
+            marker before it is reused), else None.
 
 Who may use what this returns: `tests/`, `oracle/ref_harness.py`, `scripts/plugin_on_gpu.sh` (as
 the CALLER of the plug-in: the unmodified `pydcop solve` CLI) and `bench.py`'s `cpu_baseline`
@@ -99,27 +101,45 @@ def stage(source=SOURCE, force=False):
 
 
 def _unpacked_root():
+    """The archive unpacked into a directory of the CURRENT USER (mode 0700, under
+    $XDG_CACHE_HOME or ~/.cache, the system temp directory only as a per-process mkdtemp): a
+    directory found there is used only if this user owns it, nobody else can write to it and a
+    marker written after a complete unpack names the archive's digest -- nothing another local
+    user could have prepared is ever put on sys.path."""
     if not os.path.exists(ARCHIVE):
         return None
-    tag = "x"
+    with open(ARCHIVE, "rb") as f:
+        tag = hashlib.sha256(f.read()).hexdigest()[:24]
+    base = os.environ.get("XDG_CACHE_HOME") or os.path.join(os.path.expanduser("~"), ".cache")
+    cache = os.path.join(base, "pydcop_amd_reference")
     try:
-        with open(MANIFEST) as f:
-            tag = json.load(f)["sha256_of_members"][:16]
-    except (OSError, ValueError, KeyError):
-        st = os.stat(ARCHIVE)
-        tag = f"{st.st_size:x}"
-    root = os.path.join(tempfile.gettempdir(), f"pydcop_reference_{tag}")
-    if os.path.isdir(os.path.join(root, "pydcop")):
-        return root
-    work = tempfile.mkdtemp(prefix="pydcop_reference_unpack_")
+        os.makedirs(cache, mode=0o700, exist_ok=True)
+        st = os.stat(cache)
+        if st.st_uid != os.getuid() or (st.st_mode & 0o022):
+            raise OSError("cache directory not private")
+    except OSError:
+        cache = tempfile.mkdtemp(prefix="pydcop_reference_")   # 0700, owned by this process
+    root = os.path.join(cache, tag)
+    marker = os.path.join(root, ".unpacked")
+    if os.path.isdir(os.path.join(root, "pydcop")) and os.path.exists(marker):
+        st = os.stat(root)
+        with open(marker) as f:
+            ok = f.read().strip() == tag
+        if ok and st.st_uid == os.getuid() and not (st.st_mode & 0o022):
+            return root
+        import shutil
+        shutil.rmtree(root, ignore_errors=True)
+    work = tempfile.mkdtemp(prefix="unpack_", dir=cache)
     with tarfile.open(ARCHIVE, "r:gz") as tar:
         for m in tar.getmembers():   # plain relative files only
             if m.name.startswith(("/", "..")) or ".." in m.name.split("/") or not (m.isfile() or m.isdir()):
                 raise RuntimeError(f"unexpected member in {ARCHIVE}: {m.name}")
         tar.extractall(work)
+    with open(os.path.join(work, ".unpacked"), "w") as f:
+        f.write(tag)
     try:
         os.rename(work, root)
-    except OSError:           # another process unpacked it first
+    except OSError:           # another process of this user unpacked it first
         import shutil
         shutil.rmtree(work, ignore_errors=True)
     return root if os.path.isdir(os.path.join(root, "pydcop")) else None

@@ -890,7 +890,7 @@ struct Engine : Base {
         h_moff.assign(nE + 1, 0);
         std::vector<int32_t> h_efac(nE);
         for (int f = 0; f < nF; ++f) {
-            if (h_frow[f + 1] <= h_frow[f] || h_frow[f + 1] - h_frow[f] > 30) return fail(MXS_E_INVALID, "bad factor arity");
+            if (h_frow[f + 1] <= h_frow[f] || h_frow[f + 1] - h_frow[f] > MXS_MAX_ARITY) return fail(MXS_E_INVALID, "bad factor arity");
             for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) h_efac[e] = f;
         }
         for (int e = 0; e < nE; ++e) {

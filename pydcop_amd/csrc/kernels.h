@@ -79,6 +79,21 @@ __shared__ double g_stage[BLOCK / 64][STAGE_BYTES_PER_WAVE / 8];
 struct Piece16 {  // 16 bytes, moved with one instruction
     unsigned int w[4];
 };
+// one 16-byte piece from the staging area to global memory, non-temporal when the launch streams (NT bit 3)
+template <bool NT_STORE>
+__device__ __forceinline__ void store_piece16(char* dst, const char* src) {
+#if defined(__HIPCC__)
+    if constexpr (NT_STORE) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        __builtin_nontemporal_store(*(const v4u*)__builtin_assume_aligned(src, 16), (v4u*)__builtin_assume_aligned(dst, 16));
+        return;
+    }
+#endif
+    *(Piece16*)__builtin_assume_aligned(dst, 16) = *(const Piece16*)__builtin_assume_aligned(src, 16);
+}
+#ifndef MXS_NT_TIGHT
+#define MXS_NT_TIGHT 1  // the streaming policy's non-temporal stores also on records that are no multiple of 16 bytes
+#endif
 
 // Every lane of the wave holds ELEMS contiguous elements of `arr`, lane l at element
 // wave_base + l * ELEMS.  ELEMS * sizeof(T) is a multiple of 16.  All 64 lanes take part.
@@ -100,12 +115,8 @@ __device__ __forceinline__ void wave_store_linear(T* arr, int64_t wave_base, con
         char* out = (char*)(arr + wave_base);
         constexpr int BYTES = 64 * ELEMS * (int)sizeof(T), FULL = BYTES / 1024, REST = (BYTES % 1024) / 16;
 #pragma unroll
-        for (int k = 0; k < FULL; ++k)
-            *(Piece16*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16) =
-                *(const Piece16*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16);
-        if (REST > 0 && l < REST)
-            *(Piece16*)__builtin_assume_aligned(out + FULL * 1024 + l * 16, 16) =
-                *(const Piece16*)__builtin_assume_aligned(so + FULL * 1024 + l * 16, 16);
+        for (int k = 0; k < FULL; ++k) store_piece16<NT_STORE && MXS_NT_TIGHT>(out + k * 1024 + l * 16, so + k * 1024 + l * 16);
+        if (REST > 0 && l < REST) store_piece16<NT_STORE && MXS_NT_TIGHT>(out + FULL * 1024 + l * 16, so + FULL * 1024 + l * 16);
         return;
     }
     const int w = (int)threadIdx.x >> 6, l = (int)threadIdx.x & 63;
@@ -117,18 +128,7 @@ __device__ __forceinline__ void wave_store_linear(T* arr, int64_t wave_base, con
     char* out = (char*)(arr + wave_base);
     constexpr int PIECES = ELEMS * (int)sizeof(T) / 16;
 #pragma unroll
-    for (int k = 0; k < PIECES; ++k) {
-#if defined(__HIPCC__)
-        if constexpr (NT_STORE) {
-            typedef unsigned int v4u __attribute__((ext_vector_type(4)));
-            __builtin_nontemporal_store(*(const v4u*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16),
-                                        (v4u*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16));
-            continue;
-        }
-#endif
-        *(Piece16*)__builtin_assume_aligned(out + k * 1024 + l * 16, 16) =
-            *(const Piece16*)__builtin_assume_aligned(so + k * 1024 + l * 16, 16);
-    }
+    for (int k = 0; k < PIECES; ++k) store_piece16<NT_STORE>(out + k * 1024 + l * 16, so + k * 1024 + l * 16);
 }
 
 template <typename T>

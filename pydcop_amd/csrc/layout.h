@@ -157,7 +157,7 @@ constexpr int NUM_XCD = 8;  // MI355X: workgroup b of a grid runs on XCD b % 8 (
 constexpr int MAX_REG_D = 4;
 // The reference has no limit on the arity of a constraint (maxsum.py:411-421 walks any scope); a table of
 // more than 2^31 entries cannot be addressed here, so 30 binary variables is the most a factor can have.
-constexpr int MAX_ARITY = 30;
+constexpr int MAX_ARITY = MXS_MAX_ARITY;
 constexpr int MAX_PACK_DEG = 64;  // one wave
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
 

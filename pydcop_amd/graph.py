@@ -134,21 +134,28 @@ class FlatGraph:
     def value_rank(self) -> Optional[np.ndarray]:
         """rank[cost_off[v] + d] = position of the d-th value of v's domain among v's values in ascending
         (Python) order, or None when every domain is written in ascending order / no domain values are
-        known / the values of a domain do not compare.  What the reference's `optimal_cost_value` breaks
-        cost ties on (relations.py:1661-1665: min / max over (cost, value) tuples) -- DSA and MGM start a
-        variable without neighbours there."""
+        known.  What the reference's `optimal_cost_value` breaks cost ties on (relations.py:1661-1665:
+        min / max over (cost, value) tuples) -- DSA and MGM start a variable without neighbours there.
+        Values that do not compare (or cannot be hashed): the reference's tuple comparison would raise on a
+        cost tie; here a warning is logged once and the INDEX order breaks such ties."""
         if self.domains is None:
             return None
         rank = np.empty(int(self.cost_off[-1]), dtype=np.int32)
         off, identity, seen = 0, True, {}
         for values in self.domains:
-            key = tuple(values)            # (instances share a few domains among many variables)
-            r = seen.get(key)
-            if r is None:
-                try:
+            try:
+                key = tuple(values)        # (instances share a few domains among many variables)
+                r = seen.get(key)
+                if r is None:
                     order = sorted(range(len(key)), key=lambda d: key[d])
-                except TypeError:
-                    return None
+            except TypeError:
+                import logging
+                logging.getLogger("pydcop_amd").warning(
+                    "domain values %r neither compare nor hash: cost ties of variables without neighbours "
+                    "(DSA / MGM start values) are broken on the value's INDEX, where the reference compares "
+                    "the values themselves (relations.py:1661-1665)", list(values)[:4])
+                return None
+            if r is None:
                 r = np.empty(len(key), dtype=np.int32)
                 r[order] = np.arange(len(key), dtype=np.int32)
                 seen[key] = r
