@@ -212,7 +212,12 @@ __global__ void __launch_bounds__(TPB) k_dsa_cycle_slots(Dev<T> g) {
         const int D = g.dom_size[v];
         const int s0 = g.var_rowptr[v], s1 = g.var_rowptr[v + 1];
         T c[MAXD];
-        lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, s0, s1, D, true, c);
+        if (g.slots.rows != nullptr && s0 < s1 && g.slots.row_base[s0] >= 0) {  // contiguous rows (local_search.h)
+            if (g.slots.rows_int8) lsearch::costs_of_values_rows<T, int8_t, MAXD>(g.slots, g.cur, s0, s1, D, true, c);
+            else lsearch::costs_of_values_rows<T, T, MAXD>(g.slots, g.cur, s0, s1, D, true, c);
+        } else {
+            lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, s0, s1, D, true, c);
+        }
         T best_cost = g.is_max ? -(T)INFINITY : (T)INFINITY;
         int n_best = 0, first_best = -1;
         bool has_cur = false;
@@ -376,6 +381,10 @@ struct Engine : Base {
     Buf<double> prob;
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
+    Buf<uint8_t> sl_rows;           // the row view of the variables the pack cannot take (local_search.h, Slots::rows)
+    Buf<int64_t> sl_row_base;
+    Buf<int32_t> sl_row_nb_stride, sl_row_nb0_stride;
+    bool have_rows = false;
     Buf<lsearch::PackWave> pk_waves;
     Buf<int32_t> pk_nb, pk_slot, pk_rest, pk_dom, qmap;
     Buf<uint64_t> pk_key;
@@ -503,6 +512,21 @@ struct Engine : Base {
             DSA_TRY(pk_rest.upload(hp.rest, stream));
             DSA_TRY(pk_fopt.upload(fopt_lane, stream));
             n_rest = (int)hp.rest.size();
+            // the row view for them (domains of at most 32 values; $MAXSUM_LOCAL_SEARCH_ROWS=0 leaves it out, the
+            // budget in bytes can be set: A/B runs and tests)
+            {
+                const char* renv = std::getenv("MAXSUM_LOCAL_SEARCH_ROWS");
+                const int64_t budget = renv ? std::atoll(renv) : ((int64_t)6 << 30);
+                have_rows = budget > 0 && max_dom <= 32 && hs.build_rows(hp.rest, h_dom, vrow, h_toff, h_tables, (int)sizeof(T), 32, budget);
+                if (have_rows) {
+                    DSA_TRY(sl_rows.upload(hs.rows, stream));
+                    DSA_TRY(sl_row_base.upload(hs.row_base, stream));
+                    DSA_TRY(sl_row_nb_stride.upload(hs.row_nb_stride, stream));
+                    DSA_TRY(sl_row_nb0_stride.upload(hs.row_nb0_stride, stream));
+                    hs.rows.clear();
+                    hs.rows.shrink_to_fit();
+                }
+            }
             g.pack = lsearch::Pack{pk_waves.p, pk_nb.p, pk_slot.p,
                                    pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
             g.pack_fopt = pk_fopt.p;
@@ -515,7 +539,9 @@ struct Engine : Base {
         DSA_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
         DSA_TRY(sl_conc_var.upload(hs.conc_var, stream));
         g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
-                                 sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p};
+                                 sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p,
+                                 have_rows ? sl_rows.p : nullptr, sl_row_base.p, sl_row_nb_stride.p, sl_row_nb0_stride.p,
+                                 hs.rows_int8 ? 1 : 0};
         DSA_TRY(dom_size.upload(h_dom, stream));
         DSA_TRY(factor_rowptr.upload(h_frow, stream));
         DSA_TRY(edge_var.upload(h_evar, stream));

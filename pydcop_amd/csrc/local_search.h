@@ -17,6 +17,7 @@
 #include <cmath>
 #include <cstdint>
 #include <string>
+#include <thread>
 #include <vector>
 
 namespace lsearch {
@@ -31,11 +32,116 @@ struct Slots {  // device pointers; slot s of variable v: var_rowptr[v] <= s < v
     const int32_t* nb0_stride;  //           none): a binary constraint costs no walk of the list
     const int32_t* conc_rowptr; // [n_vars+1] distinct variables of v's constraints (v included), ascending
     const int32_t* conc_var;
+    // ROW view (HostSlots::build_rows; NULL when not built): a PRIVATE copy of the constraint's table per slot with
+    // the variable's OWN axis last -- the D entries a variable needs of a constraint, for the neighbours' current
+    // values, are ONE contiguous row of round_up(D * elem, 8) bytes instead of D entries a stride apart (24 cache
+    // lines per constraint on the 24^3 tables of meeting_50k).  int8 when every entry is a small integer, else T.
+    const uint8_t* rows;
+    const int64_t* row_base;        // [n_slots] byte offset of the slot's copy, -1: none
+    const int32_t* row_nb_stride;   // per entry of nb_var: that variable's stride among the OTHER variables, in rows
+    const int32_t* row_nb0_stride;  // [n_slots] the first one's again
+    int32_t rows_int8;
 };
 
 struct HostSlots {
     std::vector<int64_t> base;
     std::vector<int32_t> stride_v, nb_rowptr, nb_var, nb_stride, nb0_var, nb0_stride, conc_rowptr, conc_var;
+    // the row view (Slots::rows), for the variables of `vars` -- built when it fits `budget` bytes
+    std::vector<uint8_t> rows;
+    std::vector<int64_t> row_base;
+    std::vector<int32_t> row_nb_stride, row_nb0_stride;
+    bool rows_int8 = false;
+
+    static bool small_int(double e) { return e >= -128.0 && e <= 127.0 && e == (double)(int)e && !(e == 0.0 && std::signbit(e)); }
+
+    // word: sizeof(T) of the engine.  Returns true when the view was built.
+    bool build_rows(const std::vector<int32_t>& vars, const std::vector<int32_t>& dom, const std::vector<int32_t>& vrow,
+                    const std::vector<int64_t>& toff, const std::vector<double>& tables, int word, int max_dom,
+                    int64_t budget) {
+        const size_t nS = base.size();
+        row_base.assign(nS, -1);
+        row_nb_stride.assign(nb_var.size(), 0);
+        row_nb0_stride.assign(nS, 0);
+        rows.clear();
+        if (vars.empty()) return false;
+        // every table a slot of these variables reads: small integers?
+        rows_int8 = true;
+        for (int v : vars)
+            if (dom[v] > max_dom) return false;
+        // (which tables: found through base[] == table_off of the constraint)
+        {
+            for (int v : vars)
+                for (int s = vrow[v]; s < vrow[v + 1] && rows_int8; ++s) {
+                    int64_t n = dom[v];
+                    for (int k = nb_rowptr[s]; k < nb_rowptr[s + 1]; ++k) n *= dom[nb_var[k]];
+                    const double* t = tables.data() + base[s];
+                    for (int64_t i = 0; i < n; ++i)
+                        if (!small_int(t[i])) {
+                            rows_int8 = false;
+                            break;
+                        }
+                }
+        }
+        const int elem = rows_int8 ? 1 : word;
+        int64_t bytes = 0;
+        for (int v : vars) {
+            const int64_t rs = ((int64_t)dom[v] * elem + 7) / 8 * 8;
+            for (int s = vrow[v]; s < vrow[v + 1]; ++s) {
+                int64_t R = 1;
+                for (int k = nb_rowptr[s]; k < nb_rowptr[s + 1]; ++k) R *= dom[nb_var[k]];
+                row_base[s] = bytes;
+                bytes += R * rs;
+            }
+        }
+        if (bytes > budget) {
+            row_base.assign(nS, -1);
+            return false;
+        }
+        rows.assign((size_t)bytes + 8, 0);
+        // fill, a few host threads over the variables
+        auto fill = [&](size_t lo, size_t hi) {
+            std::vector<int> digit;
+            for (size_t vi = lo; vi < hi; ++vi) {
+                const int v = vars[vi], D = dom[v];
+                const int64_t rs = ((int64_t)D * elem + 7) / 8 * 8;
+                for (int s = vrow[v]; s < vrow[v + 1]; ++s) {
+                    const int k0 = nb_rowptr[s], k1 = nb_rowptr[s + 1], no = k1 - k0;
+                    // nb_var lists the other variables from the LAST scope position to the first (build()): the row
+                    // index keeps that order of significance -- first listed = fastest
+                    int64_t R = 1;
+                    for (int k = k0; k < k1; ++k) {
+                        row_nb_stride[k] = (int32_t)R;
+                        R *= dom[nb_var[k]];
+                    }
+                    row_nb0_stride[s] = no > 0 ? row_nb_stride[k0] : 0;
+                    digit.assign(no, 0);
+                    int64_t src = base[s];
+                    uint8_t* dst = rows.data() + row_base[s];
+                    for (int64_t r = 0; r < R; ++r) {
+                        for (int x = 0; x < D; ++x) {
+                            const double e = tables[src + (int64_t)x * stride_v[s]];
+                            if (elem == 1) ((int8_t*)dst)[x] = (int8_t)e;
+                            else if (elem == 4) ((float*)dst)[x] = (float)e;
+                            else ((double*)dst)[x] = e;
+                        }
+                        dst += rs;
+                        for (int k = 0; k < no; ++k) {  // next combination of the others
+                            src += nb_stride[k0 + k];
+                            if (++digit[k] < dom[nb_var[k0 + k]]) break;
+                            src -= (int64_t)nb_stride[k0 + k] * digit[k];
+                            digit[k] = 0;
+                        }
+                    }
+                }
+            }
+        };
+        const unsigned hw = std::thread::hardware_concurrency();
+        const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, vars.size() / 64 + 1}));
+        std::vector<std::thread> pool;
+        for (size_t t = 0; t < nt; ++t) pool.emplace_back(fill, vars.size() * t / nt, vars.size() * (t + 1) / nt);
+        for (std::thread& th : pool) th.join();
+        return true;
+    }
 
     // "" or what is wrong with the instance
     std::string build(int nV, int nF, const std::vector<int32_t>& dom, const std::vector<int32_t>& frow,
@@ -139,6 +245,63 @@ __device__ inline void costs_of_values(const Slots& sl, const T* __restrict__ ta
 #pragma unroll
                 for (int x = 0; x < MAXD; ++x) c[x] = first ? t[i][x] : c[x] + t[i][x];
             }
+    }
+}
+
+// The same costs from the ROW view (Slots::rows): per slot one index (the neighbours' current values in the
+// slot's private copy) and ONE contiguous row of D entries, read in 8-byte pieces -- two slots' rows in flight
+// together.  int8 rows: integer sums, converted once (every entry is an integer in [-128, 127], at most a few
+// thousand of them per variable: every partial sum of the reference's left-to-right fold is an integer far below
+// 2^24, exact in f32 and f64 whatever the order -- the argument of pack_costs).
+template <typename T, typename TT, int MAXD>
+__device__ inline void costs_of_values_rows(const Slots& sl, const int32_t* __restrict__ cur, int s0, int s1, int D,
+                                            bool from_zero, T (&c)[MAXD]) {
+    constexpr int EPP = 8 / (int)sizeof(TT);             // entries per 8-byte piece
+    constexpr int NP = (MAXD + EPP - 1) / EPP;
+    const int np = (D + EPP - 1) / EPP;
+    const int64_t rs = (int64_t)np * 8;
+    int ci[MAXD];
+#pragma unroll
+    for (int x = 0; x < MAXD; ++x) {
+        c[x] = (T)0;
+        ci[x] = 0;
+    }
+    for (int s = s0; s < s1; s += 2) {
+        uint64_t w[2][NP];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int si = s + i < s1 ? s + i : s1 - 1;
+            int64_t ridx = (int64_t)cur[sl.nb0_var[si]] * sl.row_nb0_stride[si];
+            for (int k = sl.nb_rowptr[si] + 1; k < sl.nb_rowptr[si + 1]; ++k) ridx += (int64_t)cur[sl.nb_var[k]] * sl.row_nb_stride[k];
+            const uint64_t* r = (const uint64_t*)(sl.rows + sl.row_base[si] + ridx * rs);
+#pragma unroll
+            for (int q = 0; q < NP; ++q) w[i][q] = r[q < np ? q : np - 1];
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            if (s + i < s1) {
+                const bool first = !from_zero && s + i == s0;
+#pragma unroll
+                for (int x = 0; x < MAXD; ++x) {
+                    if constexpr (sizeof(TT) == 1) {
+                        ci[x] += (int)(int8_t)(uint8_t)(w[i][x / 8] >> (8 * (x % 8)));
+                    } else {
+                        TT e;
+                        const uint64_t piece = w[i][x / EPP] >> (8 * (int)sizeof(TT) * (x % EPP));
+                        if constexpr (sizeof(TT) == 8) {
+                            __builtin_memcpy(&e, &piece, 8);
+                        } else {
+                            const uint32_t lo = (uint32_t)piece;
+                            __builtin_memcpy(&e, &lo, 4);
+                        }
+                        c[x] = first ? (T)e : c[x] + (T)e;
+                    }
+                }
+            }
+    }
+    if constexpr (sizeof(TT) == 1) {
+#pragma unroll
+        for (int x = 0; x < MAXD; ++x) c[x] = (T)ci[x];
     }
 }
 

@@ -240,7 +240,15 @@ __global__ void __launch_bounds__(TPB) k_mgm_gain_slots(Dev<T> g, T* cost_rw) {
     if (g.n_neigh[v] == 0) return;
     const int D = g.dom_size[v];
     T c[MAXD];
-    lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, g.var_rowptr[v], g.var_rowptr[v + 1], D, false, c);
+    {
+        const int s0 = g.var_rowptr[v], s1 = g.var_rowptr[v + 1];
+        if (g.slots.rows != nullptr && s0 < s1 && g.slots.row_base[s0] >= 0) {  // contiguous rows (local_search.h)
+            if (g.slots.rows_int8) lsearch::costs_of_values_rows<T, int8_t, MAXD>(g.slots, g.cur, s0, s1, D, false, c);
+            else lsearch::costs_of_values_rows<T, T, MAXD>(g.slots, g.cur, s0, s1, D, false, c);
+        } else {
+            lsearch::costs_of_values<T, MAXD>(g.slots, g.tables, g.cur, s0, s1, D, false, c);
+        }
+    }
     const int qv = g.q[v];
     T cost = cost_rw[qv];
     if (!g.has_cost[qv]) {
@@ -468,6 +476,10 @@ struct Engine : Base {
     Buf<uint8_t> has_cost;
     Buf<int64_t> sl_base;
     Buf<int32_t> sl_stride_v, sl_nb_rowptr, sl_nb_var, sl_nb_stride, sl_nb0_var, sl_nb0_stride, sl_conc_rowptr, sl_conc_var;
+    Buf<uint8_t> sl_rows;           // the row view of the variables the pack cannot take (local_search.h, Slots::rows)
+    Buf<int64_t> sl_row_base;
+    Buf<int32_t> sl_row_nb_stride, sl_row_nb0_stride;
+    bool have_rows = false;
     Buf<lsearch::PackWave> pk_waves;
     Buf<int32_t> pk_nb, pk_slot, pk_rest, pk_conc, pk_conc_x, pk_dom, qmap;
     Buf<int8_t> pk_rec8;
@@ -594,6 +606,21 @@ struct Engine : Base {
             MGM_TRY(pk_conc.upload(to_q(conc), stream));
             MGM_TRY(pk_conc_x.upload(to_q(conc_x), stream));
             n_rest = (int)hp.rest.size();
+            // the row view for them (domains of at most 32 values; $MAXSUM_LOCAL_SEARCH_ROWS=0 leaves it out, the
+            // budget in bytes can be set: A/B runs and tests)
+            {
+                const char* renv = std::getenv("MAXSUM_LOCAL_SEARCH_ROWS");
+                const int64_t budget = renv ? std::atoll(renv) : ((int64_t)6 << 30);
+                have_rows = budget > 0 && max_dom <= 32 && hs.build_rows(hp.rest, h_dom, vrow, h_toff, h_tables, (int)sizeof(T), 32, budget);
+                if (have_rows) {
+                    MGM_TRY(sl_rows.upload(hs.rows, stream));
+                    MGM_TRY(sl_row_base.upload(hs.row_base, stream));
+                    MGM_TRY(sl_row_nb_stride.upload(hs.row_nb_stride, stream));
+                    MGM_TRY(sl_row_nb0_stride.upload(hs.row_nb0_stride, stream));
+                    hs.rows.clear();
+                    hs.rows.shrink_to_fit();
+                }
+            }
             g.pack = lsearch::Pack{pk_waves.p, pk_nb.p, pk_slot.p,
                                    pack_int8 ? (const void*)pk_rec8.p : (const void*)pk_recT.p, (int32_t)hp.nb.size()};
             g.pack_conc = pk_conc.p;
@@ -601,7 +628,9 @@ struct Engine : Base {
         }
         MGM_TRY(sl_conc_rowptr.upload(hs.conc_rowptr, stream));
         g.slots = lsearch::Slots{sl_base.p, sl_stride_v.p, sl_nb_rowptr.p, sl_nb_var.p, sl_nb_stride.p,
-                                 sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p};
+                                 sl_nb0_var.p, sl_nb0_stride.p, sl_conc_rowptr.p, sl_conc_var.p,
+                                 have_rows ? sl_rows.p : nullptr, sl_row_base.p, sl_row_nb_stride.p, sl_row_nb0_stride.p,
+                                 hs.rows_int8 ? 1 : 0};
         MGM_TRY(dom_size.upload(h_dom, stream));
         MGM_TRY(factor_rowptr.upload(h_frow, stream));
         MGM_TRY(edge_var.upload(h_evar, stream));

@@ -48,3 +48,15 @@ def test_dsa_slot_kernel_everywhere(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
     name, make, kw, dsa_kw = case
     compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw)
+
+
+@pytest.mark.parametrize("case", [c for c in dsa_cases() if c[0].startswith(("meeting", "mixed_arity3"))], ids=lambda c: c[0])
+def test_dsa_strided_slots_without_the_row_view(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_ROWS=0: no private row copies (local_search.h, Slots::rows) -- the variables the pack cannot
+    take read their D entries per constraint a stride apart, the path of instances whose copies exceed the budget.
+    (The default run of the same cases takes the row view: int8 rows for the meeting tables, T rows for the mixed ones.)"""
+    
+    from oracle.dsa_oracle import OracleDsa
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_ROWS", "0")
+    name, make, kw, dsa_kw = case
+    compare_dsa(OracleDsa, make(), Params(**kw), dsa_kw, steps=(0, 1, 3, 6))

@@ -49,3 +49,14 @@ def test_mgm_slot_kernels_everywhere(case, oracle_built, monkeypatch):
     monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_GENERIC", "2")
     name, make, kw = case
     compare_mgm(OracleMgm, make(), Params(**kw))
+
+
+@pytest.mark.parametrize("case", [c for c in mgm_cases() if c[0].startswith(("meeting", "mixed"))], ids=lambda c: c[0])
+def test_mgm_strided_slots_without_the_row_view(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_ROWS=0: no private row copies (local_search.h, Slots::rows) -- the strided slot reads, the
+    path of instances whose copies exceed the budget."""
+    
+    from oracle.mgm_oracle import OracleMgm
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_ROWS", "0")
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(**kw), steps=(0, 1, 3, 6))

@@ -36,3 +36,13 @@ def test_mgm_emu_slot_kernels_everywhere(case, oracle_built, monkeypatch):
     name, make, kw = case
     compare_mgm(OracleMgm, make(), Params(**kw), lib_path=build(), steps=(0, 1, 3, 6))
 
+
+@pytest.mark.parametrize("case", [c for c in mgm_cases() if c[0].startswith(("meeting", "mixed"))], ids=lambda c: c[0])
+def test_mgm_emu_strided_slots_without_the_row_view(case, oracle_built, monkeypatch):
+    """MAXSUM_LOCAL_SEARCH_ROWS=0: no private row copies (local_search.h, Slots::rows) -- the strided slot reads, the
+    path of instances whose copies exceed the budget."""
+    from emu.build_emu import build
+    from oracle.mgm_oracle import OracleMgm
+    monkeypatch.setenv("MAXSUM_LOCAL_SEARCH_ROWS", "0")
+    name, make, kw = case
+    compare_mgm(OracleMgm, make(), Params(**kw), lib_path=build(), steps=(0, 1, 3, 6))
