@@ -1435,65 +1435,20 @@ struct Engine : EngineBase {
         const char* env = getenv("MAXSUM_SHARD_DIRECT");
         if ((env && env[0] == '0') || send_buf != halo_send.p) return MXS_OK;
         const int nE = L.n_edges;
-        // (1) every sent edge is a lane of a packed variable class, and is sent once
-        std::vector<int32_t> slot(L.vell.size(), -1);
-        std::vector<const ClassInfo*> packed;
-        for (const ClassInfo& ci : L.classes)
-            if (ci.kind == K_V_PACK) packed.push_back(&ci);
-        for (size_t i = 0; i < send_ei.size(); ++i) {
-            const int64_t off = L.v2f_off[send_ei[i]];
-            const ClassInfo* home = nullptr;
-            for (const ClassInfo* ci : packed)
-                if (off >= ci->v2f_base && off < ci->v2f_base + (int64_t)ci->count * ci->H) home = ci;
-            if (!home) return MXS_OK;
-            const int64_t pos = home->ell_base + (off - home->v2f_base) / home->H;
-            if (slot[pos] >= 0) return MXS_OK;  // an edge of an n-ary cut factor going to two shards
-            slot[pos] = (int32_t)i;
-        }
-        // (2) the received edges are exactly the edges of the ghost variables, each once
-        std::vector<uint8_t> is_ghost_edge(nE, 0), seen(nE, 0);
-        int64_t n_ghost = 0, g0 = INT64_MAX, ghost_len = 0;
+        // (1)-(3) what both exchanges need (plan_direct): every sent edge is a lane of a packed variable class
+        // and is sent once, the received edges are exactly the ghost edges, the per-peer ranges, one record length
+        std::vector<int32_t> slot;
+        int64_t g_len = 0;
+        int Hs = 0;
+        if (!plan_direct(slot, g_len, Hs)) return MXS_OK;
+        // here the ghost records stay in the V2F array itself: they must be one block of it
+        int64_t n_ghost = 0, g0 = INT64_MAX;
         for (int ei = 0; ei < nE; ++ei)
             if (!L.owned[L.edge_var_int[ei]]) {
-                is_ghost_edge[ei] = 1;
                 ++n_ghost;
                 g0 = std::min<int64_t>(g0, L.v2f_off[ei]);
-                ghost_len += L.edge_half[ei];
             }
-        if ((int64_t)recv_ei.size() != n_ghost) return MXS_OK;
-        for (int32_t ei : recv_ei) {
-            if (!is_ghost_edge[ei] || seen[ei]) return MXS_OK;
-            seen[ei] = 1;
-        }
-        if (n_ghost && g0 + ghost_len > L.v2f_elems) return MXS_OK;  // the ghost slots are not one block
-        // (3) per-peer edge ranges from the per-peer element counts
-        auto split = [&](const std::vector<int32_t>& edges, const std::vector<int64_t>& cnt,
-                         std::vector<int64_t>& pcnt, std::vector<int64_t>& pat) -> bool {
-            pcnt.assign(comm_world, 0);
-            pat.assign(comm_world, 0);
-            size_t i = 0;
-            int64_t at = 0;
-            for (int q = 0; q < comm_world; ++q) {
-                pat[q] = at;
-                int64_t left = cnt[q];
-                while (left > 0 && i < edges.size()) {
-                    left -= L.edge_dom[edges[i]];
-                    pcnt[q] += L.edge_half[edges[i]];
-                    ++i;
-                }
-                if (left != 0) return false;
-                at += pcnt[q];
-            }
-            return i == edges.size();
-        };
-        if (!split(send_ei, send_cnt, psend_cnt, psend_at) || !split(recv_ei, recv_cnt, precv_cnt, precv_at))
-            return MXS_OK;
-        // uniform record length on the send side (the lane writes send_out + slot * H)
-        int Hs = 0;
-        for (int32_t ei : send_ei) {
-            if (Hs == 0) Hs = L.edge_half[ei];
-            if (L.edge_half[ei] != Hs) return MXS_OK;
-        }
+        if (n_ghost && g0 + g_len > L.v2f_elems) return MXS_OK;
         n_send_pad = (int64_t)send_ei.size() * Hs;
         { int rc = sync(); if (rc) return rc; }
         // (4) ghost slots in receive order
@@ -1570,14 +1525,14 @@ struct Engine : EngineBase {
 
     bool peer_mode() const override { return p2p; }
 
-    // Split the halo lists by peer and lay the ghost records out in receive order (shared with
-    // the direct RCCL exchange).  false: the shard does not qualify.
-    bool plan_direct(int world, const int64_t* sc, const int64_t* rc, std::vector<int32_t>& slot,
-                     int64_t& g_len, int& Hs) {
+    // ONE planner for the direct RCCL exchange (setup_direct) and the peer-store exchange (peer_export), from
+    // comm_world / send_cnt / recv_cnt: the lanes' slots in the send buffer (every sent edge is a lane of a packed
+    // variable class and is sent once), the received edges = the ghost edges, each once (g_len = their elements),
+    // the halo lists split by peer (psend_* / precv_*), one record length on the send side (Hs).
+    // false: the shard does not qualify (pack / unpack kernels and the compact staging buffers stay in use).
+    bool plan_direct(std::vector<int32_t>& slot, int64_t& g_len, int& Hs) {
         const int nE = L.n_edges;
-        comm_world = world;
-        send_cnt.assign(sc, sc + world);
-        recv_cnt.assign(rc, rc + world);
+        const int world = comm_world;
         slot.assign(L.vell.size(), -1);
         std::vector<const ClassInfo*> packed;
         for (const ClassInfo& ci : L.classes)
@@ -1652,7 +1607,10 @@ struct Engine : EngineBase {
         for (int c : L.sweep_order2) ok = ok && L.classes[c].kind == K_F_BIN;
         std::vector<int32_t> slot;
         int Hs = 0;
-        ok = ok && plan_direct(world, sc, rc, slot, ghost_len, Hs);
+        comm_world = world;
+        send_cnt.assign(sc, sc + world);
+        recv_cnt.assign(rc, rc + world);
+        ok = ok && plan_direct(slot, ghost_len, Hs);
         ok = ok && L.v2f_elems + ghost_len < ((int64_t)1 << 31) - 8192;
         const char* env = getenv("MAXSUM_SHARD_P2P");
         if (env && env[0] == '0') ok = false;
