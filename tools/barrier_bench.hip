@@ -83,6 +83,44 @@ __global__ void __launch_bounds__(BLOCK) k_persistent(v4f* a, v4f* b, int nb, in
     }
 }
 
+// (e) ONE XCD: a launch of 8 * W workgroups of which only those with blockIdx % 8 == 0 work
+// (workgroup b runs on XCD b % 8: W workgroups on the 32 CUs of XCD 0), each walking the cycle's nb virtual
+// blocks w, w + W, ...; the barrier is one counter in THAT XCD's L2 (atomics without system / agent scope bits are
+// executed in the L2 every CU of the XCD shares), the data a workgroup did not write itself is read with
+// non-temporal loads (they bypass the per-CU L1, which another CU's stores do not invalidate).
+template <bool WORK, int HALF>  // HALF: 1 = the f32-sized working set (half the bytes per virtual block)
+__global__ void __launch_bounds__(BLOCK) k_persistent_one_xcd(v4f* a, v4f* b, int nb, int cycles, unsigned* bar, int W) {
+    if ((blockIdx.x & 7) != 0) return;
+    const int w = (int)blockIdx.x >> 3;
+    unsigned* ctr = bar + 16 * 10;
+    for (int c = 0; c < cycles; ++c) {
+        if (WORK) {
+            const v4f* in = (c & 1) ? b : a;
+            v4f* out = (c & 1) ? a : b;
+            for (int vb = w; vb < nb; vb += W) {
+                const int src = (int)(((unsigned)vb * 37u + 11u) % (unsigned)nb);
+                const v4f* p = in + (size_t)src * (RD * BLOCK) + threadIdx.x;
+                v4f acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int r = 0; r < RD / (1 + HALF); ++r) acc += __builtin_nontemporal_load(p + r * BLOCK);
+                v4f* q = out + (size_t)vb * (RD * BLOCK) + threadIdx.x;
+#pragma unroll
+                for (int k = 0; k < WR / (1 + HALF); ++k) q[k * BLOCK] = acc + (float)k;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned want = (unsigned)(c + 1) * (unsigned)W;
+            // (polled with an agent-scope load: served by the L2, never by this CU's L1; bounded: a bug must not hang the GPU)
+            for (int spin = 0; spin < (1 << 14) && __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want; ++spin)
+                __builtin_amdgcn_s_sleep(1);
+        }
+        __syncthreads();
+    }
+}
+
 int main(int argc, char** argv) {
     const int nb = argc > 1 ? atoi(argv[1]) : 236;
     const int K = 2048;
@@ -135,6 +173,23 @@ int main(int argc, char** argv) {
             CHECK(hipEventRecord(e1, s));
             const float t = ms();
             if (rep) printf("{\"bench\": \"%s\", \"workgroups\": %d, \"us_per_cycle\": %.3f}\n", v.name, nb, 1e3 * t / K);
+        }
+    }
+    // (e) one XCD: W workgroups on the 32 CUs of XCD 0
+    for (int W : {32, 64, 128}) {
+        struct V1 { const char* name; void (*k)(v4f*, v4f*, int, int, unsigned*, int); };
+        const V1 v1[3] = {{"one_xcd_persistent", k_persistent_one_xcd<true, 0>}, {"one_xcd_persistent_f32_bytes", k_persistent_one_xcd<true, 1>},
+                          {"one_xcd_barrier_alone", k_persistent_one_xcd<false, 0>}};
+        for (const V1& v : v1) {
+            for (int rep = 0; rep < 2; ++rep) {
+                CHECK(hipMemsetAsync(bar, 0, 4096, s));
+                CHECK(hipEventRecord(e0, s));
+                hipLaunchKernelGGL(v.k, dim3(8 * W), dim3(BLOCK), 0, s, a, b, nb, K / 4, bar, W);
+                CHECK(hipEventRecord(e1, s));
+                const float t = ms();
+                if (rep) printf("{\"bench\": \"%s\", \"virtual_blocks\": %d, \"workgroups_on_the_xcd\": %d, \"us_per_cycle\": %.3f}\n", v.name, nb, W, 1e3 * t / (K / 4));
+                fflush(stdout);
+            }
         }
     }
     return 0;
