@@ -358,11 +358,18 @@ def other_algorithms(n_vars, device=0):
     with AMaxSumEngine(g, Params(start_messages="leafs_vars"), device=device) as eng:
         t0 = time.perf_counter()
         done = eng.run(gens)
+        dt_first = time.perf_counter() - t0   # a fresh engine: kernel code loads, the queues' buffers grow (hipMalloc)
+        eng.reset()                           # like the warm-up of every other row: the buffers stay allocated
+        t0 = time.perf_counter()
+        done = eng.run(gens)
         dt = time.perf_counter() - t0
         D = int(g.dom_size.max())
         per_msg = 2 * (D * 8 + 16)   # payload + (destination, slot) record, written once and read once
+        # (round 4: a message IS one 32-byte record -- header + payload -- produced once, gathered into destination order
+        # once, delivered once; the formula is kept so that the fraction stays comparable across rounds)
         out.append({"algo": "amaxsum (FIFO generations)", "workload": "coloring_100k", "n_vars": g.n_vars, "dtype": "f64",
                     "generations": gens, "messages": int(done), "messages_per_s": done / max(dt, 1e-12),
+                    "messages_per_s_first_run": done / max(dt_first, 1e-12),
                     "largest_generation": int(eng.generation_sizes().max()) if done else 0,
                     "roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBPS,
                                  "achieved": done * per_msg / max(dt, 1e-12) / 1e9,

@@ -14,13 +14,20 @@
 //   k_dest      per message: its destination computation and how many messages its handler
 //               can send at most (the destination's other neighbours)
 //   scan        exclusive sum of those capacities = the message's block of output slots, in
-//               FIFO order
-//   sort        stable radix sort of the messages by destination (hipCUB)
-//   k_process   one thread per destination: handles ITS messages one after the other in FIFO
+//               FIFO order; k_stamp writes it into the message's record
+//   sort        stable radix sort of (destination, FIFO index) by destination (hipCUB)
+//   k_permute   the records themselves gathered into destination order (round 4): a queue is a
+//               contiguous run, a delivery one sequential 32-byte read
+//   k_process   a lane / lane group per destination, a kernel and a stream per destination class
+//               (they run side by side): handles ITS messages one after the other in FIFO
 //               order, exactly like the reference's handler (same expressions, same order of
 //               additions -- select_value in first-arrival order of the factors, maxsum.py:609),
-//               writing what it sends into the trigger's output slots
+//               writing what it sends as one record into the trigger's output slots
 //   compact     the slots that hold a message, in slot order = the FIFO order of generation g + 1
+//
+// A message is ONE record (8-byte header + payload, 32 bytes for three f64 values): the generations
+// are bound by the number of random cache lines they touch (~32 G lines/s measured), and three
+// parallel arrays (code, slot, payload) cost three lines per delivery and two per produced message.
 //
 // Nothing here is a dense contraction: integer bookkeeping + a few adds per message element.
 // The run ends by itself when the send rule (approx_match + SAME_COUNT) has silenced every edge.
@@ -75,6 +82,7 @@ struct Buf {
 template <typename T>
 struct Dev {  // what the kernels see
     int32_t n_vars, n_factors, n_edges, dmax, is_max, start_mode, damp_f, damp_v;
+    int32_t rs;  // elements of T per queue record (rec_stride)
     T damping, stability;
     const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *init_idx;
     const int64_t *table_off, *cost_off, *msg_off;
@@ -100,6 +108,34 @@ __device__ __forceinline__ bool comp_match(T c, T prev_c, T stability) {
         }
     }
     return true;
+}
+
+// A message of the queues is ONE record: an 8-byte header (code = edge * 2 + direction, the first output slot of its
+// handler) followed by the payload, padded to a multiple of 16 bytes (D = 3 in f64: 32 bytes).  Producing or
+// delivering a message then touches one cache line at a random place, not three arrays' worth -- the generations are
+// bound by how many random lines they touch (profiles/r04_amaxsum_dispatches_v2.txt: 32 G lines/s).
+template <typename T>
+struct RecHead {
+    static constexpr int W = 8 / (int)sizeof(T);  // header length in elements of T
+};
+inline int rec_stride(int dmax, int word) { return (8 + dmax * word + 15) / 16 * 16 / word; }
+template <typename T>
+__device__ __forceinline__ int32_t rec_code(const T* r) { return ((const int32_t*)r)[0]; }
+template <typename T>
+__device__ __forceinline__ int32_t rec_base(const T* r) { return ((const int32_t*)r)[1]; }
+template <typename T>
+__device__ __forceinline__ void rec_set_head(T* r, int32_t code, int32_t base) {
+    ((int32_t*)r)[0] = code;
+    ((int32_t*)r)[1] = base;
+}
+template <typename T>
+__device__ __forceinline__ T* rec_pay(T* r) { return r + RecHead<T>::W; }
+template <typename T>
+__device__ __forceinline__ const T* rec_pay(const T* r) { return r + RecHead<T>::W; }
+// payload elements past the message's D values up to the end of the record: zeros
+template <typename T>
+__device__ __forceinline__ void rec_pad(const Dev<T>& g, T* r, int D) {
+    for (int d = RecHead<T>::W + D; d < g.rs; ++d) r[d] = (T)0;
 }
 
 // factor_costs_for_var (maxsum.py:382-447), value d of the variable at scope position pos:
@@ -286,7 +322,7 @@ __global__ void k_start_count(Dev<T> g, int32_t* cnt) {  // cnt[node] = start me
 }
 
 template <typename T>
-__global__ void k_start_emit(Dev<T> g, const int32_t* base, int32_t* q_code, T* q_pay) {
+__global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < g.n_vars) {
         const int v = i;
@@ -301,8 +337,9 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, int32_t* q_code, T* 
         if (!sends) return;
         for (int k = 0; k < deg; ++k) {
             const int64_t at = (int64_t)base[i] + k;
-            costs_for_factor(g, v, k0 + k, q_pay + at * g.dmax);
-            q_code[at] = g.var_edges[k0 + k] * 2;
+            T* r = q_rec + at * g.rs;  // (the queue was zero-filled: header base, payload padding)
+            costs_for_factor(g, v, k0 + k, rec_pay(r));
+            rec_set_head(r, g.var_edges[k0 + k] * 2, 0);
         }
     } else if (i < g.n_vars + g.n_factors) {
         const int f = i - g.n_vars;
@@ -311,18 +348,20 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, int32_t* q_code, T* 
         if (!sends) return;
         for (int p = 0; p < ar; ++p) {
             const int64_t at = (int64_t)base[i] + p;
-            factor_message_any(g, f, p, q_pay + at * g.dmax);
-            q_code[at] = (e0 + p) * 2 + 1;
+            T* r = q_rec + at * g.rs;
+            factor_message_any(g, f, p, rec_pay(r));
+            rec_set_head(r, (e0 + p) * 2 + 1, 0);
         }
     }
 }
 
 // ---- one generation --------------------------------------------------------------------------
 template <typename T>
-__global__ void k_dest(Dev<T> g, const int32_t* q_code, int64_t n, int32_t* dest, int32_t* cap) {
+__global__ void k_dest(Dev<T> g, const T* q_rec, int64_t n, int32_t* dest, int32_t* cap) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const int e = q_code[i] >> 1, dir = q_code[i] & 1;
+    const int32_t code = rec_code(q_rec + i * g.rs);
+    const int e = code >> 1, dir = code & 1;
     if (dir == 0) {
         const int f = g.edge_factor[e];
         dest[i] = g.n_vars + f;
@@ -335,7 +374,10 @@ __global__ void k_dest(Dev<T> g, const int32_t* q_code, int64_t n, int32_t* dest
 }
 
 template <typename T>
-__device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_code, T* s_pay, bool last) {
+__device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, bool last) {
+    const int32_t code = rec_code(rec);
+    const T* pay = rec_pay(rec);
+    T* s_out = s_rec + (int64_t)rec_base(rec) * g.rs;  // the handler's output slots
     const int e = code >> 1;
     const int v = g.edge_var[e], f = g.edge_factor[e];
     const int D = g.dom_size[v];
@@ -352,10 +394,13 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
             const int e2 = e0 + p;
             if (e2 == e) continue;  // not back to the sender
             const int D2 = g.dom_size[g.edge_var[e2]];
-            T* out = s_pay + (int64_t)slot * g.dmax;
+            T* orec = s_out + (int64_t)slot * g.rs;
+            T* out = rec_pay(orec);
             factor_message_any(g, f, p, out);
-            if (damp_and_decide(g, out, g.f_prev + g.msg_off[e2], &g.f_cnt[e2], D2, g.damp_f != 0))
-                s_code[slot] = e2 * 2 + 1;
+            if (damp_and_decide(g, out, g.f_prev + g.msg_off[e2], &g.f_cnt[e2], D2, g.damp_f != 0)) {
+                rec_pad(g, orec, D2);
+                rec_set_head(orec, e2 * 2 + 1, 0);
+            }
             ++slot;
         }
     } else {  // factor -> variable: amaxsum.py:366-424
@@ -373,10 +418,13 @@ __device__ void handle(const Dev<T>& g, int32_t code, const T* pay, int32_t* s_c
         for (int k = k0; k < k1; ++k) {
             const int e2 = g.var_edges[k];
             if (e2 == e) continue;
-            T* out = s_pay + (int64_t)slot * g.dmax;
+            T* orec = s_out + (int64_t)slot * g.rs;
+            T* out = rec_pay(orec);
             costs_for_factor(g, v, k, out);
-            if (damp_and_decide(g, out, g.v_prev + g.msg_off[e2], &g.v_cnt[e2], D, g.damp_v != 0))
-                s_code[slot] = e2 * 2;
+            if (damp_and_decide(g, out, g.v_prev + g.msg_off[e2], &g.v_cnt[e2], D, g.damp_v != 0)) {
+                rec_pad(g, orec, D);
+                rec_set_head(orec, e2 * 2, 0);
+            }
             ++slot;
         }
     }
@@ -409,33 +457,41 @@ __device__ __forceinline__ bool damp_and_decide_reg(const Dev<T>& g, T (&m)[N], 
     return true;
 }
 
-// One delivery, loaded one message AHEAD of its handling: the index chain order[r] -> q_code /
-// q_pay / slot_base is three dependent loads, which would otherwise be the latency of every step of a
-// chain that is sequential anyway (the longest chain of a generation is what the generation lasts).
+// The messages of a generation in DESTINATION-SORTED order (k_permute: one streaming pass gathers what the stable
+// sort's index array points at): a destination's queue is then a contiguous run -- code, first output slot, payload
+// at consecutive addresses -- and the chains below read it sequentially, RING deliveries ahead of the one they
+// handle.  (Round 3 followed order[r] -> q_code / q_pay / slot_base per delivery, one ahead: three dependent random
+// loads under full load, 3-5 us per step of a chain that is sequential anyway; the longest queue of a generation is
+// what the generation lasts -- profiles/r04_amaxsum_dispatches_v1.txt.)
+template <typename T>
+struct Sorted {
+    const int32_t* dst;        // [n] destination computation (variables first, then n_vars + factor)
+    const T* rec;              // [n * rs] the records (header: code, first output slot of the delivery's handler)
+    const int32_t* seg_first;  // [segments] position of the first message of the t-th destination to run
+    const uint64_t* seg_key;   // [segments] class << 32 | ~(queue length)
+    int64_t n;
+};
+constexpr int RING = 4;   // deliveries in flight per chain of a binary factor (a lane each: a small step body)
+constexpr int VRING = 2;  // ... of a variable's lane group (the step body is unrolled once per ring entry: with 4 the
+                          // kernels needed 248 VGPRs + scratch and 47-75 KB of code, and ran at half the speed)
 template <typename T, int N>
 struct Mail {
     int32_t code;
-    int64_t base;
+    int32_t base;
     T pay[N];
 };
 template <typename T, int N>
-__device__ __forceinline__ void fetch_mail(const Dev<T>& g, const int32_t* q_code, const T* q_pay, const int64_t* slot_base,
-                                           int64_t i, Mail<T, N>& m) {
-    m.code = q_code[i];
-    m.base = slot_base[i];
+__device__ __forceinline__ void fetch_mail(const Dev<T>& g, const Sorted<T>& sq, int64_t pos, Mail<T, N>& m) {
+    const T* r = (const T*)__builtin_assume_aligned(sq.rec + pos * g.rs, 16);
+    m.code = rec_code(r);
+    m.base = rec_base(r);
 #pragma unroll
-    for (int d = 0; d < N; ++d) m.pay[d] = q_pay[i * g.dmax + (d < g.dmax ? d : 0)];
+    for (int d = 0; d < N; ++d) m.pay[d] = rec_pay(r)[d < g.dmax ? d : 0];
 }
-// the walk over a destination's run [p, ...) of the sorted order, two indices ahead
-struct Walk {
-    int64_t r, i_next;
-    bool has_next;
-    __device__ __forceinline__ void start(const int32_t* dest_sorted, const int32_t* order, int64_t p, int64_t n) {
-        r = p;
-        has_next = p + 1 < n && dest_sorted[p + 1] == dest_sorted[p];
-        i_next = p + 1 < n ? order[p + 1] : order[p];
-    }
-};
+template <typename T>
+__device__ __forceinline__ int64_t queue_length(const Sorted<T>& sq, int64_t t) {
+    return (int64_t)(uint32_t)~(uint32_t)sq.seg_key[t];
+}
 
 // A variable of domain size D (template) and degree <= GROUP: a group of GROUP lanes (8, 16 or the
 // whole wave), lane k of the group = the variable's k-th factor (var_edges order) holding that
@@ -447,16 +503,15 @@ struct Walk {
 // sorted by queue length, so the queues of a wave are about equally long); `t` = the group's
 // destination in seg_first, groups past `seg_end` have none.
 template <typename T, int D, int GROUP>
-__device__ void chain_variable(const Dev<T>& g, const int32_t* seg_first, int64_t t, int64_t seg_end, const int32_t* q_code,
-                               const T* q_pay, const int32_t* dest_sorted, const int32_t* order, int64_t n,
-                               const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+__device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, int64_t seg_end, T* s_rec) {
     constexpr bool WHOLE = GROUP == 64;
     const int lane = (int)threadIdx.x & 63;
     const int gl = lane % GROUP, gbase = lane - gl;
     const unsigned long long gmask = WHOLE ? ~0ull : (((1ull << (GROUP % 64)) - 1ull) << gbase);
     const bool valid = t < seg_end;
-    const int64_t p = valid ? seg_first[t] : 0;
-    const int32_t dst = dest_sorted[p];
+    const int64_t p = valid ? sq.seg_first[t] : 0;
+    const int64_t len = valid ? queue_length(sq, t) : 0;
+    const int32_t dst = sq.dst[p];
     const int v = valid ? dst : 0;
     const int k0 = g.var_rowptr[v], deg = valid ? g.var_rowptr[v + 1] - k0 : 0;
     const bool active = gl < deg;
@@ -479,74 +534,74 @@ __device__ void chain_variable(const Dev<T>& g, const int32_t* seg_first, int64_
     int my_rank = -1;  // first-arrival rank of this lane's factor (select_value sums in that order)
     for (int r = 0; r < narr; ++r)
         if (g.v_order[k0 + r] == ek) my_rank = r;
-    Walk w;
-    w.start(dest_sorted, order, p, n);
-    Mail<T, D> cur, nxt;
-    fetch_mail<T, D>(g, q_code, q_pay, slot_base, order[p], cur);
-    bool alive = valid;
-    while (__ballot(alive) != 0ull) {
-        fetch_mail<T, D>(g, q_code, q_pay, slot_base, w.i_next, nxt);  // in flight while `cur` is handled
-        const int64_t r2 = w.r + 2;
-        const bool has_nn = w.has_next && r2 < n && dest_sorted[r2] == dst;
-        const int64_t i_nn = r2 < n ? order[r2] : w.i_next;
-        const int e = cur.code >> 1;
-        const unsigned long long from = __ballot(alive && active && ek == e) & gmask;
-        const int j = from ? __builtin_ctzll(from) - gbase : -1;  // the sender's lane of the group
-        const bool mine = alive && gl == j;
-        if (mine) {
+    // the queue, VRING deliveries ahead; the groups of a wave walk their queues in lock step (every lane executes
+    // every step -- the ballots and cross-lane reads need the whole wave -- a group past its queue's end idles)
+    Mail<T, D> ring[VRING];
 #pragma unroll
-            for (int d = 0; d < D; ++d) held[d] = cur.pay[d];
-        }
-        const bool is_new = (__ballot(mine && !has) & gmask) != 0ull;
-        if (mine && !has) {
-            has = true;
-            my_rank = narr;
-            g.v_order[k0 + narr] = e;
-        }
-        narr += is_new ? 1 : 0;
-        const unsigned long long hasmask = (__ballot(has) & gmask) >> gbase;
-        // costs_for_factor for this lane's factor
-        T m[D];
-        T sum_cost = (T)0;
+    for (int j = 0; j < VRING; ++j) fetch_mail<T, D>(g, sq, p + (j < len ? j : (len > 0 ? len - 1 : 0)), ring[j]);
+    auto step = [&](const Mail<T, D>& ml, bool alive) __attribute__((always_inline)) {
+            const int e = ml.code >> 1;
+            const unsigned long long from = __ballot(alive && active && ek == e) & gmask;
+            const int j = from ? __builtin_ctzll(from) - gbase : -1;  // the sender's lane of the group
+            const bool mine = alive && gl == j;
+            if (mine) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) {
-            T md = c[d];
-            if constexpr (WHOLE) {
-                for (int k2 = 0; k2 < deg; ++k2) {  // deg is wave-uniform here
-                    const T x = __shfl(held[d], k2, 64);
-                    if (k2 != gl && ((hasmask >> k2) & 1ull)) {
-                        sum_cost += x;
-                        md += x;
+                for (int d = 0; d < D; ++d) held[d] = ml.pay[d];
+            }
+            const bool is_new = (__ballot(mine && !has) & gmask) != 0ull;
+            if (mine && !has) {
+                has = true;
+                my_rank = narr;
+                g.v_order[k0 + narr] = e;
+            }
+            narr += is_new ? 1 : 0;
+            const unsigned long long hasmask = (__ballot(has) & gmask) >> gbase;
+            // costs_for_factor for this lane's factor
+            T m[D];
+            T sum_cost = (T)0;
+#pragma unroll
+            for (int d = 0; d < D; ++d) {
+                T md = c[d];
+                if constexpr (WHOLE) {
+                    for (int k2 = 0; k2 < deg; ++k2) {  // deg is wave-uniform here
+                        const T x = __shfl(held[d], k2, 64);
+                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {
+                            sum_cost += x;
+                            md += x;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int k2 = 0; k2 < GROUP; ++k2) {
+                        const T x = __shfl(held[d], k2, GROUP);
+                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {  // lanes past the degree never "have"
+                            sum_cost += x;
+                            md += x;
+                        }
                     }
                 }
-            } else {
+                m[d] = md;
+            }
+            const T avg = sum_cost / (T)D;
 #pragma unroll
-                for (int k2 = 0; k2 < GROUP; ++k2) {
-                    const T x = __shfl(held[d], k2, GROUP);
-                    if (k2 != gl && ((hasmask >> k2) & 1ull)) {  // lanes past the degree never "have"
-                        sum_cost += x;
-                        md += x;
-                    }
+            for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
+            if (alive && active && gl != j) {
+                if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
+                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)(ml.base + (gl < j ? gl : gl - 1)) * g.rs, 16);
+#pragma unroll
+                    for (int d = 0; d < D; ++d) rec_pay(o)[d] = m[d];
+                    rec_pad(g, o, D);
+                    rec_set_head(o, ek * 2, 0);
                 }
             }
-            m[d] = md;
-        }
-        const T avg = sum_cost / (T)D;
+    };
+    for (int64_t r0 = 0; __ballot(r0 < len) != 0ull; r0 += VRING) {
 #pragma unroll
-        for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-        if (alive && active && gl != j) {
-            if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
-                const int64_t at = cur.base + (gl < j ? gl : gl - 1);
-                s_code[at] = ek * 2;
-#pragma unroll
-                for (int d = 0; d < D; ++d) s_pay[at * g.dmax + d] = m[d];
-            }
+        for (int j = 0; j < VRING; ++j) {
+            const int64_t r = r0 + j;
+            step(ring[j], r < len);
+            if (r + VRING < len) fetch_mail<T, D>(g, sq, p + r + VRING, ring[j]);  // this register set's next tenant
         }
-        alive = alive && w.has_next;
-        cur = nxt;
-        w.r += 1;
-        w.i_next = i_nn;
-        w.has_next = has_nn;
     }
     // select_value on what is held now (maxsum.py:584-620): factors in first-arrival order
     {
@@ -605,9 +660,7 @@ __device__ __forceinline__ void factor2_message(const Dev<T>& g, const T (&tab)[
 // A binary factor over domains of at most 4 values: one lane, table / held costs / last-sent
 // messages in registers.
 template <typename T>
-__device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, const T* q_pay, const int32_t* dest_sorted,
-                              const int32_t* order, int64_t p, int64_t n, const int64_t* slot_base, int32_t* s_code,
-                              T* s_pay) {
+__device__ void chain_factor2(const Dev<T>& g, int f, const Sorted<T>& sq, int64_t p, int64_t len, T* s_rec) {
     const int eA = g.factor_rowptr[f], eB = eA + 1;
     const int DA = g.dom_size[g.edge_var[eA]], DB = g.dom_size[g.edge_var[eB]];
     const int64_t moA = g.msg_off[eA], moB = g.msg_off[eB];
@@ -624,52 +677,51 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const int32_t* q_code, con
     }
     bool hasA = g.f_has[eA] != 0, hasB = g.f_has[eB] != 0;
     uint8_t cntA = g.f_cnt[eA], cntB = g.f_cnt[eB];
-    const int32_t dst = dest_sorted[p];
-    Walk w;
-    w.start(dest_sorted, order, p, n);
-    Mail<T, 4> cur, nxt;
-    fetch_mail<T, 4>(g, q_code, q_pay, slot_base, order[p], cur);
-    for (;;) {
-        fetch_mail<T, 4>(g, q_code, q_pay, slot_base, w.i_next, nxt);  // in flight while `cur` is handled
-        const int64_t r2 = w.r + 2;
-        const bool has_nn = w.has_next && r2 < n && dest_sorted[r2] == dst;
-        const int64_t i_nn = r2 < n ? order[r2] : w.i_next;
-        const int e = cur.code >> 1;
+    Mail<T, 4> ring[RING];
+#pragma unroll
+    for (int j = 0; j < RING; ++j) fetch_mail<T, 4>(g, sq, p + (j < len ? j : len - 1), ring[j]);
+    auto step = [&](const Mail<T, 4>& ml) __attribute__((always_inline)) {
+        const int e = ml.code >> 1;
         T out[4];
         if (e == eA) {  // from scope variable 0: the message goes to variable 1
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cA[x] = cur.pay[x];  // past the domain: the zero padding of the slot
+            for (int x = 0; x < 4; ++x) cA[x] = ml.pay[x];  // past the domain: the zero padding of the slot
             hasA = true;
             if (hasB) {  // else: still waiting for the other variable (amaxsum.py:206)
                 factor2_message<T, true>(g, tab, cA, DA, DB, out);
                 if (damp_and_decide_reg<T, 4>(g, out, pB, cntB, DB, g.damp_f != 0)) {
-                    const int64_t at = cur.base;
-                    s_code[at] = eB * 2 + 1;
+                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
 #pragma unroll
                     for (int y = 0; y < 4; ++y)
-                        if (y < DB) s_pay[at * g.dmax + y] = out[y];
+                        if (y < DB) rec_pay(o)[y] = out[y];
+                    rec_pad(g, o, DB);
+                    rec_set_head(o, eB * 2 + 1, 0);
                 }
             }
         } else {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cB[x] = cur.pay[x];
+            for (int x = 0; x < 4; ++x) cB[x] = ml.pay[x];
             hasB = true;
             if (hasA) {
                 factor2_message<T, false>(g, tab, cB, DB, DA, out);
                 if (damp_and_decide_reg<T, 4>(g, out, pA, cntA, DA, g.damp_f != 0)) {
-                    const int64_t at = cur.base;
-                    s_code[at] = eA * 2 + 1;
+                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
 #pragma unroll
                     for (int x = 0; x < 4; ++x)
-                        if (x < DA) s_pay[at * g.dmax + x] = out[x];
+                        if (x < DA) rec_pay(o)[x] = out[x];
+                    rec_pad(g, o, DA);
+                    rec_set_head(o, eA * 2 + 1, 0);
                 }
             }
         }
-        if (!w.has_next) break;
-        cur = nxt;
-        w.r += 1;
-        w.i_next = i_nn;
-        w.has_next = has_nn;
+    };
+    for (int64_t r0 = 0; r0 < len; r0 += RING) {
+#pragma unroll
+        for (int j = 0; j < RING; ++j) {
+            const int64_t r = r0 + j;
+            if (r < len) step(ring[j]);
+            if (r + RING < len) fetch_mail<T, 4>(g, sq, p + r + RING, ring[j]);  // this register set's next tenant
+        }
     }
 #pragma unroll
     for (int x = 0; x < 4; ++x) {
@@ -710,52 +762,62 @@ __device__ __forceinline__ int class_of(const Dev<T>& g, int32_t dst) {
 }
 
 template <typename T, int GROUP>
-__device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const int32_t* seg_first, int64_t seg_begin,
-                                                  int64_t seg_end, const int32_t* q_code, const T* q_pay,
-                                                  const int32_t* dest_sorted, const int32_t* order, int64_t n,
-                                                  const int64_t* slot_base, int32_t* s_code, T* s_pay) {
+__device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const Sorted<T>& sq, int64_t seg_begin, int64_t seg_end,
+                                                  T* s_rec) {
     constexpr int PER_WAVE = 64 / GROUP;
     const int lane = (int)threadIdx.x & 63;
     const int64_t t = seg_begin + (int64_t)blockIdx.x * PER_WAVE + lane / GROUP;
     // the domain sizes of the wave's variables: one pass per size present (wave-uniform branches)
-    const int myD = t < seg_end ? g.dom_size[dest_sorted[seg_first[t]]] : 0;
+    const int myD = t < seg_end ? g.dom_size[sq.dst[sq.seg_first[t]]] : 0;
     for (int D = 2; D <= 4; ++D) {
         if (__ballot(myD == D) == 0ull) continue;
         const int64_t tt = myD == D ? t : seg_end;  // the other groups sit this pass out
-        if (D == 2) chain_variable<T, 2, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
-        else if (D == 3) chain_variable<T, 3, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
-        else chain_variable<T, 4, GROUP>(g, seg_first, tt, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+        if (D == 2) chain_variable<T, 2, GROUP>(g, sq, tt, seg_end, s_rec);
+        else if (D == 3) chain_variable<T, 3, GROUP>(g, sq, tt, seg_end, s_rec);
+        else chain_variable<T, 4, GROUP>(g, sq, tt, seg_end, s_rec);
     }
 }
 
-// order[p]: FIFO index of the p-th message after the stable sort by destination; seg_first[t]:
-// position of the first message of the t-th destination to run -- by class, longest queues first
-// (step()); a launch runs the destinations [seg_begin, seg_end) of one class.  Blocks of one wave;
-// a kernel per class, so that each has the registers of its own path only.
+// sq.seg_first[t]: position of the first message of the t-th destination to run -- by class, longest queues
+// first (step()); a launch runs the destinations [seg_begin, seg_end) of one class.  Blocks of one wave; a kernel
+// per class, so that each has the registers of its own path only.
 template <typename T, int GROUP>
-__global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, const int32_t* q_code, const T* q_pay,
-                          const int32_t* dest_sorted, const int32_t* order, int64_t n, const int32_t* seg_first,
-                          int64_t seg_begin, int64_t seg_end, const int64_t* slot_base, int32_t* s_code, T* s_pay) {
-    variables_of_wave<T, GROUP>(g, seg_first, seg_begin, seg_end, q_code, q_pay, dest_sorted, order, n, slot_base, s_code, s_pay);
+__global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, Sorted<T> sq, int64_t seg_begin, int64_t seg_end, T* s_rec) {
+    variables_of_wave<T, GROUP>(g, sq, seg_begin, seg_end, s_rec);
 }
 
-template <typename T>
-__global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, const int32_t* q_code, const T* q_pay,
-                          const int32_t* dest_sorted, const int32_t* order, int64_t n, const int32_t* seg_first,
-                          int64_t seg_begin, int64_t seg_end, const int64_t* slot_base, int32_t* s_code, T* s_pay, int cls) {
+template <typename T, bool FACTOR2>  // (two kernels: the binary-factor chains do not pay for the generic handler's registers)
+__global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, Sorted<T> sq, int64_t seg_begin, int64_t seg_end, T* s_rec) {
     const int64_t t = seg_begin + (int64_t)blockIdx.x * 64 + ((int)threadIdx.x & 63);
     if (t >= seg_end) return;
-    const int64_t p = seg_first[t];
-    const int32_t dst = dest_sorted[p];
-    if (cls == CLS_FACTOR2) {
-        chain_factor2<T>(g, dst - g.n_vars, q_code, q_pay, dest_sorted, order, p, n, slot_base, s_code, s_pay);
+    const int64_t p = sq.seg_first[t], len = queue_length(sq, t);
+    const int32_t dst = sq.dst[p];
+    if constexpr (FACTOR2) {
+        chain_factor2<T>(g, dst - g.n_vars, sq, p, len, s_rec);
         return;
     }
-    for (int64_t r = p; r < n && dest_sorted[r] == dst; ++r) {  // its messages, in FIFO order
-        const int64_t i = order[r];
-        const bool last = r + 1 >= n || dest_sorted[r + 1] != dst;
-        handle(g, q_code[i], q_pay + i * g.dmax, s_code + slot_base[i], s_pay + slot_base[i] * g.dmax, last);
-    }
+    for (int64_t r = p; r < p + len; ++r)  // its messages, in FIFO order
+        handle(g, sq.rec + r * g.rs, s_rec, r + 1 == p + len);
+}
+
+// the generation's records gathered into destination-sorted order (Sorted): order[p] = FIFO index of the p-th message
+// after the stable sort by destination.  One thread per 16-byte piece: the writes are one contiguous stream, the
+// reads one random line per message.
+template <typename T>
+__global__ void k_permute(const T* q_rec, const int32_t* order, int64_t n, int rs, T* m_rec) {
+    const int pieces = rs * (int)sizeof(T) / 16;
+    const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t p = x / pieces;
+    const int k = (int)(x - p * pieces);
+    if (p >= n) return;
+    struct alignas(16) P16 { uint32_t w[4]; };
+    ((P16*)(m_rec + p * rs))[k] = ((const P16*)(q_rec + (int64_t)order[p] * rs))[k];
+}
+// the first output slot of every message's handler into its record (after the scan of the capacities)
+template <typename T>
+__global__ void k_stamp(T* q_rec, const int64_t* slot_base, int64_t n, int rs) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) ((int32_t*)(q_rec + i * rs))[1] = (int32_t)slot_base[i];  // (fewer than 2^31 slots per generation: step())
 }
 
 __global__ void k_iota(int32_t* out, int64_t n) {
@@ -801,18 +863,17 @@ __global__ void k_class_bounds(const uint64_t* key_sorted, int64_t n_seg, int64_
 }
 
 template <typename T>
-__global__ void k_gather(const int32_t* s_code, const T* s_pay, const int64_t* pos, int64_t n_slots, int dmax,
-                         int32_t* q_code, T* q_pay) {
+__global__ void k_gather(const T* s_rec, const int64_t* pos, int64_t n_slots, int rs, T* q_rec) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots || s_code[s] < 0) return;
+    if (s >= n_slots || rec_code(s_rec + s * rs) < 0) return;
     const int64_t at = pos[s];
-    q_code[at] = s_code[s];
-    for (int d = 0; d < dmax; ++d) q_pay[at * dmax + d] = s_pay[s * dmax + d];
+    for (int d = 0; d < rs; ++d) q_rec[at * rs + d] = s_rec[s * rs + d];
 }
 
-__global__ void k_flags(const int32_t* s_code, int64_t n, int64_t* flag) {
+template <typename T>
+__global__ void k_flags(const T* s_rec, int64_t n, int rs, int64_t* flag) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) flag[s] = s_code[s] >= 0 ? 1 : 0;
+    if (s < n) flag[s] = rec_code(s_rec + s * rs) >= 0 ? 1 : 0;
 }
 
 struct Base {
@@ -845,6 +906,15 @@ template <typename T>
 struct Engine : Base {
     int device = 0;
     Dev<T> g{};
+    // One stream per destination class: the class kernels of a generation work on disjoint destinations and run
+    // SIDE BY SIDE (the few hundred waves of the high-degree variables are a latency chain of their own: alone
+    // they took as long as the 12 000 waves of the low-degree ones before them -- profiles/r04_amaxsum_dispatches_v1.txt).
+    // Blocking streams: they wait for the null stream's earlier work, the null stream's later work waits for them.
+    hipStream_t cls_stream[N_CLS] = {};
+    ~Engine() override {
+        for (hipStream_t st : cls_stream)
+            if (st) (void)hipStreamDestroy(st);
+    }
     std::vector<int32_t> h_dom, h_frow, h_evar, h_vrow, h_vedges;
     std::vector<int64_t> h_toff, h_coff, h_moff;
     std::vector<double> h_tables, h_eval_cost;
@@ -854,8 +924,8 @@ struct Engine : Base {
     Buf<uint8_t> f_has, f_cnt, v_has, v_cnt;
     Buf<int32_t> f_nhas, v_narr, v_order, sel;
     // queue of the current generation, work arrays of a step
-    Buf<int32_t> q_code, q_code2, dest, dest_sorted, order, order_in, cap, s_code, start_cnt, start_base;
-    Buf<T> q_pay, q_pay2, s_pay;
+    Buf<int32_t> dest, dest_sorted, order, order_in, cap, start_cnt, start_base;
+    Buf<T> q_rec, q_rec2, s_rec, m_rec;  // queue of the generation, of the next one, the output slots, the sorted copy
     Buf<int64_t> slot_base, flag, pos, cap64, head_idx;
     Buf<int32_t> head, seg_pos, seg_first;
     Buf<uint64_t> seg_key, seg_key_sorted;
@@ -933,6 +1003,7 @@ struct Engine : Base {
         AMX_TRY(sel.reserve(nV + 1));
         AMX_TRY(belief.reserve(nV + 1));
         g.n_vars = nV; g.n_factors = nF; g.n_edges = nE; g.dmax = dmax;
+        g.rs = rec_stride(dmax, (int)sizeof(T));
         g.is_max = p.mode == MXS_MODE_MAX;
         g.start_mode = p.start_messages;
         g.damp_f = (p.damping_nodes & MXS_DAMP_FACTORS) ? 1 : 0;
@@ -1012,10 +1083,9 @@ struct Engine : Base {
                 for (int64_t i = 0; i < nodes; ++i) hb32[i] = (int32_t)hb[i];
                 AMX_TRY(hipMemcpy(start_base.p, hb32.data(), 4 * nodes, hipMemcpyHostToDevice));
             }
-            AMX_TRY(q_code.reserve(total + 1));
-            AMX_TRY(q_pay.reserve((total + 1) * g.dmax));
-            AMX_TRY(hipMemset(q_pay.p, 0, sizeof(T) * (total + 1) * g.dmax));
-            hipLaunchKernelGGL((k_start_emit<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_base.p, q_code.p, q_pay.p);
+            AMX_TRY(q_rec.reserve((total + 1) * g.rs));
+            AMX_TRY(hipMemset(q_rec.p, 0, sizeof(T) * (total + 1) * g.rs));
+            hipLaunchKernelGGL((k_start_emit<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_base.p, q_rec.p);
             AMX_TRY(hipGetLastError());
             AMX_TRY(hipDeviceSynchronize());
             pending = total;
@@ -1033,12 +1103,14 @@ struct Engine : Base {
         AMX_TRY(order_in.reserve(n));
         AMX_TRY(cap.reserve(n));
         AMX_TRY(slot_base.reserve(n));
-        hipLaunchKernelGGL((k_dest<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, q_code.p, n, dest.p, cap.p);
+        hipLaunchKernelGGL((k_dest<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, (const T*)q_rec.p, n, dest.p, cap.p);
         AMX_TRY(hipGetLastError());
         int64_t n_slots = 0;
         { int rc = scan32(cap.p, slot_base.p, n, &n_slots); if (rc) return rc; }
         if (n_slots > (int64_t)INT32_MAX)  // the compaction scans the slots with 32-bit counts
             return fail(MXS_E_NOMEM, "amaxsum: more than 2^31 output slots in one generation");
+        hipLaunchKernelGGL((k_stamp<T>), dim3(grid(n)), dim3(TPB), 0, 0, q_rec.p, (const int64_t*)slot_base.p, n, g.rs);
+        AMX_TRY(hipGetLastError());
         {   // FIFO indices 0..n-1, then the stable sort by destination
             hipLaunchKernelGGL(k_iota, dim3(grid(n)), dim3(TPB), 0, 0, order_in.p, n);
             AMX_TRY(hipGetLastError());
@@ -1078,22 +1150,31 @@ struct Engine : Base {
             hipLaunchKernelGGL(k_class_bounds, dim3(1), dim3(64), 0, 0, seg_key_sorted.p, n_seg, cls_first.p);
             AMX_TRY(hipGetLastError());
         }
+        // the records themselves into sorted order: the chains read their queues as contiguous runs
+        AMX_TRY(m_rec.reserve(n * g.rs));
+        {
+            const int64_t pieces = n * (g.rs * (int64_t)sizeof(T) / 16);
+            hipLaunchKernelGGL((k_permute<T>), dim3(grid(pieces)), dim3(TPB), 0, 0, (const T*)q_rec.p, (const int32_t*)order.p, n, g.rs, m_rec.p);
+            AMX_TRY(hipGetLastError());
+        }
+        const Sorted<T> sq{dest_sorted.p, m_rec.p, seg_first.p, seg_key_sorted.p, n};
         int64_t h_first[N_CLS + 1];
         AMX_TRY(read_back(h_first, cls_first.p, sizeof(h_first)));
-        AMX_TRY(s_code.reserve(n_slots + 1));
-        AMX_TRY(s_pay.reserve((n_slots + 1) * g.dmax));
-        AMX_TRY(hipMemset(s_code.p, 0xFF, sizeof(int32_t) * (n_slots + 1)));
-        AMX_TRY(hipMemset(s_pay.p, 0, sizeof(T) * (n_slots + 1) * g.dmax));
+        AMX_TRY(s_rec.reserve((n_slots + 1) * g.rs));
+        AMX_TRY(hipMemset(s_rec.p, 0xFF, sizeof(T) * (n_slots + 1) * g.rs));  // code -1: empty slot
         for (int cls = 0; cls < N_CLS; ++cls) {
             const int64_t b = h_first[cls], e = h_first[cls + 1];
             if (e <= b) continue;
             const int per_wave = cls == CLS_VAR8 ? 8 : (cls == CLS_VAR16 ? 4 : (cls == CLS_VAR64 ? 1 : 64));
             const dim3 gr((unsigned)((e - b + per_wave - 1) / per_wave)), bl(64);
-#define AMX_ARGS g, q_code.p, q_pay.p, dest_sorted.p, order.p, n, seg_first.p, b, e, slot_base.p, s_code.p, s_pay.p
-            if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, 0, AMX_ARGS);
-            else if (cls == CLS_VAR16) hipLaunchKernelGGL((k_process_vars<T, 16>), gr, bl, 0, 0, AMX_ARGS);
-            else if (cls == CLS_VAR64) hipLaunchKernelGGL((k_process_vars<T, 64>), gr, bl, 0, 0, AMX_ARGS);
-            else hipLaunchKernelGGL((k_process_lanes<T>), gr, bl, 0, 0, AMX_ARGS, cls);
+#define AMX_ARGS g, sq, b, e, s_rec.p
+            if (!cls_stream[cls]) AMX_TRY(hipStreamCreateWithFlags(&cls_stream[cls], 0));
+            hipStream_t st = cls_stream[cls];
+            if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, st, AMX_ARGS);
+            else if (cls == CLS_VAR16) hipLaunchKernelGGL((k_process_vars<T, 16>), gr, bl, 0, st, AMX_ARGS);
+            else if (cls == CLS_VAR64) hipLaunchKernelGGL((k_process_vars<T, 64>), gr, bl, 0, st, AMX_ARGS);
+            else if (cls == CLS_FACTOR2) hipLaunchKernelGGL((k_process_lanes<T, true>), gr, bl, 0, st, AMX_ARGS);
+            else hipLaunchKernelGGL((k_process_lanes<T, false>), gr, bl, 0, st, AMX_ARGS);
 #undef AMX_ARGS
             AMX_TRY(hipGetLastError());
         }
@@ -1102,7 +1183,7 @@ struct Engine : Base {
         if (n_slots > 0) {
             AMX_TRY(flag.reserve(n_slots));
             AMX_TRY(pos.reserve(n_slots));
-            hipLaunchKernelGGL(k_flags, dim3(grid(n_slots)), dim3(TPB), 0, 0, s_code.p, n_slots, flag.p);
+            hipLaunchKernelGGL((k_flags<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, (const T*)s_rec.p, n_slots, g.rs, flag.p);
             AMX_TRY(hipGetLastError());
             size_t bytes = 0;
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag.p, pos.p, (int)n_slots));
@@ -1112,17 +1193,14 @@ struct Engine : Base {
             AMX_TRY(read_back(&last_pos, pos.p + n_slots - 1, 8));
             AMX_TRY(read_back(&last_flag, flag.p + n_slots - 1, 8));
             n_next = last_pos + last_flag;
-            AMX_TRY(q_code2.reserve(n_next + 1));
-            AMX_TRY(q_pay2.reserve((n_next + 1) * g.dmax));
-            hipLaunchKernelGGL((k_gather<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, s_code.p, s_pay.p, pos.p, n_slots,
-                               g.dmax, q_code2.p, q_pay2.p);
+            AMX_TRY(q_rec2.reserve((n_next + 1) * g.rs));
+            hipLaunchKernelGGL((k_gather<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, (const T*)s_rec.p, (const int64_t*)pos.p, n_slots,
+                               g.rs, q_rec2.p);
             AMX_TRY(hipGetLastError());
         }
         AMX_TRY(hipDeviceSynchronize());
-        std::swap(q_code.p, q_code2.p);
-        std::swap(q_code.n, q_code2.n);
-        std::swap(q_pay.p, q_pay2.p);
-        std::swap(q_pay.n, q_pay2.n);
+        std::swap(q_rec.p, q_rec2.p);
+        std::swap(q_rec.n, q_rec2.n);
         delivered_total += n;
         next_generation += 1;
         pending = n_next;

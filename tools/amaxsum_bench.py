@@ -19,10 +19,17 @@ for n in [int(x) for x in sys.argv[1:] if x != "--no-oracle"] or [10_000, 100_00
     eng = AMaxSumEngine(g, p)
     t0 = time.perf_counter()
     done = eng.run(gens)
+    dt_cold = time.perf_counter() - t0   # first run of a fresh engine: kernel code loads, GB-sized hipMallocs
+    eng.reset()                          # the queues' buffers stay allocated
+    t0 = time.perf_counter()
+    done2 = eng.run(gens)
     dt = time.perf_counter() - t0
+    assert done2 == done
     sizes = eng.generation_sizes()
     rec = {"n_vars": n, "n_edges": g.n_edges, "generations": gens, "messages": done, "seconds": round(dt, 4),
-           "messages_per_s": round(done / dt, 1), "largest_generation": int(sizes.max()), "pending": eng.pending}
+           "messages_per_s": round(done / dt, 1), "seconds_first_run": round(dt_cold, 4),
+           "messages_per_s_first_run": round(done / dt_cold, 1),
+           "largest_generation": int(sizes.max()), "pending": eng.pending}
     eng.close()
     if NO_ORACLE:
         print(json.dumps(rec), flush=True)
