@@ -26,6 +26,22 @@
 
 namespace mxs {
 
+#ifndef MXS_BOX_NT
+#define MXS_BOX_NT 1  // the table records (read once per cycle, 0.7 GB on meeting_50k) with non-temporal loads: cycle 249.6 -> 245.1 us (f32 164.2 -> 159.4), profiles/r04_box_nt_ab_v1.jsonl
+#endif
+// one 16-byte piece of a lane's record
+template <bool NT>
+__device__ __forceinline__ Piece16 load_piece16(const uint8_t* p) {
+#if defined(__HIPCC__)
+    if constexpr (NT) {
+        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+        const v4u v = __builtin_nontemporal_load((const v4u*)__builtin_assume_aligned(p, 16));
+        return Piece16{{v.x, v.y, v.z, v.w}};
+    }
+#endif
+    return *(const Piece16*)__builtin_assume_aligned(p, 16);
+}
+
 template <typename T>
 struct alignas(4 * sizeof(T)) BoxQuad {
     T v[4];
@@ -81,7 +97,7 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
         const uint8_t* img = a.ctables + fd.tab_off;
 #pragma unroll
         for (int k = 0; k < FULL; ++k) {
-            const Piece16 pc = *(const Piece16*)__builtin_assume_aligned(img + ((int64_t)k * 64 + lane) * 16, 16);
+            const Piece16 pc = load_piece16<MXS_BOX_NT != 0>(img + ((int64_t)k * 64 + lane) * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[4 * k + j] = pc.w[j];
         }
