@@ -116,7 +116,15 @@ typedef struct mxs_params {
                                 bit3 (8)  keep the caller's variable order where possible
                                 bit4 (16) no workgroup-per-factor kernel
                                 bit5 (32) variable side only, bit6 (64) factor side
-                                          only: TIMING ONLY, results are wrong      */
+                                          only: TIMING ONLY, results are wrong
+                                bit7 / bit8 (128 / 256) factors of a class sorted by their
+                                          first variable / in the caller's order
+                                bit9 / bit10 (512 / 1024) shard: every factor class in the
+                                          second launch / only the cut classes
+                                bit11 / bit12 (2048 / 4096) block schedule off / on
+                                bit13 / bit14 (8192 / 16384) full-width / compact tables
+                                bit15 (32768) no one-wave-per-factor box kernel (arity-3
+                                          integer tables keep the lane-packed kernel)   */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;
