@@ -63,9 +63,7 @@ constexpr int NT_STREAMING = 9;  // nt on the index / table streams and on the s
     (void)NT_IDX, (void)NT_PREV, (void)NT_GATHER
 template <bool NT, typename U>
 __device__ __forceinline__ U ldp(const U* p) {
-#if defined(__HIPCC__)
     if constexpr (NT) return __builtin_nontemporal_load(p);
-#endif
     return *p;
 }
 
@@ -80,15 +78,13 @@ struct Piece16 {  // 16 bytes, moved with one instruction
     unsigned int w[4];
 };
 // one 16-byte piece from the staging area to global memory, non-temporal when the launch streams (NT bit 3)
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
 template <bool NT_STORE>
 __device__ __forceinline__ void store_piece16(char* dst, const char* src) {
-#if defined(__HIPCC__)
     if constexpr (NT_STORE) {
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
         __builtin_nontemporal_store(*(const v4u*)__builtin_assume_aligned(src, 16), (v4u*)__builtin_assume_aligned(dst, 16));
         return;
     }
-#endif
     *(Piece16*)__builtin_assume_aligned(dst, 16) = *(const Piece16*)__builtin_assume_aligned(src, 16);
 }
 #ifndef MXS_NT_TIGHT
@@ -991,16 +987,12 @@ __device__ __forceinline__ T wave_min_to_lane63(T x) {
     return x;
 }
 // The two registers a permlane swap of (x, x) leaves behind, per 32-bit half of T.
-#if defined(__HIPCC__)
 typedef unsigned int swap2u __attribute__((ext_vector_type(2)));
-#else
-typedef hipemu_swap2 swap2u;
-#endif
 template <bool W32, bool SECOND>
 __device__ __forceinline__ unsigned int swap_word(unsigned int w) {
     const swap2u r = W32 ? __builtin_amdgcn_permlane32_swap(w, w, false, false)
                          : __builtin_amdgcn_permlane16_swap(w, w, false, false);
-    return SECOND ? r.y : r.x;
+    return SECOND ? r[1] : r[0];
 }
 template <bool W32, bool SECOND>
 __device__ __forceinline__ double swap_val(double x) {

@@ -32,13 +32,10 @@ namespace mxs {
 // one 16-byte piece of a lane's record
 template <bool NT>
 __device__ __forceinline__ Piece16 load_piece16(const uint8_t* p) {
-#if defined(__HIPCC__)
     if constexpr (NT) {
-        typedef unsigned int v4u __attribute__((ext_vector_type(4)));
         const v4u v = __builtin_nontemporal_load((const v4u*)__builtin_assume_aligned(p, 16));
-        return Piece16{{v.x, v.y, v.z, v.w}};
+        return Piece16{{v[0], v[1], v[2], v[3]}};
     }
-#endif
     return *(const Piece16*)__builtin_assume_aligned(p, 16);
 }
 

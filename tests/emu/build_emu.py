@@ -19,7 +19,7 @@ def build(force=False):
         return OUT
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
-           "-DMXS_EMULATED_HIPCUB", "-DMXS_WIDE_GRID=3",  # (3 persistent workgroups: the block pipeline of k_variable_wide runs several stages deep)
+           "-DMXS_EMULATED_HIPCUB", "-DMXS_BUILD_KIND=0",  # (build kind 0: the binding refuses this library outside tests)
            "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], srcs[4], "-o", OUT, "-ldl", "-pthread"]
     subprocess.check_call(cmd)
     return OUT

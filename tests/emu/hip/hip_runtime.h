@@ -257,21 +257,24 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     hipemu::yield_barrier();
     return out;
 }
-struct hipemu_swap2 {
-    unsigned int x, y;
-};
+// (clang's ext_vector_type spelled for g++: every vector type of the engine sources has 4-byte elements;
+// the non-temporal builtins are plain accesses here)
+#define ext_vector_type(n) vector_size(4 * (n))
+#define __builtin_nontemporal_load(p) (*(p))
+#define __builtin_nontemporal_store(v, p) (*(p) = (v))
+typedef unsigned int hipemu_swap2 __attribute__((vector_size(8)));
 // v_permlane16_swap: the odd rows (16 lanes each) of the first operand trade places with the even rows of
 // the second; v_permlane32_swap: the upper half of the first with the lower half of the second.
 inline hipemu_swap2 hipemu_permlane_swap(unsigned int a, unsigned int b, bool halves) {
     const unsigned t = threadIdx.x, lane = t % 64, base = t - lane;
     hipemu::g_xchg[t] = ((unsigned long long)b << 32) | a;
     hipemu::yield_barrier();
-    hipemu_swap2 r{a, b};
+    hipemu_swap2 r = {a, b};
     const unsigned span = halves ? 32 : 16, blk = lane / span, i = lane % span;
     if (blk & 1) {  // odd row / upper half of the first operand <- even row / lower half of the second
-        r.x = (unsigned)(hipemu::g_xchg[base + (blk - 1) * span + i] >> 32);
+        r[0] = (unsigned)(hipemu::g_xchg[base + (blk - 1) * span + i] >> 32);
     } else {        // even row / lower half of the second operand <- odd row / upper half of the first
-        r.y = (unsigned)(hipemu::g_xchg[base + (blk + 1) * span + i] & 0xffffffffull);
+        r[1] = (unsigned)(hipemu::g_xchg[base + (blk + 1) * span + i] & 0xffffffffull);
     }
     hipemu::yield_barrier();
     return r;
