@@ -40,6 +40,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../../include/maxsum_gpu.h"
@@ -120,7 +122,7 @@ struct RecHead {
 };
 inline int rec_stride(int dmax, int word) { return (8 + dmax * word + 15) / 16 * 16 / word; }
 template <typename T>
-__device__ __forceinline__ int32_t rec_code(const T* r) { return ((const int32_t*)r)[0]; }
+__host__ __device__ __forceinline__ int32_t rec_code(const T* r) { return ((const int32_t*)r)[0]; }
 template <typename T>
 __device__ __forceinline__ int32_t rec_base(const T* r) { return ((const int32_t*)r)[1]; }
 template <typename T>
@@ -493,6 +495,28 @@ __device__ __forceinline__ int64_t queue_length(const Sorted<T>& sq, int64_t t) 
     return (int64_t)(uint32_t)~(uint32_t)sq.seg_key[t];
 }
 
+// Lane K of every 16-lane row to all lanes of the row: one DPP move per 32 bits (row_newbcast) -- VALU, where
+// __shfl goes through the LDS crossbar (ds_bpermute).  The 16-lane groups of chain_variable are rows.
+template <int K>
+__device__ __forceinline__ double row_bcast(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, 0x150 + K, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, 0x150 + K, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float row_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x150 + K, 0xf, 0xf, false));
+}
+template <typename F, int... I>
+__device__ __forceinline__ void amx_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void amx_static_for(F&& f) {
+    amx_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // A variable of domain size D (template) and degree <= GROUP: a group of GROUP lanes (8, 16 or the
 // whole wave), lane k of the group = the variable's k-th factor (var_edges order) holding that
 // factor's last message, the message last sent to it and its send counter.  Per delivered message:
@@ -570,6 +594,15 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
                             md += x;
                         }
                     }
+                } else if constexpr (GROUP == 16) {  // the group is a DPP row
+                    amx_static_for<16>([&](auto kc) __attribute__((always_inline)) {
+                        constexpr int k2 = decltype(kc)::value;
+                        const T x = row_bcast<k2>(held[d]);
+                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {
+                            sum_cost += x;
+                            md += x;
+                        }
+                    });
                 } else {
 #pragma unroll
                     for (int k2 = 0; k2 < GROUP; ++k2) {
@@ -870,11 +903,13 @@ __global__ void k_gather(const T* s_rec, const int64_t* pos, int64_t n_slots, in
     for (int d = 0; d < rs; ++d) q_rec[at * rs + d] = s_rec[s * rs + d];
 }
 
+// 1 where output slot s holds a message: what the compaction scan sums, read straight from the records
 template <typename T>
-__global__ void k_flags(const T* s_rec, int64_t n, int rs, int64_t* flag) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s < n) flag[s] = rec_code(s_rec + s * rs) >= 0 ? 1 : 0;
-}
+struct SlotFilled {
+    const T* rec;
+    int rs;
+    __host__ __device__ __forceinline__ int64_t operator()(int64_t slot) const { return rec_code(rec + slot * rs) >= 0 ? 1 : 0; }
+};
 
 struct Base {
     virtual ~Base() {}
@@ -926,7 +961,7 @@ struct Engine : Base {
     // queue of the current generation, work arrays of a step
     Buf<int32_t> dest, dest_sorted, order, order_in, cap, start_cnt, start_base;
     Buf<T> q_rec, q_rec2, s_rec, m_rec;  // queue of the generation, of the next one, the output slots, the sorted copy
-    Buf<int64_t> slot_base, flag, pos, cap64, head_idx;
+    Buf<int64_t> slot_base, pos, cap64, head_idx;
     Buf<int32_t> head, seg_pos, seg_first;
     Buf<uint64_t> seg_key, seg_key_sorted;
     Buf<int64_t> cls_first;
@@ -1181,17 +1216,19 @@ struct Engine : Base {
         // compaction of the filled slots, slot order = FIFO order of the next generation
         int64_t n_next = 0;
         if (n_slots > 0) {
-            AMX_TRY(flag.reserve(n_slots));
             AMX_TRY(pos.reserve(n_slots));
-            hipLaunchKernelGGL((k_flags<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, (const T*)s_rec.p, n_slots, g.rs, flag.p);
-            AMX_TRY(hipGetLastError());
             size_t bytes = 0;
-            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, flag.p, pos.p, (int)n_slots));
+            hipcub::CountingInputIterator<int64_t> slots(0);
+            hipcub::TransformInputIterator<int64_t, SlotFilled<T>, hipcub::CountingInputIterator<int64_t>> filled(
+                slots, SlotFilled<T>{s_rec.p, g.rs});
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, filled, pos.p, (int)n_slots));
             AMX_TRY(temp.reserve(bytes));
-            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, flag.p, pos.p, (int)n_slots));
-            int64_t last_pos = 0, last_flag = 0;
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, filled, pos.p, (int)n_slots));
+            int64_t last_pos = 0;
+            int32_t last_code = -1;
             AMX_TRY(read_back(&last_pos, pos.p + n_slots - 1, 8));
-            AMX_TRY(read_back(&last_flag, flag.p + n_slots - 1, 8));
+            AMX_TRY(hipMemcpy(&last_code, s_rec.p + (n_slots - 1) * g.rs, 4, hipMemcpyDeviceToHost));
+            const int64_t last_flag = last_code >= 0 ? 1 : 0;
             n_next = last_pos + last_flag;
             AMX_TRY(q_rec2.reserve((n_next + 1) * g.rs));
             hipLaunchKernelGGL((k_gather<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, (const T*)s_rec.p, (const int64_t*)pos.p, n_slots,

@@ -250,6 +250,7 @@ inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int row_mask,
     else if (ctrl == 0x141) from = (int)((lane & ~7u) + 7 - (lane & 7));                            // row_half_mirror
     else if (ctrl == 0x142) from = row > 0 ? (int)(row * 16 - 1) : -1;     // row_bcast15: lane 15 of the previous row
     else if (ctrl == 0x143) from = row >= 2 ? 31 : -1;                     // row_bcast31: lane 31 to rows 2, 3
+    else if (ctrl >= 0x150 && ctrl < 0x160) from = (int)(row * 16 + (unsigned)(ctrl - 0x150));     // row_newbcast:n
     else if (ctrl > 0x120 && ctrl < 0x130) from = (int)(row * 16 + ((i + 16 - (unsigned)(ctrl - 0x120)) & 15));  // row_ror:n
     else abort();
     int out = old;

@@ -19,6 +19,13 @@ struct CastOp {
     To operator()(const From& x) const { return (To)x; }
 };
 
+template <typename V>
+struct CountingInputIterator {
+    V base;
+    explicit CountingInputIterator(V b) : base(b) {}
+    V operator[](std::ptrdiff_t k) const { return base + (V)k; }
+};
+
 template <typename V, typename Op, typename It>
 struct TransformInputIterator {
     It it;
