@@ -124,7 +124,9 @@ typedef struct mxs_params {
                                 bit11 / bit12 (2048 / 4096) block schedule off / on
                                 bit13 / bit14 (8192 / 16384) full-width / compact tables
                                 bit15 (32768) no one-wave-per-factor box kernel (arity-3
-                                          integer tables keep the lane-packed kernel)   */
+                                          integer tables keep the lane-packed kernel)
+                                bit16 (65536) shard: cut binary factors compute both
+                                          messages (default: only the one to their own variable) */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;

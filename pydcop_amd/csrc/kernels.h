@@ -372,7 +372,7 @@ __device__ __forceinline__ void factor_unary(const SweepArgs<T>& a, const ClassI
     }
 }
 
-template <typename T, int D, bool P2P = false, int NT = MXS_NT>
+template <typename T, int D, bool P2P = false, int NT = MXS_NT, bool CUT_HALF = true>
 __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const ClassInfo& ci, int j) {
     MXS_NT_FLAGS(NT);
     constexpr int H = Msg<T, D>::H;
@@ -381,30 +381,45 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
     const int64_t fo0 = ci.f2v_base + (int64_t)j * H, fo1 = ci.f2v_base1 + (int64_t)j * H;
     // everything addressed by j: coalesced
     constexpr bool CIM = Msg<T, D>::CNT_IN_MSG;
-    const int v0 = ldp<NT_IDX>(a.edge_v2f + e), v1 = ldp<NT_IDX>(a.edge_v2f + e + 1);
-    uint8_t cn0, cn1;
+    // A shard's cut class computes only the message to its OWN variable (ClassInfo::own_pos, block-uniform): the
+    // other one would go to a ghost variable nobody sweeps here -- its record, the owned variable's V->F message
+    // it would be computed from and its counter are neither read nor written.
+    // (CUT_HALF = false: the scheduled launch, which never holds a cut class -- no branch in the metric's instantiation)
+    const bool do0 = !CUT_HALF || ci.own_pos != 2, do1 = !CUT_HALF || ci.own_pos != 1;
+    const int v0 = do1 ? ldp<NT_IDX>(a.edge_v2f + e) : 0, v1 = do0 ? ldp<NT_IDX>(a.edge_v2f + e + 1) : 0;
+    uint8_t cn0 = 0, cn1 = 0;
     T m0[D], p0[D], m1[D], p1[D], tab[D * D];
+#pragma unroll
+    for (int d = 0; d < D; ++d) m0[d] = p0[d] = m1[d] = p1[d] = (T)0;
     if constexpr (CIM) {
-        cn0 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo0, p0);  // F->V message last sent to variable 0
-        cn1 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo1, p1);  // (+ its send counter)
+        if (do0) cn0 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo0, p0);  // F->V message last sent to variable 0
+        if (do1) cn1 = Msg<T, D>::template load_c<NT_PREV>(a.f2v_old + fo1, p1);  // (+ its send counter)
     } else {
-        cn0 = a.cF[e];
-        cn1 = a.cF[e + 1];
-        Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo0, p0);
-        Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo1, p1);
+        if (do0) {
+            cn0 = a.cF[e];
+            Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo0, p0);
+        }
+        if (do1) {
+            cn1 = a.cF[e + 1];
+            Msg<T, D>::template load<NT_PREV>(a.f2v_old + fo1, p1);
+        }
     }
     load_table<T, D * D, NT>(a, ci, j, tab);
     // the two gathers
     // (peer-store mode: the message of a ghost variable lives in the ghost region)
     if constexpr (P2P) {
         // a ghost record was stored by another GPU while this launch was already running
-        if (v0 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v0 - a.ghost_lo), m0);
-        else Msg<T, D>::load(a.v2f_old + v0, m0);
-        if (v1 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v1 - a.ghost_lo), m1);
-        else Msg<T, D>::load(a.v2f_old + v1, m1);
+        if (do1) {
+            if (v0 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v0 - a.ghost_lo), m0);
+            else Msg<T, D>::load(a.v2f_old + v0, m0);
+        }
+        if (do0) {
+            if (v1 >= a.ghost_lo) Msg<T, D>::load_sys(a.ghost_old + (v1 - a.ghost_lo), m1);
+            else Msg<T, D>::load(a.v2f_old + v1, m1);
+        }
     } else {
-        Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v0, m0);      // V->F message of scope variable 0
-        Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v1, m1);
+        if (do1) Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v0, m0);      // V->F message of scope variable 0
+        if (do0) Msg<T, D>::template load<NT_GATHER>(a.v2f_old + v1, m1);
     }
     T o0[D], o1[D];
 #pragma unroll
@@ -436,23 +451,27 @@ __device__ __forceinline__ void factor_binary(const SweepArgs<T>& a, const Class
     if constexpr ((64 * H * sizeof(T)) % 16 == 0) {
         if ((j - lw + 63) < ci.count) {  // wave-uniform: a whole wave of factors
             T full[H];
+            if (do0) {
 #pragma unroll
-            for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
-            wave_store_linear<T, H, NT>(a.f2v_new, fo0 - (int64_t)lw * H, full);
+                for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o0, CIM ? c0 : 0, d);
+                wave_store_linear<T, H, NT>(a.f2v_new, fo0 - (int64_t)lw * H, full);
+            }
+            if (do1) {
 #pragma unroll
-            for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
-            wave_store_linear<T, H, NT>(a.f2v_new, fo1 - (int64_t)lw * H, full);
+                for (int d = 0; d < H; ++d) full[d] = Msg<T, D>::padded(o1, CIM ? c1 : 0, d);
+                wave_store_linear<T, H, NT>(a.f2v_new, fo1 - (int64_t)lw * H, full);
+            }
         } else {
-            Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
-            Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
+            if (do0) Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
+            if (do1) Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
         }
     } else {
-        Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
-        Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
+        if (do0) Msg<T, D>::store_c(a.f2v_new + fo0, o0, CIM ? c0 : 0);
+        if (do1) Msg<T, D>::store_c(a.f2v_new + fo1, o1, CIM ? c1 : 0);
     }
     if constexpr (!CIM) {
-        a.cF[e] = c0;
-        a.cF[e + 1] = c1;
+        if (do0) a.cF[e] = c0;
+        if (do1) a.cF[e + 1] = c1;
     }
 }
 
@@ -722,7 +741,7 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // size only (the engine picks it when the graph has a single D), which keeps the
 // kernel's register allocation -- the maximum over all paths -- small.
 // ---------------------------------------------------------------------------
-template <typename T, int D, bool P2P = false, int NT = MXS_NT>
+template <typename T, int D, bool P2P = false, int NT = MXS_NT, bool CUT_HALF = true>
 __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     if (ci.kind == K_V_PACK) {  // one lane per edge
         variable_pack<T, D, P2P, NT>(a, ci, item);
@@ -730,7 +749,7 @@ __device__ __forceinline__ void sweep_d(const SweepArgs<T>& a, const ClassInfo& 
     }
     const int j = item + (int)threadIdx.x;
     if (j >= ci.count) return;
-    if (ci.kind == K_F_BIN) factor_binary<T, D, P2P, NT>(a, ci, j);
+    if (ci.kind == K_F_BIN) factor_binary<T, D, P2P, NT, CUT_HALF>(a, ci, j);
     else if (ci.kind == K_F_UNARY) factor_unary<T, D, NT>(a, ci, j);
 }
 
@@ -813,12 +832,12 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     // 20.5 on coloring_100k, 274 / 277 / 284 against 259 on the 1M instance, 10.3 / 13.6 / 16.5 against
     // 6.4 on the 10k one: profiles/r03_tiles_ab_v1.txt.)
     if (DSEL != 0) {
-        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT>(a, ci, item);
+        sweep_d<T, (DSEL != 0 ? DSEL : 2), P2P, NT, !SCHED>(a, ci, item);
     } else {
         switch (ci.D) {
-            case 2: sweep_d<T, 2, P2P, NT>(a, ci, item); break;
-            case 3: sweep_d<T, 3, P2P, NT>(a, ci, item); break;
-            case 4: sweep_d<T, 4, P2P, NT>(a, ci, item); break;
+            case 2: sweep_d<T, 2, P2P, NT, !SCHED>(a, ci, item); break;
+            case 3: sweep_d<T, 3, P2P, NT, !SCHED>(a, ci, item); break;
+            case 4: sweep_d<T, 4, P2P, NT, !SCHED>(a, ci, item); break;
             default: break;
         }
     }

@@ -32,6 +32,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     if (f & 16384) o.compact_tables = true;   // bit14: narrow storage of exactly-representable tables
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
+    o.half_cut = !(f & 65536);                // bit16: a shard's cut binary factors compute both messages (round 3)
     return o;
 }
 
@@ -40,10 +41,11 @@ namespace {
 struct FKey {
     int kind, D;
     int cut = 0;  // 1: the factor reads a ghost variable's message (sharded operation)
+    int own = 0;  // cut binary register factors: 1 / 2 = only scope position 0 / 1 is an owned variable (ClassInfo::own_pos)
     bool operator<(const FKey& o) const {
-        return cut != o.cut ? cut < o.cut : kind != o.kind ? kind < o.kind : D < o.D;
+        return cut != o.cut ? cut < o.cut : kind != o.kind ? kind < o.kind : D != o.D ? D < o.D : own < o.own;
     }
-    bool operator==(const FKey& o) const { return kind == o.kind && D == o.D && cut == o.cut; }
+    bool operator==(const FKey& o) const { return kind == o.kind && D == o.D && cut == o.cut && own == o.own; }
 };
 
 std::string validate(const mxs_graph& g) {
@@ -238,6 +240,13 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (g.var_owned)
             for (int i = 0; i < ar; ++i)
                 if (!g.var_owned[g.edge_var[e0 + i]]) k.cut = 1;
+        // A cut binary factor is replicated on both shards that own one of its variables; each replica's message to
+        // the OTHER shard's variable is never read by anybody (ghost variables are storage only): the replica computes
+        // only the message to its own variable -- half the records moved per replicated factor.
+        if (k.cut && k.kind == K_F_BIN && L.opt.half_cut) {
+            const bool o0 = g.var_owned[g.edge_var[e0]] != 0, o1 = g.var_owned[g.edge_var[e0 + 1]] != 0;
+            k.own = (o0 && !o1) ? 1 : ((!o0 && o1) ? 2 : 0);
+        }
         fkey[f] = k;
     }
     L.factor_i2e.resize(nF);
@@ -401,6 +410,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         ci.edge_base = L.frowptr[fi];
         ci.f2v_base = nE ? L.f2v_off[L.frowptr[fi]] : 0;
         ci.f2v_base1 = key.kind == K_F_BIN ? L.f2v_off[L.frowptr[fi] + 1] : 0;  // record (0, 1)
+        ci.own_pos = key.own;
         ci.tab_base = L.eval_tab_off[fi];
         const int cls = (int)L.classes.size();
         if (key.kind == K_F_UNARY || key.kind == K_F_BIN) {

@@ -199,6 +199,9 @@ struct ClassInfo {       // one per class, read with one scalar load
     int32_t tab_type;    // TabType: how the class's tables are stored
     int32_t ctab_rec;    // compact types: bytes per factor record in ctables
     int64_t ctab_base;   // compact types: byte offset of the class's records in ctables
+    int32_t own_pos;     // K_F_BIN of a shard's cut factors: 1 / 2 = only the message to scope position 0 / 1 is computed
+                         // (the other variable is a ghost: nobody reads what this replica would send it); 0 = both
+    int32_t pad_;
 };
 
 struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block
@@ -293,6 +296,7 @@ struct LayoutOptions {
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
+    bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable
 };
 
 struct Layout {

@@ -154,10 +154,12 @@ def test_fused_sharded_launch_is_used_and_optional(emu_lib, monkeypatch):
     assert launches["1"] == (2, 1) and launches["0"] == (2, 2)
 
 
-@pytest.mark.parametrize("flags", [512, 1024])
+@pytest.mark.parametrize("flags", [512, 1024, 65536, 65536 + 512])
 def test_shard_launch_split_variants_emu(flags, emu_lib):
     """layout_flags 512 / 1024: every factor class / only the cut factor classes in the
-    second launch of a sharded cycle -- a scheduling choice, same results."""
+    second launch of a sharded cycle -- a scheduling choice, same results.  65536: a cut binary
+    factor's replica computes BOTH messages (round 3) instead of only the one to its own variable
+    (the default since round 4: the other one goes to a ghost variable nobody sweeps)."""
     for case in ("coloring", "mixed_max"):
         g, kw = make_case(case)
         _check_against_single(g, dict(kw, layout_flags=flags), 3, emu_lib, steps=(1, 5))

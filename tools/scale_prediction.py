@@ -48,13 +48,14 @@ def main():
     ap.add_argument("--workload", default="coloring_1m_deg6")
     ap.add_argument("--dtype", default="f64")
     ap.add_argument("--ranks", type=int, nargs="*", default=[2, 4, 8])
+    ap.add_argument("--layout-flags", type=int, default=0, help="65536: cut binary factors compute both messages (round 3)")
     a = ap.parse_args()
     g, mode = make_workload(a.workload)
     word = 8 if a.dtype == "f64" else 4
-    p = Params(mode=mode, dtype=a.dtype)
+    p = Params(mode=mode, dtype=a.dtype, layout_flags=a.layout_flags)
     with MaxSumEngine(g, p) as e:
         t1 = timed(e.run, e.sync)
-    out = {"workload": a.workload, "dtype": a.dtype, "n_vars": g.n_vars, "n_factors": g.n_factors,
+    out = {"workload": a.workload, "dtype": a.dtype, "layout_flags": a.layout_flags, "n_vars": g.n_vars, "n_factors": g.n_factors,
            "one_gpu_us_per_cycle": t1, "xgmi_link_gbps": XGMI_LINK_GBPS, "measured_on": "one MI355X (no multi-GPU node)",
            "ranks": []}
     for n in a.ranks:
