@@ -468,8 +468,8 @@ struct Engine : EngineBase {
             int rc = launch_sweep(a, L.n_blocks_fused);
             if (rc) return rc;
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)(WIDE_PERSIST ? std::min<size_t>(L.wide_blocks.size(), WIDE_GRID) : L.wide_blocks.size())),
-                                   dim3(WIDE_TPB), 0, stream, a, (const WideBlock*)wide_blocks.p, (int)L.wide_blocks.size());
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()),
+                                   dim3(WIDE_TPB), 0, stream, a, (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }
             return launch_nary(a, 0);
@@ -486,8 +486,8 @@ struct Engine : EngineBase {
                 ws = side;
             }
             if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)(WIDE_PERSIST ? std::min<size_t>(L.wide_blocks.size(), WIDE_GRID) : L.wide_blocks.size())),
-                                   dim3(WIDE_TPB), 0, ws, a, (const WideBlock*)wide_blocks.p, (int)L.wide_blocks.size());
+                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()),
+                                   dim3(WIDE_TPB), 0, ws, a, (const WideBlock*)wide_blocks.p);
                 HIP_TRY(hipGetLastError());
             }
             if (fork) HIP_TRY(hipEventRecord(ev_join, side));

@@ -1674,15 +1674,6 @@ __device__ __forceinline__ T wide_chain(const T* in, const T* zero, int D, int d
 #ifndef MXS_WIDE_SKIP
 #define MXS_WIDE_SKIP 0  // timing experiments only (results wrong): 1 no chains, 2 no message arithmetic,
 #endif                   // 4 no beliefs, 8 no gathers, 16 no stores
-// Workgroups of the wide variable launch.  0: one per block.  N > 0: N PERSISTENT workgroups, each walking blocks
-// g, g + N, ... with the next block's records and the indices of the one after in flight (registers) -- measured
-// and NOT adopted (profiles/r04_wide_persistent_v1.txt: 64.5 us with 768 workgroups against 57.4 with one per
-// block; the pipeline's registers leave 3 workgroups per CU where 8 overlap their phases by themselves).
-#ifndef MXS_WIDE_GRID
-#define MXS_WIDE_GRID 0
-#endif
-constexpr int WIDE_GRID = MXS_WIDE_GRID;
-constexpr bool WIDE_PERSIST = WIDE_GRID > 0;
 constexpr int WIDE_R = WIDE_CAPB / WIDE_TPB;                          // staged elements per thread
 constexpr int WIDE_CR = (WIDE_MAX_COSTS + WIDE_TPB - 1) / WIDE_TPB;   // own costs per thread
 
@@ -1736,10 +1727,10 @@ __device__ __forceinline__ void wide_request_rec(const SweepArgs<T>& a, const Wi
     rc_.cnt = a.start ? 0 : (int)a.cV[wb.slot0 + (tid < wb.n_slots ? tid : 0)];
 }
 
-// PERSISTENT workgroups: workgroup g works on blocks g, g + G, g + 2G, ...  While it walks the LDS phases of
-// one block, the records of the next one and the indices of the one after are on their way (registers):
-// the launch moves its bytes while it computes instead of alternating (round 3: a block's life was
-// descriptor -> indices -> records -> three LDS phases -> stores, 56 us for 25 us worth of bytes).
+// One workgroup per block (layout.h WideBlock).  (A PERSISTENT variant -- a few hundred workgroups walking the blocks with
+// the next block's records and the indices of the one after in flight -- was measured and dropped: 64.5 us with 768 workgroups
+// against 57.4 then, profiles/r04_wide_phases_v1.txt: a block's LDS phases are one dependency chain, and eight co-resident
+// workgroups overlap them better than three with a prefetch pipeline.)
 #ifndef MXS_WIDE_WAVES
 #define MXS_WIDE_WAVES 8  // register budget for that many waves per SIMD (0: the compiler's choice, 80 VGPRs in f64: 45.6 us against 42.3)
 #endif
@@ -1748,7 +1739,7 @@ __global__ void __launch_bounds__(WIDE_TPB)
 #if MXS_WIDE_WAVES > 0
 __attribute__((amdgpu_waves_per_eu(MXS_WIDE_WAVES, MXS_WIDE_WAVES)))
 #endif
-k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks, int n_blocks) {
+k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks) {
     constexpr int R = WIDE_R;
     __shared__ T s_in[WIDE_CAPB];               // staged F->V messages: [slot][d]
     __shared__ T s_c[WIDE_MAX_COSTS];           // own costs: [variable][d]
@@ -1760,35 +1751,26 @@ k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks, int n_bloc
     __shared__ uint8_t s_nom[WIDE_MAX_SLOTS];   // ... 1: some element differs from the message sent last
     __shared__ int s_vk0[WIDE_MAX_VARS];        // per variable: its first (local) slot
     __shared__ int s_vdeg[WIDE_MAX_VARS];
-    const int tid = (int)threadIdx.x, G = (int)gridDim.x;
-    int b = (int)blockIdx.x;
-    if (b >= n_blocks) return;
+    const int tid = (int)threadIdx.x;
+    const WideBlock wb = blocks[blockIdx.x];    // block-uniform: scalar loads
     for (int i = tid; i < WIDE_MAX_D; i += WIDE_TPB) s_zero[i] = (T)0;
-    // ---- fill the pipeline ---------------------------------------------------------------
-    auto desc = [&](int bb) { return blocks[bb < n_blocks ? bb : n_blocks - 1]; };  // block-uniform: scalar loads
-    WideBlock wA = desc(b), wB = wA, wC = wA;
-    WideIdx<T> iA, iB{};
+    WideIdx<T> iA;
     WideRec<T> rA;
-    wide_request_idx(a, wA, tid, iA);
-    if constexpr (WIDE_PERSIST) {
-        wB = desc(b + G), wC = desc(b + 2 * G);
-        wide_request_idx(a, wB, tid, iB);
-    }
-    wide_request_rec(a, wA, tid, iA, rA);
+    wide_request_idx(a, wb, tid, iA);
+    wide_request_rec(a, wb, tid, iA, rA);
 #ifdef MXS_WIDE_PROFILE
     long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define WIDE_TICK(k) do { const long long t_ = (long long)__builtin_amdgcn_s_memtime(); prof[k] += t_ - t_last; t_last = t_; } while (0)
 #else
 #define WIDE_TICK(k) ((void)0)
 #endif
-    for (;;) {
+    {
 #ifdef MXS_WIDE_PROFILE
         long long t_last = (long long)__builtin_amdgcn_s_memtime();
         const long long t_top = t_last;
 #endif
-        const WideBlock wb = wA;
         const int D = wb.D, ns = wb.n_slots, ne = ns * D;
-        // ---- 1. stage block A; request the records of B and the indices of C ---------------------
+        // ---- 1. stage ------------------------------------------------------------------------
         int sl[R], dd[R];
         static_for<R>([&](auto rc) __attribute__((always_inline)) {
             constexpr int r = decltype(rc)::value;
@@ -1810,15 +1792,6 @@ k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks, int n_bloc
         if (tid < ns) {
             s_cnt[tid] = (uint8_t)rA.cnt;
             s_nom[tid] = 0;
-        }
-        const bool hasB = WIDE_PERSIST && b + G < n_blocks;
-        WideRec<T> rB{};
-        WideIdx<T> iC{};
-        WideBlock wD = wA;
-        if constexpr (WIDE_PERSIST) {
-            wD = desc(b + 3 * G);
-            if (hasB) wide_request_rec(a, wB, tid, iB, rB);
-            if (b + 2 * G < n_blocks) wide_request_idx(a, wC, tid, iC);
         }
         lds_barrier();
         WIDE_TICK(0);
@@ -1913,21 +1886,10 @@ k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks, int n_bloc
         WIDE_TICK(4);
 #ifdef MXS_WIDE_PROFILE
         prof[7] += 1;
-        if (!hasB) {
-            prof[6] += (long long)__builtin_amdgcn_s_memtime() - t_top;
-            if (tid == 0 && a.timeline)
-                for (int k = 0; k < 8; ++k) a.timeline[8 * blockIdx.x + k] += prof[k];
-        }
-#endif
-        if (!hasB) break;
-        lds_barrier();  // the LDS arrays are free for the next block
-        WIDE_TICK(5);
-#ifdef MXS_WIDE_PROFILE
         prof[6] += (long long)__builtin_amdgcn_s_memtime() - t_top;
+        if (tid == 0 && a.timeline)
+            for (int k = 0; k < 8; ++k) a.timeline[8 * blockIdx.x + k] += prof[k];
 #endif
-        b += G;
-        wA = wB, wB = wC, wC = wD;
-        iA = iB, iB = iC, rA = rB;
     }
 }
 
