@@ -1615,13 +1615,17 @@ __device__ __forceinline__ void lds_barrier() {
 // accumulator starts at +0 and can never become -0, so `sc + 0` is `sc` bit for bit -- no select on the
 // dependent chain, one add per term.  The reads of a pass (two values of d of four rows) are requested
 // before the additions of the previous pass.
-// NR row pointers in registers (deg <= NR), ND values of d per pass; the reads of a pass are requested before
+// NR row pointers in registers (deg - 1 <= NR: the target's own row is left out), ND values of d per pass; the reads of a pass are requested before
 // the additions of the pass before.
 template <typename T, int NR, int ND>
 __device__ __forceinline__ T wide_chain_rows(const T* in, const T* zero, int D, int deg, int ko) {
+    // the rows of the OTHER edges, in order (row i = edge i, or i + 1 from the skipped one on); the rest: zeros
     const T* r[NR];
 #pragma unroll
-    for (int k = 0; k < NR; ++k) r[k] = (k < deg && k != ko) ? in + k * D : zero;
+    for (int i = 0; i < NR; ++i) {
+        const int k = i < ko ? i : i + 1;
+        r[i] = k < deg ? in + k * D : zero;
+    }
     T q[ND][NR], sc = (T)0;
 #pragma unroll
     for (int i = 0; i < ND; ++i)
@@ -1657,8 +1661,8 @@ template <typename T>
 __device__ __forceinline__ T wide_chain(const T* in, const T* zero, int D, int deg, int ko) {
     // (the variables of the class are sorted by domain size, then by degree in steps of four: a wave rarely
     // mixes the paths)
-    if (deg <= 4) return wide_chain_rows<T, 4, 2>(in, zero, D, deg, ko);
-    if (deg <= 8) return wide_chain_rows<T, 8, 1>(in, zero, D, deg, ko);
+    if (deg <= 4) return wide_chain_rows<T, 3, 2>(in, zero, D, deg, ko);
+    if (deg <= 8) return wide_chain_rows<T, 7, 1>(in, zero, D, deg, ko);
     T sc = (T)0;
     for (int d = 0; d < D; ++d)
         for (int k = 0; k < deg; k += 8) {
