@@ -1661,7 +1661,10 @@ template <typename T>
 __device__ __forceinline__ T wide_chain(const T* in, const T* zero, int D, int deg, int ko) {
     // (the variables of the class are sorted by domain size, then by degree in steps of four: a wave rarely
     // mixes the paths)
-    if (deg <= 4) return wide_chain_rows<T, 3, 2>(in, zero, D, deg, ko);
+#ifndef MXS_WIDE_ND
+#define MXS_WIDE_ND 2  // values of d per pass of the chain at degree <= 4 (experiments: 4 = half the LDS round trips, twice the registers)
+#endif
+    if (deg <= 4) return wide_chain_rows<T, 3, MXS_WIDE_ND>(in, zero, D, deg, ko);
     if (deg <= 8) return wide_chain_rows<T, 7, 1>(in, zero, D, deg, ko);
     T sc = (T)0;
     for (int d = 0; d < D; ++d)
