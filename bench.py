@@ -269,9 +269,10 @@ def time_config(workload, dtype, graph, mode, budget_s=1.5):
         wall = time.perf_counter() - t0
         _, launches = eng.cycle_bytes()
         storage = eng.table_storage()
+        order = eng.factor_order()
     bytes_cycle = graph.cycle_bytes(word)
     return {"workload": workload, "dtype": dtype, "n_vars": graph.n_vars, "n_factors": graph.n_factors,
-            "n_edges": graph.n_edges, "steps": steps, "ms_per_step": 1e3 * wall / steps,
+            "n_edges": graph.n_edges, "steps": steps, "factor_order": order, "ms_per_step": 1e3 * wall / steps,
             "iterations_per_s": steps / wall, "edge_messages_per_s": steps / wall * 2 * graph.n_edges,
             "roofline": roofline_of(workload, dtype, bytes_cycle, event_ms * 1e-3 / steps, launches, graph, storage)}
 
@@ -550,6 +551,7 @@ def main():
         elapsed = time.perf_counter() - t0
         _, launches = runner.cycle_bytes()
         storage = runner.table_storage()
+        order = runner.factor_order()
         runner.close()
         out.update({
             "value": args.steps / elapsed, "ms_per_step": 1e3 * elapsed / args.steps, "scaling": "weak",
@@ -558,7 +560,7 @@ def main():
                        "edge_messages_per_s": args.steps / elapsed * 2 * graph.n_edges,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
                        "parallelism": "one GPU, one k_sweep launch per cycle",
-                       "parity_checked": True, "parity_test": MAIN_PARITY_TEST},
+                       "factor_order": order, "parity_checked": True, "parity_test": MAIN_PARITY_TEST},
             "roofline": roofline_of(workload, args.dtype, bytes_cycle, event_ms * 1e-3 / args.steps, launches,
                                     graph, storage),
         })

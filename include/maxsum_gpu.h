@@ -126,7 +126,11 @@ typedef struct mxs_params {
                                 bit15 (32768) no one-wave-per-factor box kernel (arity-3
                                           integer tables keep the lane-packed kernel)
                                 bit16 (65536) shard: cut binary factors compute both
-                                          messages (default: only the one to their own variable) */
+                                          messages (default: only the one to their own variable)
+                                bit17 / bit18 (131072 / 262144) tiled order of the binary
+                                          factors always / never (default: per instance --
+                                          4-byte words or a cache-resident cycle, and a
+                                          variable order that is not local already)     */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;
@@ -204,6 +208,12 @@ int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
  * fewer table bytes per cycle.  An update that does not fit (mxs_update_factor_table,
  * mxs_set_parent_table) moves the class back to full width. */
 int mxs_table_storage(const mxs_engine *e, int64_t factors[4], int64_t *table_bytes_per_cycle);
+
+/* Order of the binary factors inside their classes: *tiled = 1 when they are grouped by (window of the
+ * first variable, window of the second) so that every gather of a tile falls in two L2-sized windows,
+ * 0 when they simply follow their first variable.  A layout decision only (layout_flags bit17 / bit18,
+ * default per instance): any order computes the same messages bit for bit. */
+int mxs_factor_order(const mxs_engine *e, int32_t *tiled);
 
 /* Replace the cost table of factor `factor` (caller's factor index) by one of the
  * same shape, row-major over its scope; messages, counters and the selection

@@ -1890,6 +1890,12 @@ int mxs_cycle_bytes(const mxs_engine* e, int64_t* bytes, int32_t* launches) {
     return MXS_OK;
 }
 
+int mxs_factor_order(const mxs_engine* e, int32_t* tiled) {
+    CHECK_HANDLE(e);
+    if (tiled) *tiled = e->impl->L.tiled ? 1 : 0;
+    return MXS_OK;
+}
+
 int mxs_halo_setup(mxs_engine* e, const int32_t* se, int64_t ns, const int32_t* re, int64_t nr) {
     CHECK_HANDLE(e);
     if ((ns && !se) || (nr && !re) || ns < 0 || nr < 0) return fail(MXS_E_INVALID, "bad halo lists");

@@ -3,6 +3,7 @@
 #include "layout.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cmath>
 #include <cstring>
 #include <numeric>
@@ -33,6 +34,10 @@ LayoutOptions options_from_params(const mxs_params& p) {
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
     o.half_cut = !(f & 65536);                // bit16: a shard's cut binary factors compute both messages (round 3)
+    o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
+    if (f & 131072) o.tile_bytes = MXS_TILE_BYTES;       // bit17: always tiled
+    if (f & 262144) o.tile_bytes = 0;                    // bit18: never tiled
+    if (const char* tb = std::getenv("MAXSUM_TILE_KB")) o.tile_bytes = (int64_t)std::atoll(tb) * 1024;  // (A/B runs; 0 = off)
     return o;
 }
 
@@ -257,10 +262,52 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     // below -- the variable side reads the position-0 records as one dense stream.  One of
     // the two gathers per edge end turns from a random 64-byte request into streaming.
     // Any order gives the same arithmetic (every message is computed on its own).
-    std::vector<int32_t> floc(nF, 0);
+    std::vector<int64_t> floc(nF, 0);
     if (L.opt.sort_factors)
         for (int f = 0; f < nF; ++f)
             if (g.factor_rowptr[f + 1] > g.factor_rowptr[f]) floc[f] = L.var_e2i[g.edge_var[g.factor_rowptr[f]]];
+    // Tiled order (measurement: profiles/r04_tiled_order_ab_v1.jsonl): the binary factors of a class by (bucket of the first
+    // variable, bucket of the second, first variable) -- a bucket = a run of the internal variable order whose V->F records
+    // are about tile_bytes.  The factors of a tile gather both their variables' messages from two L2-sized windows, and a
+    // variable block finds the position-1 records it gathers in one chunk per tile of its bucket's column instead of anywhere
+    // in the array: every random 12- / 24-byte gather of the sweep falls into a window the L2 holds.  The price: the
+    // position-0 records of a variable are no longer one run -- its gathers of them are spread over its bucket's row of tiles.
+    // Measured, that trade pays on random graphs when the records are 4-byte words (-7 % at 100k variables, -10 % at 1M) or the
+    // instance is resident in the Infinity Cache (-3 % on coloring_100k f64), costs 8-11 % on an HBM-resident f64 instance
+    // (coloring_1m) and does nothing where the caller's order is already local (Ising grid: +-1 %).  tile_bytes < 0 applies
+    // exactly that rule; layout flags 131072 / 262144 force it on / off.
+    if (L.opt.sort_factors && L.opt.tile_bytes != 0 && nV > 0) {
+        const int64_t tile = L.opt.tile_bytes > 0 ? L.opt.tile_bytes : MXS_TILE_BYTES;
+        const int64_t per_var = std::max<int64_t>(1, (int64_t)nE * 3 * L.opt.word / std::max(1, nV));  // ~ V->F bytes per variable
+        const int64_t W = std::max<int64_t>(256, tile / per_var);
+        const int64_t NB = (nV + W - 1) / W;
+        bool on = NB > 1;
+        if (on && L.opt.tile_bytes < 0) {
+            // (a) is the caller's order local already?  (b) the cycle's bytes (the formula of section 8d, from the graph)
+            int64_t n_bin = 0, n_near = 0, bytes = 0;
+            for (int f = 0; f < nF; ++f) {
+                const int e0 = g.factor_rowptr[f];
+                int64_t cells = 1;
+                for (int e = e0; e < g.factor_rowptr[f + 1]; ++e) cells *= g.dom_size[g.edge_var[e]];
+                bytes += cells * L.opt.word;
+                if (fkey[f].kind != K_F_BIN) continue;
+                const int64_t b0 = L.var_e2i[g.edge_var[e0]] / W, b1 = L.var_e2i[g.edge_var[e0 + 1]] / W;
+                ++n_bin;
+                n_near += b0 == b1;  // (a random graph: 1 / NB of them)
+            }
+            for (int e = 0; e < nE; ++e) bytes += 6 * (int64_t)g.dom_size[g.edge_var[e]] * L.opt.word + 8;
+            for (int v = 0; v < nV; ++v) bytes += (int64_t)g.dom_size[v] * L.opt.word + 8 + L.opt.word;
+            on = n_bin > 0 && 2 * n_near < n_bin && (L.opt.word == 4 || bytes <= MXS_TILE_RESIDENT_BYTES);
+        }
+        if (on)
+            for (int f = 0; f < nF; ++f) {
+                const int e0 = g.factor_rowptr[f];
+                if (fkey[f].kind != K_F_BIN) continue;
+                const int64_t v0 = L.var_e2i[g.edge_var[e0]], v1 = L.var_e2i[g.edge_var[e0 + 1]];
+                floc[f] = ((v0 / W) * NB + v1 / W) * (int64_t)nV + v0;
+            }
+        L.tiled = on;
+    }
     std::stable_sort(L.factor_i2e.begin(), L.factor_i2e.end(), [&](int a, int b) {
         return fkey[a] < fkey[b] || (fkey[a] == fkey[b] && floc[a] < floc[b]);
     });

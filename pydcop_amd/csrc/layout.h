@@ -71,6 +71,12 @@ constexpr int BLOCK = MXS_BLOCK;
 #ifndef MXS_SCHEDULE_DEFAULT
 #define MXS_SCHEDULE_DEFAULT 1  // layout_flags bit11 (2048) forces the block schedule off, bit12 (4096) on
 #endif
+#ifndef MXS_TILE_BYTES
+#define MXS_TILE_BYTES (512 << 10)  // window of the tiled factor order (layout.cpp); flags bit17 (131072) on, bit18 (262144) off
+#endif
+#ifndef MXS_TILE_RESIDENT_BYTES
+#define MXS_TILE_RESIDENT_BYTES (256ll << 20)  // 8-byte words: tiled only when a cycle's bytes fit the Infinity Cache
+#endif
 #ifndef MXS_COMPACT_TABLES_DEFAULT
 #define MXS_COMPACT_TABLES_DEFAULT 1  // layout_flags bit13 (8192) forces full-width tables, bit14 (16384) compact
 #endif
@@ -297,6 +303,7 @@ struct LayoutOptions {
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable
+    int64_t tile_bytes = -1;     // binary factors in tiled order: > 0 windows of about this many bytes, 0 never, < 0 per instance (layout.cpp)
 };
 
 struct Layout {
@@ -389,6 +396,7 @@ struct Layout {
     std::vector<int32_t> frowptr;       // [n_factors+1] internal
 
     int64_t algorithmic_bytes = 0;   // SURVEY.md section 8d formula
+    bool tiled = false;              // the binary factors are in tiled order
 
     int half(int D) const { return half_stride(D, opt.word); }
 };

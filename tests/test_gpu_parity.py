@@ -42,6 +42,24 @@ def test_golden_reference_vectors(path):
     check_golden(g, params, meta, ref_idx, ref_cost, layout_flags=4)
 
 
+@pytest.mark.parametrize("dtype", ["f64", "f32"])
+def test_tiled_factor_order(dtype, oracle_built, monkeypatch):
+    """The binary factors in tiled order (layout.cpp): default rule on the bench instance, forced on
+    an Ising grid, forced off, and with 8 KB windows on small graphs -- always the oracle's messages."""
+    from pydcop_amd.engine import MaxSumEngine
+    g = G.random_coloring(100_000, seed=0, names=False)
+    assert MaxSumEngine(g, Params(dtype=dtype)).factor_order() == "tiled"
+    compare_with_oracle(oracle_built, g, Params(dtype=dtype), 0, steps=[1, 7])
+    assert MaxSumEngine(g, Params(dtype=dtype, layout_flags=262144)).factor_order() == "by_first_variable"
+    compare_with_oracle(oracle_built, g, Params(dtype=dtype, layout_flags=262144), 0, steps=[3])
+    grid = G.ising_grid(200, 200, seed=2, names=False)
+    assert MaxSumEngine(grid, Params(dtype=dtype)).factor_order() == "by_first_variable"
+    compare_with_oracle(oracle_built, grid, Params(dtype=dtype, layout_flags=131072), 0, steps=[1, 5])
+    monkeypatch.setenv("MAXSUM_TILE_KB", "8")
+    for name, make, kw in parity_cases():
+        compare_with_oracle(oracle_built, make(), Params(dtype=dtype, **kw), 0, steps=[1, 9])
+
+
 def test_config2_10k_coloring(oracle_built):
     """BASELINE.json configs[1]: random 3-colouring, 10k vars, degree 4."""
     for variant in ("soft", "hard"):
