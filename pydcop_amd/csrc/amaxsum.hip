@@ -37,8 +37,11 @@
 #include <climits>
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <numeric>
+#include <algorithm>
 #include <string>
 #include <type_traits>
 #include <utility>
@@ -138,6 +141,20 @@ __device__ __forceinline__ const T* rec_pay(const T* r) { return r + RecHead<T>:
 template <typename T>
 __device__ __forceinline__ void rec_pad(const Dev<T>& g, T* r, int D) {
     for (int d = RecHead<T>::W + D; d < g.rs; ++d) r[d] = (T)0;
+}
+
+// Beside its record, every produced message leaves one word in the dense array s_hdr[slot]: its destination
+// computation + 1 (variables first, then n_vars + factor) -- 0 = the slot holds no message.  The bookkeeping between
+// two generations (compaction, sort keys, the next generation's slot numbers) reads these 4 bytes per slot and
+// never the 32-byte records; how many output slots the message's handler needs follows from the destination
+// (its other neighbours: node_cap, a static table).
+template <typename T>
+__device__ __forceinline__ int32_t hdr_to_factor(const Dev<T>& g, int e) {  // a variable's message on edge e
+    return g.n_vars + g.edge_factor[e] + 1;
+}
+template <typename T>
+__device__ __forceinline__ int32_t hdr_to_var(const Dev<T>& g, int e) {  // a factor's message on edge e
+    return g.edge_var[e] + 1;
 }
 
 // factor_costs_for_var (maxsum.py:382-447), value d of the variable at scope position pos:
@@ -324,7 +341,7 @@ __global__ void k_start_count(Dev<T> g, int32_t* cnt) {  // cnt[node] = start me
 }
 
 template <typename T>
-__global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec) {
+__global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec, int32_t* s_hdr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < g.n_vars) {
         const int v = i;
@@ -342,6 +359,7 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec) {
             T* r = q_rec + at * g.rs;  // (the queue was zero-filled: header base, payload padding)
             costs_for_factor(g, v, k0 + k, rec_pay(r));
             rec_set_head(r, g.var_edges[k0 + k] * 2, 0);
+            s_hdr[at] = hdr_to_factor(g, g.var_edges[k0 + k]);
         }
     } else if (i < g.n_vars + g.n_factors) {
         const int f = i - g.n_vars;
@@ -353,30 +371,14 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec) {
             T* r = q_rec + at * g.rs;
             factor_message_any(g, f, p, rec_pay(r));
             rec_set_head(r, (e0 + p) * 2 + 1, 0);
+            s_hdr[at] = hdr_to_var(g, e0 + p);
         }
     }
 }
 
 // ---- one generation --------------------------------------------------------------------------
 template <typename T>
-__global__ void k_dest(Dev<T> g, const T* q_rec, int64_t n, int32_t* dest, int32_t* cap) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const int32_t code = rec_code(q_rec + i * g.rs);
-    const int e = code >> 1, dir = code & 1;
-    if (dir == 0) {
-        const int f = g.edge_factor[e];
-        dest[i] = g.n_vars + f;
-        cap[i] = g.factor_rowptr[f + 1] - g.factor_rowptr[f] - 1;
-    } else {
-        const int v = g.edge_var[e];
-        dest[i] = v;
-        cap[i] = g.var_rowptr[v + 1] - g.var_rowptr[v] - 1;
-    }
-}
-
-template <typename T>
-__device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, bool last) {
+__device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, int32_t* s_hdr, bool last) {
     const int32_t code = rec_code(rec);
     const T* pay = rec_pay(rec);
     T* s_out = s_rec + (int64_t)rec_base(rec) * g.rs;  // the handler's output slots
@@ -402,6 +404,7 @@ __device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, bool last) {
             if (damp_and_decide(g, out, g.f_prev + g.msg_off[e2], &g.f_cnt[e2], D2, g.damp_f != 0)) {
                 rec_pad(g, orec, D2);
                 rec_set_head(orec, e2 * 2 + 1, 0);
+                s_hdr[(int64_t)rec_base(rec) + slot] = hdr_to_var(g, e2);
             }
             ++slot;
         }
@@ -426,6 +429,7 @@ __device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, bool last) {
             if (damp_and_decide(g, out, g.v_prev + g.msg_off[e2], &g.v_cnt[e2], D, g.damp_v != 0)) {
                 rec_pad(g, orec, D);
                 rec_set_head(orec, e2 * 2, 0);
+                s_hdr[(int64_t)rec_base(rec) + slot] = hdr_to_factor(g, e2);
             }
             ++slot;
         }
@@ -459,18 +463,20 @@ __device__ __forceinline__ bool damp_and_decide_reg(const Dev<T>& g, T (&m)[N], 
     return true;
 }
 
-// The messages of a generation in DESTINATION-SORTED order (k_permute: one streaming pass gathers what the stable
-// sort's index array points at): a destination's queue is then a contiguous run -- code, first output slot, payload
-// at consecutive addresses -- and the chains below read it sequentially, RING deliveries ahead of the one they
-// handle.  (Round 3 followed order[r] -> q_code / q_pay / slot_base per delivery, one ahead: three dependent random
+// The messages of a generation in DESTINATION-SORTED order (k_permute: one pass gathers the records the stable
+// sort's slot array points at and stamps each with its handler's first output slot): a destination's queue is then a
+// contiguous run -- code, first output slot, payload at consecutive addresses -- and the chains below read it
+// sequentially, RING deliveries ahead of the one they handle.  (Round 3 followed order[r] -> q_code / q_pay / slot_base per delivery, one ahead: three dependent random
 // loads under full load, 3-5 us per step of a chain that is sequential anyway; the longest queue of a generation is
 // what the generation lasts -- profiles/r04_amaxsum_dispatches_v1.txt.)
 template <typename T>
 struct Sorted {
-    const int32_t* dst;        // [n] destination computation (variables first, then n_vars + factor)
     const T* rec;              // [n * rs] the records (header: code, first output slot of the delivery's handler)
-    const int32_t* seg_first;  // [segments] position of the first message of the t-th destination to run
-    const uint64_t* seg_key;   // [segments] class << 32 | ~(queue length)
+    const int32_t* seg_node;   // [nodes] the t-th destination to run (variables first, then n_vars + factor): static,
+                               // by class, inside a class by expected queue length (Engine::init)
+    const int32_t* run_first;  // [nodes] a destination's queue: the records [run_first, run_last) (equal: no mail)
+    const int32_t* run_last;
+    const int64_t* cls_first;  // [N_CLS + 1] first t of every class
     int64_t n;
 };
 constexpr int RING = 4;   // deliveries in flight per chain of a binary factor (a lane each: a small step body)
@@ -489,10 +495,6 @@ __device__ __forceinline__ void fetch_mail(const Dev<T>& g, const Sorted<T>& sq,
     m.base = rec_base(r);
 #pragma unroll
     for (int d = 0; d < N; ++d) m.pay[d] = rec_pay(r)[d < g.dmax ? d : 0];
-}
-template <typename T>
-__device__ __forceinline__ int64_t queue_length(const Sorted<T>& sq, int64_t t) {
-    return (int64_t)(uint32_t)~(uint32_t)sq.seg_key[t];
 }
 
 // Lane K of every 16-lane row to all lanes of the row: one DPP move per 32 bits (row_newbcast) -- VALU, where
@@ -527,20 +529,20 @@ __device__ __forceinline__ void amx_static_for(F&& f) {
 // sorted by queue length, so the queues of a wave are about equally long); `t` = the group's
 // destination in seg_first, groups past `seg_end` have none.
 template <typename T, int D, int GROUP>
-__device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, int64_t seg_end, T* s_rec) {
+__device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, int64_t seg_end, T* s_rec, int32_t* s_hdr) {
     constexpr bool WHOLE = GROUP == 64;
     const int lane = (int)threadIdx.x & 63;
     const int gl = lane % GROUP, gbase = lane - gl;
     const unsigned long long gmask = WHOLE ? ~0ull : (((1ull << (GROUP % 64)) - 1ull) << gbase);
     const bool valid = t < seg_end;
-    const int64_t p = valid ? sq.seg_first[t] : 0;
-    const int64_t len = valid ? queue_length(sq, t) : 0;
-    const int32_t dst = sq.dst[p];
-    const int v = valid ? dst : 0;
+    const int v = valid ? sq.seg_node[t] : 0;
+    const int64_t p = valid ? sq.run_first[v] : 0;
+    const int64_t len = valid ? sq.run_last[v] - p : 0;
     const int k0 = g.var_rowptr[v], deg = valid ? g.var_rowptr[v + 1] - k0 : 0;
     const bool active = gl < deg;
     const int ek = active ? g.var_edges[k0 + gl] : -1;
     const int64_t mo = active ? g.msg_off[ek] : 0;
+    const int32_t my_hdr = active ? hdr_to_factor(g, ek) : 0;  // what a message to this lane's factor leaves in s_hdr
     T held[D], prev[D], c[D];
     uint8_t cnt = 0;
     bool has = false;
@@ -620,11 +622,13 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
             for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
             if (alive && active && gl != j) {
                 if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
-                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)(ml.base + (gl < j ? gl : gl - 1)) * g.rs, 16);
+                    const int64_t slot = (int64_t)ml.base + (gl < j ? gl : gl - 1);
+                    T* o = (T*)__builtin_assume_aligned(s_rec + slot * g.rs, 16);
 #pragma unroll
                     for (int d = 0; d < D; ++d) rec_pay(o)[d] = m[d];
                     rec_pad(g, o, D);
                     rec_set_head(o, ek * 2, 0);
+                    s_hdr[slot] = my_hdr;
                 }
             }
     };
@@ -672,92 +676,108 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
     }
 }
 
-// out[y] = opt over the sender's values x of  tab(x, y) + (0 + cost[x])  -- factor_costs_for_var of
-// a binary factor; SENDER_FIRST: the sender is scope position 0 (rows of the table)
-template <typename T, bool SENDER_FIRST>
-__device__ __forceinline__ void factor2_message(const Dev<T>& g, const T (&tab)[16], const T (&cost)[4], int Ds, int Dt,
-                                                T (&out)[4]) {
-#pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        T best = g.is_max ? -(T)INFINITY : (T)INFINITY;
-#pragma unroll
-        for (int x = 0; x < 4; ++x)
-            if (x < Ds && y < Dt) {
-                const T cur = (SENDER_FIRST ? tab[x * 4 + y] : tab[y * 4 + x]) + ((T)0 + cost[x]);
-                if (g.is_max ? best < cur : best > cur) best = cur;
-            }
-        out[y] = best;
-    }
+// approx_match's component test without a branch: prev == c, or (prev + c != 0 and 2 |prev - c| / |prev + c| < stability).
+// The same expressions as comp_match in the same order; the quotient is computed whether it is needed or not.
+template <typename T>
+__device__ __forceinline__ bool comp_match_flat(T c, T prev_c, T stability) {
+    const T delta = absT(prev_c - c), sum = prev_c + c;
+    const bool close = ((T)2 * delta / absT(sum)) < stability;
+    return !(prev_c != c) | ((sum != (T)0) & close);
 }
 
-// A binary factor over domains of at most 4 values: one lane, table / held costs / last-sent
-// messages in registers.
-template <typename T>
-__device__ void chain_factor2(const Dev<T>& g, int f, const Sorted<T>& sq, int64_t p, int64_t len, T* s_rec) {
+// A binary factor over domains of at most N <= 4 values: one lane, table / held costs / last-sent messages in
+// registers.  A step (one delivered message) is STRAIGHT-LINE code: the direction (from scope variable 0 or 1), "is
+// the other variable heard from", "is it sent" are data -- selects -- not control flow.  (Round 3/4 branched on each of
+// them per lane: 909 basic blocks, both directions executed by every wave for every message, 3.8 us per step of the
+// longest queue -- and a generation lasts as long as its longest queue, profiles/r04_amaxsum_dispatches_v4.txt.)
+//   out[j] = opt over the sender's values k of  t(k, j) + (0 + in[k])            factor_costs_for_var, maxsum.py:382-447
+// with in[k] = the received cost, or the optimum's identity (+-inf) past the sender's domain: such a k never wins.
+template <typename T, int N, bool MAX>
+__device__ void chain_factor2(const Dev<T>& g, int f, const Sorted<T>& sq, int64_t p, int64_t len, T* s_rec, int32_t* s_hdr) {
     const int eA = g.factor_rowptr[f], eB = eA + 1;
+    const int32_t hdrA = hdr_to_var(g, eA), hdrB = hdr_to_var(g, eB);
     const int DA = g.dom_size[g.edge_var[eA]], DB = g.dom_size[g.edge_var[eB]];
     const int64_t moA = g.msg_off[eA], moB = g.msg_off[eB];
-    T tab[16], cA[4], cB[4], pA[4], pB[4];
+    const bool damp_on = g.damp_f != 0;
+    const T padv = MAX ? -(T)INFINITY : (T)INFINITY;
+    T tab[N * N], cA[N], cB[N], pA[N], pB[N];
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
+    for (int x = 0; x < N; ++x) {
 #pragma unroll
-        for (int y = 0; y < 4; ++y)
-            tab[x * 4 + y] = g.tables[g.table_off[f] + (int64_t)(x < DA ? x : DA - 1) * DB + (y < DB ? y : DB - 1)];
+        for (int y = 0; y < N; ++y)
+            tab[x * N + y] = g.tables[g.table_off[f] + (int64_t)(x < DA ? x : DA - 1) * DB + (y < DB ? y : DB - 1)];
         cA[x] = g.f_cost[moA + (x < DA ? x : DA - 1)];
         pA[x] = g.f_prev[moA + (x < DA ? x : DA - 1)];
         cB[x] = g.f_cost[moB + (x < DB ? x : DB - 1)];
         pB[x] = g.f_prev[moB + (x < DB ? x : DB - 1)];
     }
     bool hasA = g.f_has[eA] != 0, hasB = g.f_has[eB] != 0;
-    uint8_t cntA = g.f_cnt[eA], cntB = g.f_cnt[eB];
-    Mail<T, 4> ring[RING];
+    int cntA = g.f_cnt[eA], cntB = g.f_cnt[eB];
+    Mail<T, N> ring[RING];
+    const int64_t last = len > 0 ? len - 1 : 0;
 #pragma unroll
-    for (int j = 0; j < RING; ++j) fetch_mail<T, 4>(g, sq, p + (j < len ? j : len - 1), ring[j]);
-    auto step = [&](const Mail<T, 4>& ml) __attribute__((always_inline)) {
-        const int e = ml.code >> 1;
-        T out[4];
-        if (e == eA) {  // from scope variable 0: the message goes to variable 1
+    for (int j = 0; j < RING; ++j) fetch_mail<T, N>(g, sq, p + (j < last ? j : last), ring[j]);
+    auto step = [&](const Mail<T, N>& ml, bool live) __attribute__((always_inline)) {
+        const bool fromA = (ml.code >> 1) == eA;
+        const int Ds = fromA ? DA : DB, Dt = fromA ? DB : DA;
+        const bool ready = live & (fromA ? hasB : hasA);  // else: still waiting for the other variable (amaxsum.py:206)
+        const int cnt = fromA ? cntB : cntA;              // of the message to the OTHER variable
+        T in[N], pt[N], out[N];
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cA[x] = ml.pay[x];  // past the domain: the zero padding of the slot
-            hasA = true;
-            if (hasB) {  // else: still waiting for the other variable (amaxsum.py:206)
-                factor2_message<T, true>(g, tab, cA, DA, DB, out);
-                if (damp_and_decide_reg<T, 4>(g, out, pB, cntB, DB, g.damp_f != 0)) {
-                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
+        for (int k = 0; k < N; ++k) {
+            in[k] = k < Ds ? ml.pay[k] : padv;
+            pt[k] = fromA ? pB[k] : pA[k];
+        }
 #pragma unroll
-                    for (int y = 0; y < 4; ++y)
-                        if (y < DB) rec_pay(o)[y] = out[y];
-                    rec_pad(g, o, DB);
-                    rec_set_head(o, eB * 2 + 1, 0);
-                }
+        for (int j = 0; j < N; ++j) {
+            T best = padv;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const T cur = (fromA ? tab[k * N + j] : tab[j * N + k]) + ((T)0 + in[k]);
+                best = (MAX ? best < cur : best > cur) ? cur : best;
             }
-        } else {
+            out[j] = best;
+        }
+        // apply_damping + the send rule (damp_and_decide_reg, without branches)
+        const bool c0 = cnt > 0;
+        bool match = c0;
 #pragma unroll
-            for (int x = 0; x < 4; ++x) cB[x] = ml.pay[x];
-            hasB = true;
-            if (hasA) {
-                factor2_message<T, false>(g, tab, cB, DB, DA, out);
-                if (damp_and_decide_reg<T, 4>(g, out, pA, cntA, DA, g.damp_f != 0)) {
-                    T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
+        for (int j = 0; j < N; ++j) {
+            out[j] = (c0 & damp_on) ? g.damping * pt[j] + ((T)1 - g.damping) * out[j] : out[j];
+            match &= (j >= Dt) | comp_match_flat(out[j], pt[j], g.stability);
+        }
+        const bool sent = ready & !(match & (cnt >= SAME_COUNT));
+        const int cnt2 = sent ? (match ? cnt + 1 : 1) : cnt;
 #pragma unroll
-                    for (int x = 0; x < 4; ++x)
-                        if (x < DA) rec_pay(o)[x] = out[x];
-                    rec_pad(g, o, DA);
-                    rec_set_head(o, eA * 2 + 1, 0);
-                }
-            }
+        for (int k = 0; k < N; ++k) {
+            cA[k] = (live & fromA) ? ml.pay[k] : cA[k];
+            cB[k] = (live & !fromA) ? ml.pay[k] : cB[k];
+            pB[k] = (sent & fromA) ? out[k] : pB[k];
+            pA[k] = (sent & !fromA) ? out[k] : pA[k];
+        }
+        hasA |= live & fromA;
+        hasB |= live & !fromA;
+        cntB = fromA ? cnt2 : cntB;
+        cntA = fromA ? cntA : cnt2;
+        if (live) {  // the delivery's one output slot: the record (past the target's domain: never read), the slot word
+            T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
+            rec_set_head(o, (fromA ? eB : eA) * 2 + 1, 0);
+#pragma unroll
+            for (int j = 0; j < N; ++j) rec_pay(o)[j] = out[j];
+            s_hdr[ml.base] = sent ? (fromA ? hdrB : hdrA) : 0;
         }
     };
     for (int64_t r0 = 0; r0 < len; r0 += RING) {
 #pragma unroll
         for (int j = 0; j < RING; ++j) {
             const int64_t r = r0 + j;
-            if (r < len) step(ring[j]);
-            if (r + RING < len) fetch_mail<T, 4>(g, sq, p + r + RING, ring[j]);  // this register set's next tenant
+            step(ring[j], r < len);
+            const int64_t nx = r + RING;
+            fetch_mail<T, N>(g, sq, p + (nx < last ? nx : last), ring[j]);  // this register set's next tenant (always a load)
         }
     }
 #pragma unroll
-    for (int x = 0; x < 4; ++x) {
+    for (int x = 0; x < N; ++x) {
         if (x < DA) {
             g.f_cost[moA + x] = cA[x];
             g.f_prev[moA + x] = pA[x];
@@ -769,8 +789,8 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const Sorted<T>& sq, int64
     }
     g.f_has[eA] = hasA ? 1 : 0;
     g.f_has[eB] = hasB ? 1 : 0;
-    g.f_cnt[eA] = cntA;
-    g.f_cnt[eB] = cntB;
+    g.f_cnt[eA] = (uint8_t)cntA;
+    g.f_cnt[eB] = (uint8_t)cntB;
     g.f_nhas[f] = (hasA ? 1 : 0) + (hasB ? 1 : 0);
 }
 
@@ -780,7 +800,8 @@ constexpr int CLS_VAR8 = 1;     // variable, domain 2..4, degree <= 8: 8 lanes, 
 constexpr int CLS_VAR16 = 2;    //                        degree <= 16: 16 lanes, 4 per wave
 constexpr int CLS_VAR64 = 3;    //                        degree <= 64: the wave
 constexpr int CLS_GENERIC = 4;  // everything else: a lane on the per-message handler, 64 per wave
-constexpr int N_CLS = 5;
+constexpr int N_CLS = 5;        // (N_CLS itself: a destination without mail in this generation)
+constexpr int64_t DYNAMIC_ORDER_FROM = 1 << 20;  // messages in a generation from which its destinations are re-ordered
 
 template <typename T>
 __device__ __forceinline__ int class_of(const Dev<T>& g, int32_t dst) {
@@ -795,121 +816,185 @@ __device__ __forceinline__ int class_of(const Dev<T>& g, int32_t dst) {
 }
 
 template <typename T, int GROUP>
-__device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const Sorted<T>& sq, int64_t seg_begin, int64_t seg_end,
-                                                  T* s_rec) {
+__device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const Sorted<T>& sq, int cls, T* s_rec, int32_t* s_hdr) {
     constexpr int PER_WAVE = 64 / GROUP;
     const int lane = (int)threadIdx.x & 63;
+    const int64_t seg_begin = sq.cls_first[cls], seg_end = sq.cls_first[cls + 1];
+    if (seg_begin + (int64_t)blockIdx.x * PER_WAVE >= seg_end) return;  // (the grid covers every variable of the class)
     const int64_t t = seg_begin + (int64_t)blockIdx.x * PER_WAVE + lane / GROUP;
     // the domain sizes of the wave's variables: one pass per size present (wave-uniform branches)
-    const int myD = t < seg_end ? g.dom_size[sq.dst[sq.seg_first[t]]] : 0;
+    int myD = 0;  // (0: no destination for this group, or one without mail in this generation)
+    if (t < seg_end) {
+        const int v = sq.seg_node[t];
+        if (sq.run_last[v] > sq.run_first[v]) myD = g.dom_size[v];
+    }
     for (int D = 2; D <= 4; ++D) {
         if (__ballot(myD == D) == 0ull) continue;
         const int64_t tt = myD == D ? t : seg_end;  // the other groups sit this pass out
-        if (D == 2) chain_variable<T, 2, GROUP>(g, sq, tt, seg_end, s_rec);
-        else if (D == 3) chain_variable<T, 3, GROUP>(g, sq, tt, seg_end, s_rec);
-        else chain_variable<T, 4, GROUP>(g, sq, tt, seg_end, s_rec);
+        if (D == 2) chain_variable<T, 2, GROUP>(g, sq, tt, seg_end, s_rec, s_hdr);
+        else if (D == 3) chain_variable<T, 3, GROUP>(g, sq, tt, seg_end, s_rec, s_hdr);
+        else chain_variable<T, 4, GROUP>(g, sq, tt, seg_end, s_rec, s_hdr);
     }
 }
 
 // sq.seg_first[t]: position of the first message of the t-th destination to run -- by class, longest queues
-// first (step()); a launch runs the destinations [seg_begin, seg_end) of one class.  Blocks of one wave; a kernel
-// per class, so that each has the registers of its own path only.
+// first (step()); a launch runs the destinations of one class, [cls_first[cls], cls_first[cls + 1]) -- read from
+// device memory: the grid is sized for every computation of the class (static), the blocks past this generation's
+// count leave at once, and the host does not wait for the counts.  Blocks of one wave; a kernel per class, so that
+// each has the registers of its own path only.
 template <typename T, int GROUP>
-__global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, Sorted<T> sq, int64_t seg_begin, int64_t seg_end, T* s_rec) {
-    variables_of_wave<T, GROUP>(g, sq, seg_begin, seg_end, s_rec);
+__global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, Sorted<T> sq, int cls, T* s_rec, int32_t* s_hdr) {
+    variables_of_wave<T, GROUP>(g, sq, cls, s_rec, s_hdr);
 }
 
 template <typename T, bool FACTOR2>  // (two kernels: the binary-factor chains do not pay for the generic handler's registers)
-__global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, Sorted<T> sq, int64_t seg_begin, int64_t seg_end, T* s_rec) {
-    const int64_t t = seg_begin + (int64_t)blockIdx.x * 64 + ((int)threadIdx.x & 63);
-    if (t >= seg_end) return;
-    const int64_t p = sq.seg_first[t], len = queue_length(sq, t);
-    const int32_t dst = sq.dst[p];
+__global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, Sorted<T> sq, int cls, T* s_rec, int32_t* s_hdr) {
+    const int64_t t = sq.cls_first[cls] + (int64_t)blockIdx.x * 64 + ((int)threadIdx.x & 63);
+    const bool in_class = t < sq.cls_first[cls + 1];
+    const int32_t dst = in_class ? sq.seg_node[t] : 0;
+    const int64_t p = in_class ? sq.run_first[dst] : 0, len = in_class ? sq.run_last[dst] - p : 0;
+    const bool valid = len > 0;  // (a destination without mail in this generation: nothing to do)
     if constexpr (FACTOR2) {
-        chain_factor2<T>(g, dst - g.n_vars, sq, p, len, s_rec);
+        // the wave's largest domain (wave-uniform): registers and work for 2, 3 or 4 values
+        const int f = valid ? dst - g.n_vars : 0;
+        int dm = 0;
+        if (valid) {
+            const int e0 = g.factor_rowptr[f];
+            const int d0 = g.dom_size[g.edge_var[e0]], d1 = g.dom_size[g.edge_var[e0 + 1]];
+            dm = d0 > d1 ? d0 : d1;
+        }
+        const int n = __ballot(dm > 3) != 0ull ? 4 : (__ballot(dm > 2) != 0ull ? 3 : 2);
+        if (!valid) return;
+        if (g.is_max) {
+            if (n == 4) chain_factor2<T, 4, true>(g, f, sq, p, len, s_rec, s_hdr);
+            else if (n == 3) chain_factor2<T, 3, true>(g, f, sq, p, len, s_rec, s_hdr);
+            else chain_factor2<T, 2, true>(g, f, sq, p, len, s_rec, s_hdr);
+        } else {
+            if (n == 4) chain_factor2<T, 4, false>(g, f, sq, p, len, s_rec, s_hdr);
+            else if (n == 3) chain_factor2<T, 3, false>(g, f, sq, p, len, s_rec, s_hdr);
+            else chain_factor2<T, 2, false>(g, f, sq, p, len, s_rec, s_hdr);
+        }
         return;
     }
+    if (!valid) return;
     for (int64_t r = p; r < p + len; ++r)  // its messages, in FIFO order
-        handle(g, sq.rec + r * g.rs, s_rec, r + 1 == p + len);
+        handle(g, sq.rec + r * g.rs, s_rec, s_hdr, r + 1 == p + len);
 }
 
-// the generation's records gathered into destination-sorted order (Sorted): order[p] = FIFO index of the p-th message
-// after the stable sort by destination.  One thread per 16-byte piece: the writes are one contiguous stream, the
-// reads one random line per message.
+// ---- between two generations: 4 bytes per output slot, one random record read per message -------------------
+// ONE scan over the slot words gives both numbers every filled slot needs: how many messages sit in earlier slots
+// (its FIFO index) and how many output slots their handlers take (its handler's first output slot), packed as
+// count << 33 | slots.  (The totals must stay below 2^30 messages and 2^31 slots -- finish() -- so neither field
+// overflows when slots * (largest capacity + 1) < 2^33; past that, finish() scans the two separately.)
+constexpr int PACK_SHIFT = 33;
+constexpr int64_t PACK_MASK = ((int64_t)1 << PACK_SHIFT) - 1;
+struct SlotFilled {  // 1 where the slot holds a message
+    __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const { return h ? 1 : 0; }
+};
+struct SlotCap {  // output slots the handler of the slot's message needs (0 for an empty slot)
+    const int32_t* node_cap;
+    __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const { return h ? (int64_t)node_cap[h - 1] : 0; }
+};
+struct SlotPacked {
+    const int32_t* node_cap;
+    __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const {
+        return h ? (((int64_t)1 << PACK_SHIFT) | (int64_t)node_cap[h - 1]) : 0;
+    }
+};
+__global__ void k_pack(const int64_t* pos, const int64_t* slot_base, int64_t n_slots, int64_t* packed) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n_slots) packed[s] = (pos[s] << PACK_SHIFT) | (slot_base[s] & PACK_MASK);
+}
+
+// out[0] = messages of the generation, out[1] = output slots its handlers need (the scan's totals)
+__global__ void k_totals(const int32_t* s_hdr, const int64_t* packed, const int32_t* node_cap, int64_t n_slots, int64_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t h = s_hdr[n_slots - 1];
+    out[0] = (packed[n_slots - 1] >> PACK_SHIFT) + SlotFilled()(h);
+    out[1] = (packed[n_slots - 1] & PACK_MASK) + SlotCap{node_cap}(h);
+}
+// the same from the two separate scans (before k_pack folds them: the totals are checked first)
+__global__ void k_totals2(const int32_t* s_hdr, const int64_t* pos, const int64_t* slot_base, const int32_t* node_cap,
+                          int64_t n_slots, int64_t* out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const int32_t h = s_hdr[n_slots - 1];
+    out[0] = pos[n_slots - 1] + SlotFilled()(h);
+    out[1] = slot_base[n_slots - 1] + SlotCap{node_cap}(h);
+}
+
+// the sort's input: destination and slot of every message, compacted in slot order = the FIFO order
+__global__ void k_compact(const int32_t* s_hdr, const int64_t* packed, int64_t n_slots, int32_t* dest, int32_t* slot_in) {
+    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= n_slots) return;
+    const int32_t h = s_hdr[s];
+    if (!h) return;
+    const int64_t at = packed[s] >> PACK_SHIFT;
+    dest[at] = h - 1;
+    slot_in[at] = (int32_t)s;  // (fewer than 2^31 slots per generation: finish())
+}
+
+// The generation's records gathered into destination-sorted order (Sorted): slot[p] = output slot holding the p-th
+// message after the stable sort by destination.  One thread per 16-byte piece: the writes are one contiguous stream,
+// the reads one random line per message (+ its handler's first output slot, stamped into the header).
 template <typename T>
-__global__ void k_permute(const T* q_rec, const int32_t* order, int64_t n, int rs, T* m_rec) {
+__global__ void k_permute(const T* s_rec, const int32_t* slot, const int64_t* packed, int64_t n, int rs, T* m_rec) {
     const int pieces = rs * (int)sizeof(T) / 16;
     const int64_t x = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int64_t p = x / pieces;
     const int k = (int)(x - p * pieces);
     if (p >= n) return;
     struct alignas(16) P16 { uint32_t w[4]; };
-    ((P16*)(m_rec + p * rs))[k] = ((const P16*)(q_rec + (int64_t)order[p] * rs))[k];
-}
-// the first output slot of every message's handler into its record (after the scan of the capacities)
-template <typename T>
-__global__ void k_stamp(T* q_rec, const int64_t* slot_base, int64_t n, int rs) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) ((int32_t*)(q_rec + i * rs))[1] = (int32_t)slot_base[i];  // (fewer than 2^31 slots per generation: step())
+    const int64_t s = slot[p];
+    P16 piece = ((const P16*)(s_rec + s * rs))[k];
+    if (k == 0) piece.w[1] = (uint32_t)(packed[s] & PACK_MASK);
+    ((P16*)(m_rec + p * rs))[k] = piece;
 }
 
-__global__ void k_iota(int32_t* out, int64_t n) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) out[i] = (int32_t)i;
-}
-
-// head[p] = 1 where a destination's run starts in the sorted order
-__global__ void k_heads(const int32_t* dest_sorted, int64_t n, int32_t* head) {
+// run of every destination in the sorted order: first[d] .. last[d] (both 0 for a destination without mail)
+__global__ void k_bounds(const int32_t* dest_sorted, int64_t n, int32_t* first, int32_t* last) {
     const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) head[p] = (p == 0 || dest_sorted[p] != dest_sorted[p - 1]) ? 1 : 0;
+    if (p >= n) return;
+    const int32_t b = dest_sorted[p];
+    if (p == 0 || dest_sorted[p - 1] != b) {
+        first[b] = (int32_t)p;
+        if (p > 0) last[dest_sorted[p - 1]] = (int32_t)p;
+    }
+    if (p + 1 == n) last[b] = (int32_t)n;
 }
 
-// seg_pos[idx[p]] = p for every head p
-__global__ void k_seg_starts(const int32_t* head, const int64_t* idx, int64_t n, int32_t* seg_pos) {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n && head[p]) seg_pos[idx[p]] = (int32_t)p;
-}
-
-// key = class << 32 | ~length: an ascending sort groups the classes and runs the longest queues of
-// each class first
+// class of every computation (static)
 template <typename T>
-__global__ void k_seg_keys(Dev<T> g, const int32_t* dest_sorted, const int32_t* seg_pos, int64_t n_seg, int64_t n,
-                           int generic_only, uint64_t* key) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_seg) return;
-    const int64_t end = t + 1 < n_seg ? seg_pos[t + 1] : n;
-    const int cls = generic_only ? CLS_GENERIC : class_of(g, dest_sorted[seg_pos[t]]);
-    key[t] = ((uint64_t)cls << 32) | (uint32_t)~(uint32_t)(end - seg_pos[t]);
+__global__ void k_node_class(Dev<T> g, int32_t* cls) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < g.n_vars + g.n_factors) cls[i] = class_of(g, i);
 }
 
+// A LARGE generation re-orders its destinations by their actual queue lengths (the static order of Engine::init ranks
+// them by expected length: good enough while a generation is short, 30 % slower chains at 10 M messages):
+// key = class << 13 | (8191 - min(length, 8191)), 16 bits; a destination without mail sorts behind them all.
+constexpr int LEN_BITS = 13;
+__global__ void k_node_keys(const int32_t* node_cls, const int32_t* first, const int32_t* last, int64_t nodes,
+                            uint32_t* key, int32_t* node) {
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nodes) return;
+    const int32_t len = last[d] - first[d];
+    const int cls = len == 0 ? N_CLS : node_cls[d];
+    const int32_t cl = len < (1 << LEN_BITS) - 1 ? len : (1 << LEN_BITS) - 1;
+    key[d] = ((uint32_t)cls << LEN_BITS) | (uint32_t)((1 << LEN_BITS) - 1 - cl);
+    node[d] = (int32_t)d;
+}
 // first[c] = number of sorted keys below class c (c = 0 .. N_CLS)
-__global__ void k_class_bounds(const uint64_t* key_sorted, int64_t n_seg, int64_t* first) {
+__global__ void k_class_bounds(const uint32_t* key_sorted, int64_t n_seg, int64_t* first) {
     const int c = threadIdx.x;
     if (c > N_CLS) return;
     int64_t lo = 0, hi = n_seg;
     while (lo < hi) {
         const int64_t mid = (lo + hi) / 2;
-        if ((key_sorted[mid] >> 32) < (uint64_t)c) lo = mid + 1;
+        if ((key_sorted[mid] >> LEN_BITS) < (uint32_t)c) lo = mid + 1;
         else hi = mid;
     }
     first[c] = lo;
 }
-
-template <typename T>
-__global__ void k_gather(const T* s_rec, const int64_t* pos, int64_t n_slots, int rs, T* q_rec) {
-    const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= n_slots || rec_code(s_rec + s * rs) < 0) return;
-    const int64_t at = pos[s];
-    for (int d = 0; d < rs; ++d) q_rec[at * rs + d] = s_rec[s * rs + d];
-}
-
-// 1 where output slot s holds a message: what the compaction scan sums, read straight from the records
-template <typename T>
-struct SlotFilled {
-    const T* rec;
-    int rs;
-    __host__ __device__ __forceinline__ int64_t operator()(int64_t slot) const { return rec_code(rec + slot * rs) >= 0 ? 1 : 0; }
-};
 
 struct Base {
     virtual ~Base() {}
@@ -953,19 +1038,28 @@ struct Engine : Base {
     std::vector<int32_t> h_dom, h_frow, h_evar, h_vrow, h_vedges;
     std::vector<int64_t> h_toff, h_coff, h_moff;
     std::vector<double> h_tables, h_eval_cost;
-    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx;
+    Buf<int32_t> dom_size, factor_rowptr, edge_var, edge_factor, var_rowptr, var_edges, init_idx, node_cap;
     Buf<int64_t> table_off, cost_off, msg_off;
     Buf<T> tables, var_cost, f_cost, f_prev, v_cost, v_prev, belief;
     Buf<uint8_t> f_has, f_cnt, v_has, v_cnt;
     Buf<int32_t> f_nhas, v_narr, v_order, sel;
-    // queue of the current generation, work arrays of a step
-    Buf<int32_t> dest, dest_sorted, order, order_in, cap, start_cnt, start_base;
-    Buf<T> q_rec, q_rec2, s_rec, m_rec;  // queue of the generation, of the next one, the output slots, the sorted copy
-    Buf<int64_t> slot_base, pos, cap64, head_idx;
-    Buf<int32_t> head, seg_pos, seg_first;
-    Buf<uint64_t> seg_key, seg_key_sorted;
+    // The pending generation: its messages sit in the output slots their senders wrote them to -- s_rec (records),
+    // s_hdr (8 bytes per slot: destination, capacity + 1, 0 = empty) -- `slots` of them, `pending` filled, and the
+    // scan over s_hdr is done: packed (messages before the slot << 33 | output slots before its handler's).
+    Buf<T> s_rec, m_rec;  // the output slots; the generation's records in destination-sorted order
+    Buf<int32_t> s_hdr;
+    Buf<int64_t> packed, pos, slot_base, totals;
+    int64_t slots = 0, slots_next = 0;  // slots of the pending generation, slots its handlers need
+    int64_t max_cap = 0;                // largest number of output slots a handler needs
+    Buf<int32_t> dest, dest_sorted, slot_in, slot_sorted, start_cnt, start_base;
+    Buf<int32_t> node_cls, run_first, run_last, seg_node;  // (seg_node, cls_first: the static running order)
+    Buf<int32_t> node_in, seg_node_dyn;                    // the order by actual queue length of a large generation
+    Buf<uint32_t> seg_key, seg_key_sorted;
+    Buf<int64_t> cls_first_dyn;
+    bool generic_only = false;
     Buf<int64_t> cls_first;
     Buf<uint8_t> temp;
+    int64_t cls_nodes[N_CLS] = {};  // computations of every class (static): the class kernels' grids
     int64_t nm = 0;
 
     int grid(int64_t n) const { return (int)((n + TPB - 1) / TPB); }
@@ -1013,6 +1107,14 @@ struct Engine : Base {
         AMX_TRY(factor_rowptr.upload(h_frow));
         AMX_TRY(edge_var.upload(h_evar));
         AMX_TRY(edge_factor.upload(h_efac));
+        {   // output slots the handler of a message to a computation needs: its other neighbours
+            std::vector<int32_t> nc((size_t)nV + nF + 1, 0);
+            max_cap = 0;
+            for (int v = 0; v < nV; ++v) nc[v] = std::max(0, h_vrow[v + 1] - h_vrow[v] - 1);
+            for (int f = 0; f < nF; ++f) nc[(size_t)nV + f] = h_frow[f + 1] - h_frow[f] - 1;
+            for (int32_t c : nc) max_cap = std::max<int64_t>(max_cap, c);
+            AMX_TRY(node_cap.upload(nc));
+        }
         AMX_TRY(var_rowptr.upload(h_vrow));
         AMX_TRY(var_edges.upload(h_vedges));
         AMX_TRY(table_off.upload(h_toff));
@@ -1053,6 +1155,59 @@ struct Engine : Base {
         g.f_cost = f_cost.p; g.f_prev = f_prev.p; g.v_cost = v_cost.p; g.v_prev = v_prev.p;
         g.f_has = f_has.p; g.f_cnt = f_cnt.p; g.v_has = v_has.p; g.v_cnt = v_cnt.p;
         g.f_nhas = f_nhas.p; g.v_narr = v_narr.p; g.v_order = v_order.p; g.sel = sel.p; g.belief = belief.p;
+        {   // The computations in running order, once: by class, and inside a class by how much mail they can expect --
+            // a generation lasts as long as its longest queue, and the lanes of a wave walk their queues in lock
+            // step, so a wave should hold queues of similar length.  The number of messages a computation gets in
+            // generation g is the number of (non-backtracking, not yet silenced) walks of length g that end at it; the
+            // plain walk count after a few steps ranks the computations nearly the same way, and it is static.
+            // (Sorting the destinations by their actual queue length every generation cost 130 us of a small
+            // generation's 500 -- profiles/r04_amaxsum_dispatches_v4.txt; any order is correct.)
+            const int64_t nodes = (int64_t)nV + nF;
+            AMX_TRY(node_cls.reserve(nodes + 1));
+            std::vector<int32_t> hc((size_t)nodes);
+            if (nodes) {
+                hipLaunchKernelGGL((k_node_class<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, node_cls.p);
+                AMX_TRY(hipGetLastError());
+                AMX_TRY(hipMemcpy(hc.data(), node_cls.p, 4 * nodes, hipMemcpyDeviceToHost));
+            }
+            const char* env = std::getenv("MAXSUM_AMAXSUM_GENERIC");  // =1: the per-message handler only (A/B, tests)
+            generic_only = env && env[0] == '1';
+            if (generic_only) {
+                for (int32_t& c : hc) c = CLS_GENERIC;
+                if (nodes) AMX_TRY(hipMemcpy(node_cls.p, hc.data(), 4 * nodes, hipMemcpyHostToDevice));
+            }
+            std::vector<double> w((size_t)nodes, 1.0), w2((size_t)nodes);
+            for (int it = 0; it < 8; ++it) {
+                double top = 0;
+                for (int v = 0; v < nV; ++v) {
+                    double a = 0;
+                    for (int k = h_vrow[v]; k < h_vrow[v + 1]; ++k) a += w[(size_t)nV + h_efac[h_vedges[k]]];
+                    w2[v] = a;
+                    top = std::max(top, a);
+                }
+                for (int f = 0; f < nF; ++f) {
+                    double a = 0;
+                    for (int e = h_frow[f]; e < h_frow[f + 1]; ++e) a += w[h_evar[e]];
+                    w2[(size_t)nV + f] = a;
+                    top = std::max(top, a);
+                }
+                const double scale = top > 0 ? 1.0 / top : 1.0;
+                for (int64_t i = 0; i < nodes; ++i) w[i] = w2[i] * scale;
+            }
+            std::vector<int32_t> order((size_t)nodes);
+            std::iota(order.begin(), order.end(), 0);
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) {
+                return hc[a] != hc[b] ? hc[a] < hc[b] : w[a] > w[b];
+            });
+            std::vector<int64_t> first(N_CLS + 1, 0);
+            for (int c = 0; c < N_CLS; ++c) cls_nodes[c] = 0;
+            for (int32_t c : hc) cls_nodes[c] += 1;
+            for (int c = 0; c < N_CLS; ++c) first[c + 1] = first[c] + cls_nodes[c];
+            AMX_TRY(seg_node.upload(order));
+            AMX_TRY(cls_first.upload(first));
+            AMX_TRY(cls_first_dyn.reserve(N_CLS + 1));
+            AMX_TRY(totals.reserve(2));
+        }
         return reset();
     }
 
@@ -1118,91 +1273,146 @@ struct Engine : Base {
                 for (int64_t i = 0; i < nodes; ++i) hb32[i] = (int32_t)hb[i];
                 AMX_TRY(hipMemcpy(start_base.p, hb32.data(), 4 * nodes, hipMemcpyHostToDevice));
             }
-            AMX_TRY(q_rec.reserve((total + 1) * g.rs));
-            AMX_TRY(hipMemset(q_rec.p, 0, sizeof(T) * (total + 1) * g.rs));
-            hipLaunchKernelGGL((k_start_emit<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_base.p, q_rec.p);
+            if (total > (int64_t)INT32_MAX) return fail(MXS_E_NOMEM, "amaxsum: more than 2^31 start messages");
+            AMX_TRY(s_rec.reserve((total + 1) * g.rs));
+            AMX_TRY(s_hdr.reserve(total + 1));
+            AMX_TRY(hipMemset(s_rec.p, 0, sizeof(T) * (total + 1) * g.rs));  // (header base, payload padding)
+            AMX_TRY(hipMemset(s_hdr.p, 0, 4 * (total + 1)));
+            hipLaunchKernelGGL((k_start_emit<T>), dim3(grid(nodes)), dim3(TPB), 0, 0, g, start_base.p, s_rec.p, s_hdr.p);
             AMX_TRY(hipGetLastError());
-            AMX_TRY(hipDeviceSynchronize());
-            pending = total;
+            int rc = finish(total);
+            if (rc) return rc;
         }
         if (pending) gen_sizes.push_back(pending);
         return MXS_OK;
     }
 
+    // The generation just produced sits in `n_slots` output slots: count it and number its handlers' output slots
+    // (one scan over the 4-byte slot words), totals back to the host -- the one wait of a generation.
+    int finish(int64_t n_slots) {
+        slots = n_slots;
+        pending = 0;
+        slots_next = 0;
+        if (n_slots == 0) return MXS_OK;
+        AMX_TRY(packed.reserve(n_slots));
+        const char* env = std::getenv("MAXSUM_AMAXSUM_TWO_SCANS");  // =1: the separate scans whatever the size (tests)
+        const bool one_scan = !(env && env[0] == '1') && n_slots < ((int64_t)1 << PACK_SHIFT) / (max_cap + 1);
+        size_t bytes = 0;
+        if (one_scan) {
+            hipcub::TransformInputIterator<int64_t, SlotPacked, const int32_t*> both(s_hdr.p, SlotPacked{node_cap.p});
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, both, packed.p, (int)n_slots));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, both, packed.p, (int)n_slots));
+            hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)packed.p,
+                               (const int32_t*)node_cap.p, n_slots, totals.p);
+        } else {
+            AMX_TRY(pos.reserve(n_slots));
+            AMX_TRY(slot_base.reserve(n_slots));
+            hipcub::TransformInputIterator<int64_t, SlotFilled, const int32_t*> filled(s_hdr.p, SlotFilled());
+            hipcub::TransformInputIterator<int64_t, SlotCap, const int32_t*> caps(s_hdr.p, SlotCap{node_cap.p});
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, filled, pos.p, (int)n_slots));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, filled, pos.p, (int)n_slots));
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, caps, slot_base.p, (int)n_slots));
+            AMX_TRY(temp.reserve(bytes));
+            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, caps, slot_base.p, (int)n_slots));
+            hipLaunchKernelGGL(k_totals2, dim3(1), dim3(64), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)pos.p,
+                               (const int64_t*)slot_base.p, (const int32_t*)node_cap.p, n_slots, totals.p);
+        }
+        AMX_TRY(hipGetLastError());
+        int64_t h[2] = {0, 0};
+        AMX_TRY(read_back(h, totals.p, sizeof(h)));
+        pending = h[0];
+        slots_next = h[1];
+        if (pending > (int64_t)1 << 30) return fail(MXS_E_NOMEM, "amaxsum: more than 2^30 messages in one generation");
+        if (slots_next > (int64_t)INT32_MAX)  // slot numbers are 32-bit in the records and the sort
+            return fail(MXS_E_NOMEM, "amaxsum: more than 2^31 output slots in one generation");
+        if (!one_scan) {
+            hipLaunchKernelGGL(k_pack, dim3(grid(n_slots)), dim3(TPB), 0, 0, (const int64_t*)pos.p, (const int64_t*)slot_base.p,
+                               n_slots, packed.p);
+            AMX_TRY(hipGetLastError());
+        }
+        return MXS_OK;
+    }
+
     int step() {  // deliver the whole pending generation
-        const int64_t n = pending;
-        if (n > (int64_t)1 << 30) return fail(MXS_E_NOMEM, "amaxsum: more than 2^30 messages in one generation");
+        const int64_t n = pending, nodes = (int64_t)g.n_vars + g.n_factors;
         AMX_TRY(dest.reserve(n));
         AMX_TRY(dest_sorted.reserve(n));
-        AMX_TRY(order.reserve(n));
-        AMX_TRY(order_in.reserve(n));
-        AMX_TRY(cap.reserve(n));
-        AMX_TRY(slot_base.reserve(n));
-        hipLaunchKernelGGL((k_dest<T>), dim3(grid(n)), dim3(TPB), 0, 0, g, (const T*)q_rec.p, n, dest.p, cap.p);
+        AMX_TRY(slot_in.reserve(n));
+        AMX_TRY(slot_sorted.reserve(n));
+        hipLaunchKernelGGL(k_compact, dim3(grid(slots)), dim3(TPB), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)packed.p, slots,
+                           dest.p, slot_in.p);
         AMX_TRY(hipGetLastError());
-        int64_t n_slots = 0;
-        { int rc = scan32(cap.p, slot_base.p, n, &n_slots); if (rc) return rc; }
-        if (n_slots > (int64_t)INT32_MAX)  // the compaction scans the slots with 32-bit counts
-            return fail(MXS_E_NOMEM, "amaxsum: more than 2^31 output slots in one generation");
-        hipLaunchKernelGGL((k_stamp<T>), dim3(grid(n)), dim3(TPB), 0, 0, q_rec.p, (const int64_t*)slot_base.p, n, g.rs);
-        AMX_TRY(hipGetLastError());
-        {   // FIFO indices 0..n-1, then the stable sort by destination
-            hipLaunchKernelGGL(k_iota, dim3(grid(n)), dim3(TPB), 0, 0, order_in.p, n);
-            AMX_TRY(hipGetLastError());
+        {   // the stable sort by destination: a queue = a run, in FIFO order
             size_t bytes = 0;
             int bits = 1;
-            while (((int64_t)1 << bits) < (int64_t)g.n_vars + g.n_factors + 1) ++bits;
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dest.p, dest_sorted.p, order_in.p, order.p, (int)n, 0, bits));
+            while (((int64_t)1 << bits) < nodes + 1) ++bits;
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, dest.p, dest_sorted.p, slot_in.p, slot_sorted.p, (int)n, 0, bits));
             AMX_TRY(temp.reserve(bytes));
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, dest.p, dest_sorted.p, order_in.p, order.p, (int)n, 0, bits));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, dest.p, dest_sorted.p, slot_in.p, slot_sorted.p, (int)n, 0, bits));
         }
-        // One thread per DESTINATION that has mail (not per message), the destinations with the
-        // longest queues first: a handler chain is sequential, so the generation lasts as long as
-        // its longest chain or as the total work over the machine, whichever is larger -- full
-        // waves of chains of similar length instead of one or two busy lanes per wave.
-        int64_t n_seg = 0;
-        {
-            AMX_TRY(head.reserve(n));
-            AMX_TRY(head_idx.reserve(n));
-            hipLaunchKernelGGL(k_heads, dim3(grid(n)), dim3(TPB), 0, 0, dest_sorted.p, n, head.p);
-            AMX_TRY(hipGetLastError());
-            { int rc = scan32(head.p, head_idx.p, n, &n_seg); if (rc) return rc; }
-            AMX_TRY(seg_pos.reserve(n_seg));
-            AMX_TRY(seg_first.reserve(n_seg));
-            AMX_TRY(seg_key.reserve(n_seg));
-            AMX_TRY(seg_key_sorted.reserve(n_seg));
-            hipLaunchKernelGGL(k_seg_starts, dim3(grid(n)), dim3(TPB), 0, 0, head.p, head_idx.p, n, seg_pos.p);
-            AMX_TRY(hipGetLastError());
-            const char* env = std::getenv("MAXSUM_AMAXSUM_GENERIC");  // =1: the per-message handler only (A/B, tests)
-            hipLaunchKernelGGL((k_seg_keys<T>), dim3(grid(n_seg)), dim3(TPB), 0, 0, g, dest_sorted.p, seg_pos.p, n_seg, n,
-                               (env && env[0] == '1') ? 1 : 0, seg_key.p);
+        // One thread (or lane group) per DESTINATION, not per message: where its queue starts and ends
+        AMX_TRY(run_first.reserve(nodes));
+        AMX_TRY(run_last.reserve(nodes));
+        AMX_TRY(hipMemset(run_first.p, 0, 4 * nodes));
+        AMX_TRY(hipMemset(run_last.p, 0, 4 * nodes));
+        hipLaunchKernelGGL(k_bounds, dim3(grid(n)), dim3(TPB), 0, 0, (const int32_t*)dest_sorted.p, n, run_first.p, run_last.p);
+        AMX_TRY(hipGetLastError());
+        const char* env_order = std::getenv("MAXSUM_AMAXSUM_ORDER");  // static / dynamic: force one (A/B, tests)
+        const bool dynamic_order = env_order ? env_order[0] == 'd' : n >= DYNAMIC_ORDER_FROM;
+        if (dynamic_order) {
+            AMX_TRY(node_in.reserve(nodes));
+            AMX_TRY(seg_node_dyn.reserve(nodes));
+            AMX_TRY(seg_key.reserve(nodes));
+            AMX_TRY(seg_key_sorted.reserve(nodes));
+            hipLaunchKernelGGL(k_node_keys, dim3(grid(nodes)), dim3(TPB), 0, 0, (const int32_t*)node_cls.p,
+                               (const int32_t*)run_first.p, (const int32_t*)run_last.p, nodes, seg_key.p, node_in.p);
             AMX_TRY(hipGetLastError());
             size_t bytes = 0;
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg, 0, 35));
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(nullptr, bytes, seg_key.p, seg_key_sorted.p, node_in.p, seg_node_dyn.p, (int)nodes, 0, LEN_BITS + 3));
             AMX_TRY(temp.reserve(bytes));
-            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, seg_key.p, seg_key_sorted.p, seg_pos.p, seg_first.p, (int)n_seg, 0, 35));
-            AMX_TRY(cls_first.reserve(N_CLS + 1));
-            hipLaunchKernelGGL(k_class_bounds, dim3(1), dim3(64), 0, 0, seg_key_sorted.p, n_seg, cls_first.p);
+            AMX_TRY(hipcub::DeviceRadixSort::SortPairs(temp.p, bytes, seg_key.p, seg_key_sorted.p, node_in.p, seg_node_dyn.p, (int)nodes, 0, LEN_BITS + 3));
+            hipLaunchKernelGGL(k_class_bounds, dim3(1), dim3(64), 0, 0, (const uint32_t*)seg_key_sorted.p, nodes, cls_first_dyn.p);
             AMX_TRY(hipGetLastError());
+        }
+        if (const char* dbg = std::getenv("MAXSUM_AMAXSUM_DEBUG"); dbg && dbg[0] == '1') {  // longest queue of every class
+            std::vector<int32_t> hf((size_t)nodes), hl((size_t)nodes), hcls((size_t)nodes);
+            AMX_TRY(read_back(hf.data(), run_first.p, 4 * nodes));
+            AMX_TRY(hipMemcpy(hl.data(), run_last.p, 4 * nodes, hipMemcpyDeviceToHost));
+            AMX_TRY(hipMemcpy(hcls.data(), node_cls.p, 4 * nodes, hipMemcpyDeviceToHost));
+            int32_t longest[N_CLS] = {};
+            int64_t with_mail[N_CLS] = {};
+            for (int64_t d = 0; d < nodes; ++d) {
+                longest[hcls[d]] = std::max(longest[hcls[d]], hl[d] - hf[d]);
+                with_mail[hcls[d]] += hl[d] > hf[d];
+            }
+            std::fprintf(stderr, "amaxsum generation %d: %lld messages in %lld slots;", next_generation, (long long)n, (long long)slots);
+            for (int c = 0; c < N_CLS; ++c)
+                std::fprintf(stderr, " class %d: %lld destinations, longest queue %d;", c, (long long)with_mail[c], longest[c]);
+            std::fprintf(stderr, "\n");
         }
         // the records themselves into sorted order: the chains read their queues as contiguous runs
         AMX_TRY(m_rec.reserve(n * g.rs));
         {
             const int64_t pieces = n * (g.rs * (int64_t)sizeof(T) / 16);
-            hipLaunchKernelGGL((k_permute<T>), dim3(grid(pieces)), dim3(TPB), 0, 0, (const T*)q_rec.p, (const int32_t*)order.p, n, g.rs, m_rec.p);
+            hipLaunchKernelGGL((k_permute<T>), dim3(grid(pieces)), dim3(TPB), 0, 0, (const T*)s_rec.p, (const int32_t*)slot_sorted.p,
+                               (const int64_t*)packed.p, n, g.rs, m_rec.p);
             AMX_TRY(hipGetLastError());
         }
-        const Sorted<T> sq{dest_sorted.p, m_rec.p, seg_first.p, seg_key_sorted.p, n};
-        int64_t h_first[N_CLS + 1];
-        AMX_TRY(read_back(h_first, cls_first.p, sizeof(h_first)));
-        AMX_TRY(s_rec.reserve((n_slots + 1) * g.rs));
-        AMX_TRY(hipMemset(s_rec.p, 0xFF, sizeof(T) * (n_slots + 1) * g.rs));  // code -1: empty slot
+        // the handlers' output slots (the records of this generation are in m_rec now)
+        const int64_t n_out = slots_next;
+        AMX_TRY(s_rec.reserve((n_out + 1) * g.rs));
+        AMX_TRY(s_hdr.reserve(n_out + 1));
+        AMX_TRY(hipMemset(s_hdr.p, 0, 4 * (n_out + 1)));
+        const Sorted<T> sq{m_rec.p, dynamic_order ? seg_node_dyn.p : seg_node.p, run_first.p, run_last.p,
+                           dynamic_order ? cls_first_dyn.p : cls_first.p, n};
         for (int cls = 0; cls < N_CLS; ++cls) {
-            const int64_t b = h_first[cls], e = h_first[cls + 1];
-            if (e <= b) continue;
+            const int64_t count = cls_nodes[cls];
+            if (count <= 0) continue;
             const int per_wave = cls == CLS_VAR8 ? 8 : (cls == CLS_VAR16 ? 4 : (cls == CLS_VAR64 ? 1 : 64));
-            const dim3 gr((unsigned)((e - b + per_wave - 1) / per_wave)), bl(64);
-#define AMX_ARGS g, sq, b, e, s_rec.p
+            const dim3 gr((unsigned)((count + per_wave - 1) / per_wave)), bl(64);
+#define AMX_ARGS g, sq, cls, s_rec.p, s_hdr.p
             if (!cls_stream[cls]) AMX_TRY(hipStreamCreateWithFlags(&cls_stream[cls], 0));
             hipStream_t st = cls_stream[cls];
             if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, st, AMX_ARGS);
@@ -1213,35 +1423,20 @@ struct Engine : Base {
 #undef AMX_ARGS
             AMX_TRY(hipGetLastError());
         }
-        // compaction of the filled slots, slot order = FIFO order of the next generation
-        int64_t n_next = 0;
-        if (n_slots > 0) {
-            AMX_TRY(pos.reserve(n_slots));
-            size_t bytes = 0;
-            hipcub::CountingInputIterator<int64_t> slots(0);
-            hipcub::TransformInputIterator<int64_t, SlotFilled<T>, hipcub::CountingInputIterator<int64_t>> filled(
-                slots, SlotFilled<T>{s_rec.p, g.rs});
-            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, filled, pos.p, (int)n_slots));
-            AMX_TRY(temp.reserve(bytes));
-            AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, filled, pos.p, (int)n_slots));
-            int64_t last_pos = 0;
-            int32_t last_code = -1;
-            AMX_TRY(read_back(&last_pos, pos.p + n_slots - 1, 8));
-            AMX_TRY(hipMemcpy(&last_code, s_rec.p + (n_slots - 1) * g.rs, 4, hipMemcpyDeviceToHost));
-            const int64_t last_flag = last_code >= 0 ? 1 : 0;
-            n_next = last_pos + last_flag;
-            AMX_TRY(q_rec2.reserve((n_next + 1) * g.rs));
-            hipLaunchKernelGGL((k_gather<T>), dim3(grid(n_slots)), dim3(TPB), 0, 0, (const T*)s_rec.p, (const int64_t*)pos.p, n_slots,
-                               g.rs, q_rec2.p);
-            AMX_TRY(hipGetLastError());
-        }
-        AMX_TRY(hipDeviceSynchronize());
-        std::swap(q_rec.p, q_rec2.p);
-        std::swap(q_rec.n, q_rec2.n);
         delivered_total += n;
         next_generation += 1;
-        pending = n_next;
-        if (n_next) gen_sizes.push_back(n_next);
+        if (const char* dbg = std::getenv("MAXSUM_AMAXSUM_DEBUG"); dbg && dbg[0] == '2') {  // the output slots as written
+            AMX_TRY(hipDeviceSynchronize());
+            std::vector<int32_t> hh((size_t)n_out);
+            std::vector<T> hr((size_t)n_out * g.rs);
+            AMX_TRY(hipMemcpy(hh.data(), s_hdr.p, 4 * n_out, hipMemcpyDeviceToHost));
+            AMX_TRY(hipMemcpy(hr.data(), s_rec.p, sizeof(T) * n_out * g.rs, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n_out && i < 400; ++i)
+                std::fprintf(stderr, "slot %lld: dest + 1 %d code %d\n", (long long)i, (int)hh[i], rec_code(hr.data() + i * g.rs));
+        }
+        int rc = finish(n_out);
+        if (rc) return rc;
+        if (pending) gen_sizes.push_back(pending);
         return MXS_OK;
     }
 
