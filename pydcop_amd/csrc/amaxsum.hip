@@ -115,6 +115,15 @@ __device__ __forceinline__ bool comp_match(T c, T prev_c, T stability) {
     return true;
 }
 
+// approx_match's component test without a branch: prev == c, or (prev + c != 0 and 2 |prev - c| / |prev + c| < stability).
+// The same expressions as comp_match in the same order; the quotient is computed whether it is needed or not.
+template <typename T>
+__device__ __forceinline__ bool comp_match_flat(T c, T prev_c, T stability) {
+    const T delta = absT(prev_c - c), sum = prev_c + c;
+    const bool close = ((T)2 * delta / absT(sum)) < stability;
+    return !(prev_c != c) | ((sum != (T)0) & close);
+}
+
 // A message of the queues is ONE record: an 8-byte header (code = edge * 2 + direction, the first output slot of its
 // handler) followed by the payload, padded to a multiple of 16 bytes (D = 3 in f64: 32 bytes).  Producing or
 // delivering a message then touches one cache line at a random place, not three arrays' worth -- the generations are
@@ -392,7 +401,10 @@ __device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, int32_t* s_hdr, 
             g.f_nhas[f] += 1;
         }
         const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
-        if (g.f_nhas[f] != ar) return;  // still waiting for some variable (:206)
+        if (g.f_nhas[f] != ar) {  // still waiting for some variable (:206): nothing in its output slots
+            for (int k = 0; k < ar - 1; ++k) s_hdr[(int64_t)rec_base(rec) + k] = 0;
+            return;
+        }
         int slot = 0;
         for (int p = 0; p < ar; ++p) {
             const int e2 = e0 + p;
@@ -405,6 +417,8 @@ __device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, int32_t* s_hdr, 
                 rec_pad(g, orec, D2);
                 rec_set_head(orec, e2 * 2 + 1, 0);
                 s_hdr[(int64_t)rec_base(rec) + slot] = hdr_to_var(g, e2);
+            } else {
+                s_hdr[(int64_t)rec_base(rec) + slot] = 0;
             }
             ++slot;
         }
@@ -430,6 +444,8 @@ __device__ void handle(const Dev<T>& g, const T* rec, T* s_rec, int32_t* s_hdr, 
                 rec_pad(g, orec, D);
                 rec_set_head(orec, e2 * 2, 0);
                 s_hdr[(int64_t)rec_base(rec) + slot] = hdr_to_factor(g, e2);
+            } else {
+                s_hdr[(int64_t)rec_base(rec) + slot] = 0;
             }
             ++slot;
         }
@@ -565,21 +581,23 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
     Mail<T, D> ring[VRING];
 #pragma unroll
     for (int j = 0; j < VRING; ++j) fetch_mail<T, D>(g, sq, p + (j < len ? j : (len > 0 ? len - 1 : 0)), ring[j]);
+    // A step is straight-line code (like chain_factor2's): "is it my factor's message", "has that factor been heard
+    // from", "is it sent" are selects.  A factor that does not count contributes -0.0: x + (-0.0) == x for every x,
+    // bit for bit, so the sums are the reference's sums over the factors that do count, in its order.
+    const bool damp_on = g.damp_v != 0;
+    const int64_t last = len > 0 ? len - 1 : 0;
     auto step = [&](const Mail<T, D>& ml, bool alive) __attribute__((always_inline)) {
             const int e = ml.code >> 1;
-            const unsigned long long from = __ballot(alive && active && ek == e) & gmask;
+            const unsigned long long from = __ballot(alive & active & (ek == e)) & gmask;
             const int j = from ? __builtin_ctzll(from) - gbase : -1;  // the sender's lane of the group
-            const bool mine = alive && gl == j;
-            if (mine) {
+            const bool mine = alive & (gl == j);
 #pragma unroll
-                for (int d = 0; d < D; ++d) held[d] = ml.pay[d];
-            }
-            const bool is_new = (__ballot(mine && !has) & gmask) != 0ull;
-            if (mine && !has) {
-                has = true;
-                my_rank = narr;
-                g.v_order[k0 + narr] = e;
-            }
+            for (int d = 0; d < D; ++d) held[d] = mine ? ml.pay[d] : held[d];
+            const bool fresh = mine & !has;
+            const bool is_new = (__ballot(fresh) & gmask) != 0ull;
+            if (fresh) g.v_order[k0 + narr] = e;
+            my_rank = fresh ? narr : my_rank;
+            has |= mine;
             narr += is_new ? 1 : 0;
             const unsigned long long hasmask = (__ballot(has) & gmask) >> gbase;
             // costs_for_factor for this lane's factor
@@ -591,45 +609,52 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
                 if constexpr (WHOLE) {
                     for (int k2 = 0; k2 < deg; ++k2) {  // deg is wave-uniform here
                         const T x = __shfl(held[d], k2, 64);
-                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {
-                            sum_cost += x;
-                            md += x;
-                        }
+                        const T xx = ((k2 != gl) & (((hasmask >> k2) & 1ull) != 0ull)) ? x : -(T)0;
+                        sum_cost += xx;
+                        md += xx;
                     }
-                } else if constexpr (GROUP == 16) {  // the group is a DPP row
-                    amx_static_for<16>([&](auto kc) __attribute__((always_inline)) {
+                } else {  // the group is a DPP row (16 lanes) or half of one (8)
+                    amx_static_for<GROUP>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k2 = decltype(kc)::value;
-                        const T x = row_bcast<k2>(held[d]);
-                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {
-                            sum_cost += x;
-                            md += x;
+                        T x;
+                        if constexpr (GROUP == 16) {
+                            x = row_bcast<k2>(held[d]);
+                        } else {
+                            const T lo = row_bcast<k2>(held[d]), hi = row_bcast<k2 + 8>(held[d]);
+                            x = (lane & 8) ? hi : lo;
                         }
+                        const T xx = ((k2 != gl) & (((hasmask >> k2) & 1ull) != 0ull)) ? x : -(T)0;  // lanes past the degree never "have"
+                        sum_cost += xx;
+                        md += xx;
                     });
-                } else {
-#pragma unroll
-                    for (int k2 = 0; k2 < GROUP; ++k2) {
-                        const T x = __shfl(held[d], k2, GROUP);
-                        if (k2 != gl && ((hasmask >> k2) & 1ull)) {  // lanes past the degree never "have"
-                            sum_cost += x;
-                            md += x;
-                        }
-                    }
                 }
                 m[d] = md;
             }
             const T avg = sum_cost / (T)D;
 #pragma unroll
             for (int d = 0; d < D; ++d) m[d] = m[d] - avg;
-            if (alive && active && gl != j) {
-                if (damp_and_decide_reg<T, D>(g, m, prev, cnt, D, g.damp_v != 0)) {
-                    const int64_t slot = (int64_t)ml.base + (gl < j ? gl : gl - 1);
-                    T* o = (T*)__builtin_assume_aligned(s_rec + slot * g.rs, 16);
+            // apply_damping + the send rule (damp_and_decide_reg, without branches)
+            const bool emit = alive & active & (gl != j);
+            const bool c0 = cnt > 0;
+            bool match = c0;
 #pragma unroll
-                    for (int d = 0; d < D; ++d) rec_pay(o)[d] = m[d];
-                    rec_pad(g, o, D);
-                    rec_set_head(o, ek * 2, 0);
-                    s_hdr[slot] = my_hdr;
-                }
+            for (int d = 0; d < D; ++d) {
+                m[d] = (c0 & damp_on) ? g.damping * prev[d] + ((T)1 - g.damping) * m[d] : m[d];
+                match &= comp_match_flat(m[d], prev[d], g.stability);
+            }
+            const bool sent = emit & !(match & (cnt >= SAME_COUNT));
+            cnt = sent ? (uint8_t)(match ? cnt + 1 : 1) : cnt;
+#pragma unroll
+            for (int d = 0; d < D; ++d) prev[d] = sent ? m[d] : prev[d];
+            // this lane's output slot of the delivery: the slot word always (0: not sent -- the slots are not cleared
+            // between generations, every handler writes all of its own), the record when there is one
+            const int64_t slot = (int64_t)ml.base + (gl < j ? gl : gl - 1);
+            if (emit) s_hdr[slot] = sent ? my_hdr : 0;
+            if (sent) {
+                T* o = (T*)__builtin_assume_aligned(s_rec + slot * g.rs, 16);
+                rec_set_head(o, ek * 2, 0);
+#pragma unroll
+                for (int d = 0; d < D; ++d) rec_pay(o)[d] = m[d];
             }
     };
     for (int64_t r0 = 0; __ballot(r0 < len) != 0ull; r0 += VRING) {
@@ -637,7 +662,8 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
         for (int j = 0; j < VRING; ++j) {
             const int64_t r = r0 + j;
             step(ring[j], r < len);
-            if (r + VRING < len) fetch_mail<T, D>(g, sq, p + r + VRING, ring[j]);  // this register set's next tenant
+            const int64_t nx = r + VRING;
+            fetch_mail<T, D>(g, sq, p + (nx < last ? nx : last), ring[j]);  // this register set's next tenant (always a load)
         }
     }
     // select_value on what is held now (maxsum.py:584-620): factors in first-arrival order
@@ -674,15 +700,6 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
         g.v_cnt[ek] = cnt;
         g.v_has[ek] = has ? 1 : 0;
     }
-}
-
-// approx_match's component test without a branch: prev == c, or (prev + c != 0 and 2 |prev - c| / |prev + c| < stability).
-// The same expressions as comp_match in the same order; the quotient is computed whether it is needed or not.
-template <typename T>
-__device__ __forceinline__ bool comp_match_flat(T c, T prev_c, T stability) {
-    const T delta = absT(prev_c - c), sum = prev_c + c;
-    const bool close = ((T)2 * delta / absT(sum)) < stability;
-    return !(prev_c != c) | ((sum != (T)0) & close);
 }
 
 // A binary factor over domains of at most N <= 4 values: one lane, table / held costs / last-sent messages in
@@ -759,12 +776,14 @@ __device__ void chain_factor2(const Dev<T>& g, int f, const Sorted<T>& sq, int64
         hasB |= live & !fromA;
         cntB = fromA ? cnt2 : cntB;
         cntA = fromA ? cntA : cnt2;
-        if (live) {  // the delivery's one output slot: the record (past the target's domain: never read), the slot word
+        // the delivery's one output slot: the slot word always (0: not sent), the record when there is one (past the
+        // target's domain: never read)
+        if (live) s_hdr[ml.base] = sent ? (fromA ? hdrB : hdrA) : 0;
+        if (sent) {
             T* o = (T*)__builtin_assume_aligned(s_rec + (int64_t)ml.base * g.rs, 16);
             rec_set_head(o, (fromA ? eB : eA) * 2 + 1, 0);
 #pragma unroll
             for (int j = 0; j < N; ++j) rec_pay(o)[j] = out[j];
-            s_hdr[ml.base] = sent ? (fromA ? hdrB : hdrA) : 0;
         }
     };
     for (int64_t r0 = 0; r0 < len; r0 += RING) {
@@ -1404,7 +1423,8 @@ struct Engine : Base {
         const int64_t n_out = slots_next;
         AMX_TRY(s_rec.reserve((n_out + 1) * g.rs));
         AMX_TRY(s_hdr.reserve(n_out + 1));
-        AMX_TRY(hipMemset(s_hdr.p, 0, 4 * (n_out + 1)));
+        if (const char* clr = std::getenv("MAXSUM_AMAXSUM_CLEAR_SLOTS"); clr && clr[0] == '1')  // (every handler writes the
+            AMX_TRY(hipMemset(s_hdr.p, 0xFF, 4 * (n_out + 1)));  // words of all its slots; =1 poisons them first: tests)
         const Sorted<T> sq{m_rec.p, dynamic_order ? seg_node_dyn.p : seg_node.p, run_first.p, run_last.p,
                            dynamic_order ? cls_first_dyn.p : cls_first.p, n};
         for (int cls = 0; cls < N_CLS; ++cls) {

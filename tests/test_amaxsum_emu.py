@@ -45,3 +45,21 @@ def test_amaxsum_emu_per_message_handler(case, oracle_built, monkeypatch):
 def test_amaxsum_emu_golden_reference_vectors(path):
     from emu.build_emu import build
     check_golden(lambda g, p: AMaxSumEngine(g, p, lib_path=build()), path)
+
+
+@pytest.mark.parametrize("env", [{"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1"}, {"MAXSUM_AMAXSUM_TWO_SCANS": "1"},
+                                 {"MAXSUM_AMAXSUM_ORDER": "dynamic"}, {"MAXSUM_AMAXSUM_ORDER": "static"},
+                                 {"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1", "MAXSUM_AMAXSUM_GENERIC": "1"}],
+                         ids=lambda e: "+".join(k[15:].lower() + "=" + v for k, v in e.items()))
+def test_amaxsum_bookkeeping_variants(env, oracle_built, monkeypatch):
+    """The switches of the generation bookkeeping (amaxsum.hip, step / finish): slot words poisoned before the
+    handlers run (every handler must write the words of all its output slots -- they are not cleared), the two
+    separate scans of very large generations, the destinations re-ordered by queue length / in the static order."""
+    from emu.build_emu import build
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, make, kw in amaxsum_cases(k=2)[:5]:
+        g = make()
+        p = Params(**kw)
+        compare_amaxsum(AMaxSumEngine(g, p, lib_path=build()), OracleAMaxSum(g, p), first=(1, 2, 3, 6), last_generation=14, largest=20_000)

@@ -46,3 +46,20 @@ def test_amaxsum_errors():
     g = G.random_coloring(20, seed=0)
     with pytest.raises(MaxSumGpuError):
         AMaxSumEngine(g, Params(), device=99)
+
+
+@pytest.mark.parametrize("env", [{"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1"}, {"MAXSUM_AMAXSUM_TWO_SCANS": "1"},
+                                 {"MAXSUM_AMAXSUM_ORDER": "dynamic"}, {"MAXSUM_AMAXSUM_ORDER": "static"},
+                                 {"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1", "MAXSUM_AMAXSUM_GENERIC": "1"}],
+                         ids=lambda e: "+".join(k[15:].lower() + "=" + v for k, v in e.items()))
+def test_amaxsum_bookkeeping_variants(env, oracle_built, monkeypatch):
+    """The switches of the generation bookkeeping (amaxsum.hip, step / finish): slot words poisoned before the
+    handlers run (every handler must write the words of all its output slots -- they are not cleared), the two
+    separate scans of very large generations, the destinations re-ordered by queue length / in the static order."""
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    for name, make, kw in amaxsum_cases(k=2)[:5]:
+        g = make()
+        p = Params(**kw)
+        compare_amaxsum(AMaxSumEngine(g, p), OracleAMaxSum(g, p), first=(1, 2, 3, 6), last_generation=14, largest=20_000)
