@@ -88,6 +88,8 @@ template <typename T>
 struct Dev {  // what the kernels see
     int32_t n_vars, n_factors, n_edges, dmax, is_max, start_mode, damp_f, damp_v;
     int32_t rs;  // elements of T per queue record (rec_stride)
+    int32_t cap_bits;         // slot words: low bits holding the handler's output slot count (0: looked up in node_cap)
+    const int32_t* node_cap;  // [computation] output slots the handler of a message to it needs (its other neighbours)
     T damping, stability;
     const int32_t *dom_size, *factor_rowptr, *edge_var, *edge_factor, *var_rowptr, *var_edges, *init_idx;
     const int64_t *table_off, *cost_off, *msg_off;
@@ -152,18 +154,26 @@ __device__ __forceinline__ void rec_pad(const Dev<T>& g, T* r, int D) {
     for (int d = RecHead<T>::W + D; d < g.rs; ++d) r[d] = (T)0;
 }
 
-// Beside its record, every produced message leaves one word in the dense array s_hdr[slot]: its destination
-// computation + 1 (variables first, then n_vars + factor) -- 0 = the slot holds no message.  The bookkeeping between
-// two generations (compaction, sort keys, the next generation's slot numbers) reads these 4 bytes per slot and
-// never the 32-byte records; how many output slots the message's handler needs follows from the destination
-// (its other neighbours: node_cap, a static table).
+// Beside its record, every produced message leaves one word in the dense array s_hdr[slot]: (its destination
+// computation + 1) << cap_bits | the output slots its handler needs (the destination's other neighbours) -- 0 = the
+// slot holds no message.  The bookkeeping between two generations (compaction, sort keys, the next generation's slot
+// numbers) reads these 4 bytes per slot and never the 32-byte records.  (cap_bits = 0 when destination and count do
+// not fit 31 bits together: the count is then looked up in node_cap by the destination.)
+__host__ __device__ __forceinline__ int32_t slot_dest(int32_t h, int cap_bits) { return (int32_t)((uint32_t)h >> cap_bits) - 1; }
+__host__ __device__ __forceinline__ int64_t slot_cap(int32_t h, int cap_bits, const int32_t* node_cap) {
+    return cap_bits ? (int64_t)(h & ((1 << cap_bits) - 1)) : (int64_t)node_cap[h - 1];
+}
+template <typename T>
+__device__ __forceinline__ int32_t slot_word(const Dev<T>& g, int dest) {
+    return ((dest + 1) << g.cap_bits) | (g.cap_bits ? g.node_cap[dest] : 0);
+}
 template <typename T>
 __device__ __forceinline__ int32_t hdr_to_factor(const Dev<T>& g, int e) {  // a variable's message on edge e
-    return g.n_vars + g.edge_factor[e] + 1;
+    return slot_word(g, g.n_vars + g.edge_factor[e]);
 }
 template <typename T>
 __device__ __forceinline__ int32_t hdr_to_var(const Dev<T>& g, int e) {  // a factor's message on edge e
-    return g.edge_var[e] + 1;
+    return slot_word(g, g.edge_var[e]);
 }
 
 // factor_costs_for_var (maxsum.py:382-447), value d of the variable at scope position pos:
@@ -912,12 +922,14 @@ struct SlotFilled {  // 1 where the slot holds a message
 };
 struct SlotCap {  // output slots the handler of the slot's message needs (0 for an empty slot)
     const int32_t* node_cap;
-    __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const { return h ? (int64_t)node_cap[h - 1] : 0; }
+    int cap_bits;
+    __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const { return h ? slot_cap(h, cap_bits, node_cap) : 0; }
 };
 struct SlotPacked {
     const int32_t* node_cap;
+    int cap_bits;
     __host__ __device__ __forceinline__ int64_t operator()(int32_t h) const {
-        return h ? (((int64_t)1 << PACK_SHIFT) | (int64_t)node_cap[h - 1]) : 0;
+        return h ? (((int64_t)1 << PACK_SHIFT) | slot_cap(h, cap_bits, node_cap)) : 0;
     }
 };
 __global__ void k_pack(const int64_t* pos, const int64_t* slot_base, int64_t n_slots, int64_t* packed) {
@@ -926,29 +938,31 @@ __global__ void k_pack(const int64_t* pos, const int64_t* slot_base, int64_t n_s
 }
 
 // out[0] = messages of the generation, out[1] = output slots its handlers need (the scan's totals)
-__global__ void k_totals(const int32_t* s_hdr, const int64_t* packed, const int32_t* node_cap, int64_t n_slots, int64_t* out) {
+__global__ void k_totals(const int32_t* s_hdr, const int64_t* packed, const int32_t* node_cap, int cap_bits, int64_t n_slots,
+                         int64_t* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int32_t h = s_hdr[n_slots - 1];
     out[0] = (packed[n_slots - 1] >> PACK_SHIFT) + SlotFilled()(h);
-    out[1] = (packed[n_slots - 1] & PACK_MASK) + SlotCap{node_cap}(h);
+    out[1] = (packed[n_slots - 1] & PACK_MASK) + SlotCap{node_cap, cap_bits}(h);
 }
 // the same from the two separate scans (before k_pack folds them: the totals are checked first)
 __global__ void k_totals2(const int32_t* s_hdr, const int64_t* pos, const int64_t* slot_base, const int32_t* node_cap,
-                          int64_t n_slots, int64_t* out) {
+                          int cap_bits, int64_t n_slots, int64_t* out) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     const int32_t h = s_hdr[n_slots - 1];
     out[0] = pos[n_slots - 1] + SlotFilled()(h);
-    out[1] = slot_base[n_slots - 1] + SlotCap{node_cap}(h);
+    out[1] = slot_base[n_slots - 1] + SlotCap{node_cap, cap_bits}(h);
 }
 
 // the sort's input: destination and slot of every message, compacted in slot order = the FIFO order
-__global__ void k_compact(const int32_t* s_hdr, const int64_t* packed, int64_t n_slots, int32_t* dest, int32_t* slot_in) {
+__global__ void k_compact(const int32_t* s_hdr, const int64_t* packed, int64_t n_slots, int cap_bits, int32_t* dest,
+                          int32_t* slot_in) {
     const int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_slots) return;
     const int32_t h = s_hdr[s];
     if (!h) return;
     const int64_t at = packed[s] >> PACK_SHIFT;
-    dest[at] = h - 1;
+    dest[at] = slot_dest(h, cap_bits);
     slot_in[at] = (int32_t)s;  // (fewer than 2^31 slots per generation: finish())
 }
 
@@ -1133,6 +1147,11 @@ struct Engine : Base {
             for (int f = 0; f < nF; ++f) nc[(size_t)nV + f] = h_frow[f + 1] - h_frow[f] - 1;
             for (int32_t c : nc) max_cap = std::max<int64_t>(max_cap, c);
             AMX_TRY(node_cap.upload(nc));
+            int cb = 0;
+            while (((int64_t)1 << cb) <= max_cap) ++cb;
+            g.cap_bits = ((int64_t)nV + nF + 2) < ((int64_t)1 << (31 - cb)) ? cb : 0;
+            if (const char* env = std::getenv("MAXSUM_AMAXSUM_CAP_LOOKUP"); env && env[0] == '1') g.cap_bits = 0;  // (tests)
+            g.node_cap = node_cap.p;
         }
         AMX_TRY(var_rowptr.upload(h_vrow));
         AMX_TRY(var_edges.upload(h_vedges));
@@ -1318,17 +1337,17 @@ struct Engine : Base {
         const bool one_scan = !(env && env[0] == '1') && n_slots < ((int64_t)1 << PACK_SHIFT) / (max_cap + 1);
         size_t bytes = 0;
         if (one_scan) {
-            hipcub::TransformInputIterator<int64_t, SlotPacked, const int32_t*> both(s_hdr.p, SlotPacked{node_cap.p});
+            hipcub::TransformInputIterator<int64_t, SlotPacked, const int32_t*> both(s_hdr.p, SlotPacked{node_cap.p, g.cap_bits});
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, both, packed.p, (int)n_slots));
             AMX_TRY(temp.reserve(bytes));
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, both, packed.p, (int)n_slots));
             hipLaunchKernelGGL(k_totals, dim3(1), dim3(64), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)packed.p,
-                               (const int32_t*)node_cap.p, n_slots, totals.p);
+                               (const int32_t*)node_cap.p, g.cap_bits, n_slots, totals.p);
         } else {
             AMX_TRY(pos.reserve(n_slots));
             AMX_TRY(slot_base.reserve(n_slots));
             hipcub::TransformInputIterator<int64_t, SlotFilled, const int32_t*> filled(s_hdr.p, SlotFilled());
-            hipcub::TransformInputIterator<int64_t, SlotCap, const int32_t*> caps(s_hdr.p, SlotCap{node_cap.p});
+            hipcub::TransformInputIterator<int64_t, SlotCap, const int32_t*> caps(s_hdr.p, SlotCap{node_cap.p, g.cap_bits});
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, filled, pos.p, (int)n_slots));
             AMX_TRY(temp.reserve(bytes));
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, filled, pos.p, (int)n_slots));
@@ -1336,7 +1355,7 @@ struct Engine : Base {
             AMX_TRY(temp.reserve(bytes));
             AMX_TRY(hipcub::DeviceScan::ExclusiveSum(temp.p, bytes, caps, slot_base.p, (int)n_slots));
             hipLaunchKernelGGL(k_totals2, dim3(1), dim3(64), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)pos.p,
-                               (const int64_t*)slot_base.p, (const int32_t*)node_cap.p, n_slots, totals.p);
+                               (const int64_t*)slot_base.p, (const int32_t*)node_cap.p, g.cap_bits, n_slots, totals.p);
         }
         AMX_TRY(hipGetLastError());
         int64_t h[2] = {0, 0};
@@ -1361,7 +1380,7 @@ struct Engine : Base {
         AMX_TRY(slot_in.reserve(n));
         AMX_TRY(slot_sorted.reserve(n));
         hipLaunchKernelGGL(k_compact, dim3(grid(slots)), dim3(TPB), 0, 0, (const int32_t*)s_hdr.p, (const int64_t*)packed.p, slots,
-                           dest.p, slot_in.p);
+                           g.cap_bits, dest.p, slot_in.p);
         AMX_TRY(hipGetLastError());
         {   // the stable sort by destination: a queue = a run, in FIFO order
             size_t bytes = 0;

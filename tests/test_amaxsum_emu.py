@@ -48,7 +48,7 @@ def test_amaxsum_emu_golden_reference_vectors(path):
 
 
 @pytest.mark.parametrize("env", [{"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1"}, {"MAXSUM_AMAXSUM_TWO_SCANS": "1"},
-                                 {"MAXSUM_AMAXSUM_ORDER": "dynamic"}, {"MAXSUM_AMAXSUM_ORDER": "static"},
+                                 {"MAXSUM_AMAXSUM_ORDER": "dynamic"}, {"MAXSUM_AMAXSUM_ORDER": "static"}, {"MAXSUM_AMAXSUM_CAP_LOOKUP": "1"},
                                  {"MAXSUM_AMAXSUM_CLEAR_SLOTS": "1", "MAXSUM_AMAXSUM_GENERIC": "1"}],
                          ids=lambda e: "+".join(k[15:].lower() + "=" + v for k, v in e.items()))
 def test_amaxsum_bookkeeping_variants(env, oracle_built, monkeypatch):
