@@ -376,9 +376,10 @@ def other_algorithms(n_vars, device=0):
                                  "achieved": done * per_msg / max(dt, 1e-12) / 1e9,
                                  "frac": done * per_msg / max(dt, 1e-12) / 1e9 / HBM_PEAK_GBPS,
                                  "algorithmic_bytes_per_message": per_msg,
-                                 "formula": "2 * (D * w + 16) per delivered message: payload and (destination, slot) "
-                                            "record written when produced, read when delivered; the sorts / scans that "
-                                            "order a generation move more (wall time, host read-backs included)"},
+                                 "formula": "2 * (D * w + 16) per delivered message: its record (header + payload) and "
+                                            "slot word written when produced, read when delivered; bound by random cache "
+                                            "lines, not by these bytes (DESIGN.md 3.4); wall time, the one host wait per "
+                                            "generation included"},
                     "parity_test": "tests/test_gpu_amaxsum.py::test_amaxsum_bit_exact_vs_oracle"})
     cycles = 5 if small else 500
     for name, make, test, mgm in (

@@ -11,23 +11,32 @@
 // generation interact only when they go to the SAME computation.  So a generation is processed
 // as a batch:
 //
-//   k_dest      per message: its destination computation and how many messages its handler
-//               can send at most (the destination's other neighbours)
-//   scan        exclusive sum of those capacities = the message's block of output slots, in
-//               FIFO order; k_stamp writes it into the message's record
-//   sort        stable radix sort of (destination, FIFO index) by destination (hipCUB)
-//   k_permute   the records themselves gathered into destination order (round 4): a queue is a
-//               contiguous run, a delivery one sequential 32-byte read
-//   k_process   a lane / lane group per destination, a kernel and a stream per destination class
-//               (they run side by side): handles ITS messages one after the other in FIFO
-//               order, exactly like the reference's handler (same expressions, same order of
-//               additions -- select_value in first-arrival order of the factors, maxsum.py:609),
-//               writing what it sends as one record into the trigger's output slots
-//   compact     the slots that hold a message, in slot order = the FIFO order of generation g + 1
+//   k_process   (the previous step) every handler writes what it sends as one record into its own OUTPUT SLOTS --
+//               numbered in FIFO order of the deliveries, one per message the handler can send -- and, beside
+//               it, one 4-byte word per slot into a dense array: destination, the slots the message's own handler
+//               will need; 0 = nothing sent.  Slot order = the FIFO order of the next generation.
+//   scan        ONE exclusive scan over the slot words: messages in earlier slots (the FIFO index) and output slots
+//               their handlers take (the message's first output slot), packed in one 64-bit sum; the totals are
+//               the one thing the host waits for per generation
+//   k_compact   (destination, slot) of every message, in slot order
+//   sort        stable radix sort of those pairs by destination (hipCUB): a queue = a run, in FIFO order
+//   k_permute   the records gathered from their slots into destination order (one random 32-byte read per
+//               message) and stamped with their first output slot: a delivery is one sequential read
+//   k_process   a lane / lane group per destination, a kernel and a stream per destination class (they run side
+//               by side): handles ITS messages one after the other in FIFO order, exactly like the reference's
+//               handler (same expressions, same order of additions -- select_value in first-arrival order of
+//               the factors, maxsum.py:609).  A step of a chain is straight-line code: direction, "heard from",
+//               "sent" are selects (round 4: the branchy version executed both directions for every message).
 //
-// A message is ONE record (8-byte header + payload, 32 bytes for three f64 values): the generations
-// are bound by the number of random cache lines they touch (~32 G lines/s measured), and three
-// parallel arrays (code, slot, payload) cost three lines per delivery and two per produced message.
+// Round 3/4 compacted the sent messages into a queue (gather of every slot's record), computed destination and
+// capacity per message, scanned, stamped, sorted, and sorted the destinations by queue length every generation:
+// half of a generation was bookkeeping over 32-byte records.  Now the bookkeeping reads 4 bytes per slot, the only
+// pass over the records is k_permute's gather, and the destinations run in a static order (re-ordered by actual
+// queue length only in generations of a million messages and more).
+//
+// A message is ONE record (8-byte header + payload, 32 bytes for three f64 values): the generations are bound by
+// the number of random cache lines they touch (~32 G lines/s measured) -- per message one in k_permute, one for the
+// record and one for the slot word in k_process.
 //
 // Nothing here is a dense contraction: integer bookkeeping + a few adds per message element.
 // The run ends by itself when the send rule (approx_match + SAME_COUNT) has silenced every edge.
@@ -892,16 +901,19 @@ __global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, Sorted<T> sq, in
             const int d0 = g.dom_size[g.edge_var[e0]], d1 = g.dom_size[g.edge_var[e0 + 1]];
             dm = d0 > d1 ? d0 : d1;
         }
-        const int n = __ballot(dm > 3) != 0ull ? 4 : (__ballot(dm > 2) != 0ull ? 3 : 2);
+        // (never more than the largest domain of the instance: a record has room for dmax values)
+        const int n = __ballot(dm > 3) != 0ull ? 4 : (__ballot(dm > 2) != 0ull ? 3 : (__ballot(dm > 1) != 0ull ? 2 : 1));
         if (!valid) return;
         if (g.is_max) {
             if (n == 4) chain_factor2<T, 4, true>(g, f, sq, p, len, s_rec, s_hdr);
             else if (n == 3) chain_factor2<T, 3, true>(g, f, sq, p, len, s_rec, s_hdr);
-            else chain_factor2<T, 2, true>(g, f, sq, p, len, s_rec, s_hdr);
+            else if (n == 2) chain_factor2<T, 2, true>(g, f, sq, p, len, s_rec, s_hdr);
+            else chain_factor2<T, 1, true>(g, f, sq, p, len, s_rec, s_hdr);
         } else {
             if (n == 4) chain_factor2<T, 4, false>(g, f, sq, p, len, s_rec, s_hdr);
             else if (n == 3) chain_factor2<T, 3, false>(g, f, sq, p, len, s_rec, s_hdr);
-            else chain_factor2<T, 2, false>(g, f, sq, p, len, s_rec, s_hdr);
+            else if (n == 2) chain_factor2<T, 2, false>(g, f, sq, p, len, s_rec, s_hdr);
+            else chain_factor2<T, 1, false>(g, f, sq, p, len, s_rec, s_hdr);
         }
         return;
     }

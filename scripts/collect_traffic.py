@@ -19,6 +19,11 @@ traffic, profiles/r01_pmc_calibration_v4.txt, r01_pmc_requests_calibration_v4.tx
     class sorted by their first variable (the default since v7) one of the two gathers per
     edge end is near-sequential, G = 1 per edge; on a graph with locality (Ising grid) the
     gathers merge into line requests, G = 0 and 2 * FETCH is an upper bound.
+  * TILED factor order (round 4): every gather falls into an L2-sized window, so a record
+    line goes to the fabric once -- as the 64-byte request of the first gather that touches it -- however many
+    gathers hit it afterwards; "64 bytes per random gather" no longer describes what the memory system sees.
+    Model for it (spec suffix :tiled, n_gather = the gathered record BYTES per launch, R):
+    FETCH = streams / 2 + R  =>  read bytes = 2 * (FETCH - R) + R.  Both raw counters stay in the file.
 usage: python scripts/collect_traffic.py TAG workload/dtype=file.txt:n_gather ...
 A workload whose cycle is several launches (the n-ary classes: k_factor_nary* + k_variable_wide,
 each once per cycle) is given as workload/dtype=file.txt:n_gather:cycle -- the counters of every
@@ -64,6 +69,17 @@ def main():
         n_gather = int(n_gather)
         c = read_cycle_counters(path) if mode == ["cycle"] else read_counters(path)
         fetch, write = c["FETCH_SIZE"] * 1024, c["WRITE_SIZE"] * 1024
+        if mode == ["tiled"]:
+            read_bytes = 2 * (fetch - n_gather) + n_gather
+            data[key] = {
+                "fetch_size_bytes": int(fetch), "write_size_bytes": int(write),
+                "gathered_record_bytes_per_launch": n_gather,
+                "bytes_per_launch": int(read_bytes + write),
+                "model": "tiled factor order: 2*(FETCH_SIZE - R) + R + WRITE_SIZE, R = gathered record bytes "
+                         "(see scripts/collect_traffic.py)",
+                "source": tag, "file": os.path.relpath(path, ROOT),
+            }
+            continue
         read_bytes = 2 * fetch - 64 * n_gather
         data[key] = {
             "fetch_size_bytes": int(fetch), "write_size_bytes": int(write),
