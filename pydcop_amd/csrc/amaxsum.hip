@@ -369,7 +369,7 @@ __global__ void k_start_count(Dev<T> g, int32_t* cnt) {  // cnt[node] = start me
 }
 
 template <typename T>
-__global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec, int32_t* s_hdr) {
+__global__ void k_start_emit(Dev<T> g, const int32_t* base, T* s_rec, int32_t* s_hdr) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < g.n_vars) {
         const int v = i;
@@ -384,7 +384,7 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec, int32_t* s
         if (!sends) return;
         for (int k = 0; k < deg; ++k) {
             const int64_t at = (int64_t)base[i] + k;
-            T* r = q_rec + at * g.rs;  // (the queue was zero-filled: header base, payload padding)
+            T* r = s_rec + at * g.rs;  // (the slots were zero-filled: header base, payload padding)
             costs_for_factor(g, v, k0 + k, rec_pay(r));
             rec_set_head(r, g.var_edges[k0 + k] * 2, 0);
             s_hdr[at] = hdr_to_factor(g, g.var_edges[k0 + k]);
@@ -396,7 +396,7 @@ __global__ void k_start_emit(Dev<T> g, const int32_t* base, T* q_rec, int32_t* s
         if (!sends) return;
         for (int p = 0; p < ar; ++p) {
             const int64_t at = (int64_t)base[i] + p;
-            T* r = q_rec + at * g.rs;
+            T* r = s_rec + at * g.rs;
             factor_message_any(g, f, p, rec_pay(r));
             rec_set_head(r, (e0 + p) * 2 + 1, 0);
             s_hdr[at] = hdr_to_var(g, e0 + p);
@@ -501,9 +501,9 @@ __device__ __forceinline__ bool damp_and_decide_reg(const Dev<T>& g, T (&m)[N], 
 // The messages of a generation in DESTINATION-SORTED order (k_permute: one pass gathers the records the stable
 // sort's slot array points at and stamps each with its handler's first output slot): a destination's queue is then a
 // contiguous run -- code, first output slot, payload at consecutive addresses -- and the chains below read it
-// sequentially, RING deliveries ahead of the one they handle.  (Round 3 followed order[r] -> q_code / q_pay / slot_base per delivery, one ahead: three dependent random
-// loads under full load, 3-5 us per step of a chain that is sequential anyway; the longest queue of a generation is
-// what the generation lasts -- profiles/r04_amaxsum_dispatches_v1.txt.)
+// sequentially, RING deliveries ahead of the one they handle.  (Round 3 followed an index array into three arrays per
+// delivery, one ahead: three dependent random loads under full load, 3-5 us per step of a chain that is sequential
+// anyway; the longest queue of a generation is what the generation lasts -- profiles/r04_amaxsum_dispatches_v1.txt.)
 template <typename T>
 struct Sorted {
     const T* rec;              // [n * rs] the records (header: code, first output slot of the delivery's handler)
@@ -560,9 +560,9 @@ __device__ __forceinline__ void amx_static_for(F&& f) {
 // the sender's lane takes the costs, every other lane builds its factor's message from the held costs
 // of the group (D * deg cross-lane reads, the reference's order of additions: d outer, factors inner,
 // maxsum.py:651-665), damps, applies the send rule and writes its output slot.  The groups of a
-// wave walk their own queues in lock step (a group whose queue is done idles: the destinations are
-// sorted by queue length, so the queues of a wave are about equally long); `t` = the group's
-// destination in seg_first, groups past `seg_end` have none.
+// wave walk their own queues in lock step (a group whose queue is done idles: the destinations run in
+// order of (expected) queue length, so the queues of a wave are about equally long); `t` = the group's
+// destination in seg_node, groups past `seg_end` have none.
 template <typename T, int D, int GROUP>
 __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, int64_t seg_end, T* s_rec, int32_t* s_hdr) {
     constexpr bool WHOLE = GROUP == 64;
@@ -875,11 +875,11 @@ __device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const Sorted<
     }
 }
 
-// sq.seg_first[t]: position of the first message of the t-th destination to run -- by class, longest queues
-// first (step()); a launch runs the destinations of one class, [cls_first[cls], cls_first[cls + 1]) -- read from
-// device memory: the grid is sized for every computation of the class (static), the blocks past this generation's
-// count leave at once, and the host does not wait for the counts.  Blocks of one wave; a kernel per class, so that
-// each has the registers of its own path only.
+// sq.seg_node[t]: the t-th destination to run -- by class, longest (expected) queues first (Engine::init, step());
+// a launch runs the destinations of one class, [cls_first[cls], cls_first[cls + 1]) -- read from device memory: the
+// grid is sized for every computation of the class (static), the blocks past the count leave at once, a destination
+// without mail sits the generation out, and the host waits for nothing.  Blocks of one wave; a kernel per class, so
+// that each has the registers of its own path only.
 template <typename T, int GROUP>
 __global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, Sorted<T> sq, int cls, T* s_rec, int32_t* s_hdr) {
     variables_of_wave<T, GROUP>(g, sq, cls, s_rec, s_hdr);
