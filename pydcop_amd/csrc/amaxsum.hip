@@ -545,6 +545,18 @@ template <int K>
 __device__ __forceinline__ float row_bcast(float x) {
     return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), 0x150 + K, 0xf, 0xf, false));
 }
+// lane K of every quad to the four lanes of the quad (DPP quad_perm: [K, K, K, K])
+template <int K>
+__device__ __forceinline__ double quad_bcast(double x) {
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, K * 0x55, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, K * 0x55, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int K>
+__device__ __forceinline__ float quad_bcast(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(x), __float_as_int(x), K * 0x55, 0xf, 0xf, false));
+}
 template <typename F, int... I>
 __device__ __forceinline__ void amx_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
     (f(std::integral_constant<int, I>{}), ...);
@@ -632,12 +644,14 @@ __device__ void chain_variable(const Dev<T>& g, const Sorted<T>& sq, int64_t t, 
                         sum_cost += xx;
                         md += xx;
                     }
-                } else {  // the group is a DPP row (16 lanes) or half of one (8)
+                } else {  // the group is a DPP row (16 lanes), half of one (8) or a quad
                     amx_static_for<GROUP>([&](auto kc) __attribute__((always_inline)) {
                         constexpr int k2 = decltype(kc)::value;
                         T x;
                         if constexpr (GROUP == 16) {
                             x = row_bcast<k2>(held[d]);
+                        } else if constexpr (GROUP == 4) {
+                            x = quad_bcast<k2>(held[d]);
                         } else {
                             const T lo = row_bcast<k2>(held[d]), hi = row_bcast<k2 + 8>(held[d]);
                             x = (lane & 8) ? hi : lo;
@@ -838,7 +852,10 @@ constexpr int CLS_VAR8 = 1;     // variable, domain 2..4, degree <= 8: 8 lanes, 
 constexpr int CLS_VAR16 = 2;    //                        degree <= 16: 16 lanes, 4 per wave
 constexpr int CLS_VAR64 = 3;    //                        degree <= 64: the wave
 constexpr int CLS_GENERIC = 4;  // everything else: a lane on the per-message handler, 64 per wave
-constexpr int N_CLS = 5;        // (N_CLS itself: a destination without mail in this generation)
+constexpr int CLS_VAR4 = 5;     // variable, domain 2..4, degree <= 4: a quad, 16 per wave (the variable kernels are
+                                // bound by instruction issue -- 530 per step of 8 deliveries in the 8-lane groups,
+                                // profiles/r04_amaxsum_chain_pmc_v1.txt -- and half the variables of a degree-4 graph fit a quad)
+constexpr int N_CLS = 6;        // (N_CLS itself: a destination without mail in this generation)
 constexpr int64_t DYNAMIC_ORDER_FROM = 1 << 20;  // messages in a generation from which its destinations are re-ordered
 
 template <typename T>
@@ -846,11 +863,21 @@ __device__ __forceinline__ int class_of(const Dev<T>& g, int32_t dst) {
     if (dst < g.n_vars) {
         const int D = g.dom_size[dst], deg = g.var_rowptr[dst + 1] - g.var_rowptr[dst];
         if (D < 2 || D > 4 || deg > 64) return CLS_GENERIC;
-        return deg <= 8 ? CLS_VAR8 : (deg <= 16 ? CLS_VAR16 : CLS_VAR64);
+        return deg <= 4 ? CLS_VAR4 : (deg <= 8 ? CLS_VAR8 : (deg <= 16 ? CLS_VAR16 : CLS_VAR64));
     }
     const int f = dst - g.n_vars, e0 = g.factor_rowptr[f];
     return (g.factor_rowptr[f + 1] - e0 == 2 && g.dom_size[g.edge_var[e0]] <= 4 && g.dom_size[g.edge_var[e0 + 1]] <= 4)
                ? CLS_FACTOR2 : CLS_GENERIC;
+}
+
+// A generation lasts as long as its longest queue, and the destinations run longest (expected) queue first: the first
+// waves of a class kernel are its critical path.  They get the issue priority over the waves they share a SIMD with.
+__device__ __forceinline__ void chain_priority() {
+#ifndef AMX_NO_PRIORITY
+    if (blockIdx.x < 64) __builtin_amdgcn_s_setprio(3);
+    else if (blockIdx.x < 512) __builtin_amdgcn_s_setprio(2);
+    else if (blockIdx.x < 4096) __builtin_amdgcn_s_setprio(1);
+#endif
 }
 
 template <typename T, int GROUP>
@@ -859,6 +886,7 @@ __device__ __forceinline__ void variables_of_wave(const Dev<T>& g, const Sorted<
     const int lane = (int)threadIdx.x & 63;
     const int64_t seg_begin = sq.cls_first[cls], seg_end = sq.cls_first[cls + 1];
     if (seg_begin + (int64_t)blockIdx.x * PER_WAVE >= seg_end) return;  // (the grid covers every variable of the class)
+    chain_priority();
     const int64_t t = seg_begin + (int64_t)blockIdx.x * PER_WAVE + lane / GROUP;
     // the domain sizes of the wave's variables: one pass per size present (wave-uniform branches)
     int myD = 0;  // (0: no destination for this group, or one without mail in this generation)
@@ -887,6 +915,7 @@ __global__ void __launch_bounds__(64) k_process_vars(Dev<T> g, Sorted<T> sq, int
 
 template <typename T, bool FACTOR2>  // (two kernels: the binary-factor chains do not pay for the generic handler's registers)
 __global__ void __launch_bounds__(64) k_process_lanes(Dev<T> g, Sorted<T> sq, int cls, T* s_rec, int32_t* s_hdr) {
+    chain_priority();
     const int64_t t = sq.cls_first[cls] + (int64_t)blockIdx.x * 64 + ((int)threadIdx.x & 63);
     const bool in_class = t < sq.cls_first[cls + 1];
     const int32_t dst = in_class ? sq.seg_node[t] : 0;
@@ -1075,7 +1104,11 @@ struct Engine : Base {
     // SIDE BY SIDE (the few hundred waves of the high-degree variables are a latency chain of their own: alone
     // they took as long as the 12 000 waves of the low-degree ones before them -- profiles/r04_amaxsum_dispatches_v1.txt).
     // Blocking streams: they wait for the null stream's earlier work, the null stream's later work waits for them.
-    hipStream_t cls_stream[N_CLS] = {};
+    // (four streams: the runtime maps streams onto four hardware queues by default, and kernels of streams that share a
+    // queue run one after the other -- with a stream per class the quads started when the 8-lane groups had finished;
+    // the classes that share a stream here rarely have mail in the same generation)
+    static constexpr int N_STREAMS = 4;
+    hipStream_t cls_stream[N_STREAMS] = {};
     ~Engine() override {
         for (hipStream_t st : cls_stream)
             if (st) (void)hipStreamDestroy(st);
@@ -1458,15 +1491,18 @@ struct Engine : Base {
             AMX_TRY(hipMemset(s_hdr.p, 0xFF, 4 * (n_out + 1)));  // words of all its slots; =1 poisons them first: tests)
         const Sorted<T> sq{m_rec.p, dynamic_order ? seg_node_dyn.p : seg_node.p, run_first.p, run_last.p,
                            dynamic_order ? cls_first_dyn.p : cls_first.p, n};
-        for (int cls = 0; cls < N_CLS; ++cls) {
+        static const int launch_order[N_CLS] = {CLS_VAR16, CLS_VAR8, CLS_VAR64, CLS_GENERIC, CLS_VAR4, CLS_FACTOR2};  // long chains first
+        static const int stream_of[N_CLS] = {/*FACTOR2*/ 0, /*VAR8*/ 1, /*VAR16*/ 2, /*VAR64*/ 3, /*GENERIC*/ 3, /*VAR4*/ 0};
+        for (int cls : launch_order) {
             const int64_t count = cls_nodes[cls];
             if (count <= 0) continue;
-            const int per_wave = cls == CLS_VAR8 ? 8 : (cls == CLS_VAR16 ? 4 : (cls == CLS_VAR64 ? 1 : 64));
+            const int per_wave = cls == CLS_VAR4 ? 16 : (cls == CLS_VAR8 ? 8 : (cls == CLS_VAR16 ? 4 : (cls == CLS_VAR64 ? 1 : 64)));
             const dim3 gr((unsigned)((count + per_wave - 1) / per_wave)), bl(64);
 #define AMX_ARGS g, sq, cls, s_rec.p, s_hdr.p
-            if (!cls_stream[cls]) AMX_TRY(hipStreamCreateWithFlags(&cls_stream[cls], 0));
-            hipStream_t st = cls_stream[cls];
-            if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, st, AMX_ARGS);
+            hipStream_t& st = cls_stream[stream_of[cls]];
+            if (!st) AMX_TRY(hipStreamCreateWithFlags(&st, 0));
+            if (cls == CLS_VAR4) hipLaunchKernelGGL((k_process_vars<T, 4>), gr, bl, 0, st, AMX_ARGS);
+            else if (cls == CLS_VAR8) hipLaunchKernelGGL((k_process_vars<T, 8>), gr, bl, 0, st, AMX_ARGS);
             else if (cls == CLS_VAR16) hipLaunchKernelGGL((k_process_vars<T, 16>), gr, bl, 0, st, AMX_ARGS);
             else if (cls == CLS_VAR64) hipLaunchKernelGGL((k_process_vars<T, 64>), gr, bl, 0, st, AMX_ARGS);
             else if (cls == CLS_FACTOR2) hipLaunchKernelGGL((k_process_lanes<T, true>), gr, bl, 0, st, AMX_ARGS);

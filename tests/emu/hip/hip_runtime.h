@@ -378,4 +378,5 @@ template <typename U>
 inline U atomicAdd(U* addr, U val) { const U old = *addr; *addr = old + val; return old; }
 
 // ---- gfx950 builtins the kernels use -------------------------------------------
-inline int __builtin_amdgcn_readfirstlane(int x) { return x; }  // callers pass wave-uniform values
+inline int __builtin_amdgcn_readfirstlane(int x) { return x; }
+inline void __builtin_amdgcn_s_setprio(int) {}  // wave priority: nothing to emulate  // callers pass wave-uniform values
