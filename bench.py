@@ -380,7 +380,7 @@ def other_algorithms(n_vars, device=0):
                                             "slot word written when produced, read when delivered; bound by random cache "
                                             "lines, not by these bytes (DESIGN.md 3.4); wall time, the one host wait per "
                                             "generation included"},
-                    "parity_test": "tests/test_gpu_amaxsum.py::test_amaxsum_bit_exact_vs_oracle"})
+                    "parity_test": "tests/test_gpu_amaxsum.py::test_amaxsum_bench_instance_100k"})
     cycles = 5 if small else 500
     for name, make, test, mgm in (
             ("dsa (variant B, p 0.7)", lambda: DsaEngine(g, Params(), variant="B", probability=0.7, seed=1, device=device),

@@ -63,3 +63,20 @@ def test_amaxsum_bookkeeping_variants(env, oracle_built, monkeypatch):
         g = make()
         p = Params(**kw)
         compare_amaxsum(AMaxSumEngine(g, p), OracleAMaxSum(g, p), first=(1, 2, 3, 6), last_generation=14, largest=20_000)
+
+
+def test_amaxsum_bench_instance_100k(oracle_built):
+    """The instance tools/amaxsum_bench.py and the bench line's amaxsum row run (100k variables, start_messages
+    leafs_vars), through the generations of 3, 9, 7 and 14 million messages -- the sizes at which a generation's
+    destinations are re-ordered by queue length and the class kernels run thousands of waves: every held / last-sent
+    message, counter, selection and cost against the oracle, bit for bit."""
+    from amaxsum_common import same_state
+    from oracle.amaxsum_oracle import OracleAMaxSum
+    g = G.random_coloring(100_000, avg_degree=4, n_colors=3, seed=0, names=False)
+    p = Params(start_messages="leafs_vars")
+    eng, ora = AMaxSumEngine(g, p), OracleAMaxSum(g, p)
+    for gens in (5, 7, 9):
+        assert eng.run(gens) == ora.run(gens)
+        same_state(eng, ora, f"generations < {gens}")
+    assert int(eng.generation_sizes().max()) > 10_000_000
+    eng.close(), ora.close()
