@@ -165,6 +165,15 @@ def test_shard_launch_split_variants_emu(flags, emu_lib):
         _check_against_single(g, dict(kw, layout_flags=flags), 3, emu_lib, steps=(1, 5))
 
 
+def test_shards_in_tiled_factor_order_emu(emu_lib, monkeypatch):
+    """The binary factors -- also the cut classes, split by owned position -- in tiled order (layout.cpp; 8 KB
+    windows so that these small shards are cut into many tiles): shards == the single engine."""
+    monkeypatch.setenv("MAXSUM_TILE_KB", "8")
+    for case, k in (("coloring", 3), ("coloring_deg9", 2), ("ising", 4)):
+        g, kw = make_case(case)
+        _check_against_single(g, kw, k, emu_lib, steps=(1, 5))
+
+
 def test_local_shards_parity_cases_emu(emu_lib):
     for name, make, kw in parity_cases()[:4] + parity_cases()[9:11]:
         _check_against_single(make(), kw, 3, emu_lib, steps=(1, 6))
