@@ -98,6 +98,12 @@ def make_workload(name, scale=1, per_gpu=100_000):
         return G.random_coloring(per_gpu * 10, avg_degree=6, n_colors=3, seed=0, names=False), "min"
     if name == "meeting_50k":       # configs[4]
         return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max"
+    if name == "peav_50k":          # the reference's own meeting-scheduling model (PEAV): ~50k variables, D = 18..24,
+        return G.peav_like(seed=0, names=False), "max"   # binary + a few unary factors (generators.peav_like)
+    if name == "coloring_100k_d8":  # graphcoloring.py with --colors_count 8: binary 8 x 8 tables
+        return G.random_coloring(per_gpu, avg_degree=4, n_colors=8, seed=0, names=False), "min"
+    if name == "meeting_50k_float": # configs[4] with real-valued utilities: the full-width 24^3 path
+        return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False, float_tables=True), "max"
     raise SystemExit(f"unknown workload {name}")
 
 

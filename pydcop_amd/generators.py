@@ -11,6 +11,12 @@ build_computation_graph O(V*F)); these follow their *instance conventions* only:
                    unary [u,-u] with u~U(-ur, ur) kept as real unary factors
                    (ising.py:285, 362-383, 412-420)
   meeting_like     arity-3, D=24 tables, objective max (SURVEY.md section 8d cfg 5)
+  peav_like        the reference's OWN meeting-scheduling model (PEAV,
+                   meetingscheduling.py:317-365, 441-640): one variable per (resource, event),
+                   domains `range(0, slots - length + 2)` (:450-454), binary intra-resource
+                   utility / conflict tables (:540-585), binary inter-resource equality tables
+                   of 0 / -penalty (:588-599), a unary utility table for a resource with a
+                   single event (:497-510); objective max
 
 Symmetry is broken by per-variable unary costs U(0, 0.01) stored as variable
 costs: the deterministic stand-in for the reference's unseeded noise
@@ -111,10 +117,12 @@ def ising_grid(rows, cols, seed=0, bin_range=1.6, un_range=0.05, names=True) -> 
 
 
 def meeting_like(n_vars, n_factors=None, dom=24, arity=3, seed=0, penalty=100.0,
-                 unary_noise=0.01, names=True) -> FlatGraph:
+                 unary_noise=0.01, names=True, float_tables=False) -> FlatGraph:
     """Meeting-scheduling-like instance: arity-`arity` factors over D=`dom`
     slot variables; utility `integers(-10, 10)` minus `penalty` when the
-    participants do not all pick the same slot.  To be solved with mode 'max'."""
+    participants do not all pick the same slot.  To be solved with mode 'max'.
+    `float_tables`: utilities `uniform(-10, 10)` -- no narrow type holds them, the tables
+    are read at full width."""
     rng = np.random.default_rng(seed)
     n_factors = n_factors or n_vars
     scope = np.empty((n_factors, arity), dtype=np.int64)
@@ -131,7 +139,10 @@ def meeting_like(n_vars, n_factors=None, dom=24, arity=3, seed=0, penalty=100.0,
     dom_size = np.full(n_vars, dom, dtype=np.int32)
     var_cost = rng.uniform(0.0, unary_noise, size=n_vars * dom) if unary_noise else np.zeros(n_vars * dom)
     size = dom ** arity
-    tables = rng.integers(-10, 10, size=(n_factors, size)).astype(np.float64)
+    if float_tables:
+        tables = rng.uniform(-10.0, 10.0, size=(n_factors, size))
+    else:
+        tables = rng.integers(-10, 10, size=(n_factors, size)).astype(np.float64)
     grid = np.indices((dom,) * arity).reshape(arity, -1)
     same = (grid == grid[0]).all(axis=0)
     tables -= np.where(same, 0.0, penalty)[None, :]  # one broadcast pass (x - 0.0 == x exactly)
@@ -162,3 +173,102 @@ def random_mixed(n_vars, n_factors, seed=0, max_arity=3, dom_choices=(2, 3, 4, 5
     return _finish(dom_size, var_cost, np.array(rowptr, dtype=np.int32),
                    np.array(edge_var, dtype=np.int32), np.concatenate(tables),
                    np.array(table_off, dtype=np.int64), names)
+
+
+def peav_problem(n_events, n_resources, slots=23, max_length=7, max_resources_event=5, max_value=10, seed=0):
+    """The problem definition of the reference's `generate_problem_definition`
+    (meetingscheduling.py:380-438) with a seeded generator: per resource the value of every slot
+    if kept free (`randint(0, max_value)`), per event its length (`randint(1, max_length)`), its
+    resources (`sample(resources, randint(1, max_resources_event))`) and their values
+    (`randint(1, max_value)`).  -> (value_free [R, slots + 1] (column 0 unused), lengths [E],
+    list of (resource ids, values) per event)."""
+    rng = np.random.default_rng(seed)
+    value_free = np.zeros((n_resources, slots + 1), dtype=np.int64)
+    value_free[:, 1:] = rng.integers(0, max_value + 1, size=(n_resources, slots))
+    lengths = rng.integers(1, max_length + 1, size=n_events)
+    counts = rng.integers(1, min(max_resources_event, n_resources) + 1, size=n_events)
+    events = []
+    for i in range(n_events):
+        res = rng.choice(n_resources, size=int(counts[i]), replace=False) if n_resources < 64 else None
+        if res is None:  # (large pools: draw and re-draw the rare duplicates)
+            res = rng.integers(0, n_resources, size=int(counts[i]))
+            while len(set(res.tolist())) < len(res):
+                res = rng.integers(0, n_resources, size=int(counts[i]))
+        events.append((res.astype(np.int64), rng.integers(1, max_value + 1, size=int(counts[i]))))
+    return value_free, lengths, events
+
+
+def peav_like(n_events=16_700, n_resources=12_500, slots=23, max_length=7, max_resources_event=5,
+              max_value=10, seed=0, penalty=None, unary_noise=0.01, names=True) -> FlatGraph:
+    """The reference's PEAV meeting-scheduling DCOP (`pydcop generate meetings`,
+    meetingscheduling.py:211-365), built in O(E): one variable per (resource, event) the resource
+    takes part in, in the reference's order (resources, then events); the tables are the
+    reference's expressions (`peav_intra_extensive_constraint_value` :540-585 with
+    `resource_value_for_event` :602-640, `peav_inter_extensive_constraint` :588-599).  The defaults
+    give about 50 000 variables with domains of 18..24 values and 165 000 factors.  To be solved
+    with mode 'max'.  `penalty` defaults to the reference's `max_value * slots * n_resources`
+    (:222)."""
+    value_free, lengths, events = peav_problem(n_events, n_resources, slots, max_length,
+                                               max_resources_event, max_value, seed)
+    if penalty is None:
+        penalty = max_value * slots * n_resources
+    penalty = float(penalty)
+    # variables: per resource, the events it takes part in (event order)
+    per_res = [[] for _ in range(n_resources)]          # (event id, value of the resource for it)
+    for ev, (res, vals) in enumerate(events):
+        for r, v in zip(res.tolist(), vals.tolist()):
+            per_res[r].append((ev, v))
+    var_of = {}
+    dom_size = []
+    for r in range(n_resources):
+        per_res[r].sort()
+        for ev, _ in per_res[r]:
+            var_of[(r, ev)] = len(dom_size)
+            dom_size.append(slots - int(lengths[ev]) + 2)
+    dom_size = np.array(dom_size, dtype=np.int32)
+    n_vars = len(dom_size)
+    csum = np.concatenate([np.zeros((n_resources, 1), dtype=np.int64), np.cumsum(value_free[:, 1:], axis=1)], axis=1)
+
+    def utility(r, ev, val):  # resource_value_for_event for t = 0 .. D - 1 (integers)
+        ln = int(lengths[ev])
+        D = slots - ln + 2
+        t = np.arange(1, D)
+        free = csum[r, t + ln - 1] - csum[r, t - 1]
+        return np.concatenate([[0], val * ln - free]).astype(np.float64)
+
+    rowptr, edge_var, tables, table_off = [0], [], [], [0]
+
+    def add(scope, tab):
+        edge_var.extend(scope)
+        rowptr.append(len(edge_var))
+        tables.append(np.ascontiguousarray(tab, dtype=np.float64).reshape(-1))
+        table_off.append(table_off[-1] + tab.size)
+
+    for r in range(n_resources):
+        evs = per_res[r]
+        n = len(evs)
+        if n == 1:
+            ev, val = evs[0]
+            add([var_of[(r, ev)]], utility(r, ev, val))
+            continue
+        us = [utility(r, ev, val) for ev, val in evs]
+        for i in range(n):
+            for j in range(i + 1, n):
+                (e1, _), (e2, _) = evs[i], evs[j]
+                l1, l2 = int(lengths[e1]), int(lengths[e2])
+                t1 = np.arange(len(us[i]))[:, None]
+                t2 = np.arange(len(us[j]))[None, :]
+                tab = 1 / (n - 1) * (us[i][:, None] + us[j][None, :])
+                clash = (t1 != 0) & (t2 != 0) & (((t1 <= t2) & (t2 <= t1 + l1 - 1)) | ((t2 <= t1) & (t1 <= t2 + l2 - 1)))
+                add([var_of[(r, e1)], var_of[(r, e2)]], np.where(clash, -penalty, tab))
+    for ev, (res, _) in enumerate(events):
+        res = res.tolist()
+        D = slots - int(lengths[ev]) + 2
+        eq = np.where(np.eye(D, dtype=bool), 0.0, -penalty)
+        for i in range(len(res)):
+            for j in range(i + 1, len(res)):
+                add([var_of[(res[i], ev)], var_of[(res[j], ev)]], eq)
+    rng = np.random.default_rng(seed + 7919)
+    var_cost = rng.uniform(0.0, unary_noise, size=int(dom_size.sum())) if unary_noise else np.zeros(int(dom_size.sum()))
+    return _finish(dom_size, var_cost, np.array(rowptr, dtype=np.int32), np.array(edge_var, dtype=np.int32),
+                   np.concatenate(tables) if tables else np.zeros(0), np.array(table_off, dtype=np.int64), names)
