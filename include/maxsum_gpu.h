@@ -130,7 +130,12 @@ typedef struct mxs_params {
                                 bit17 / bit18 (131072 / 262144) tiled order of the binary
                                           factors always / never (default: per instance --
                                           4-byte words or a cache-resident cycle, and a
-                                          variable order that is not local already)     */
+                                          variable order that is not local already).  Where
+                                          neither bit is set, $MAXSUM_TILE_KB = <kilobytes>
+                                          overrides the window size (0 = off; A/B runs and the
+                                          parity tests of the tiled order only)
+                                bit19 (524288) no lane-grid kernel for binary / unary factors
+                                          beyond the register classes (thread per edge instead) */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;
@@ -214,6 +219,15 @@ int mxs_table_storage(const mxs_engine *e, int64_t factors[4], int64_t *table_by
  * 0 when they simply follow their first variable.  A layout decision only (layout_flags bit17 / bit18,
  * default per instance): any order computes the same messages bit for bit. */
 int mxs_factor_order(const mxs_engine *e, int32_t *tiled);
+
+/* Which kernel computes factor_costs_for_var (maxsum.py:382-447) for how many factors:
+ * counts[0] register class, unary (thread per factor, D <= 4); [1] register class, binary (D x D, D <= 4);
+ * [2] generic (thread per edge, scalar loops: whatever nothing else takes); [3] workgroup per factor
+ * (arity 2..4, 64..1024 entries per value of the first variable; full-width or lane-packed tables);
+ * [4] one wave per factor (arity 3, integer tables in box records); [5] lane grid per factor (binary /
+ * unary tables beyond the register classes, up to 64 x 64: 4 / 16 / 64 lanes per factor).
+ * A layout decision only: every kernel computes the same messages bit for bit. */
+int mxs_factor_kernels(const mxs_engine *e, int64_t counts[6]);
 
 /* Replace the cost table of factor `factor` (caller's factor index) by one of the
  * same shape, row-major over its scope; messages, counters and the selection

@@ -26,6 +26,7 @@
 #include "../../include/maxsum_gpu.h"
 #include "kernels.h"
 #include "nary_box.h"
+#include "bin_box.h"
 #include "layout.h"
 
 namespace mxs {
@@ -422,6 +423,11 @@ struct Engine : EngineBase {
         for (const NaryLaunch& nl : L.nary_launches) {
             if (nl.cut != cut) continue;
             const NaryDesc* d = ndesc.p + nl.first;
+            if (is_bin2(nl.box)) {  // binary / unary tables: a lane grid per factor (bin_box.h)
+                if (!launch_factor_bin2<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no lane-grid kernel for this launch group");
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             if (nl.box) {  // one wave per factor, minima in registers (nary_box.h)
                 if (!launch_factor_box3<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no box kernel for this launch group");
                 HIP_TRY(hipGetLastError());
@@ -543,10 +549,15 @@ struct Engine : EngineBase {
 
     // Factor fi can no longer be read from its narrow image: a register class goes back to full
     // width as a whole; a workgroup-per-factor factor just gets its descriptor switched.
-    int widen_factor(int fi) {
+    int widen_factor(int fi, const double* values = nullptr) {
         if (L.f_tab_type[fi] == TAB_FULL) return MXS_OK;
         if (L.f_class[fi] >= 0) return promote_class(L.f_class[fi]);
         { int rc = sync(); if (rc) return rc; }
+        int64_t bin2_at = -1;  // a lane-grid factor: its new full-width image (bin_box.h reads an image at every width)
+        if (const NaryLaunch* nl = launch_of(fi); nl && is_bin2(nl->box)) {
+            int rc = append_bin2_full_image(fi, *nl, values, &bin2_at);
+            if (rc) return rc;
+        }
         // the factor moves to the full-width launch group of its (arity, size): regroup the
         // descriptors (stable: every other factor keeps its relative place)
         struct Item { int cut, code, type, fi; NaryDesc d; };
@@ -558,7 +569,10 @@ struct Engine : EngineBase {
             for (int j = 0; j < nl.count; ++j) {
                 Item it{nl.cut, nary_group_code(nl.box, nl.arity, nl.nj, nl.threads / 64), nl.tab_type, fi_of[nl.first + j],
                         L.ndesc[nl.first + j]};
-                if (it.fi == fi) {  // (out of a box group: the full-width kernel's group of its size)
+                if (it.fi == fi && bin2_at >= 0) {  // (the same lane grid, reading the full-width image)
+                    it.type = TAB_FULL;
+                    it.d.tab_off = bin2_at;
+                } else if (it.fi == fi) {  // (out of a box group: the full-width kernel's group of its size)
                     it.type = TAB_FULL;
                     it.d.tab_off = L.f_tab_base[fi];
                     int64_t R = 1;
@@ -583,6 +597,7 @@ struct Engine : EngineBase {
             L.ndesc.push_back(it.d);
         }
         L.f_tab_type[fi] = (uint8_t)TAB_FULL;
+        if (bin2_at >= 0) L.f_ctab_off[fi] = bin2_at;
         if (graph_exec) {  // the captured loop has the old launch groups
             (void)hipGraphExecDestroy(graph_exec);
             graph_exec = nullptr;
@@ -1080,7 +1095,12 @@ struct Engine : EngineBase {
         HIP_TRY(hipGetLastError());
         HIP_TRY(copy_sync(eval_tables.p + L.eval_tab_off[fi], table, sizeof(double) * (size_t)n,
                           hipMemcpyHostToDevice, stream));  // also waits for the kernel above
-        if (L.f_tab_type[fi] != TAB_FULL) {  // the factor's table is read from a narrow image
+        const NaryLaunch* grp = L.f_class[fi] < 0 && L.f_ndesc[fi] >= 0 ? launch_of(fi) : nullptr;
+        if (grp && is_bin2(grp->box) && L.f_tab_type[fi] == TAB_FULL) {
+            // a lane-grid factor reads its image at every width (bin_box.h): re-encode it in the arithmetic type
+            int rc = write_bin2_image(fi, *grp, table, n);
+            if (rc) return rc;
+        } else if (L.f_tab_type[fi] != TAB_FULL) {  // the factor's table is read from a narrow image
             const int t = L.f_tab_type[fi];
             const int fit = narrowest_tab_type(table, n, (int)sizeof(T));
             if (fit >= t) {  // (TAB_I8 > TAB_I16 > TAB_F32: at least as narrow as the stored type)
@@ -1091,16 +1111,55 @@ struct Engine : EngineBase {
                     encode_tab_record(table, (int)n, t, rec.data());
                 } else {  // workgroup-per-factor: the lane-packed / box image (layout.h, nary_place_pos)
                     const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
-                    const NaryPlace pl = nary_place(*launch_of(fi), d);
+                    const NaryPlace pl = nary_place(*launch_of(fi), d, (int)sizeof(T));
                     rec.assign((size_t)nary_place_bytes(pl, d.dom[0]), 0);
                     for (int64_t k = 0; k < n; ++k) encode_tab_record(table + k, 1, t, rec.data() + nary_place_pos(pl, k));
                 }
                 HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
             } else {
-                int rc = widen_factor(fi);
+                int rc = widen_factor(fi, table);
                 if (rc) return rc;
             }
         }
+        return MXS_OK;
+    }
+
+    // The image of lane-grid factor fi (bin_box.h), in the storage type of its launch group `nl`, from the n
+    // un-negated values `table` -- at the image's current place.
+    int write_bin2_image(int fi, const NaryLaunch& nl, const double* table, int64_t n) {
+        const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+        const NaryPlace pl = nary_place(nl, d, (int)sizeof(T));
+        std::vector<uint8_t> rec((size_t)nary_place_bytes(pl, d.dom[0]), 0);
+        for (int64_t k = 0; k < n; ++k) encode_tab_entry(table[k], nl.tab_type, (int)sizeof(T), rec.data() + nary_place_pos(pl, k));
+        HIP_TRY(copy_sync(ctables.p + L.f_ctab_off[fi], rec.data(), rec.size(), hipMemcpyHostToDevice, stream));
+        return MXS_OK;
+    }
+
+    // A lane-grid factor leaves its narrow image: a full-width image of its own is appended to the compact-table
+    // buffer (the buffer grows: a rare event, the run is stopped anyway) and filled from `values` (un-negated; NULL:
+    // the factor's current table, read back from the device).  -> its byte offset in `at`.
+    int append_bin2_full_image(int fi, const NaryLaunch& nl, const double* values, int64_t* at) {
+        const NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
+        NaryLaunch full = nl;
+        full.tab_type = TAB_FULL;
+        const NaryPlace pl = nary_place(full, d, (int)sizeof(T));
+        const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
+        std::vector<double> cur;
+        if (!values) {
+            cur.resize((size_t)n);
+            HIP_TRY(copy_sync(cur.data(), eval_tables.p + L.eval_tab_off[fi], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
+            values = cur.data();
+        }
+        const size_t old_bytes = ctables.n, off = (old_bytes + 15) / 16 * 16, bytes = (size_t)nary_place_bytes(pl, d.dom[0]);
+        std::vector<uint8_t> rec(bytes, 0);
+        for (int64_t k = 0; k < n; ++k) encode_tab_entry(values[k], TAB_FULL, (int)sizeof(T), rec.data() + nary_place_pos(pl, k));
+        DevBuf<uint8_t> grown;
+        HIP_TRY(grown.alloc(off + bytes));
+        if (old_bytes) HIP_TRY(copy_sync(grown.p, ctables.p, old_bytes, hipMemcpyDeviceToDevice, stream));
+        HIP_TRY(copy_sync(grown.p + off, rec.data(), bytes, hipMemcpyHostToDevice, stream));
+        std::swap(ctables.p, grown.p);
+        std::swap(ctables.n, grown.n);
+        *at = (int64_t)off;
         return MXS_OK;
     }
 
@@ -1177,13 +1236,15 @@ struct Engine : EngineBase {
         const int64_t n = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         const int ctype = L.f_tab_type[fi];
         NaryPlace place{};   // narrow image of a workgroup-per-factor table (nt == 0 && box == 0: a register class)
-        if (ctype != TAB_FULL && L.f_class[fi] < 0) place = nary_place(*launch_of(fi), L.ndesc[L.f_ndesc[fi]]);
+        const NaryLaunch* grp = L.f_class[fi] < 0 && L.f_ndesc[fi] >= 0 ? launch_of(fi) : nullptr;
+        const bool image = ctype != TAB_FULL || (grp && is_bin2(grp->box));  // (a lane-grid factor: an image at every width)
+        if (image && L.f_class[fi] < 0) place = nary_place(*grp, L.ndesc[L.f_ndesc[fi]], (int)sizeof(T));
         else place.elem = tab_elem_bytes(ctype);
         hipLaunchKernelGGL((k_table_slice<T>), dim3((unsigned)((n + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, stream,
                            tables.p, L.f_tab_base[fi], (int64_t)L.f_tab_stride[fi],
                            eval_tables.p + L.eval_tab_off[fi], (const double*)pt.buf.p, sd,
                            L.is_max ? -1.0 : 1.0, n,
-                           ctype != TAB_FULL ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype, place);
+                           image ? ctables.p + L.f_ctab_off[fi] : (uint8_t*)nullptr, ctype, place);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(stream));
         return MXS_OK;
@@ -1852,13 +1913,14 @@ int mxs_table_storage(const mxs_engine* e, int64_t factors[4], int64_t* table_by
         const int t = L.f_tab_type[fi];
         const int64_t entries = L.eval_tab_off[fi + 1] - L.eval_tab_off[fi];
         n[t] += 1;
-        if (t == mxs::TAB_FULL) bytes += entries * w;
-        else if (L.f_class[fi] >= 0) bytes += L.classes[L.f_class[fi]].ctab_rec;
-        else {  // lane-packed image (D0 * threads * slot) or box records
+        if (L.f_class[fi] >= 0) bytes += t == mxs::TAB_FULL ? entries * w : L.classes[L.f_class[fi]].ctab_rec;
+        else if (L.f_ndesc[fi] < 0) bytes += entries * w;
+        else {  // full-width rows, a lane-packed image (D0 * threads * slot), box records, or the lane-grid image of a binary table
             for (const mxs::NaryLaunch& x : L.nary_launches)
                 if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count) {
                     const mxs::NaryDesc& d = L.ndesc[L.f_ndesc[fi]];
-                    bytes += mxs::nary_place_bytes(mxs::nary_place(x, d), d.dom[0]);
+                    if (t == mxs::TAB_FULL && !mxs::is_bin2(x.box)) bytes += entries * w;
+                    else bytes += mxs::nary_place_bytes(mxs::nary_place(x, d, (int)w), d.dom[0]);
                 }
         }
     }
@@ -1893,6 +1955,26 @@ int mxs_cycle_bytes(const mxs_engine* e, int64_t* bytes, int32_t* launches) {
 int mxs_factor_order(const mxs_engine* e, int32_t* tiled) {
     CHECK_HANDLE(e);
     if (tiled) *tiled = e->impl->L.tiled ? 1 : 0;
+    return MXS_OK;
+}
+
+int mxs_factor_kernels(const mxs_engine* e, int64_t counts[6]) {
+    CHECK_HANDLE(e);
+    if (!counts) return MXS_OK;
+    const mxs::Layout& L = e->impl->L;
+    for (int i = 0; i < 6; ++i) counts[i] = 0;
+    for (int fi = 0; fi < L.n_factors; ++fi) {
+        if (L.f_class[fi] >= 0) {
+            const int k = L.classes[L.f_class[fi]].kind;
+            counts[k == mxs::K_F_UNARY ? 0 : k == mxs::K_F_BIN ? 1 : 2] += 1;
+        } else if (L.f_ndesc[fi] >= 0) {
+            for (const mxs::NaryLaunch& x : L.nary_launches)
+                if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count)
+                    counts[mxs::is_bin2(x.box) ? 5 : x.box ? 4 : 3] += 1;
+        } else {
+            counts[2] += 1;
+        }
+    }
     return MXS_OK;
 }
 
@@ -1976,9 +2058,13 @@ int mxs_destroy(mxs_engine* e) {
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
 int32_t mxs_version(void) { return 200; }
-#ifndef MXS_BUILD_KIND
-#define MXS_BUILD_KIND 1  // this is the hipcc build for gfx950 (the host emulation of tests/emu is compiled with 0 and is
-#endif                    // refused by the binding: pydcop_amd/engine.py, load_library)
+#ifndef MXS_BUILD_KIND   // 1: the hipcc build for gfx950; 0: anything else (the host emulation of tests/emu), refused by the
+#if defined(__HIPCC__)   // binding outside tests (pydcop_amd/engine.py, load_library).  Derived from the compiler: a build that
+#define MXS_BUILD_KIND 1 // forgets the flag cannot claim to be the device build.
+#else
+#define MXS_BUILD_KIND 0
+#endif
+#endif
 int32_t mxs_build_kind(void) { return MXS_BUILD_KIND; }
   // 2.0: mxs_graph gained eval_var_cost
 

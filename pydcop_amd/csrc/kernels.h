@@ -1683,6 +1683,9 @@ __device__ __forceinline__ T wide_chain(const T* in, const T* zero, int D, int d
 #endif                   // 4 no beliefs, 8 no gathers, 16 no stores
 constexpr int WIDE_R = WIDE_CAPB / WIDE_TPB;                          // staged elements per thread
 constexpr int WIDE_CR = (WIDE_MAX_COSTS + WIDE_TPB - 1) / WIDE_TPB;   // own costs per thread
+// (a thread holds ONE variable's slot range and ONE slot's counter, WideRec: the block size is no free build knob)
+static_assert(WIDE_TPB >= WIDE_MAX_VARS && WIDE_TPB >= WIDE_MAX_SLOTS && WIDE_CAPB % WIDE_TPB == 0,
+              "k_variable_wide: one variable and one slot per thread");
 
 // What a thread holds of a block between the request and the staging (registers; the loads are in flight
 // while the workgroup works on the block before).
@@ -1923,7 +1926,8 @@ struct EvalArgs {
     double infinity;
 };
 
-__global__ void __launch_bounds__(BLOCK) k_eval(EvalArgs a) {
+// (the kernels that are no templates are `static`: this header is compiled into more than one translation unit)
+static __global__ void __launch_bounds__(BLOCK) k_eval(EvalArgs a) {
     __shared__ double s_cost[BLOCK];
     __shared__ unsigned long long s_viol[BLOCK];
     double cost = 0.0;
@@ -2005,7 +2009,8 @@ __global__ void __launch_bounds__(BLOCK) k_table_slice(T* tables, int64_t tab_ba
         uint8_t* at = crec + ((place.nt > 0 || place.box > 0) ? nary_place_pos(place, k) : k * place.elem);
         if (ctype == TAB_I8) *(int8_t*)at = (int8_t)v;
         else if (ctype == TAB_I16) *(int16_t*)at = (int16_t)v;
-        else *(float*)at = (float)v;
+        else if (ctype == TAB_F32) *(float*)at = (float)v;
+        else *(T*)at = (T)v;  // (the lane-grid image of a binary table at full width: un-negated, like every image)
     }
 }
 
@@ -2026,7 +2031,7 @@ __global__ void __launch_bounds__(BLOCK) k_halo_unpack(T* rec, const int64_t* el
 // kernel boundary makes the ghost messages visible device-wide ONCE -- a release fence inside
 // the unpack kernel writes the L2 back per block, with the sweep's dirty lines in it
 // (measured: 249 us instead of 3).
-__global__ void k_halo_publish(uint32_t* flags, uint32_t epoch) {
+static __global__ void k_halo_publish(uint32_t* flags, uint32_t epoch) {
     __hip_atomic_store(flags, epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // Peer-store mode: tell every other rank that the records of launch `epoch` are in its ghost
@@ -2034,7 +2039,7 @@ __global__ void k_halo_publish(uint32_t* flags, uint32_t epoch) {
 struct PeerFlags {
     uint32_t* p[MXS_MAX_PEERS];
 };
-__global__ void k_p2p_publish(PeerFlags peers, int me, int world, uint32_t epoch) {
+static __global__ void k_p2p_publish(PeerFlags peers, int me, int world, uint32_t epoch) {
     const int q = (int)threadIdx.x;
     if (q < world && q != me)
         __hip_atomic_store(peers.p[q] + me, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

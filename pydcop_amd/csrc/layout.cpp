@@ -34,10 +34,18 @@ LayoutOptions options_from_params(const mxs_params& p) {
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
     o.half_cut = !(f & 65536);                // bit16: a shard's cut binary factors compute both messages (round 3)
+    o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
     if (f & 131072) o.tile_bytes = MXS_TILE_BYTES;       // bit17: always tiled
     if (f & 262144) o.tile_bytes = 0;                    // bit18: never tiled
-    if (const char* tb = std::getenv("MAXSUM_TILE_KB")) o.tile_bytes = (int64_t)std::atoll(tb) * 1024;  // (A/B runs; 0 = off)
+    // $MAXSUM_TILE_KB (A/B runs and the parity tests of the tiled order; 0 = off): only where the caller's flags
+    // leave the choice open, and only a number counts
+    if (!(f & (131072 | 262144)))
+        if (const char* tb = std::getenv("MAXSUM_TILE_KB")) {
+            char* end = nullptr;
+            const long long kb = std::strtoll(tb, &end, 10);
+            if (end != tb && *end == '\0' && kb >= 0) o.tile_bytes = (int64_t)kb * 1024;
+        }
     return o;
 }
 
@@ -143,6 +151,17 @@ void encode_tab_record(const double* v, int entries, int t, uint8_t* dst) {
     }
 }
 
+void encode_tab_entry(double v, int t, int word, uint8_t* dst) {
+    if (t != TAB_FULL) {
+        encode_tab_record(&v, 1, t, dst);
+    } else if (word == 8) {
+        std::memcpy(dst, &v, 8);
+    } else {
+        const float x = (float)v;
+        std::memcpy(dst, &x, 4);
+    }
+}
+
 std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     {
         std::string e = validate(g);
@@ -236,6 +255,19 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         }
                     }
                     k = FKey{K_F_NARY, (box ? nary_group_code(box, ar, 0, BOX_WAVES) : nary_group_code(0, ar, nj, waves)) * 4 + t};
+                }
+            }
+            // binary / unary factors none of the above takes (a domain of more than MAX_REG_D values, two different
+            // domain sizes; fewer than 64 entries per value of the first variable), up to 64 x 64: a group of 4 / 16 /
+            // 64 lanes per factor (layout.h Bin2Shape, bin_box.h) -- launch groups by (shape, storage type)
+            if (k.kind == K_F_GEN && L.opt.bin2 && ar <= 2) {
+                const int D1 = ar == 2 ? g.dom_size[g.edge_var[e0 + 1]] : 1;
+                const int box = bin2_shape_for(D0, D1, ar == 1);
+                if (box) {
+                    int t = TAB_FULL;
+                    if (L.opt.compact_tables)
+                        t = narrowest_tab_type(g.tables + g.table_off[f], g.table_off[f + 1] - g.table_off[f], L.opt.word);
+                    k = FKey{K_F_NARY, nary_group_code(box, ar, 0, BIN2_WAVES) * 4 + t};
                 }
             }
         }
@@ -527,14 +559,16 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.magic[i] = d.dom[i] > 1 ? (uint32_t)((((uint64_t)1 << 32) + d.dom[i] - 1) / d.dom[i]) : 0u;
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
-                    if (t != TAB_FULL) {  // narrow image: lane-packed slots or a box record per lane (layout.h)
-                        const NaryPlace pl = nary_place(nl, d);
+                    if (t != TAB_FULL || is_bin2(nl.box)) {  // narrow image: lane-packed slots or a box record per lane (layout.h);
+                        // a lane-grid group reads its image at every width
+                        const NaryPlace pl = nary_place(nl, d, L.opt.word);
                         const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];
-                        const int64_t at = (int64_t)((L.ctables.size() + 255) / 256 * 256);
+                        const int64_t al = is_bin2(nl.box) ? 16 : 256;
+                        const int64_t at = (int64_t)((L.ctables.size() + al - 1) / al * al);
                         L.ctables.resize((size_t)(at + nary_place_bytes(pl, d.dom[0])), 0);
                         const double* src = L.eval_tables.data() + L.eval_tab_off[f2];
                         for (int64_t k = 0; k < ne; ++k)
-                            encode_tab_record(src + k, 1, t, L.ctables.data() + at + nary_place_pos(pl, k));
+                            encode_tab_entry(src[k], t, L.opt.word, L.ctables.data() + at + nary_place_pos(pl, k));
                         L.f_tab_type[f2] = (uint8_t)t;
                         L.f_ctab_off[f2] = at;
                         d.tab_off = at;

@@ -133,9 +133,53 @@ constexpr int nary_box_shape(int d0, int d1, int d2, int elem) {
     }
     return 0;
 }
+// ---- lane-grid layout of a BINARY (or unary) factor's table (kernels: bin_box.h, k_factor_bin) ------------
+// For the factors the register classes cannot take (a domain of more than MAX_REG_D values, or two different
+// ones) and the workgroup-per-factor kernel neither (fewer than 64 entries per value of the first variable):
+// what the reference's own generators emit for meeting scheduling (meetingscheduling.py:450-454, 588-599:
+// binary tables over 18..24 slots) and for colourings with 5..8 colours (graphcoloring.py:271).
+// G = L0 x L1 lanes work on one factor, 64 / G factors share a wave.  Lane (l0, l1) owns the rows
+// d0 = l0 + r * L0 (r < B0) and the columns d1 = l1 * B1 + i1 (i1 < B1): B0 * B1 table entries in registers,
+// B0 partial minima towards variable 0 and B1 towards variable 1, merged across the group's lanes ONCE per
+// factor through LDS.  The image is the row-major table with every row cut into L1 lane pieces of
+// roundup(B1 * elem, 4) bytes -- D0 rows, none padded: a lane whose row does not exist re-reads the last one and
+// the +inf staged for a digit past the domain (the semiring's identity) keeps the entry out of every minimum.
+// Stored in ctables for EVERY storage type, full width included (`elem` = the word).
+struct Bin2Shape {
+    int L0, L1, B0, B1;
+};
+constexpr Bin2Shape BIN2_SHAPES[] = {
+    {2, 2, 2, 2},  {2, 2, 3, 3},  {2, 2, 4, 4},                                  // 4 lanes:  up to 4x4, 6x6, 8x8
+    {4, 4, 3, 3},  {4, 4, 4, 4},  {4, 4, 5, 5},  {4, 4, 6, 6},  {4, 4, 8, 8},    // 16 lanes: up to 12, 16, 20, 24, 32
+    {8, 8, 5, 5},  {8, 8, 6, 6},  {8, 8, 8, 8},                                  // 64 lanes: up to 40, 48, 64
+    {16, 1, 1, 1}, {16, 1, 2, 1}, {16, 1, 4, 1},                                 // unary factors: up to 16, 32, 64 values
+};
+constexpr int BIN2_N_SHAPES = (int)(sizeof(BIN2_SHAPES) / sizeof(BIN2_SHAPES[0]));
+constexpr int BIN2_BASE = 32;      // NaryLaunch::box >= BIN2_BASE: shape BIN2_SHAPES[box - BIN2_BASE]
+constexpr int BIN2_WAVES = 4;      // waves per workgroup
+constexpr int BIN2_MAX_D = 64;
+constexpr bool is_bin2(int box) { return box >= BIN2_BASE; }
+constexpr int bin2_piece_bytes(int b1, int elem) { return (b1 * elem + 3) / 4 * 4; }
+// the shape (index + BIN2_BASE) a table of d0 x d1 entries takes (d1 = 1, unary = true: a unary factor), 0 = none:
+// the fewest image bytes + message slots, then the fewest lanes
+constexpr int bin2_shape_for(int d0, int d1, bool unary) {
+    int best = 0;
+    long best_cost = 0;
+    for (int s = 0; s < BIN2_N_SHAPES; ++s) {
+        const Bin2Shape sh = BIN2_SHAPES[s];
+        if ((sh.L1 == 1) != unary) continue;
+        if (sh.L0 * sh.B0 < d0 || sh.L1 * sh.B1 < d1) continue;
+        const long cost = (long)(sh.L0 * sh.B0) * (sh.L1 * sh.B1) * 64 + sh.L0 * sh.L1;  // padded entries, then lanes
+        if (!best || cost < best_cost) {
+            best = s + BIN2_BASE;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
 // Where entry k (row-major) of a workgroup-per-factor table lives in its narrow image.
 struct NaryPlace {
-    int32_t box;          // 0: lane-packed slots (nary_packed_pos), else the box shape id
+    int32_t box;          // 0: lane-packed slots (nary_packed_pos), else the box shape id (>= BIN2_BASE: lane grid of a binary table)
     int32_t elem;         // bytes per entry
     int32_t nt, slot;     // lane-packed: threads of the block, bytes of a slot
     int32_t R;            // lane-packed: entries per value of the first variable
@@ -143,6 +187,11 @@ struct NaryPlace {
 };
 constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
     if (p.box == 0) return nary_packed_pos(k / p.R, k % p.R, p.nt, p.slot, p.elem);
+    if (is_bin2(p.box)) {
+        const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
+        const int64_t piece = bin2_piece_bytes(sh.B1, p.elem), x1 = k % p.d1, x0 = k / p.d1;
+        return x0 * (sh.L1 * piece) + (x1 / sh.B1) * piece + (x1 % sh.B1) * p.elem;
+    }
     const int b0 = BOX_SHAPES[p.box - 1][0], b1 = BOX_SHAPES[p.box - 1][1], b2 = BOX_SHAPES[p.box - 1][2];
     const int64_t x2 = k % p.d2, x1 = (k / p.d2) % p.d1, x0 = k / ((int64_t)p.d1 * p.d2);
     const int l1n = p.d1 / b1, l2n = p.d2 / b2;
@@ -156,6 +205,10 @@ constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
 // bytes of the narrow image of one factor (D0 = its first domain size)
 constexpr int64_t nary_place_bytes(const NaryPlace& p, int D0) {
     if (p.box == 0) return (int64_t)D0 * p.nt * p.slot;
+    if (is_bin2(p.box)) {
+        const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
+        return ((int64_t)D0 * sh.L1 * bin2_piece_bytes(sh.B1, p.elem) + 15) / 16 * 16;
+    }
     const int* b = BOX_SHAPES[p.box - 1];
     return (int64_t)64 * 4 * box_rec_words(b[0] * b[1] * b[2], p.elem);
 }
@@ -257,13 +310,15 @@ struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY fa
     int32_t cut;         // 1: factors reading ghost variables (second phase of a sharded cycle)
     int32_t tab_type;    // TabType the tables of the group are stored in (one kernel instantiation each)
     int32_t box;         // 0: lane-packed / full-width kernels; else the box shape id (nary_box.h: one wave per
-                         // factor, BOX_WAVES factors per workgroup; nj = 0, threads = BOX_WAVES * 64)
+                         // factor, BOX_WAVES factors per workgroup; nj = 0, threads = BOX_WAVES * 64);
+                         // >= BIN2_BASE: the lane grid of a binary / unary table (bin_box.h; arity 1 or 2, nj = 0)
 };
-// the image parameters of a factor of launch group `nl` (narrow types only)
-inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d) {
+// the image parameters of a factor of launch group `nl` (narrow types; lane-grid groups also at full width:
+// `word` = bytes of the arithmetic type)
+inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 0) {
     NaryPlace p{};
     p.box = nl.box;
-    p.elem = tab_elem_bytes(nl.tab_type);
+    p.elem = nl.tab_type == TAB_FULL ? word : tab_elem_bytes(nl.tab_type);
     p.nt = nl.threads;
     p.slot = nary_slot_bytes(nl.nj > 0 ? nl.nj : 1, p.elem);
     int64_t R = 1;
@@ -302,6 +357,7 @@ struct LayoutOptions {
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
+    bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable
     int64_t tile_bytes = -1;     // binary factors in tiled order: > 0 windows of about this many bytes, 0 never, < 0 per instance (layout.cpp)
 };
@@ -407,6 +463,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& out);
 int narrowest_tab_type(const double* v, int64_t n, int word);
 // Encode one factor's `entries` values (un-negated) as a compact record of type `t` at `dst`.
 void encode_tab_record(const double* v, int entries, int t, uint8_t* dst);
+// One entry (un-negated) in storage type `t`; TAB_FULL = the arithmetic type of `word` bytes (lane-grid images).
+void encode_tab_entry(double v, int t, int word, uint8_t* dst);
 LayoutOptions options_from_params(const mxs_params& p);
 
 }  // namespace mxs

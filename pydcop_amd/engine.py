@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
     "mxs_build_kind", "mxs_set_state", "mxs_set_parent_table", "mxs_slice_factor",
-    "mxs_table_storage", "mxs_factor_order",
+    "mxs_table_storage", "mxs_factor_order", "mxs_factor_kernels",
     "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
     "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
     "mxs_amaxsum_eval_cost", "mxs_amaxsum_update_factor_table", "mxs_amaxsum_destroy",
@@ -177,6 +177,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_dsa_destroy": ([vp], C.c_int),
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_factor_order": ([vp, C.POINTER(i32)], C.c_int),
+        "mxs_factor_kernels": ([vp, vp], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
         "mxs_halo_bind": ([vp, vp, vp], C.c_int),
@@ -369,6 +370,14 @@ class MaxSumEngine:
         t = C.c_int32(0)
         self._check(self._lib.mxs_factor_order(self._h, C.byref(t)))
         return "tiled" if t.value else "by_first_variable"
+
+    def factor_kernels(self) -> dict:
+        """Factors per kernel of the factor side (mxs_factor_kernels): register classes, generic
+        (thread per edge), workgroup per factor, one wave per factor (box records), lane grid."""
+        n = (C.c_int64 * 6)()
+        self._check(self._lib.mxs_factor_kernels(self._h, n))
+        return dict(zip(("reg_unary", "reg_binary", "generic", "workgroup", "wave_box", "lane_grid"),
+                        (int(x) for x in n)))
 
     def table_storage(self) -> dict:
         """{"full", "f32", "i16", "i8"}: factors per table storage type, and "bytes_per_cycle": the

@@ -10,8 +10,8 @@ OUT = os.path.join(HERE, "_build", "libmaxsum_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "nary_box.h", "layout.h", "local_search.h")] + [
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip", "bin_box.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "nary_box.h", "bin_box.h", "layout.h", "local_search.h")] + [
         os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hipcub", "hipcub.hpp"),
         os.path.join(ROOT, "include", "maxsum_gpu.h")]
     if not force and os.path.exists(OUT) and all(
@@ -20,7 +20,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(OUT), exist_ok=True)
     cmd = ["g++", "-O1", "-g", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-Wno-attributes",
            "-DMXS_EMULATED_HIPCUB", "-DMXS_BUILD_KIND=0",  # (build kind 0: the binding refuses this library outside tests)
-           "-I", HERE, "-x", "c++", srcs[0], srcs[1], srcs[2], srcs[3], srcs[4], "-o", OUT, "-ldl", "-pthread"]
+           "-I", HERE, "-x", "c++"] + srcs + ["-o", OUT, "-ldl", "-pthread"]
     subprocess.check_call(cmd)
     return OUT
 

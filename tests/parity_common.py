@@ -208,6 +208,24 @@ def parity_cases():
                                                      np.inf, "var_cost"), {"damping_nodes": "factors"}),
         ("hard_wide_coloring6_deg30", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=46), 46, 0.6, np.inf),
          {}),
+        # lane-grid kernel of the binary / unary factors beyond the register classes (bin_box.h): every storage type,
+        # every lane grid (4 / 16 / 64 lanes), unequal domains, unary tables, the reference's own PEAV model
+        ("bin2_coloring8_i8", lambda: G.random_coloring(150, n_colors=8, seed=51), {}),
+        ("bin2_coloring8_hard_i16_max_all", lambda: G.random_coloring(120, n_colors=8, seed=52, variant="hard"),
+         {"mode": "max", "start_messages": "all"}),
+        ("bin2_coloring7_quarters_f32", lambda: scaled(G.random_coloring(120, n_colors=7, seed=53), 0.25),
+         {"damping_nodes": "factors"}),
+        ("bin2_coloring6_float_max", lambda: scaled(G.random_coloring(120, n_colors=6, seed=54), 0.37), {"mode": "max"}),
+        ("bin2_peav_slots10", lambda: G.peav_like(40, 25, slots=10, max_length=4, max_resources_event=4, seed=55), {"mode": "max"}),
+        ("bin2_peav_slots23", lambda: G.peav_like(24, 14, slots=23, max_length=7, max_resources_event=4, seed=56),
+         {"mode": "max", "start_messages": "leafs_vars"}),
+        ("bin2_domains_to_64", lambda: G.random_mixed(16, 22, seed=57, max_arity=2, dom_choices=(33, 40, 48, 64, 5, 13, 21, 27)),
+         {"start_messages": "all"}),
+        ("bin2_domains_to_64_int_max", lambda: G.random_mixed(16, 22, seed=58, max_arity=2, float_tables=False,
+                                                              dom_choices=(1, 2, 9, 17, 29, 37, 50, 64)), {"mode": "max"}),
+        ("hard_bin2_coloring8_inf", lambda: hard(G.random_coloring(100, n_colors=8, seed=59), 59, 0.5, np.inf), {}),
+        ("hard_bin2_coloring6_neg_inf_max", lambda: hard(G.random_coloring(100, n_colors=6, seed=60), 60, 0.5, -np.inf),
+         {"mode": "max", "start_messages": "all"}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
     ]

@@ -87,7 +87,8 @@ def test_emu_errors(emu_lib):
 
 
 @pytest.mark.parametrize("case", [c for c in parity_cases() if c[0] in
-                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims")],
+                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims", "bin2_coloring8_i8",
+                                   "bin2_peav_slots10", "bin2_domains_to_64_int_max")],
                          ids=lambda c: c[0])
 def test_emu_table_updates(case, emu_lib, oracle_built):
     name, make, kw = case
@@ -185,3 +186,25 @@ def test_emu_tiled_factor_order_policy(emu_lib, oracle_built):
     assert MaxSumEngine(grid, Params(dtype="f32", layout_flags=131072), lib_path=emu_lib).factor_order() == "tiled"
     compare_with_oracle(oracle_built, g, Params(dtype="f32"), 0, lib_path=emu_lib, steps=[1, 2])
     compare_with_oracle(oracle_built, grid, Params(dtype="f32", layout_flags=131072), 0, lib_path=emu_lib, steps=[2])
+
+
+def test_emu_lane_grid_takes_the_binary_factors_beyond_the_register_classes(emu_lib):
+    """layout.cpp: binary / unary factors with a domain of more than 4 values, or two different domain sizes, go to
+    the lane-grid kernel (bin_box.h), not to the thread-per-edge generic one; flag 524288 sends them back."""
+    from pydcop_amd import generators as G
+    g = G.random_coloring(150, n_colors=8, seed=51)
+    with MaxSumEngine(g, Params(), lib_path=emu_lib) as e:
+        k = e.factor_kernels()
+        assert k["lane_grid"] == g.n_factors and k["generic"] == 0, k
+        assert e.table_storage()["i8"] == g.n_factors
+        assert e.table_storage()["bytes_per_cycle"] == g.n_factors * 64      # 8 x 8 int8 entries, no padding
+    with MaxSumEngine(g, Params(layout_flags=524288), lib_path=emu_lib) as e:
+        assert e.factor_kernels()["generic"] == g.n_factors
+    peav = G.peav_like(40, 25, slots=10, max_length=4, max_resources_event=4, seed=55)
+    with MaxSumEngine(peav, Params(mode="max"), lib_path=emu_lib) as e:
+        k, st = e.factor_kernels(), e.table_storage()
+        assert k["lane_grid"] == peav.n_factors and k["generic"] == 0, k
+        assert st["full"] > 0 and st["i16"] > 0, st          # real-valued utilities; 0 / -penalty equality tables
+    three = G.random_coloring(100, seed=1)
+    with MaxSumEngine(three, Params(), lib_path=emu_lib) as e:
+        assert e.factor_kernels()["reg_binary"] == three.n_factors

@@ -91,6 +91,9 @@ _FULL = {
     "coloring_1m_deg6": (lambda: G.random_coloring(1_000_000, avg_degree=6, n_colors=3, seed=0, names=False),
                          "min", [1, 5, 34]),
     "meeting_50k": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False), "max", [1, 3, 26]),
+    # round 5: what the reference's own generators emit between "tiny" and "huge" -- the lane-grid kernel (bin_box.h)
+    "peav_50k": (lambda: G.peav_like(seed=0, names=False), "max", [1, 3, 26]),
+    "coloring_100k_d8": (lambda: G.random_coloring(100_000, avg_degree=4, n_colors=8, seed=0, names=False), "min", [1, 5, 34]),
 }
 _full_cache = {}
 
@@ -179,7 +182,8 @@ def test_max_mode_is_negated_min_mode():
 
 
 @pytest.mark.parametrize("case", [c for c in parity_cases() if c[0] in
-                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims")],
+                                  ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims", "bin2_coloring8_i8",
+                                   "bin2_peav_slots10", "bin2_domains_to_64_int_max")],
                          ids=lambda c: c[0])
 @pytest.mark.parametrize("dtype", ["f64", "f32"])
 def test_table_updates(case, dtype, oracle_built):
