@@ -164,6 +164,12 @@ int mxs_run(mxs_engine *e, int32_t n_cycles);
  * events recorded on the engine's own stream (milliseconds). */
 int mxs_run_timed(mxs_engine *e, int32_t n_cycles, float *elapsed_ms);
 
+/* `reps` repetitions of `n_cycles` cycles enqueued back to back, one HIP event between two repetitions
+ * and ONE host wait at the end; elapsed_ms[r] = device time of repetition r.  For benchmarks: a
+ * median over a timed region long enough for the clocks to settle, when one repetition is a fraction
+ * of a millisecond (bench.py).  Not on a sharded engine. */
+int mxs_run_reps(mxs_engine *e, int32_t n_cycles, int32_t reps, float *elapsed_ms);
+
 /* Enqueue `n_cycles` cycles on the engine's stream without waiting. */
 int mxs_run_async(mxs_engine *e, int32_t n_cycles);
 int mxs_sync(mxs_engine *e);

@@ -1379,7 +1379,10 @@ struct Engine : Base {
         if (n_slots == 0) return MXS_OK;
         AMX_TRY(packed.reserve(n_slots));
         const char* env = std::getenv("MAXSUM_AMAXSUM_TWO_SCANS");  // =1: the separate scans whatever the size (tests)
-        const bool one_scan = !(env && env[0] == '1') && n_slots < ((int64_t)1 << PACK_SHIFT) / (max_cap + 1);
+        // (the packed sum carries the message count above bit PACK_SHIFT of a SIGNED 64-bit word: at most 2^30 slots --
+        // as many messages at most -- so that it cannot overflow before the guards below see the totals)
+        const bool one_scan = !(env && env[0] == '1') && n_slots < ((int64_t)1 << PACK_SHIFT) / (max_cap + 1) &&
+                              n_slots <= ((int64_t)1 << 30);
         size_t bytes = 0;
         if (one_scan) {
             hipcub::TransformInputIterator<int64_t, SlotPacked, const int32_t*> both(s_hdr.p, SlotPacked{node_cap.p, g.cap_bits});

@@ -49,6 +49,7 @@ struct Buf {
     U* p = nullptr;
     size_t n = 0;
     hipError_t upload(const std::vector<U>& h, hipStream_t st) {
+        release();
         n = h.size();
         hipError_t e = hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
         if (e != hipSuccess || h.empty()) return e;
@@ -59,6 +60,11 @@ struct Buf {
     hipError_t alloc(size_t count) {
         n = count;
         return hipMalloc((void**)&p, (n ? n : 1) * sizeof(U));
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        n = 0;
     }
     ~Buf() {
         if (p) (void)hipFree(p);
@@ -515,14 +521,18 @@ struct Engine : Base {
             // the row view for them (domains of at most 32 values; $MAXSUM_LOCAL_SEARCH_ROWS=0 leaves it out, the
             // budget in bytes can be set: A/B runs and tests)
             {
-                const char* renv = std::getenv("MAXSUM_LOCAL_SEARCH_ROWS");
-                const int64_t budget = renv ? std::atoll(renv) : ((int64_t)6 << 30);
+                const int64_t budget = lsearch::HostSlots::rows_budget();
                 have_rows = budget > 0 && max_dom <= 32 && hs.build_rows(hp.rest, h_dom, vrow, h_toff, h_tables, (int)sizeof(T), 32, budget);
                 if (have_rows) {
-                    DSA_TRY(sl_rows.upload(hs.rows, stream));
-                    DSA_TRY(sl_row_base.upload(hs.row_base, stream));
-                    DSA_TRY(sl_row_nb_stride.upload(hs.row_nb_stride, stream));
-                    DSA_TRY(sl_row_nb0_stride.upload(hs.row_nb0_stride, stream));
+                    // an upload that fails (device memory) leaves the strided path: free what was allocated and carry on
+                    const bool ok = sl_rows.upload(hs.rows, stream) == hipSuccess && sl_row_base.upload(hs.row_base, stream) == hipSuccess &&
+                                    sl_row_nb_stride.upload(hs.row_nb_stride, stream) == hipSuccess &&
+                                    sl_row_nb0_stride.upload(hs.row_nb0_stride, stream) == hipSuccess;
+                    if (!ok) {
+                        (void)hipGetLastError();
+                        sl_rows.release(), sl_row_base.release(), sl_row_nb_stride.release(), sl_row_nb0_stride.release();
+                        have_rows = false;
+                    }
                     hs.rows.clear();
                     hs.rows.shrink_to_fit();
                 }

@@ -157,6 +157,7 @@ struct EngineBase {
     virtual int run_async(int n) = 0;
     virtual int sync() = 0;
     virtual int run_timed(int n, float* ms) = 0;
+    virtual int run_reps(int n, int reps, float* ms) = 0;
     virtual int get_assignment(int32_t* idx, double* belief) = 0;
     virtual int get_messages(double* v2f, double* f2v, uint8_t* cv, uint8_t* cf) = 0;
     virtual int set_state(const double* v2f, const double* f2v, const uint8_t* cv, const uint8_t* cf,
@@ -225,6 +226,14 @@ struct Engine : EngineBase {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false, capturing = false;
     bool streaming = false;  // non-temporal stores / index loads in the sweep (cycle larger than the Infinity Cache)
+    // Sharded cycle (round 5): the cut factor classes of cycle t (launch 2) read nothing that launch 1 of cycle t writes --
+    // ghost V->F messages of t-1, their own F->V records of t-1 -- and write records nobody else writes: they run on a
+    // stream of their own BESIDE launch 1 instead of behind it (profiles/r05_shard0_of_8_kernel_stats_v1.csv: 27.4 + 17.5
+    // us one after the other in a 52.7-us cycle, the second one a single generation of latency-bound blocks).
+    hipStream_t cut_stream = nullptr;
+    hipEvent_t ev_c0 = nullptr;    // cycle t begins on the compute stream (everything of t-1's launch 1 is done)
+    hipEvent_t ev_l2 = nullptr;    // launch 2 of the last cycle is done
+    bool cut_beside = false, l2_pending = false;
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
     bool halo_pending = false;
@@ -252,6 +261,9 @@ struct Engine : EngineBase {
         wide_profile_dump();
 #endif
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        if (ev_c0) (void)hipEventDestroy(ev_c0);
+        if (ev_l2) (void)hipEventDestroy(ev_l2);
+        if (cut_stream) (void)hipStreamDestroy(cut_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -463,6 +475,17 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
+    // The wide variable class (k_variable_wide: a workgroup per run of variables of one domain size).
+    int launch_wide(const SweepArgs<T>& a, hipStream_t ws) {
+        if (!L.wide_blocks.empty()) {
+            hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
+                               (const WideBlock*)wide_blocks.p);
+            HIP_TRY(hipGetLastError());
+        }
+        return MXS_OK;
+    }
+    int n_wide_launches() const { return L.wide_blocks.empty() ? 0 : 1; }
+
     // Enqueue (part of) one cycle reading buffer `from` on the compute stream.
     //   phase 1: every variable class and every factor class that reads owned variables only
     //   phase 2: the cut factor classes of a shard (they read ghost messages, i.e. they are
@@ -473,11 +496,7 @@ struct Engine : EngineBase {
         if (phase == 3) {  // everything of the cycle; the cut factor blocks wait inside the sweep
             int rc = launch_sweep(a, L.n_blocks_fused);
             if (rc) return rc;
-            if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()),
-                                   dim3(WIDE_TPB), 0, stream, a, (const WideBlock*)wide_blocks.p);
-                HIP_TRY(hipGetLastError());
-            }
+            { int rc2 = launch_wide(a, stream); if (rc2) return rc2; }
             return launch_nary(a, 0);
         }
         if (phase == 1) {
@@ -491,11 +510,8 @@ struct Engine : EngineBase {
                 HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
                 ws = side;
             }
-            if (!L.wide_blocks.empty()) {
-                hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()),
-                                   dim3(WIDE_TPB), 0, ws, a, (const WideBlock*)wide_blocks.p);
-                HIP_TRY(hipGetLastError());
-            }
+            rc = launch_wide(a, ws);
+            if (rc) return rc;
             if (fork) HIP_TRY(hipEventRecord(ev_join, side));
             rc = launch_nary(a, 0);
             if (rc) return rc;
@@ -605,7 +621,7 @@ struct Engine : EngineBase {
         }
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         launches_per_cycle = ((L.n_blocks_sweep > 0 && L.sweep_regular) ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
-                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
+                             (int)L.nary_launches.size() + n_wide_launches();
         return MXS_OK;
     }
 
@@ -657,9 +673,14 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
-        {
+        {   // Two streams pay when a cycle is long: measured (profiles/r05_variable_wave_ab_v1.txt, flags=1048576 rows =
+            // this code) peav_50k 218.6 -> 205.5 us (f32 151.0 -> 136.1), meeting_50k 252.6 -> 249.4, but the
+            // cache-resident coloring_100k_d8 53.3 -> 64.2 us (f32 42.8 -> 53.6): two latency-bound launches of full
+            // occupancy only get in each other's way, and the fork / join events are not free.  Default: from 400 MB per
+            // cycle on; $MAXSUM_NARY_OVERLAP=0/1 forces it.
             const char* env = getenv("MAXSUM_NARY_OVERLAP");
-            overlap = !(env && env[0] == '0');
+            overlap = L.algorithmic_bytes >= ((int64_t)400 << 20);
+            if (env && (env[0] == '0' || env[0] == '1')) overlap = env[0] == '1';
         }
         {   // the comm stream's kernels (pack, RCCL, unpack) go first whenever a slot frees up
             int lo = 0, hi = 0;
@@ -667,6 +688,13 @@ struct Engine : EngineBase {
             HIP_TRY(hipStreamCreateWithPriority(&comm, hipStreamNonBlocking, hi));
         }
         HIP_TRY(hipEventCreateWithFlags(&ev_p1, hipEventDisableTiming));
+        if (g.var_owned) {  // a shard: the cut factor classes beside launch 1 ($MAXSUM_SHARD_CUT_BESIDE=0: behind it, as rounds 1-4)
+            const char* env = getenv("MAXSUM_SHARD_CUT_BESIDE");
+            cut_beside = !(env && env[0] == '0');
+            HIP_TRY(hipStreamCreateWithFlags(&cut_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_c0, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_l2, hipEventDisableTiming));
+        }
         HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
 
         auto conv = [](const std::vector<double>& src) {
@@ -721,7 +749,7 @@ struct Engine : EngineBase {
         HIP_TRY(part_cost.alloc(EVAL_BLOCKS));
         HIP_TRY(part_viol.alloc(EVAL_BLOCKS));
         launches_per_cycle = ((L.n_blocks_sweep > 0 && L.sweep_regular) ? 1 : 0) + (L.n_blocks_sweep2 > 0 ? 1 : 0) +
-                             (int)L.nary_launches.size() + (int)L.wide_classes.size();
+                             (int)L.nary_launches.size() + n_wide_launches();
         return reset();
     }
 
@@ -731,6 +759,8 @@ struct Engine : EngineBase {
         // or a direct RCCL receive of the previous run (comm stream) would leave stale ghost
         // V->F messages where cycle 0 expects zeros.  Callers need not sync first.
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
+        if (cut_stream) HIP_TRY(hipStreamSynchronize(cut_stream));
+        l2_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
         for (int b = 0; b < 2; ++b) {
             HIP_TRY(hipMemsetAsync(v2f[b].p, 0, std::max<size_t>(v2f[b].n, 1) * sizeof(T), stream));
@@ -844,6 +874,7 @@ struct Engine : EngineBase {
 #endif
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
+        if (cut_stream) HIP_TRY(hipStreamSynchronize(cut_stream));
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
         if (fused || p2p) {  // did a cut factor block give up waiting for its halo?
             uint32_t h[1] = {0};
@@ -870,6 +901,38 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventElapsedTime(&t, ev0, ev1));
         if (ms) *ms = t;
         return MXS_OK;
+    }
+
+    // `reps` repetitions of n cycles enqueued BACK TO BACK -- one HIP event between two repetitions, ONE host wait at
+    // the end -- and the device time of every repetition: what a benchmark needs to quote a median over a timed
+    // region long enough for the clocks to settle when one repetition is a fraction of a millisecond.
+    int run_reps(int n, int reps, float* ms) override {
+        HIP_TRY(hipSetDevice(device));
+        if (n < 1 || reps < 1 || reps > 100000) return fail(MXS_E_INVALID, "mxs_run_reps: n >= 1, 1 <= reps <= 100000");
+        if (halo_ready || p2p) return fail(MXS_E_STATE, "mxs_run_reps: not on a sharded engine");
+        if (!graph_tried && cur == 0 && n >= 2 * std::max(2, params.graph_chunk < 0 ? 32 : params.graph_chunk))
+            try_build_graph();
+        std::vector<hipEvent_t> evs((size_t)reps + 1, nullptr);
+        int rc = MXS_OK;
+        hipError_t he = hipSuccess;
+        for (hipEvent_t& e : evs)
+            if (he == hipSuccess) he = hipEventCreate(&e);
+        for (int r = 0; r < reps && he == hipSuccess && rc == MXS_OK; ++r) {
+            if (r == 0) he = hipEventRecord(evs[0], stream);
+            if (he == hipSuccess) rc = run_async(n);
+            if (rc == MXS_OK && he == hipSuccess) he = hipEventRecord(evs[r + 1], stream);
+        }
+        if (he == hipSuccess && rc == MXS_OK) he = hipEventSynchronize(evs[reps]);
+        for (int r = 0; r < reps && he == hipSuccess && rc == MXS_OK; ++r) {
+            float t = 0.f;
+            he = hipEventElapsedTime(&t, evs[r], evs[r + 1]);
+            if (ms) ms[r] = t;
+        }
+        for (hipEvent_t e : evs)
+            if (e) (void)hipEventDestroy(e);
+        if (rc) return rc;
+        HIP_TRY(he);
+        return sync();
     }
 
     int get_assignment(int32_t* idx, double* bel) override {
@@ -1370,6 +1433,27 @@ struct Engine : EngineBase {
             cycles += 1;
             return direct ? MXS_OK : pack();
         }
+        if (cut_beside && cut_stream && (L.n_blocks_sweep2 > 0 || has_cut_nary())) {
+            // launch 1 (t) needs the F->V records launch 2 (t-1) wrote; launch 2 (t) needs the exchange of t-1 -- which
+            // implies launch 1 (t-1) -- and, through the stream's own order, launch 2 (t-1); nothing else.
+            if (l2_pending) HIP_TRY(hipStreamWaitEvent(stream, ev_l2, 0));
+            HIP_TRY(hipEventRecord(ev_c0, stream));
+            int rc = launch_phase(cur, false, 1);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_p1, stream));
+            HIP_TRY(hipStreamWaitEvent(cut_stream, ev_c0, 0));
+            if (halo_pending) HIP_TRY(hipStreamWaitEvent(cut_stream, ev_halo, 0));
+            std::swap(stream, cut_stream);  // (launch_sweep / launch_nary enqueue on `stream`)
+            rc = launch_phase(cur, false, 2);
+            std::swap(stream, cut_stream);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(ev_l2, cut_stream));
+            l2_pending = true;
+            cur ^= 1;
+            cycles += 1;
+            if (direct) return MXS_OK;
+            return pack();
+        }
         int rc = launch_phase(cur, false, 1);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev_p1, stream));
@@ -1380,6 +1464,11 @@ struct Engine : EngineBase {
         cycles += 1;
         if (direct) return MXS_OK;  // the variable kernel has written the send buffer itself
         return pack();  // comm stream, behind ev_p1: one host call per cycle before the collective
+    }
+    bool has_cut_nary() const {
+        for (const NaryLaunch& nl : L.nary_launches)
+            if (nl.cut) return true;
+        return false;
     }
 
     int step_pack() override {  // kept for callers that pack separately: packs again (idempotent)
@@ -1755,7 +1844,7 @@ struct Engine : EngineBase {
         HIP_TRY(hipStreamSynchronize(stream));
         p2p = true;
         fused = true;
-        launches_per_cycle = 1 + (int)L.wide_classes.size() + (int)L.nary_launches.size();
+        launches_per_cycle = 1 + n_wide_launches() + (int)L.nary_launches.size();
         gen = 0;
         return p2p_push();
     }
@@ -1879,6 +1968,7 @@ int mxs_run(mxs_engine* e, int32_t n) {
 }
 
 int mxs_run_timed(mxs_engine* e, int32_t n, float* ms) { CHECK_HANDLE(e); return e->impl->run_timed(n, ms); }
+int mxs_run_reps(mxs_engine* e, int32_t n, int32_t reps, float* ms) { CHECK_HANDLE(e); return e->impl->run_reps(n, reps, ms); }
 int mxs_run_async(mxs_engine* e, int32_t n) { CHECK_HANDLE(e); return e->impl->run_async(n); }
 int mxs_sync(mxs_engine* e) { CHECK_HANDLE(e); return e->impl->sync(); }
 

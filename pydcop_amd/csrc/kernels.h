@@ -1903,6 +1903,12 @@ k_variable_wide(SweepArgs<T> a, const WideBlock* __restrict__ blocks) {
     }
 }
 
+// (Round 5: ONE WAVE per run of variables -- the same phases and helpers, a run cut for 64 lanes x 12 staged elements, every
+// barrier a wave barrier so that the chain phase has a lane per edge of a full wave and no wave waits for another -- was built,
+// parity-tested and measured SLOWER than the workgroup above: peav_50k 128.4 us against 77.4, coloring_100k_d8 51.1 against
+// 32.4, meeting_50k cycle 269 against 249 (profiles/r05_variable_wave_*): 145 VGPRs and 11 KB of LDS per wave leave 3 waves per
+// SIMD where the workgroup version runs 8, and a run's life is the same chain of dependent global loads either way.  Removed.)
+
 // ---------------------------------------------------------------------------
 // solution_cost (pydcop/dcop/dcop.py:319-367): per-block partial sums of the
 // factor and variable costs of an assignment; a term equal to `infinity` is a

@@ -15,7 +15,10 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <atomic>
+#include <new>
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <thread>
 #include <vector>
@@ -97,9 +100,17 @@ struct HostSlots {
             row_base.assign(nS, -1);
             return false;
         }
-        rows.assign((size_t)bytes + 8, 0);
-        // fill, a few host threads over the variables
+        try {
+            rows.assign((size_t)bytes + 8, 0);
+        } catch (const std::bad_alloc&) {  // a small host: no row view, the strided path works everywhere
+            rows.clear();
+            row_base.assign(nS, -1);
+            return false;
+        }
+        // fill, a few host threads over the variables (nothing may leave a worker: an exception there would terminate)
+        std::atomic<bool> failed{false};
         auto fill = [&](size_t lo, size_t hi) {
+            try {
             std::vector<int> digit;
             for (size_t vi = lo; vi < hi; ++vi) {
                 const int v = vars[vi], D = dom[v];
@@ -134,13 +145,33 @@ struct HostSlots {
                     }
                 }
             }
+            } catch (...) {
+                failed = true;
+            }
         };
         const unsigned hw = std::thread::hardware_concurrency();
         const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)32, vars.size() / 64 + 1}));
         std::vector<std::thread> pool;
         for (size_t t = 0; t < nt; ++t) pool.emplace_back(fill, vars.size() * t / nt, vars.size() * (t + 1) / nt);
         for (std::thread& th : pool) th.join();
+        if (failed) {
+            rows.clear();
+            rows.shrink_to_fit();
+            row_base.assign(nS, -1);
+            return false;
+        }
         return true;
+    }
+
+    // The budget of the row view in bytes: $MAXSUM_LOCAL_SEARCH_ROWS (0 = none; A/B runs and tests), else at most 6 GiB
+    // and at most half of the device memory that is free NOW -- the view is an optimisation, an instance that ran without
+    // it must not fail to load because of it.
+    static int64_t rows_budget() {
+        if (const char* renv = std::getenv("MAXSUM_LOCAL_SEARCH_ROWS")) return std::atoll(renv);
+        int64_t budget = (int64_t)6 << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) budget = std::min<int64_t>(budget, (int64_t)(free_b / 2));
+        return budget;
     }
 
     // "" or what is wrong with the instance

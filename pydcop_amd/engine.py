@@ -35,7 +35,7 @@ def register_test_engine(path: str, make_default: bool = False):
 
 # every symbol include/maxsum_gpu.h declares
 ABI_SYMBOLS = (
-    "mxs_device_count", "mxs_create", "mxs_reset", "mxs_run", "mxs_run_timed",
+    "mxs_device_count", "mxs_create", "mxs_reset", "mxs_run", "mxs_run_timed", "mxs_run_reps",
     "mxs_run_async", "mxs_sync", "mxs_cycle_count", "mxs_get_assignment",
     "mxs_get_messages", "mxs_eval_cost", "mxs_cycle_bytes", "mxs_halo_setup",
     "mxs_halo_buffers", "mxs_halo_bind", "mxs_step_compute", "mxs_step_pack", "mxs_step_unpack", "mxs_stream",
@@ -138,6 +138,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_reset": ([vp], C.c_int),
         "mxs_run": ([vp, i32], C.c_int),
         "mxs_run_timed": ([vp, i32, C.POINTER(C.c_float)], C.c_int),
+        "mxs_run_reps": ([vp, i32, i32, vp], C.c_int),
         "mxs_run_async": ([vp, i32], C.c_int),
         "mxs_sync": ([vp], C.c_int),
         "mxs_cycle_count": ([vp, C.POINTER(i64)], C.c_int),
@@ -286,6 +287,14 @@ class MaxSumEngine:
         ms = C.c_float(0)
         self._check(self._lib.mxs_run_timed(self._h, int(n_cycles), C.byref(ms)))
         return float(ms.value)
+
+    def run_reps(self, n_cycles: int, reps: int) -> np.ndarray:
+        """`reps` repetitions of `n_cycles` cycles enqueued back to back (one HIP event between two
+        repetitions, one host wait at the end) -> the device time of every repetition in
+        milliseconds (mxs_run_reps)."""
+        ms = np.zeros(int(reps), dtype=np.float32)
+        self._check(self._lib.mxs_run_reps(self._h, int(n_cycles), int(reps), ms.ctypes.data))
+        return ms.astype(np.float64)
 
     def run_async(self, n_cycles: int):
         self._check(self._lib.mxs_run_async(self._h, int(n_cycles)))

@@ -62,6 +62,11 @@ inline hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
 }
 inline hipError_t hipMalloc(void** p, size_t n) { *p = std::malloc(n); return *p ? hipSuccess : 2; }
 inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
+inline hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b) {  // "a device" with 64 GiB, half of it free
+    *total_b = (size_t)64 << 30;
+    *free_b = (size_t)32 << 30;
+    return hipSuccess;
+}
 inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) {
     std::memcpy(d, s, n);
     return hipSuccess;

@@ -41,29 +41,29 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "extras"):
         assert key in out, key
     assert out["n_gpus"] == 2 and out["steps"] == 6 and out["warmup"] == 2
-    # N > 1 = WEAK scaling of the metric's own instance family (here 300 variables per GPU): value is the
-    # whole-job aggregate, N x iterations/s of the one N x 300-variable instance
-    # (the unit says that the N > 1 headline is an aggregate, not the rate of one instance -- ADVICE r3)
-    assert out["scaling"] == "weak" and out["unit"].startswith("iterations/s per 100k variables of work") and out["dtype"] == "f64"
-    assert abs(out["iterations_per_s_of_the_instance"] * 2 - out["value"]) < 1e-9 * out["value"]
-    ns = out["north_star_speedup"]   # north_star's ">= 6x at 8 GPUs" reading: configs[3] strong-scaled, at the top level
-    assert ns["workload"].startswith("coloring_1m_deg6") and ns["scaling"] == "strong" and ns["speedup_vs_one_gpu"] > 0
+    # N > 1 = STRONG scaling of ONE fixed instance, BASELINE configs[3] (here scaled down 1 : 333): value is the rate of
+    # that instance -- no multiplication by N (VERDICT r4 / ADVICE r3: the weak-scaling aggregate is a labelled extra)
+    assert out["scaling"] == "strong" and out["unit"].startswith("iterations/s of ONE 3000-variable instance") and out["dtype"] == "f64"
     cfg = out["config"]
-    assert cfg["workload"].startswith("coloring_100k x2 (weak scaling")
-    assert cfg["n_vars"] == 600 and cfg["n_factors"] == 1200
-    assert f"exchange: {collective}" in cfg["parallelism"]
     its = cfg["iterations_per_s_of_this_instance"]
+    assert out["value"] == its == out["iterations_per_s_of_the_instance"]
     assert its > 0 and abs(its - 1e3 / out["ms_per_step"]) < 1e-6 * its
-    assert abs(out["value"] - 2 * its) < 1e-9 * out["value"]
+    ns = out["north_star_speedup"]   # north_star's ">= 6x at 8 GPUs" reading, at the top level
+    assert ns["workload"].startswith("coloring_1m_deg6") and ns["scaling"] == "strong" and ns["speedup_vs_one_gpu"] > 0
+    assert abs(ns["speedup_vs_one_gpu"] - out["value"] / out["one_gpu_iterations_per_s"]) < 1e-9
+    assert cfg["workload"].startswith("coloring_1m_deg6 (BASELINE configs[3]): strong scaling")
+    assert cfg["n_vars"] == 3000 and cfg["n_factors"] == 9000
+    assert f"exchange: {collective}" in cfg["parallelism"]
     assert cfg["one_gpu_iterations_per_s"] > 0 and cfg["speedup_vs_one_gpu_on_this_instance"] > 0
     assert "cpu_baseline" not in out  # rank 0 at N = 1 only
     assert cfg["check"] == {"cycles": 8, "identical_to_single_engine": True, "differences": 0}
-    # labelled extras: BASELINE configs[3] (here scaled down 1 : 333) and the metric's instance, both split
-    # two ways (strong scaling)
-    big, small = out["extras"]
-    assert big["scaling"] == "strong" and big["n_vars"] == 3000 and big["workload"].startswith("coloring_1m_deg6")
+    # labelled extras: the weak-scaling aggregate of the metric's family (ONE 2 x 300-variable instance) and the metric's
+    # own instance split two ways
+    weak, small = out["extras"]
+    assert weak["scaling"] == "weak" and weak["n_vars"] == 600 and weak["workload"] == "coloring_100k x2"
+    assert abs(weak["aggregate_iterations_per_s_per_100k_variables"] - 2 * weak["iterations_per_s_of_this_instance"]) < 1e-9 * weak["iterations_per_s_of_this_instance"]
     assert small["scaling"] == "strong" and small["n_vars"] == 300 and small["workload"] == "coloring_100k"
-    for e in (big, small):
+    for e in (weak, small):
         assert e["check"]["identical_to_single_engine"] and e["iterations_per_s_of_this_instance"] > 0
         assert e["speedup_vs_one_gpu"] > 0
 
@@ -81,6 +81,8 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
         "G.ising_grid = lambda r, c, **k: _ising(12, 12, **k)\n"
         "G.meeting_like = lambda n, **k: _meet(40, **{**k, 'dom': 6})\n"
         "G.random_coloring = lambda n, **k: _col(min(n, 600), **k)\n"
+        "_peav = G.peav_like\n"
+        "G.peav_like = lambda *a, **k: _peav(40, 25, slots=10, max_length=4, max_resources_event=4, **k)\n"
         f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
@@ -89,6 +91,11 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     assert len(lines) == 1
     out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["config"]["workload"] == "coloring_100k" and out["dtype"] == "f64"
+    # the timed region: repetitions of exactly `steps` cycles, the median one is the line's ms_per_step
+    tm = out["timing"]
+    assert tm["steps_per_repetition"] == out["steps"] == 4 and tm["repeats"] >= 3 and tm["warmup_by_time_steps"] > 0
+    assert tm["ms_per_step_min"] <= out["ms_per_step"] == tm["ms_per_step_median"] <= tm["ms_per_step_max"]
+    assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-9 * out["value"]
     from oracle.stage_reference import locate
     cb = out["cpu_baseline"]
     if locate():   # the reference's own thread-agent runtime, timed in this run, leads; the C port is an extra
@@ -106,7 +113,9 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     got = {(c["workload"], c["dtype"]) for c in out["configs"]}
     assert got == {("coloring_100k", "f32"), ("coloring_10k", "f64"), ("coloring_10k", "f32"),
                    ("ising_1024", "f64"), ("ising_1024", "f32"), ("coloring_1m_deg6", "f64"),
-                   ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32")}
+                   ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32"),
+                   ("peav_50k", "f64"), ("peav_50k", "f32"), ("coloring_100k_d8", "f64"), ("coloring_100k_d8", "f32"),
+                   ("meeting_50k_float", "f64"), ("meeting_50k_float", "f32")}
     for c in out["configs"]:
         assert c["parity_checked"] is True and c["parity_test"].startswith("tests/test_gpu_parity.py::")
         rf = c["roofline"]
