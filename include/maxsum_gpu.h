@@ -135,7 +135,9 @@ typedef struct mxs_params {
                                           overrides the window size (0 = off; A/B runs and the
                                           parity tests of the tiled order only)
                                 bit19 (524288) no lane-grid kernel for binary / unary factors
-                                          beyond the register classes (thread per edge instead) */
+                                          beyond the register classes (thread per edge instead)
+                                bit20 (1048576) no lane-per-edge kernel for variables of 5..8 values
+                                          (the workgroup-per-run kernel of the wide class instead) */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;
@@ -234,6 +236,12 @@ int mxs_factor_order(const mxs_engine *e, int32_t *tiled);
  * unary tables beyond the register classes, up to 64 x 64: 4 / 16 / 64 lanes per factor).
  * A layout decision only: every kernel computes the same messages bit for bit. */
 int mxs_factor_kernels(const mxs_engine *e, int64_t counts[6]);
+
+/* Which kernel runs on_new_cycle of how many variables (maxsum.py:525-565): counts[0] packed class (lane per
+ * edge, D <= 4, degree <= 64: part of the sweep launch); [1] the same scheme on 8-element records (5 <= D <= 8;
+ * own launch); [2] wide class (a workgroup per run of variables of one domain size, messages staged in LDS);
+ * [3] generic (thread per variable); [4] not swept (isolated variables after cycle 0, a shard's ghosts). */
+int mxs_variable_kernels(const mxs_engine *e, int64_t counts[5]);
 
 /* Replace the cost table of factor `factor` (caller's factor index) by one of the
  * same shape, row-major over its scope; messages, counters and the selection

@@ -207,6 +207,7 @@ struct Engine : EngineBase {
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
     DevBuf<ClassInfo> classes_f; // both lists as ONE grid (fused sharded launch), cut classes last
+    DevBuf<ClassInfo> classes8;  // the K_V_PACK8 class (its own launch)
     DevBuf<uint32_t> halo_flags; // [0] exchanges unpacked so far, [1] error bits, [2] unpack block counter
     bool fused = false;          // sharded cycles use the fused launch
     uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
@@ -226,14 +227,6 @@ struct Engine : EngineBase {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false, capturing = false;
     bool streaming = false;  // non-temporal stores / index loads in the sweep (cycle larger than the Infinity Cache)
-    // Sharded cycle (round 5): the cut factor classes of cycle t (launch 2) read nothing that launch 1 of cycle t writes --
-    // ghost V->F messages of t-1, their own F->V records of t-1 -- and write records nobody else writes: they run on a
-    // stream of their own BESIDE launch 1 instead of behind it (profiles/r05_shard0_of_8_kernel_stats_v1.csv: 27.4 + 17.5
-    // us one after the other in a 52.7-us cycle, the second one a single generation of latency-bound blocks).
-    hipStream_t cut_stream = nullptr;
-    hipEvent_t ev_c0 = nullptr;    // cycle t begins on the compute stream (everything of t-1's launch 1 is done)
-    hipEvent_t ev_l2 = nullptr;    // launch 2 of the last cycle is done
-    bool cut_beside = false, l2_pending = false;
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
     bool halo_pending = false;
@@ -261,9 +254,6 @@ struct Engine : EngineBase {
         wide_profile_dump();
 #endif
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
-        if (ev_c0) (void)hipEventDestroy(ev_c0);
-        if (ev_l2) (void)hipEventDestroy(ev_l2);
-        if (cut_stream) (void)hipStreamDestroy(cut_stream);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -475,8 +465,15 @@ struct Engine : EngineBase {
         return MXS_OK;
     }
 
-    // The wide variable class (k_variable_wide: a workgroup per run of variables of one domain size).
+    // The wide variable class (k_variable_wide: a workgroup per run of variables of one domain size) and the
+    // lane-per-edge class of the domains of 5..8 values (k_variable_pack8).
     int launch_wide(const SweepArgs<T>& a, hipStream_t ws) {
+        if (!L.pack8_classes.empty()) {
+            const ClassInfo& ci = L.classes[L.pack8_classes[0]];
+            hipLaunchKernelGGL((k_variable_pack8<T>), dim3((unsigned)((ci.count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ws, a,
+                               (const ClassInfo*)classes8.p);
+            HIP_TRY(hipGetLastError());
+        }
         if (!L.wide_blocks.empty()) {
             hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
                                (const WideBlock*)wide_blocks.p);
@@ -484,7 +481,7 @@ struct Engine : EngineBase {
         }
         return MXS_OK;
     }
-    int n_wide_launches() const { return L.wide_blocks.empty() ? 0 : 1; }
+    int n_wide_launches() const { return (L.wide_blocks.empty() ? 0 : 1) + (L.pack8_classes.empty() ? 0 : 1); }
 
     // Enqueue (part of) one cycle reading buffer `from` on the compute stream.
     //   phase 1: every variable class and every factor class that reads owned variables only
@@ -503,7 +500,7 @@ struct Engine : EngineBase {
             // isolated variables only act in cycle 0
             int rc = launch_sweep(a, (start || L.sweep_regular) ? L.n_blocks_sweep : 0);
             if (rc) return rc;
-            const bool fork = overlap && !capturing && !L.wide_classes.empty() && !L.nary_launches.empty();
+            const bool fork = overlap && !capturing && n_wide_launches() > 0 && !L.nary_launches.empty();
             hipStream_t ws = stream;
             if (fork) {  // the side stream starts where the compute stream is now
                 HIP_TRY(hipEventRecord(ev_fork, stream));
@@ -544,6 +541,9 @@ struct Engine : EngineBase {
             for (size_t i = 0; i < order.size(); ++i) order[i].block_base = L.fused_block_base[i];
         }
         HIP_TRY(classes_f.upload(order, stream));
+        order.clear();
+        for (int c : L.pack8_classes) order.push_back(L.classes[c]);
+        HIP_TRY(classes8.upload(order, stream));
         return MXS_OK;
     }
 
@@ -688,13 +688,6 @@ struct Engine : EngineBase {
             HIP_TRY(hipStreamCreateWithPriority(&comm, hipStreamNonBlocking, hi));
         }
         HIP_TRY(hipEventCreateWithFlags(&ev_p1, hipEventDisableTiming));
-        if (g.var_owned) {  // a shard: the cut factor classes beside launch 1 ($MAXSUM_SHARD_CUT_BESIDE=0: behind it, as rounds 1-4)
-            const char* env = getenv("MAXSUM_SHARD_CUT_BESIDE");
-            cut_beside = !(env && env[0] == '0');
-            HIP_TRY(hipStreamCreateWithFlags(&cut_stream, hipStreamNonBlocking));
-            HIP_TRY(hipEventCreateWithFlags(&ev_c0, hipEventDisableTiming));
-            HIP_TRY(hipEventCreateWithFlags(&ev_l2, hipEventDisableTiming));
-        }
         HIP_TRY(hipEventCreateWithFlags(&ev_halo, hipEventDisableTiming));
 
         auto conv = [](const std::vector<double>& src) {
@@ -759,8 +752,6 @@ struct Engine : EngineBase {
         // or a direct RCCL receive of the previous run (comm stream) would leave stale ghost
         // V->F messages where cycle 0 expects zeros.  Callers need not sync first.
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
-        if (cut_stream) HIP_TRY(hipStreamSynchronize(cut_stream));
-        l2_pending = false;
         HIP_TRY(hipStreamSynchronize(stream));
         for (int b = 0; b < 2; ++b) {
             HIP_TRY(hipMemsetAsync(v2f[b].p, 0, std::max<size_t>(v2f[b].n, 1) * sizeof(T), stream));
@@ -874,7 +865,6 @@ struct Engine : EngineBase {
 #endif
     int sync() override {
         HIP_TRY(hipStreamSynchronize(stream));
-        if (cut_stream) HIP_TRY(hipStreamSynchronize(cut_stream));
         if (comm) HIP_TRY(hipStreamSynchronize(comm));
         if (fused || p2p) {  // did a cut factor block give up waiting for its halo?
             uint32_t h[1] = {0};
@@ -1433,27 +1423,10 @@ struct Engine : EngineBase {
             cycles += 1;
             return direct ? MXS_OK : pack();
         }
-        if (cut_beside && cut_stream && (L.n_blocks_sweep2 > 0 || has_cut_nary())) {
-            // launch 1 (t) needs the F->V records launch 2 (t-1) wrote; launch 2 (t) needs the exchange of t-1 -- which
-            // implies launch 1 (t-1) -- and, through the stream's own order, launch 2 (t-1); nothing else.
-            if (l2_pending) HIP_TRY(hipStreamWaitEvent(stream, ev_l2, 0));
-            HIP_TRY(hipEventRecord(ev_c0, stream));
-            int rc = launch_phase(cur, false, 1);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(ev_p1, stream));
-            HIP_TRY(hipStreamWaitEvent(cut_stream, ev_c0, 0));
-            if (halo_pending) HIP_TRY(hipStreamWaitEvent(cut_stream, ev_halo, 0));
-            std::swap(stream, cut_stream);  // (launch_sweep / launch_nary enqueue on `stream`)
-            rc = launch_phase(cur, false, 2);
-            std::swap(stream, cut_stream);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(ev_l2, cut_stream));
-            l2_pending = true;
-            cur ^= 1;
-            cycles += 1;
-            if (direct) return MXS_OK;
-            return pack();
-        }
+        // (Round 5: the cut factor classes on a stream of their own BESIDE launch 1 -- they read nothing launch 1 of the same
+        // cycle writes -- measured SLOWER than behind it: shard 0 of the 8-way cut of configs[3] 53.1 us per RCCL-loopback cycle
+        // against 50.7 (profiles/r05_shard_cut_beside_ab_v1.txt): the chain launch 1 (t) -> exchange (t) -> launch 2 (t+1) ->
+        // launch 1 (t+2) then crosses three streams, and every crossing costs more than the 17 us it could hide.  Removed.)
         int rc = launch_phase(cur, false, 1);
         if (rc) return rc;
         HIP_TRY(hipEventRecord(ev_p1, stream));
@@ -1464,11 +1437,6 @@ struct Engine : EngineBase {
         cycles += 1;
         if (direct) return MXS_OK;  // the variable kernel has written the send buffer itself
         return pack();  // comm stream, behind ev_p1: one host call per cycle before the collective
-    }
-    bool has_cut_nary() const {
-        for (const NaryLaunch& nl : L.nary_launches)
-            if (nl.cut) return true;
-        return false;
     }
 
     int step_pack() override {  // kept for callers that pack separately: packs again (idempotent)
@@ -2065,6 +2033,28 @@ int mxs_factor_kernels(const mxs_engine* e, int64_t counts[6]) {
             counts[2] += 1;
         }
     }
+    return MXS_OK;
+}
+
+int mxs_variable_kernels(const mxs_engine* e, int64_t counts[5]) {
+    CHECK_HANDLE(e);
+    if (!counts) return MXS_OK;
+    const mxs::Layout& L = e->impl->L;
+    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    int64_t swept = 0;
+    for (const mxs::ClassInfo& ci : L.classes) {
+        int64_t n = 0;
+        if (ci.kind == mxs::K_V_PACK || ci.kind == mxs::K_V_PACK8) {  // (count = lanes: the variables are in the wave records)
+            for (int64_t w = ci.ell_base >> 6; w < (ci.ell_base + ci.count) >> 6; ++w) n += ((uint32_t)L.vwave[w].deg_nv >> 8) & 255u;
+            counts[ci.kind == mxs::K_V_PACK ? 0 : 1] += n;
+        } else if (ci.kind == mxs::K_V_WIDE) {
+            counts[2] += (n = ci.count);
+        } else if (ci.kind == mxs::K_V_GEN && !ci.start_only) {
+            counts[3] += (n = ci.count);
+        }
+        swept += n;
+    }
+    counts[4] = L.n_vars - swept;
     return MXS_OK;
 }
 

@@ -67,6 +67,19 @@ __device__ __forceinline__ U ldp(const U* p) {
     return *p;
 }
 
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a
+// compile-time constant in every copy of the body, so that per-thread arrays indexed by it are
+// registers from the start (a `#pragma unroll` loop around bodies with inner run-time loops left
+// them in scratch memory).
+template <typename F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
 // A wave hands its outgoing messages over through LDS so that every store instruction of
 // the wave writes 1 KB of contiguous bytes (16 per lane) instead of 16-byte pieces at the
 // stride of a message record: measured 1.5 % (cache-resident) to 4 % (HBM-resident) faster.
@@ -664,6 +677,110 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
         Msg<T, D>::store(a.v2f_new + vo, m);
     }
     if constexpr (!CIM) a.cV[ci.cv_base + lane_id] = co;
+}
+
+// ---------------------------------------------------------------------------
+// Variable side, packed class for domains of 5..8 values (round 5; K_V_PACK8, own launch): the lane-per-edge
+// scheme of variable_pack with the record length of these domains -- 8 elements, whatever D (half_stride: 5..8
+// values pad to 64 / 32 bytes) -- and the variable's own D at run time: elements past the domain are zeros on
+// the way in (the `sum_cost` chain adds +0: exact, the accumulator starts at +0 and never becomes -0), are
+// skipped by the selection and the send rule, and are stored as zeros.  What graph colouring with 5..8 colours
+// (graphcoloring.py:271) puts on the variable side: until round 5 k_variable_wide's workgroup-per-run staging,
+// 32 us per cycle for the 77 MB of coloring_100k_d8 (profiles/r05_kernel_stats_serial_coloring_100k_d8_f64_v1.csv).
+// Arithmetic as variable_pack: select_value maxsum.py:584-620, costs_for_factor :623-676.
+// ---------------------------------------------------------------------------
+constexpr int PACK8_D = 8;
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_variable_pack8(SweepArgs<T> a, const ClassInfo* __restrict__ cls) {
+    constexpr int H = PACK8_D;
+    static_assert(half_stride(5, (int)sizeof(T)) == H && half_stride(8, (int)sizeof(T)) == H, "records of 5..8 values are 8 elements long");
+    const ClassInfo ci = cls[0];
+    const int lane_id = (int)blockIdx.x * BLOCK + (int)threadIdx.x;
+    if (lane_id >= ci.count) return;  // whole waves (count is a multiple of 64)
+    const int64_t pos = ci.ell_base + lane_id;
+    const WaveMeta wm = a.vwave[__builtin_amdgcn_readfirstlane((int)(pos >> 6))];
+    const uint32_t dn = (uint32_t)wm.deg_nv;
+    const int deg = (int)(dn & 255u), nv = (int)((dn >> 8) & 255u);
+    const int l = (int)threadIdx.x & 63;
+    const int var = (int)(((uint32_t)l * (dn >> 16)) >> 15);  // l / deg (exact for l < 64)
+    const int k = l - var * deg;                              // edge position in the variable
+    const bool has = var < nv;
+    const int v = wm.first_var + (has ? var : 0);
+    const int32_t slot = a.vell[pos];
+    const int D = a.vdom[v];
+    const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
+    const uint8_t cnt = a.cV[ci.cv_base + lane_id];
+    T pv[H], in[H], c[H], m[H];
+    Msg<T, H>::load(a.v2f_old + vo, pv);                               // V->F message last sent on this edge
+    Msg<T, H>::load(a.f2v_old + (has ? slot : a.null_f2v), in);        // F->V held from this factor
+    const T* cp = a.var_cost + a.vcost_off[v];
+#pragma unroll
+    for (int d = 0; d < H; ++d) {
+        c[d] = d < D ? cp[d < D ? d : 0] : (T)0;
+        in[d] = d < D ? in[d] : (T)0;
+    }
+    int init = -1;
+    if (a.start) init = a.init_idx[v];
+    const int seg = l - (has ? k : 0);  // first lane of the variable
+    // d outer / factors inner, as the reference sums (maxsum.py:607-610, 651-665): ONE accumulator runs through all of it
+    T sum_cost = (T)0, best_c = (T)0;
+    int best = 0;
+    static_for<H>([&](auto dc) __attribute__((always_inline)) {
+        constexpr int d = decltype(dc)::value;
+        T bd = c[d], md = c[d];
+        for (int kk = 0; kk < deg; ++kk) {
+            const T x = __shfl(in[d], seg + kk, 64);
+            bd += x;                   // select_value: every factor
+            if (kk != k) {             // costs_for_factor: every factor but the target
+                sum_cost += x;
+                md += x;
+            }
+        }
+        m[d] = md;
+        if (d == 0 || (d < D && bd < best_c)) {  // first index attaining the minimum
+            best = d;
+            best_c = bd;
+        }
+    });
+    if (init >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+        best = init;
+        best_c = (T)0;
+    }
+    if (has && k == 0) {
+        a.sel[v] = best;
+        a.belief[v] = best_c;
+    }
+    const T avg = sum_cost / (T)D;
+#pragma unroll
+    for (int d = 0; d < H; ++d) m[d] = m[d] - avg;
+    uint8_t co = 0;
+    if (a.start) {
+        const bool sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) || a.start_mode != MXS_START_LEAFS;
+#pragma unroll
+        for (int d = 0; d < H; ++d) m[d] = sends ? m[d] : (T)0;
+    } else {  // apply_damping + the send rule on the D live elements (damp_and_filter with a run-time length)
+        if (cnt > 0 && a.damp_v) {
+#pragma unroll
+            for (int d = 0; d < H; ++d) m[d] = a.damping * pv[d] + ((T)1 - a.damping) * m[d];
+        }
+        bool match = cnt > 0;
+#pragma unroll
+        for (int d = 0; d < H; ++d) match = match && (d >= D || comp_match(m[d], pv[d], a.stability));
+        if (!match) {
+            co = 1;
+        } else if (cnt < SAME_COUNT) {
+            co = (uint8_t)(cnt + 1);
+        } else {
+            co = cnt;
+#pragma unroll
+            for (int d = 0; d < H; ++d) m[d] = pv[d];
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < H; ++d) m[d] = (has && d < D) ? m[d] : (T)0;  // padding lanes and elements past the domain: zeros
+    if (!has) co = 0;
+    wave_store_linear<T, H>(a.v2f_new, vo - (int64_t)l * H, m);
+    a.cV[ci.cv_base + lane_id] = co;
 }
 
 // Variable side, generic class: thread per variable, any domain size / degree,
@@ -1587,19 +1704,6 @@ __device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, in
         if (rem > 2 && k + 2 != skip) acc += x2;
     }
     return acc;
-}
-
-// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a
-// compile-time constant in every copy of the body, so that per-thread arrays indexed by it are
-// registers from the start (a `#pragma unroll` loop around bodies with inner run-time loops left
-// them in scratch memory).
-template <typename F, int... I>
-__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F&& f) {
-    static_for_impl(f, std::make_integer_sequence<int, N>{});
 }
 
 // Workgroup barrier that orders the block's LDS traffic only: the global loads a wave has in flight stay

@@ -34,6 +34,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
     o.half_cut = !(f & 65536);                // bit16: a shard's cut binary factors compute both messages (round 3)
+    o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
     if (f & 131072) o.tile_bytes = MXS_TILE_BYTES;       // bit17: always tiled
@@ -192,6 +193,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         else if (deg == 0) { kind = 80; sub = 0; }              // isolated: cycle 0 only
         else if (!L.opt.no_specialise && D >= 2 && D <= MAX_REG_D && deg <= MAX_PACK_DEG) {
             kind = K_V_PACK; sub = D;
+        } else if (!L.opt.no_specialise && L.opt.pack8 && D > MAX_REG_D && D <= MAX_PACK8_D && deg <= MAX_PACK_DEG) {
+            kind = K_V_PACK8;  // lane per edge on 8-element records, D at run time
+            sub = 0;
         } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
             kind = K_V_WIDE;  // workgroup per run of variables of one D, messages staged in LDS
             sub = 0;
@@ -199,7 +203,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         // sort key: class, then degree (the packed class needs equal degrees side
         // by side; bit3 of layout_flags keeps the caller's order elsewhere).  The wide class
         // is ordered by domain size instead: its workgroups take runs of ONE D (WideBlock).
-        const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK;
+        const bool by_deg = L.opt.sort_by_degree || kind == K_V_PACK || kind == K_V_PACK8;
         // (wide class: by domain size, then by degree in steps of four -- the chains of a wave then
         // take the same path through wide_sum_cost, kernels.h)
         vsort[v] = (kind * 1024 + sub) * 4096 +
@@ -405,7 +409,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         // packed variable classes (32-byte aligned)
         off = (off + align - 1) / align * align;
         L.null_f2v = off;
-        off += L.half(MAX_REG_D);
+        off += std::max(L.half(MAX_REG_D), L.half(MAX_PACK8_D));
         L.f2v_elems = off;
     }
 
@@ -607,6 +611,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.kind = K_V_PACK;
             ci.D = sub;
             ci.H = L.half(ci.D);
+        } else if (kind == K_V_PACK8) {
+            ci.kind = K_V_PACK8;
+            ci.D = MAX_PACK8_D;  // the record length; a variable's own domain size is read from vdom
+            ci.H = L.half(ci.D);
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
         } else if (kind == K_V_WIDE) {
@@ -632,7 +640,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         } else {  // ghosts: storage only
             swept = false;
         }
-        if (ci.kind == K_V_PACK) {
+        if (ci.kind == K_V_PACK || ci.kind == K_V_PACK8) {
             // One lane per edge.  The variables are sorted by degree; a wave holds
             // floor(64/deg) variables of one degree side by side (lane = var*deg + k)
             // and its tail lanes are padding.  Per lane: F2V offset of its edge (-1 =
@@ -683,6 +691,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (ci.kind == K_V_WIDE) {
                 L.classes[cls].per_block = 1;  // (its grid is wide_blocks.size())
                 L.wide_classes.push_back(cls);
+            } else if (ci.kind == K_V_PACK8) {
+                L.classes[cls].per_block = BLOCK;  // (its own launch: count / BLOCK workgroups)
+                L.pack8_classes.push_back(cls);
             } else {
                 sweep_class(cls, BLOCK);
             }

@@ -55,6 +55,8 @@ enum Kind : int32_t {
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
     K_V_WIDE = 7,   // 5 <= D <= 256 or deg > 64, deg * D <= 1024: a workgroup per run of variables
                     // of one domain size (WideBlock), messages staged in LDS (own launch)
+    K_V_PACK8 = 8,  // 5 <= D <= 8, 1 <= deg <= 64: the lane-per-edge scheme of K_V_PACK on records of 8 elements,
+                    // the variable's own D at run time (own launch, k_variable_pack8)
 };
 
 #ifndef MXS_BLOCK
@@ -120,18 +122,36 @@ constexpr int BOX_MAX_WORDS = 64;   // dwords of a lane's record
 constexpr int box_rec_words(int entries, int elem) { return (entries * elem + 3) / 4; }
 constexpr bool box_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 // shape id (1 ..) of the box layout an arity-3 table of `elem`-byte entries can take, 0 = none
+// lanes along a dimension of d values cut into boxes of b: ceil(d / b) rounded up to a power of two.  Round 5: the
+// dimensions need not be multiples of the box -- the lane grid may overhang the table (24 x 23 x 22 on 4 x 4 x 4
+// lanes of 6 x 6 x 6 boxes); the digits past a domain are staged as +inf, the semiring's identity, and their
+// (zero-filled) entries never win a minimum.
+constexpr int box_lanes(int d, int b) {
+    int l = 1;
+    while (l * b < d) l *= 2;
+    return l;
+}
+#ifndef MXS_BOX_MAX_PAD_PCT
+#define MXS_BOX_MAX_PAD_PCT 150  // padded entries (= instructions) at most this many percent of the table's
+#endif
 constexpr int nary_box_shape(int d0, int d1, int d2, int elem) {
-    if (d0 + d1 + d2 > BOX_MAX_SUMD) return 0;
+    int best = 0;
+    long best_cells = 0;
     for (int s = 0; s < BOX_N_SHAPES; ++s) {
         const int b0 = BOX_SHAPES[s][0], b1 = BOX_SHAPES[s][1], b2 = BOX_SHAPES[s][2];
-        if (d0 % b0 || d1 % b1 || d2 % b2) continue;
-        const int l0 = d0 / b0, l1 = d1 / b1, l2 = d2 / b2;
-        if (!box_pow2(l0) || !box_pow2(l1) || !box_pow2(l2) || l0 * l1 * l2 != 64) continue;
+        const int l0 = box_lanes(d0, b0), l1 = box_lanes(d1, b1), l2 = box_lanes(d2, b2);
+        if (l0 * l1 * l2 != 64) continue;
         if (l0 > 16 || l1 > 16 || l2 > 16) continue;  // >= 4 lanes share every digit (16-byte LDS reads)
+        if (l0 * b0 + l1 * b1 + l2 * b2 > BOX_MAX_SUMD) continue;
         if (box_rec_words(b0 * b1 * b2, elem) > BOX_MAX_WORDS) continue;
-        return s + 1;
+        const long cells = 64L * b0 * b1 * b2;
+        if (cells * 100 > (long)MXS_BOX_MAX_PAD_PCT * d0 * d1 * d2) continue;
+        if (!best || cells < best_cells) {
+            best = s + 1;
+            best_cells = cells;
+        }
     }
-    return 0;
+    return best;
 }
 // ---- lane-grid layout of a BINARY (or unary) factor's table (kernels: bin_box.h, k_factor_bin) ------------
 // For the factors the register classes cannot take (a domain of more than MAX_REG_D values, or two different
@@ -194,7 +214,7 @@ constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
     }
     const int b0 = BOX_SHAPES[p.box - 1][0], b1 = BOX_SHAPES[p.box - 1][1], b2 = BOX_SHAPES[p.box - 1][2];
     const int64_t x2 = k % p.d2, x1 = (k / p.d2) % p.d1, x0 = k / ((int64_t)p.d1 * p.d2);
-    const int l1n = p.d1 / b1, l2n = p.d2 / b2;
+    const int l1n = box_lanes(p.d1, b1), l2n = box_lanes(p.d2, b2);
     const int64_t lane = ((x0 / b0) * l1n + x1 / b1) * l2n + x2 / b2;
     const int64_t byte = (((x0 % b0) * b1 + x1 % b1) * b2 + x2 % b2) * p.elem;
     const int words = box_rec_words(b0 * b1 * b2, p.elem), full = words / 4, rest = words % 4;
@@ -218,6 +238,7 @@ constexpr int MAX_REG_D = 4;
 // more than 2^31 entries cannot be addressed here, so 30 binary variables is the most a factor can have.
 constexpr int MAX_ARITY = MXS_MAX_ARITY;
 constexpr int MAX_PACK_DEG = 64;  // one wave
+constexpr int MAX_PACK8_D = 8;    // K_V_PACK8: domains of 5..8 values, records of 8 elements
 constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel arguments
 
 // Padded message length (elements) for a domain of D values of `word` bytes.
@@ -230,7 +251,7 @@ constexpr int MAX_CLASSES = 24;  // block_base table travels in the kernel argum
 #endif
 constexpr int half_stride(int D, int word) {
     const int bytes = D * word;
-    if (MXS_TIGHT && bytes <= 32) return D;
+    if (MXS_TIGHT && bytes <= 32 && D <= 4) return D;  // (5..8 values: 8 elements in both widths -- K_V_PACK8's record)
     const int padded = bytes <= 8 ? 8 : bytes <= 16 ? 16 : (bytes + 31) / 32 * 32;
     return padded / word;
 }
@@ -357,6 +378,7 @@ struct LayoutOptions {
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
+    bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable
     int64_t tile_bytes = -1;     // binary factors in tiled order: > 0 windows of about this many bytes, 0 never, < 0 per instance (layout.cpp)
@@ -400,6 +422,7 @@ struct Layout {
     bool sweep_regular = false;        // the sweep has work after cycle 0 (not only isolated variables)
     std::vector<NaryDesc> ndesc;          // K_F_NARY factors, grouped by (arity, nj)
     std::vector<NaryLaunch> nary_launches;
+    std::vector<int32_t> pack8_classes;   // K_V_PACK8 classes (at most one): their own launch
     std::vector<int32_t> wide_classes;    // K_V_WIDE classes (at most one: every wide variable, sorted by D)
     std::vector<WideBlock> wide_blocks;   // the workgroups of the K_V_WIDE launch
 

@@ -63,9 +63,13 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
     if (f >= n_factors) return;
     const NaryDesc fd = descs[f];  // wave-uniform: scalar loads
     const int D0 = fd.dom[0], D1 = fd.dom[1], D2 = fd.dom[2];
-    // one lane per message ELEMENT (two passes cover D0 + D1 + D2 <= 128): request the incoming message
-    // element and what the epilogue needs of the outgoing one (the message sent last, its send counter) ...
-    const int off1 = D0, off2 = D0 + D1, sumd = off2 + D2;
+    // the lane grid (L1, L2 powers of two, L0 * L1 * L2 = 64: layout.h); it may overhang the table: P_i = L_i * B_i >= D_i
+    const int L1 = box_lanes(D1, B1), L2 = box_lanes(D2, B2);
+    const int sh2 = __builtin_ctz((unsigned)L2), sh1 = __builtin_ctz((unsigned)L1);
+    const int P0 = (64 >> (sh1 + sh2)) * B0, P1 = L1 * B1;
+    // one lane per message ELEMENT SLOT of the padded scope (two passes cover P0 + P1 + P2 <= 128): request the incoming
+    // message element and what the epilogue needs of the outgoing one (the message sent last, its send counter) ...
+    const int off1 = P0, off2 = P0 + P1, sumd = off2 + L2 * B2;
     int el_i[2], el_d[2], el_cnt[2];
     T el_prev[2], el_in[2];
 #pragma unroll
@@ -73,11 +77,12 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
         const int idx = lane + 64 * ps;
         const int i = (idx >= off1 ? 1 : 0) + (idx >= off2 ? 1 : 0);
         const int d = idx - (i == 0 ? 0 : i == 1 ? off1 : off2);
-        el_i[ps] = idx < sumd ? i : -1;
+        const bool valid = idx < sumd && d < (i == 0 ? D0 : i == 1 ? D1 : D2);
+        el_i[ps] = valid ? i : -1;
         el_d[ps] = d;
         el_prev[ps] = el_in[ps] = (T)0;
         el_cnt[ps] = 0;
-        if (idx < sumd) {
+        if (valid) {
             const int vo = i == 0 ? fd.v2f_off[0] : i == 1 ? fd.v2f_off[1] : fd.v2f_off[2];
             const int fo = i == 0 ? fd.f2v_off[0] : i == 1 ? fd.f2v_off[1] : fd.f2v_off[2];
             el_in[ps] = a.v2f_old[vo + d];
@@ -108,12 +113,12 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
     for (int ps = 0; ps < 2; ++ps) {
         // (dimension 0's message is staged as `0 + m`: the first step of the reference's sum_cost for the
         // outputs to variables 1 and 2, maxsum.py:430-441)
-        if (el_i[ps] >= 0) s_in[wv][lane + 64 * ps] = el_i[ps] == 0 ? (T)0 + el_in[ps] : el_in[ps];
+        // a digit past its domain: +inf, the identity of the min-plus semiring -- its (zero-filled) entries never win
+        if (lane + 64 * ps < sumd)
+            s_in[wv][lane + 64 * ps] = el_i[ps] < 0 ? pos_inf<T>() : el_i[ps] == 0 ? (T)0 + el_in[ps] : el_in[ps];
     }
     __builtin_amdgcn_wave_barrier();
-    // the lane's place in the lane grid (L1, L2 powers of two, L0 * L1 * L2 = 64: layout.h)
-    const int L1 = D1 / B1, L2 = D2 / B2;
-    const int sh2 = __builtin_ctz((unsigned)L2), sh1 = __builtin_ctz((unsigned)L1);
+    // the lane's place in the lane grid
     const int l2 = lane & (L2 - 1), l1 = (lane >> sh2) & (L1 - 1), l0 = lane >> (sh1 + sh2);
     T a0[B0], m1[B1], z1[B1], m2[B2], acc1[B1], acc2[B2];
 #pragma unroll

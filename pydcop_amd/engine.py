@@ -43,7 +43,7 @@ ABI_SYMBOLS = (
     "mxs_peer_export", "mxs_peer_connect",
     "mxs_debug_timeline", "mxs_update_factor_table", "mxs_destroy", "mxs_last_error", "mxs_version",
     "mxs_build_kind", "mxs_set_state", "mxs_set_parent_table", "mxs_slice_factor",
-    "mxs_table_storage", "mxs_factor_order", "mxs_factor_kernels",
+    "mxs_table_storage", "mxs_factor_order", "mxs_factor_kernels", "mxs_variable_kernels",
     "mxs_amaxsum_create", "mxs_amaxsum_reset", "mxs_amaxsum_run", "mxs_amaxsum_status",
     "mxs_amaxsum_generation_sizes", "mxs_amaxsum_get_assignment", "mxs_amaxsum_get_messages",
     "mxs_amaxsum_eval_cost", "mxs_amaxsum_update_factor_table", "mxs_amaxsum_destroy",
@@ -179,6 +179,7 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
         "mxs_cycle_bytes": ([vp, C.POINTER(i64), C.POINTER(i32)], C.c_int),
         "mxs_factor_order": ([vp, C.POINTER(i32)], C.c_int),
         "mxs_factor_kernels": ([vp, vp], C.c_int),
+        "mxs_variable_kernels": ([vp, vp], C.c_int),
         "mxs_halo_setup": ([vp, vp, i64, vp, i64], C.c_int),
         "mxs_halo_buffers": ([vp, C.POINTER(vp), C.POINTER(i64), C.POINTER(vp), C.POINTER(i64)], C.c_int),
         "mxs_halo_bind": ([vp, vp, vp], C.c_int),
@@ -387,6 +388,12 @@ class MaxSumEngine:
         self._check(self._lib.mxs_factor_kernels(self._h, n))
         return dict(zip(("reg_unary", "reg_binary", "generic", "workgroup", "wave_box", "lane_grid"),
                         (int(x) for x in n)))
+
+    def variable_kernels(self) -> dict:
+        """Variables per kernel of the variable side (mxs_variable_kernels)."""
+        n = (C.c_int64 * 5)()
+        self._check(self._lib.mxs_variable_kernels(self._h, n))
+        return dict(zip(("packed", "packed8", "wide", "generic", "not_swept"), (int(x) for x in n)))
 
     def table_storage(self) -> dict:
         """{"full", "f32", "i16", "i8"}: factors per table storage type, and "bytes_per_cycle": the

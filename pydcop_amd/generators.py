@@ -152,6 +152,37 @@ def meeting_like(n_vars, n_factors=None, dom=24, arity=3, seed=0, penalty=100.0,
                    tables.reshape(-1), table_off, names)
 
 
+def meeting_hetero(n_vars, n_factors=None, doms=(24, 23, 22), arity=3, seed=0, penalty=100.0, unary_noise=0.01,
+                   names=True) -> FlatGraph:
+    """meeting_like with HETEROGENEOUS domains: every variable draws its number of slots from `doms`
+    (the PEAV model's `slots - length + 2`, meetingscheduling.py:450-454), integer utilities
+    `integers(-10, 10)` minus `penalty` off the all-equal diagonal.  To be solved with mode 'max'."""
+    rng = np.random.default_rng(seed)
+    n_factors = n_factors or n_vars
+    dom_size = rng.choice(np.array(doms), size=n_vars).astype(np.int32)
+    scope = np.stack([rng.choice(n_vars, size=arity, replace=False) for _ in range(n_factors)]) if n_vars < 4096 \
+        else rng.integers(0, n_vars, size=(n_factors, arity))
+    if n_vars >= 4096:
+        for _ in range(8):
+            bad = (np.diff(np.sort(scope, axis=1), axis=1) == 0).any(axis=1)
+            if not bad.any():
+                break
+            scope[bad] = rng.integers(0, n_vars, size=(int(bad.sum()), arity))
+    var_cost = rng.uniform(0.0, unary_noise, size=int(dom_size.sum())) if unary_noise else np.zeros(int(dom_size.sum()))
+    sizes = np.prod(dom_size[scope], axis=1).astype(np.int64)
+    table_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    tables = rng.integers(-10, 10, size=int(table_off[-1])).astype(np.float64)
+    cache = {}
+    for f in range(n_factors):
+        shape = tuple(int(d) for d in dom_size[scope[f]])
+        if shape not in cache:
+            grid = np.indices(shape).reshape(arity, -1)
+            cache[shape] = np.where((grid == grid[0]).all(axis=0), 0.0, penalty)
+        tables[table_off[f]:table_off[f + 1]] -= cache[shape]
+    factor_rowptr = np.arange(0, arity * n_factors + 1, arity, dtype=np.int32)
+    return _finish(dom_size, var_cost, factor_rowptr, scope.reshape(-1).astype(np.int32), tables, table_off, names)
+
+
 def random_mixed(n_vars, n_factors, seed=0, max_arity=3, dom_choices=(2, 3, 4, 5),
                  unary_noise=0.01, float_tables=True, names=True) -> FlatGraph:
     """Small heterogeneous instances for parity tests: mixed domain sizes,

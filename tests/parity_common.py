@@ -226,6 +226,13 @@ def parity_cases():
         ("hard_bin2_coloring8_inf", lambda: hard(G.random_coloring(100, n_colors=8, seed=59), 59, 0.5, np.inf), {}),
         ("hard_bin2_coloring6_neg_inf_max", lambda: hard(G.random_coloring(100, n_colors=6, seed=60), 60, 0.5, -np.inf),
          {"mode": "max", "start_messages": "all"}),
+        # one-wave-per-factor box kernel on tables its lane grid overhangs (round 5: dimensions that are no multiples of the box)
+        ("box_overhang_24_23_22", lambda: G.meeting_hetero(14, n_factors=8, doms=(24, 23, 22), seed=61), {"mode": "max"}),
+        ("box_overhang_24_20", lambda: G.meeting_hetero(14, n_factors=8, doms=(24, 20, 21), seed=62),
+         {"mode": "max", "start_messages": "all"}),
+        ("box_overhang_small", lambda: G.meeting_hetero(30, n_factors=24, doms=(10, 11, 12, 8, 7), seed=63), {"mode": "max"}),
+        ("hard_box_overhang_varcost", lambda: hard(G.meeting_hetero(14, n_factors=8, doms=(24, 23, 22), seed=64), 64, 0.4,
+                                                   -np.inf, "var_cost"), {"mode": "max", "start_messages": "all"}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
     ]

@@ -208,3 +208,28 @@ def test_emu_lane_grid_takes_the_binary_factors_beyond_the_register_classes(emu_
     three = G.random_coloring(100, seed=1)
     with MaxSumEngine(three, Params(), lib_path=emu_lib) as e:
         assert e.factor_kernels()["reg_binary"] == three.n_factors
+        assert e.variable_kernels()["packed"] == three.n_vars - int((np.diff(three.var_rowptr) == 0).sum())
+
+
+def test_emu_variables_of_5_to_8_values_take_the_lane_per_edge_kernel(emu_lib, oracle_built):
+    """layout.cpp: 5 <= D <= 8 and degree <= 64 -> K_V_PACK8 (k_variable_pack8), in both widths (records of 8 elements);
+    flag 1048576 leaves them in the wide class; larger domains stay wide.  Every message the oracle's."""
+    from pydcop_amd import generators as G
+    for dtype in ("f64", "f32"):
+        for colors in (5, 6, 7, 8):
+            g = G.random_coloring(160, n_colors=colors, avg_degree=5, seed=70 + colors)
+            connected = g.n_vars - int((np.diff(g.var_rowptr) == 0).sum())
+            with MaxSumEngine(g, Params(dtype=dtype), lib_path=emu_lib) as e:
+                assert e.variable_kernels()["packed8"] == connected, (dtype, colors, e.variable_kernels())
+            with MaxSumEngine(g, Params(dtype=dtype, layout_flags=1048576), lib_path=emu_lib) as e:
+                assert e.variable_kernels()["wide"] == connected
+            compare_with_oracle(oracle_built, g, Params(dtype=dtype, start_messages="all"), 0, lib_path=emu_lib, steps=[0, 1, 2, 9])
+            compare_with_oracle(oracle_built, g, Params(dtype=dtype, layout_flags=1048576), 0, lib_path=emu_lib, steps=[1, 5])
+    mixed = G.random_mixed(60, 90, seed=77, max_arity=3, dom_choices=(2, 5, 6, 8, 9, 12))   # three variable kernels in one graph
+    with MaxSumEngine(mixed, Params(), lib_path=emu_lib) as e:
+        vk = e.variable_kernels()
+        assert vk["packed"] > 0 and vk["packed8"] > 0 and vk["wide"] > 0, vk
+    compare_with_oracle(oracle_built, mixed, Params(mode="max"), 0, lib_path=emu_lib, steps=[0, 1, 2, 9])
+    nine = G.random_coloring(100, n_colors=9, seed=3)
+    with MaxSumEngine(nine, Params(), lib_path=emu_lib) as e:
+        assert e.variable_kernels()["packed8"] == 0 and e.variable_kernels()["wide"] > 0
