@@ -106,6 +106,8 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
     }
     // ... then the lane's B0 row pieces (the loads return in order: the messages are staged while the table is on its way)
     uint32_t w[B0][PW];
+    // (non-temporal loads of the image on instances beyond the Infinity Cache -- it is read once per cycle -- measured
+    // SLOWER: peav_50k f64 214-219 us against 196, f32 unchanged, profiles/r05_bin2_nt_tables_ab_v1.txt)
 #pragma unroll
     for (int r = 0; r < B0; ++r) {
         const int d0 = l0 + r * L0;

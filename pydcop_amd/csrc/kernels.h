@@ -707,13 +707,13 @@ __global__ void __launch_bounds__(BLOCK) k_variable_pack8(SweepArgs<T> a, const 
     const bool has = var < nv;
     const int v = wm.first_var + (has ? var : 0);
     const int32_t slot = a.vell[pos];
-    const int D = a.vdom[v];
+    const int D = ci.uni_D ? ci.uni_D : a.vdom[v];  // (one domain size in the class: no load, and the costs by arithmetic)
     const int64_t vo = ci.v2f_base + (int64_t)lane_id * H;
     const uint8_t cnt = a.cV[ci.cv_base + lane_id];
     T pv[H], in[H], c[H], m[H];
     Msg<T, H>::load(a.v2f_old + vo, pv);                               // V->F message last sent on this edge
     Msg<T, H>::load(a.f2v_old + (has ? slot : a.null_f2v), in);        // F->V held from this factor
-    const T* cp = a.var_cost + a.vcost_off[v];
+    const T* cp = a.var_cost + (ci.uni_D ? ci.cost_base + (int64_t)(v - ci.first) * ci.uni_D : a.vcost_off[v]);
 #pragma unroll
     for (int d = 0; d < H; ++d) {
         c[d] = d < D ? cp[d < D ? d : 0] : (T)0;

@@ -236,7 +236,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     if (i) R *= Di;
                 }
                 // one launch group per (arity, R / BLOCK rounded up): compile-time loop bounds
-                if (R >= 64 && R <= 1024 && sumd <= 1024) {
+                // (round 5: arity >= 3 also below 64 entries per value of the first variable -- one wave with idle lanes beats
+                // the thread-per-edge scalar loops of the generic class by far -- as long as the table has 64 entries at all)
+                if ((R >= 64 || (ar >= 3 && (int64_t)D0 * R >= 64)) && R <= 1024 && sumd <= 1024) {
                     const int nj = nary_classic_nj(R);
                     const int waves = nary_classic_waves(R);  // 1..4
                     // storage type of this factor's table (one launch group = one kernel
@@ -615,6 +617,9 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             ci.kind = K_V_PACK8;
             ci.D = MAX_PACK8_D;  // the record length; a variable's own domain size is read from vdom
             ci.H = L.half(ci.D);
+            ci.uni_D = L.vdom[vi];
+            for (int w = vi; w < vj; ++w)
+                if (L.vdom[w] != ci.uni_D) ci.uni_D = 0;
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
         } else if (kind == K_V_WIDE) {

@@ -47,8 +47,8 @@ enum Kind : int32_t {
     K_F_UNARY = 1,  // arity 1, D in {2,3,4}: thread per factor, registers
     K_F_BIN = 2,    // arity 2, D x D, D in {2,3,4}: thread per factor, registers
     K_F_GEN = 3,    // anything: thread per edge, scalar loops
-    K_F_NARY = 4,   // arity 2..4 with 64..1024 entries per value of the first variable:
-                    // workgroup per factor, wavefront min-reductions (own launch)
+    K_F_NARY = 4,   // arity 2..4 with 64..1024 entries per value of the first variable (arity 3..4: any number up to
+                    // 1024 once the table has 64 entries): workgroup per factor, wavefront min-reductions (own launch)
     K_V_PACK = 5,   // D in {2,3,4}, 1 <= deg <= 64: one lane per incoming edge, the
                     // variables of a wave have the same degree and are packed side
                     // by side (64/deg per wave), cross-lane sums
@@ -281,7 +281,8 @@ struct ClassInfo {       // one per class, read with one scalar load
     int64_t ctab_base;   // compact types: byte offset of the class's records in ctables
     int32_t own_pos;     // K_F_BIN of a shard's cut factors: 1 / 2 = only the message to scope position 0 / 1 is computed
                          // (the other variable is a ghost: nobody reads what this replica would send it); 0 = both
-    int32_t pad_;
+    int32_t uni_D;       // K_V_PACK8: the domain size every variable of the class has, 0 when they differ (then the kernel
+                         // reads vdom / vcost_off per variable: one more dependent load)
 };
 
 struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block

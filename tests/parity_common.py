@@ -233,6 +233,9 @@ def parity_cases():
         ("box_overhang_small", lambda: G.meeting_hetero(30, n_factors=24, doms=(10, 11, 12, 8, 7), seed=63), {"mode": "max"}),
         ("hard_box_overhang_varcost", lambda: hard(G.meeting_hetero(14, n_factors=8, doms=(24, 23, 22), seed=64), 64, 0.4,
                                                    -np.inf, "var_cost"), {"mode": "max", "start_messages": "all"}),
+        # arity 3 / 4 with FEWER than 64 entries per value of the first variable: one wave with idle lanes (round 5; generic before)
+        ("nary_small_rows_5x5x5", lambda: G.meeting_like(30, n_factors=20, dom=5, arity=3, seed=65), {"mode": "max"}),
+        ("nary_small_rows_mixed", lambda: G.random_mixed(40, 40, seed=66, max_arity=4, dom_choices=(3, 4, 5, 7)), {"start_messages": "all"}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
     ]
