@@ -187,7 +187,12 @@ int mxs_get_assignment(mxs_engine *e, int32_t *idx, double *belief);
 
 /* Parity/debug: the messages every receiver currently holds, in the caller's
  * edge order (msg_off layout above), and the per-directed-edge send counters
- * (`_prev_messages[...][1]`, maxsum.py:303,474).  Any pointer may be NULL. */
+ * (`_prev_messages[...][1]`, maxsum.py:303,474).  Any pointer may be NULL.
+ * On a SHARD (var_owned given) the state of the edges towards ghost variables is not this shard's
+ * to hold: a cut binary factor computes only the message to its own variable (layout_flags bit16
+ * off, the default), so the F->V record and send counter of its edge to the ghost variable stay
+ * zero here -- the shard that owns that variable holds them -- and a ghost variable's V->F record
+ * is whatever the last exchange delivered.  The same applies to what mxs_set_state restores. */
 int mxs_get_messages(mxs_engine *e, double *v2f, double *f2v,
                      uint8_t *count_v2f, uint8_t *count_f2v);
 
