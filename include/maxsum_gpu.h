@@ -137,7 +137,9 @@ typedef struct mxs_params {
                                 bit19 (524288) no lane-grid kernel for binary / unary factors
                                           beyond the register classes (thread per edge instead)
                                 bit20 (1048576) no lane-per-edge kernel for variables of 5..8 values
-                                          (the workgroup-per-run kernel of the wide class instead) */
+                                          (the workgroup-per-run kernel of the wide class instead)
+                                bit21 (2097152) that kernel as a launch of its own (default: its workgroups
+                                          are the first ones of the largest lane-grid factor launch)   */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;

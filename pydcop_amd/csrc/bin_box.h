@@ -8,7 +8,8 @@
 // 50k-variable PEAV instance, 0.77 ms on the 100k-variable 8-colouring: profiles/r05_before_generic_v1.json).
 //
 // Here G = L0 x L1 lanes (4, 16 or 64: layout.h Bin2Shape) work on one factor and 64 / G factors share a
-// wave.  Lane (l0, l1) owns the rows d0 = l0 + r * L0 (r < B0) and the columns d1 = l1 * B1 + i1 (i1 < B1)
+// wave.  Lane (l0, l1) owns the rows d0 = l0 + r * L0 (r < B0) and B1 columns (narrow entries: d1 = l1 * B1 + i1;
+// entries of 4 / 8 bytes: chunks of up to 16 bytes interleaved across the L1 lanes of a row, see the kernel)
 // of the table [D0][D1]: its B0 row pieces are read into registers before anything else (the image is the
 // row-major table cut into lane pieces, layout.h: the G lanes of a factor read L0 whole rows per
 // instruction), every entry feeds BOTH outputs
@@ -26,9 +27,12 @@
 namespace mxs {
 
 // Launch of one lane-grid group (engine.hip, launch_nary).  Returns false when no instantiation exists.
-// Defined in bin_box.hip (a translation unit of its own: 14 shapes x 4 storage types x 2 signs x 2 words).
+// Defined in bin_box.hip (a translation unit of its own: 14 shapes x 4 storage types x 2 signs x 2 words x with / without
+// the variable class riding in the grid).
+// `cls8` / `n_blocks8`: the K_V_PACK8 variable class rides in this launch as its first n_blocks8 workgroups (0: it does not).
 template <typename T>
-bool launch_factor_bin2(const NaryLaunch& nl, const SweepArgs<T>& a, const NaryDesc* d, hipStream_t stream);
+bool launch_factor_bin2(const NaryLaunch& nl, const SweepArgs<T>& a, const NaryDesc* d, hipStream_t stream,
+                        const ClassInfo* cls8 = nullptr, int n_blocks8 = 0);
 
 #ifdef MXS_BIN2_IMPL
 
@@ -61,20 +65,40 @@ __device__ __forceinline__ T bin2_min_run(const T* p, T m) {
     return m;
 }
 
-template <typename T, typename TT, bool NEG, int L0, int L1, int B0, int B1>
-__global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, const NaryDesc* descs, int n_factors) {
+// PACK8: the instantiation that hosts the variable class (its registers are the larger of the two paths': a template
+// parameter so that a launch without the class does not pay for it)
+template <typename T, typename TT, bool NEG, int L0, int L1, int B0, int B1, bool PACK8>
+__global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, const NaryDesc* descs, int n_factors,
+                                                                const ClassInfo* cls8, int n_blocks8) {
+    static_assert(BIN2_WAVES * 64 == BLOCK, "the variable class's workgroups ride in this grid");
+    if (PACK8 && (int)blockIdx.x < n_blocks8) {  // (block-uniform) the lane-per-edge variable class of 5..8 values: the grid's first workgroups
+        const ClassInfo ci = cls8[0];
+        variable_pack8_block<T>(a, ci, (int)blockIdx.x);
+        return;
+    }
     constexpr int G = L0 * L1, FPW = 64 / G;            // lanes per factor, factors per wave
     constexpr int P0 = L0 * B0, P1 = L1 * B1, NP = P0 + P1;
     constexpr int EPL = (NP + G - 1) / G;               // message elements per lane
     constexpr int PIECE = bin2_piece_bytes(B1, (int)sizeof(TT)), PW = PIECE / 4, ROWB = L1 * PIECE;
-    constexpr int PAL = PIECE % 16 == 0 ? 16 : PIECE % 8 == 0 ? 8 : 4;
+    // A lane's B1 columns of a row are NCH chunks of CE entries (CB bytes): entries of 4 / 8 bytes in chunks of 16, 8 or 4 bytes
+    // INTERLEAVED across the L1 lanes of the row -- chunk j of lane l1 is chunk l1 + L1 * j of the row, so that one load
+    // instruction of the group reads L1 consecutive chunks of every row it touches (a contiguous piece per lane made every
+    // instruction touch PIECE / CB times the lines it used: TCP_TOTAL_CACHE_ACCESSES 3 x the data's lines on 48-byte pieces,
+    // profiles/r05_pmc_peav_50k_f64_v1.txt); narrow entries: the piece itself (at most 16 bytes) is the one chunk.
+    // The image is the row-major table either way (layout.h): only the lane <-> column assignment differs.
+    constexpr int EL = (int)sizeof(TT);
+    constexpr int CE = EL < 4 ? B1 : (B1 * EL) % 16 == 0 ? 16 / EL : (B1 * EL) % 8 == 0 ? 8 / EL : 4 / EL;
+    constexpr int NCH = B1 / CE, CB = EL < 4 ? PIECE : CE * EL, CW = CB / 4;
+    static_assert(NCH * CE == B1 && NCH * CW == PW, "chunks tile the piece");
+    constexpr int PAL = CB % 16 == 0 ? 16 : CB % 8 == 0 ? 8 : 4;
     constexpr int NPART = P0 * L1 + P1 * L0;
     static_assert(64 % G == 0 && G * (B0 + B1) * (int)sizeof(T) % 16 == 0, "lane grid");
     __shared__ T s_in[BIN2_WAVES][FPW][NP];                       // incoming V->F messages, `0 + m`; +inf past a domain
     __shared__ __attribute__((aligned(16))) T s_part[BIN2_WAVES][FPW][NPART];  // partial minima: [d0][l1], then [d1][l0]
     const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int fw = lane / G, g = lane % G, l1 = g % L1, l0 = g / L1;
-    const int f_wave = ((int)blockIdx.x * BIN2_WAVES + wv) * FPW;
+    auto col = [&](int i1) { return (l1 + L1 * (i1 / CE)) * CE + i1 % CE; };  // the column of the lane's i1-th entry of a row
+    const int f_wave = (((int)blockIdx.x - (PACK8 ? n_blocks8 : 0)) * BIN2_WAVES + wv) * FPW;
     if (f_wave >= n_factors) return;                    // (wave-uniform; only wave-level barriers below)
     const bool active = f_wave + fw < n_factors;        // the last wave: idle groups shadow the last factor, store nothing
     const NaryDesc* fd = descs + (active ? f_wave + fw : n_factors - 1);
@@ -82,7 +106,7 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
     const bool unary = fd->arity == 1;
     const int e0 = fd->edge_base;
     const int vo0 = fd->v2f_off[0], vo1 = fd->v2f_off[1], fo0 = fd->f2v_off[0], fo1 = fd->f2v_off[1];
-    const uint8_t* img = a.ctables + fd->tab_off + l1 * PIECE;
+    const uint8_t* img = a.ctables + fd->tab_off + l1 * CB;
     // one lane per message ELEMENT slot p = g + G * k of the padded scope [0, P0) + [P0, P0 + P1): request the
     // incoming element and what the epilogue needs of the outgoing one (the message sent last, its counter) ...
     int el_i[EPL], el_d[EPL], el_cnt[EPL];
@@ -111,9 +135,13 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
 #pragma unroll
     for (int r = 0; r < B0; ++r) {
         const int d0 = l0 + r * L0;
-        const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(img + (int64_t)(d0 < D0 ? d0 : D0 - 1) * ROWB, PAL);
+        const uint8_t* row = img + (int64_t)(d0 < D0 ? d0 : D0 - 1) * ROWB;
 #pragma unroll
-        for (int j = 0; j < PW; ++j) w[r][j] = q[j];
+        for (int j = 0; j < NCH; ++j) {
+            const uint32_t* q = (const uint32_t*)__builtin_assume_aligned(row + j * (L1 * CB), PAL);
+#pragma unroll
+            for (int x = 0; x < CW; ++x) w[r][j * CW + x] = q[x];
+        }
     }
     T* in = s_in[wv][fw];
 #pragma unroll
@@ -128,7 +156,7 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
     for (int r = 0; r < B0; ++r) z0[r] = in[l0 + r * L0];
 #pragma unroll
     for (int i1 = 0; i1 < B1; ++i1) {
-        z1[i1] = in[P0 + l1 * B1 + i1];
+        z1[i1] = in[P0 + col(i1)];
         acc1[i1] = pos_inf<T>();
     }
     T* part = s_part[wv][fw];
@@ -145,7 +173,7 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
         part[(l0 + r * L0) * L1 + l1] = b0;             // (= g + r * G: the wave's lanes write one contiguous run)
     }
 #pragma unroll
-    for (int i1 = 0; i1 < B1; ++i1) part[P0 * L1 + (l1 * B1 + i1) * L0 + l0] = acc1[i1];
+    for (int i1 = 0; i1 < B1; ++i1) part[P0 * L1 + col(i1) * L0 + l0] = acc1[i1];
     __builtin_amdgcn_wave_barrier();
     // element lanes: the minimum over the lanes that share the digit, apply_damping, approx_match
     T el_m[EPL];
@@ -199,29 +227,33 @@ __global__ void __launch_bounds__(BIN2_WAVES * 64) k_factor_bin(SweepArgs<T> a, 
 }
 
 template <typename T, typename TT, int S>
-inline void launch_bin2_shape(const SweepArgs<T>& a, const NaryDesc* d, int count, hipStream_t stream) {
+inline void launch_bin2_shape(const SweepArgs<T>& a, const NaryDesc* d, int count, hipStream_t stream, const ClassInfo* cls8, int nb8) {
     constexpr Bin2Shape sh = BIN2_SHAPES[S];
     constexpr int FPB = BIN2_WAVES * (64 / (sh.L0 * sh.L1));
-    const dim3 grid((unsigned)((count + FPB - 1) / FPB)), block((unsigned)(BIN2_WAVES * 64));
-    if (a.tab_neg) hipLaunchKernelGGL((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1>), grid, block, 0, stream, a, d, count);
-    else hipLaunchKernelGGL((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1>), grid, block, 0, stream, a, d, count);
+    const dim3 grid((unsigned)(nb8 + (count + FPB - 1) / FPB)), block((unsigned)(BIN2_WAVES * 64));
+    if (nb8 > 0) {
+        if (a.tab_neg) hipLaunchKernelGGL((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
+        else hipLaunchKernelGGL((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
+    } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
+    else hipLaunchKernelGGL((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
 }
 
 template <typename T, typename TT, int... S>
-inline bool launch_bin2_any(int s, const SweepArgs<T>& a, const NaryDesc* d, int count, hipStream_t stream,
-                            std::integer_sequence<int, S...>) {
-    return ((s == S ? (launch_bin2_shape<T, TT, S>(a, d, count, stream), true) : false) || ...);
+inline bool launch_bin2_any(int s, const SweepArgs<T>& a, const NaryDesc* d, int count, hipStream_t stream, const ClassInfo* cls8,
+                            int nb8, std::integer_sequence<int, S...>) {
+    return ((s == S ? (launch_bin2_shape<T, TT, S>(a, d, count, stream, cls8, nb8), true) : false) || ...);
 }
 
 template <typename T>
-bool launch_factor_bin2(const NaryLaunch& nl, const SweepArgs<T>& a, const NaryDesc* d, hipStream_t stream) {
+bool launch_factor_bin2(const NaryLaunch& nl, const SweepArgs<T>& a, const NaryDesc* d, hipStream_t stream,
+                        const ClassInfo* cls8, int n_blocks8) {
     const int s = nl.box - BIN2_BASE;
     const auto all = std::make_integer_sequence<int, BIN2_N_SHAPES>{};
     switch (nl.tab_type) {
-        case TAB_I8: return launch_bin2_any<T, int8_t>(s, a, d, nl.count, stream, all);
-        case TAB_I16: return launch_bin2_any<T, int16_t>(s, a, d, nl.count, stream, all);
-        case TAB_F32: return launch_bin2_any<T, float>(s, a, d, nl.count, stream, all);
-        default: return launch_bin2_any<T, T>(s, a, d, nl.count, stream, all);
+        case TAB_I8: return launch_bin2_any<T, int8_t>(s, a, d, nl.count, stream, cls8, n_blocks8, all);
+        case TAB_I16: return launch_bin2_any<T, int16_t>(s, a, d, nl.count, stream, cls8, n_blocks8, all);
+        case TAB_F32: return launch_bin2_any<T, float>(s, a, d, nl.count, stream, cls8, n_blocks8, all);
+        default: return launch_bin2_any<T, T>(s, a, d, nl.count, stream, cls8, n_blocks8, all);
     }
 }
 

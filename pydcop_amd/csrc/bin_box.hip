@@ -4,6 +4,6 @@
 #include "bin_box.h"
 
 namespace mxs {
-template bool launch_factor_bin2<double>(const NaryLaunch&, const SweepArgs<double>&, const NaryDesc*, hipStream_t);
-template bool launch_factor_bin2<float>(const NaryLaunch&, const SweepArgs<float>&, const NaryDesc*, hipStream_t);
+template bool launch_factor_bin2<double>(const NaryLaunch&, const SweepArgs<double>&, const NaryDesc*, hipStream_t, const ClassInfo*, int);
+template bool launch_factor_bin2<float>(const NaryLaunch&, const SweepArgs<float>&, const NaryDesc*, hipStream_t, const ClassInfo*, int);
 }  // namespace mxs

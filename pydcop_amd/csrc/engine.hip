@@ -421,12 +421,31 @@ struct Engine : EngineBase {
         return nullptr;
     }
 
+    // The launch group the K_V_PACK8 variable class rides in (its workgroups become the first ones of that grid): the
+    // LARGEST lane-grid group that reads no ghost -- -1: none, the class has a launch of its own.  (Two latency-bound launches
+    // of a cache-resident cycle overlap only inside one grid: on two streams coloring_100k_d8 runs 59-61 us against 51.8 one
+    // after the other, the fork / join events cost more than the overlap hides -- profiles/r05_d8_overlap_ab_v1.txt.)
+    int pack8_host_group() const {
+        if (L.pack8_classes.empty() || !L.opt.pack8_fused) return -1;
+        int best = -1;
+        for (size_t i = 0; i < L.nary_launches.size(); ++i) {
+            const NaryLaunch& nl = L.nary_launches[i];
+            if (!is_bin2(nl.box) || nl.cut) continue;
+            if (best < 0 || nl.count > L.nary_launches[best].count) best = (int)i;
+        }
+        return best;
+    }
+
     int launch_nary(const SweepArgs<T>& a, int cut) {
+        const int host8 = cut == 0 ? pack8_host_group() : -1;
         for (const NaryLaunch& nl : L.nary_launches) {
             if (nl.cut != cut) continue;
             const NaryDesc* d = ndesc.p + nl.first;
             if (is_bin2(nl.box)) {  // binary / unary tables: a lane grid per factor (bin_box.h)
-                if (!launch_factor_bin2<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no lane-grid kernel for this launch group");
+                const bool host = host8 >= 0 && &nl == &L.nary_launches[host8];
+                const int nb8 = host ? (L.classes[L.pack8_classes[0]].count + BLOCK - 1) / BLOCK : 0;
+                if (!launch_factor_bin2<T>(nl, a, d, stream, host ? (const ClassInfo*)classes8.p : nullptr, nb8))
+                    return fail(MXS_E_STATE, "no lane-grid kernel for this launch group");
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -468,7 +487,7 @@ struct Engine : EngineBase {
     // The wide variable class (k_variable_wide: a workgroup per run of variables of one domain size) and the
     // lane-per-edge class of the domains of 5..8 values (k_variable_pack8).
     int launch_wide(const SweepArgs<T>& a, hipStream_t ws) {
-        if (!L.pack8_classes.empty()) {
+        if (!L.pack8_classes.empty() && pack8_host_group() < 0) {
             const ClassInfo& ci = L.classes[L.pack8_classes[0]];
             hipLaunchKernelGGL((k_variable_pack8<T>), dim3((unsigned)((ci.count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ws, a,
                                (const ClassInfo*)classes8.p);
@@ -481,7 +500,7 @@ struct Engine : EngineBase {
         }
         return MXS_OK;
     }
-    int n_wide_launches() const { return (L.wide_blocks.empty() ? 0 : 1) + (L.pack8_classes.empty() ? 0 : 1); }
+    int n_wide_launches() const { return (L.wide_blocks.empty() ? 0 : 1) + ((L.pack8_classes.empty() || pack8_host_group() >= 0) ? 0 : 1); }
 
     // Enqueue (part of) one cycle reading buffer `from` on the compute stream.
     //   phase 1: every variable class and every factor class that reads owned variables only

@@ -690,12 +690,13 @@ __device__ __forceinline__ void variable_pack(const SweepArgs<T>& a, const Class
 // Arithmetic as variable_pack: select_value maxsum.py:584-620, costs_for_factor :623-676.
 // ---------------------------------------------------------------------------
 constexpr int PACK8_D = 8;
+// (a device function: the class's workgroups run as a launch of their own, k_variable_pack8, or as the first workgroups of a
+// lane-grid factor launch, bin_box.h -- two latency-bound launches of a cache-resident cycle overlap only inside ONE grid)
 template <typename T>
-__global__ void __launch_bounds__(BLOCK) k_variable_pack8(SweepArgs<T> a, const ClassInfo* __restrict__ cls) {
+__device__ __forceinline__ void variable_pack8_block(const SweepArgs<T>& a, const ClassInfo& ci, int block) {
     constexpr int H = PACK8_D;
     static_assert(half_stride(5, (int)sizeof(T)) == H && half_stride(8, (int)sizeof(T)) == H, "records of 5..8 values are 8 elements long");
-    const ClassInfo ci = cls[0];
-    const int lane_id = (int)blockIdx.x * BLOCK + (int)threadIdx.x;
+    const int lane_id = block * BLOCK + (int)threadIdx.x;
     if (lane_id >= ci.count) return;  // whole waves (count is a multiple of 64)
     const int64_t pos = ci.ell_base + lane_id;
     const WaveMeta wm = a.vwave[__builtin_amdgcn_readfirstlane((int)(pos >> 6))];
@@ -781,6 +782,11 @@ __global__ void __launch_bounds__(BLOCK) k_variable_pack8(SweepArgs<T> a, const 
     if (!has) co = 0;
     wave_store_linear<T, H>(a.v2f_new, vo - (int64_t)l * H, m);
     a.cV[ci.cv_base + lane_id] = co;
+}
+template <typename T>
+__global__ void __launch_bounds__(BLOCK) k_variable_pack8(SweepArgs<T> a, const ClassInfo* __restrict__ cls) {
+    const ClassInfo ci = cls[0];
+    variable_pack8_block<T>(a, ci, (int)blockIdx.x);
 }
 
 // Variable side, generic class: thread per variable, any domain size / degree,

@@ -34,6 +34,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     if (f & 8192) o.compact_tables = false;   // bit13: full-width tables
     o.box = !(f & 32768);                     // bit15: no one-wave-per-factor box kernel (lane-packed instead)
     o.half_cut = !(f & 65536);                // bit16: a shard's cut binary factors compute both messages (round 3)
+    o.pack8_fused = !(f & 2097152);           // bit21: the lane-per-edge class of 5..8 values in a launch of its own
     o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)

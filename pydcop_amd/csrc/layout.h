@@ -379,6 +379,7 @@ struct LayoutOptions {
     bool schedule = false;       // co-schedule the blocks that touch the same records (Layout::sched)
     bool compact_tables = false; // tables whose every entry a narrower type holds exactly are stored in it
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
+    bool pack8_fused = true;     // ... as the first workgroups of the largest lane-grid factor launch instead of a launch of their own
     bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable

@@ -126,7 +126,7 @@ def test_no_kernel_uses_scratch():
     assert len(sweep) >= 2 and max(sweep.values()) <= 72, sweep
 
 
-@pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6), ("bin_box.hip", 150)])
+@pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6), ("bin_box.hip", 300)])
 def test_no_kernel_of_the_other_engines_uses_scratch(source, at_least):
     """The same for the DSA / MGM / A-Max-Sum sources (the register arrays of the slot kernels:
     lsearch::pick) and for the lane-grid kernels of the binary / unary factors (bin_box.hip: a lane's B0 row pieces).  rocPRIM's own sort kernels (amaxsum.hip) are not ours to judge."""

@@ -225,6 +225,11 @@ def test_emu_variables_of_5_to_8_values_take_the_lane_per_edge_kernel(emu_lib, o
                 assert e.variable_kernels()["wide"] == connected
             compare_with_oracle(oracle_built, g, Params(dtype=dtype, start_messages="all"), 0, lib_path=emu_lib, steps=[0, 1, 2, 9])
             compare_with_oracle(oracle_built, g, Params(dtype=dtype, layout_flags=1048576), 0, lib_path=emu_lib, steps=[1, 5])
+            # (default: the class's workgroups ride in the largest lane-grid factor launch; 2097152: a launch of their own)
+            with MaxSumEngine(g, Params(dtype=dtype), lib_path=emu_lib) as e, \
+                    MaxSumEngine(g, Params(dtype=dtype, layout_flags=2097152), lib_path=emu_lib) as e2:
+                assert e.cycle_bytes()[1] + 1 == e2.cycle_bytes()[1]
+            compare_with_oracle(oracle_built, g, Params(dtype=dtype, layout_flags=2097152), 0, lib_path=emu_lib, steps=[1, 5])
     mixed = G.random_mixed(60, 90, seed=77, max_arity=3, dom_choices=(2, 5, 6, 8, 9, 12))   # three variable kernels in one graph
     with MaxSumEngine(mixed, Params(), lib_path=emu_lib) as e:
         vk = e.variable_kernels()
