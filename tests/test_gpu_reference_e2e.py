@@ -114,3 +114,53 @@ def test_generated_2k_variable_yaml_with_the_fast_graph_builder(tmp_path, oracle
     assert res["violation"] == violations == 0
     assert abs(res["cost"] - cost) <= 1e-9 * max(1.0, abs(cost))
     ora.close()
+
+
+def test_reference_generated_meeting_scheduling_through_the_cli(tmp_path, oracle_built):
+    """The reference's OWN generator and CLI end to end: the code of `pydcop generate meetings` (the PEAV model,
+    pydcop/commands/generators/meetingscheduling.py:211-365: binary utility / conflict and equality tables over
+    `slots - length + 2` values, unary tables for single-event resources) writes the YAML, `pydcop solve --algo
+    maxsum_gpu` runs it on the MI355X -- every factor of it on the lane-grid kernel (bin_box.h) -- and the assignment
+    and cost are what the oracle computes on the arrays `pydcop_amd.api.compile_dcop` makes of the same file."""
+    # (the generator's own code, in this process: its `NAryMatrixRelation.set_value_for_assignment` needs `ndarray.itemset`,
+    # gone in numpy 2 -- oracle/ref_harness.install_shims carries the stand-in; the YAML is written by the reference's dcop_yaml)
+    import random
+    from oracle import ref_harness
+    ref_harness.install_shims()
+    from pydcop.commands.generators import meetingscheduling as M
+    from pydcop.dcop.dcop import DCOP
+    from pydcop.dcop.objects import AgentDef
+    from pydcop.dcop.yamldcop import dcop_yaml
+    random.seed(11)
+    slots, events, resources = M.generate_problem_definition(9, 5, 10, 8, 4, 3)   # slots, resources, max value, events, max length, max resources
+    variables, constraints, agents = M.peav_model(slots, events, resources, 10 * 9 * 5)   # penalty as generate() sets it (:222)
+    dcop = DCOP("MeetingSceduling", objective="max",
+                domains={v.domain.name: v.domain for v in variables.values()},
+                variables={v.name: v for v in variables.values()}, constraints=constraints,
+                agents={a: AgentDef(a, capacity=100000) for a in agents})
+    dcop_path = str(tmp_path / "meetings.yaml")
+    with open(dcop_path, "w", encoding="utf-8") as f:
+        f.write(dcop_yaml(dcop))
+    res = run_cli(["-t", "120", "solve", "--algo", "maxsum_gpu", "-p", "stop_cycle:20", "-p", "noise:0", "-d", "adhoc", dcop_path])
+    assert res["status"] == "FINISHED" and res["cycle"] == 20
+    # the same file, loaded by the reference's loader in this process, compiled to the flat arrays, on the oracle
+    from pydcop.dcop.yamldcop import load_dcop_from_file
+    from pydcop_amd.api import compile_dcop
+    from pydcop_amd.compile import assignment_to_values
+    from pydcop_amd.engine import MaxSumEngine
+    from pydcop_amd.graph import Params
+    dcop = load_dcop_from_file([dcop_path])
+    assert dcop.objective == "max"
+    g = compile_dcop(dcop, noise=0.0)
+    assert int(g.dom_size.max()) > 4                        # beyond the register classes
+    with MaxSumEngine(g, Params(mode="max")) as eng:
+        k = eng.factor_kernels()
+        assert k["lane_grid"] == g.n_factors and k["generic"] == 0, k
+    ora = oracle_built.OracleMaxSum(g, Params(mode="max"))
+    ora.run(20)
+    idx, _ = ora.assignment()
+    assert assignment_to_values(g, idx) == res["assignment"]
+    cost, violations = ora.eval_cost()
+    assert res["violation"] == violations
+    assert abs(res["cost"] - cost) <= 1e-9 * max(1.0, abs(cost))
+    ora.close()
