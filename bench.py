@@ -56,7 +56,8 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 KERNEL_OF = {"meeting_50k": "k_factor_box3 + k_variable_wide (one cycle)",
              "meeting_50k_float": "k_factor_nary (full-width tables) + k_variable_wide (one cycle)",
              "peav_50k": "k_factor_bin (lane grids 4x4 of 5x5 / 6x6 boxes, full-width + f32 images) + k_variable_wide (one cycle)",
-             "coloring_100k_d8": "k_factor_bin (lane grid 2x2 of 4x4 boxes, int8 image) + k_variable_wide (one cycle)"}
+             "coloring_100k_d8": "k_factor_bin (lane grid 2x2 of 4x4 boxes, int8 image) with the k_variable_pack8 workgroups "
+                                 "first in its grid: ONE launch per cycle"}
 INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MB of Infinity Cache in front of the HBM
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 REFERENCE_BASELINE_FILE = os.path.join(ROOT, "profiles", "reference_thread_agents.json")

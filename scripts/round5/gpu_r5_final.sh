@@ -30,4 +30,11 @@ for spec in "default:--steps 2000 --warmup 200" "driver:--steps 20 --warmup 5"; 
   f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_coloring100k_$name.csv && cut -c1-200 $OUT/kernel_stats_coloring100k_$name.csv | head -4
   rm -rf $OUT/p
 done
+echo "== the stated multi-GPU prediction, re-measured on this code"
+cd $R
+timeout 900 python tools/scale_prediction.py --out $OUT/scale_prediction.json > $OUT/scale_prediction.log 2>&1
+grep '^{"n"' $OUT/scale_prediction.log | python -c "
+import sys, json
+for line in sys.stdin:
+    d = json.loads(line); print('N', d['n'], 'compute', round(d['shard_compute_us'],1), 'loopback', round(d.get('shard_cycle_us_rccl_loopback',-1),1), d.get('predicted_speedup_vs_one_gpu'))"
 exit 0
