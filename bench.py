@@ -118,6 +118,10 @@ def make_workload(name, scale=1, per_gpu=100_000):
         return G.random_coloring(per_gpu, avg_degree=4, n_colors=8, seed=0, names=False), "min"
     if name == "meeting_50k_float": # configs[4] with real-valued utilities: the full-width 24^3 path
         return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False, float_tables=True), "max"
+    if name == "meeting_50k_i16":   # configs[4] with a penalty no int8 holds: int16 box records (two passes per record)
+        return G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False, penalty=1000.0), "max"
+    if name == "meeting_50k_hetero":  # configs[4] with the PEAV model's heterogeneous slots: the lane grid overhangs the tables
+        return G.meeting_hetero(50_000, doms=(24, 23, 22, 21, 20, 19, 18), arity=3, seed=0, names=False), "max"
     raise SystemExit(f"unknown workload {name}")
 
 

@@ -118,7 +118,13 @@ constexpr int BOX_SHAPES[][3] = {{2, 2, 2}, {3, 3, 3}, {4, 4, 4}, {6, 6, 6}};  /
 constexpr int BOX_N_SHAPES = 4;
 constexpr int BOX_WAVES = 4;        // factors (waves) per workgroup
 constexpr int BOX_MAX_SUMD = 128;   // D0 + D1 + D2: two element passes of a wave in the epilogue
-constexpr int BOX_MAX_WORDS = 64;   // dwords of a lane's record
+constexpr int BOX_MAX_WORDS = 64;   // dwords of a lane's record that are in registers at a time
+// A record of up to twice that is worked through in TWO passes over the leading box digit (round 5: int16 tables on the 6 x 6 x 6
+// shape -- 108 dwords per lane): it must be whole 16-byte pieces and the box's leading extent even.
+constexpr bool box_record_fits(int b0, int b1, int b2, int elem) {
+    const int words = (b0 * b1 * b2 * elem + 3) / 4;
+    return words <= BOX_MAX_WORDS || (words <= 2 * BOX_MAX_WORDS - 8 && words % 4 == 0 && b0 % 2 == 0);
+}
 constexpr int box_rec_words(int entries, int elem) { return (entries * elem + 3) / 4; }
 constexpr bool box_pow2(int x) { return x > 0 && (x & (x - 1)) == 0; }
 // shape id (1 ..) of the box layout an arity-3 table of `elem`-byte entries can take, 0 = none
@@ -132,8 +138,9 @@ constexpr int box_lanes(int d, int b) {
     return l;
 }
 #ifndef MXS_BOX_MAX_PAD_PCT
-#define MXS_BOX_MAX_PAD_PCT 150  // padded entries (= instructions) at most this many percent of the table's
-#endif
+#define MXS_BOX_MAX_PAD_PCT 240  // padded entries (= instructions) at most this many percent of the table's: the box kernel at 10
+#endif                           // instructions per padded entry beats the lane-packed workgroup kernel even on 18^3 tables in a 24^3 grid
+                                 // (meeting_50k_hetero 338.8 -> 246.2 us, f32 233.1 -> 161.3 with 240 against 150: profiles/r05_box_pad_cap_ab_v1.txt)
 constexpr int nary_box_shape(int d0, int d1, int d2, int elem) {
     int best = 0;
     long best_cells = 0;
@@ -143,7 +150,7 @@ constexpr int nary_box_shape(int d0, int d1, int d2, int elem) {
         if (l0 * l1 * l2 != 64) continue;
         if (l0 > 16 || l1 > 16 || l2 > 16) continue;  // >= 4 lanes share every digit (16-byte LDS reads)
         if (l0 * b0 + l1 * b1 + l2 * b2 > BOX_MAX_SUMD) continue;
-        if (box_rec_words(b0 * b1 * b2, elem) > BOX_MAX_WORDS) continue;
+        if (!box_record_fits(b0, b1, b2, elem)) continue;
         const long cells = 64L * b0 * b1 * b2;
         if (cells * 100 > (long)MXS_BOX_MAX_PAD_PCT * d0 * d1 * d2) continue;
         if (!best || cells < best_cells) {

@@ -55,7 +55,16 @@ template <typename T, typename TT, bool NEG, int B0, int B1, int B2>
 __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, const NaryDesc* descs, int n_factors) {
     constexpr int E = B0 * B1 * B2, NV = B0 + B1 + B2;
     constexpr int NW = box_rec_words(E, (int)sizeof(TT)), FULL = NW / 4, REST = NW % 4;
-    static_assert(NW <= BOX_MAX_WORDS, "a lane's record lives in registers");
+    // A record of more than BOX_MAX_WORDS dwords (int16 entries on 6 x 6 x 6 boxes: 108) is worked through in TWO passes over
+    // the leading box digit: the pieces that hold the entries of i0 < B0 / 2, then the ones of the rest (the piece that
+    // straddles the middle is read twice) -- the same registers hold either half.
+    constexpr int PASSES = NW <= BOX_MAX_WORDS ? 1 : 2;
+    static_assert(box_record_fits(B0, B1, B2, (int)sizeof(TT)), "a lane's record (or half of it) lives in registers");
+    constexpr int EH = E / PASSES;                                    // entries of a pass
+    constexpr int P_LAST0 = (EH * (int)sizeof(TT) - 1) / 16;          // last piece of pass 0
+    constexpr int P_FIRST1 = (EH * (int)sizeof(TT)) / 16;             // first piece of pass 1
+    constexpr int NPW = PASSES == 1 ? NW : 4 * ((P_LAST0 + 1) > (FULL - P_FIRST1) ? (P_LAST0 + 1) : (FULL - P_FIRST1));  // dwords in registers
+    static_assert(NPW <= BOX_MAX_WORDS, "a pass's pieces live in registers");
     __shared__ T s_in[BOX_WAVES][BOX_MAX_SUMD];      // the incoming V->F messages of the wave's factor
     __shared__ BoxQuad<T> s_part[BOX_WAVES][NV][16]; // partial minima: [value of a digit][lanes sharing it]
     const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
@@ -94,16 +103,17 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
     }
     // ... then the lane's record (the loads return in order: the wave can stage the messages while the
     // table is still on its way)
-    uint32_t w[NW];
+    uint32_t w[NPW];
+    const uint8_t* img = a.ctables + fd.tab_off;
     {
-        const uint8_t* img = a.ctables + fd.tab_off;
+        constexpr int K1 = PASSES == 1 ? FULL : P_LAST0 + 1;  // pieces of the first (or only) pass
 #pragma unroll
-        for (int k = 0; k < FULL; ++k) {
+        for (int k = 0; k < K1; ++k) {
             const Piece16 pc = load_piece16<MXS_BOX_NT != 0>(img + ((int64_t)k * 64 + lane) * 16);
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[4 * k + j] = pc.w[j];
         }
-        if constexpr (REST > 0) {
+        if constexpr (PASSES == 1 && REST > 0) {
             const uint32_t* r = (const uint32_t*)__builtin_assume_aligned(img + (int64_t)FULL * 1024 + lane * (REST * 4), 4);
 #pragma unroll
             for (int j = 0; j < REST; ++j) w[4 * FULL + j] = r[j];
@@ -142,6 +152,18 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
     const int slot2 = l2 * (64 >> sh2) + (lane >> sh2);
 #pragma unroll
     for (int i0 = 0; i0 < B0; ++i0) {
+        if constexpr (PASSES == 2) {
+            if (i0 == B0 / 2) {  // the second half of the record into the same registers
+#pragma unroll
+                for (int k = P_FIRST1; k < FULL; ++k) {
+                    const Piece16 pc = load_piece16<MXS_BOX_NT != 0>(img + ((int64_t)k * 64 + lane) * 16);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[4 * (k - P_FIRST1) + j] = pc.w[j];
+                }
+            }
+        }
+        // (entry index relative to the first entry the registers hold)
+        const int e_base = (PASSES == 2 && i0 >= B0 / 2) ? P_FIRST1 * (16 / (int)sizeof(TT)) : 0;
         T sp1[B2];
 #pragma unroll
         for (int i2 = 0; i2 < B2; ++i2) sp1[i2] = a0[i0] + m2[i2];
@@ -151,7 +173,7 @@ __global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, 
             const T sp2 = a0[i0] + m1[i1];
 #pragma unroll
             for (int i2 = 0; i2 < B2; ++i2) {
-                const T v = box_entry<T, TT>(w, (i0 * B1 + i1) * B2 + i2);
+                const T v = box_entry<T, TT>(w, (i0 * B1 + i1) * B2 + i2 - e_base);
                 const T t = NEG ? -v : v;
                 b0 = min2(b0, t + (z1[i1] + m2[i2]));
                 acc1[i1] = min2(acc1[i1], t + sp1[i2]);
@@ -248,6 +270,7 @@ inline bool launch_factor_box3(const NaryLaunch& nl, const SweepArgs<T>& a, cons
             case 1: MXS_BOX_LAUNCH(int16_t, 2, 2, 2);
             case 2: MXS_BOX_LAUNCH(int16_t, 3, 3, 3);
             case 3: MXS_BOX_LAUNCH(int16_t, 4, 4, 4);
+            case 4: MXS_BOX_LAUNCH(int16_t, 6, 6, 6);  // (two passes over the record: 108 dwords per lane)
         }
     }
 #undef MXS_BOX_LAUNCH

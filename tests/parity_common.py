@@ -231,6 +231,10 @@ def parity_cases():
         ("box_overhang_24_20", lambda: G.meeting_hetero(14, n_factors=8, doms=(24, 20, 21), seed=62),
          {"mode": "max", "start_messages": "all"}),
         ("box_overhang_small", lambda: G.meeting_hetero(30, n_factors=24, doms=(10, 11, 12, 8, 7), seed=63), {"mode": "max"}),
+        # int16 tables on the 6 x 6 x 6 box shape: a lane's record (108 dwords) in two passes (round 5)
+        ("box_i16_d24_two_passes", lambda: G.meeting_like(12, n_factors=6, dom=24, arity=3, seed=67, penalty=1000.0), {"mode": "max"}),
+        ("box_i16_overhang_min_all", lambda: G.meeting_hetero(14, n_factors=8, doms=(24, 23, 22), seed=68, penalty=3000.0),
+         {"start_messages": "all"}),
         ("hard_box_overhang_varcost", lambda: hard(G.meeting_hetero(14, n_factors=8, doms=(24, 23, 22), seed=64), 64, 0.4,
                                                    -np.inf, "var_cost"), {"mode": "max", "start_messages": "all"}),
         # arity 3 / 4 with FEWER than 64 entries per value of the first variable: one wave with idle lanes (round 5; generic before)
