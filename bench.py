@@ -55,6 +55,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # the launch(es) one cycle is made of, per workload (roofline.avg_launch_us covers them all)
 KERNEL_OF = {"meeting_50k": "k_factor_box3 + k_variable_wide (one cycle)",
              "meeting_50k_float": "k_factor_nary (full-width tables) + k_variable_wide (one cycle)",
+             "meeting_50k_hetero": "k_factor_box3 (4 x 4 x 4 lanes of 6^3 boxes overhanging tables of 18..24 values) + k_variable_wide (one cycle)",
              "peav_50k": "k_factor_bin (lane grids 4x4 of 5x5 / 6x6 boxes, full-width + f32 images) + k_variable_wide (one cycle)",
              "coloring_100k_d8": "k_factor_bin (lane grid 2x2 of 4x4 boxes, int8 image) with the k_variable_pack8 workgroups "
                                  "first in its grid: ONE launch per cycle"}
@@ -78,6 +79,8 @@ EXTRA_CONFIGS = [
     ("peav_50k", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[peav_50k-{dtype}]"),
     ("coloring_100k_d8", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[coloring_100k_d8-{dtype}]"),
     ("meeting_50k_float", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[meeting_50k_float-{dtype}]"),
+    # configs[4] with the PEAV model's heterogeneous slot counts (18..24): the box kernel's lane grid overhangs the tables
+    ("meeting_50k_hetero", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[meeting_50k_hetero-{dtype}]"),
 ]
 MAIN_PARITY_TEST = "tests/test_gpu_parity.py::test_north_star_100k_coloring"
 

@@ -81,6 +81,8 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
         "G.ising_grid = lambda r, c, **k: _ising(12, 12, **k)\n"
         "G.meeting_like = lambda n, **k: _meet(40, **{**k, 'dom': 6})\n"
         "G.random_coloring = lambda n, **k: _col(min(n, 600), **k)\n"
+        "_het = G.meeting_hetero\n"
+        "G.meeting_hetero = lambda n, **k: _het(40, **{**k, 'doms': (6, 5)})\n"
         "_peav = G.peav_like\n"
         "G.peav_like = lambda *a, **k: _peav(40, 25, slots=10, max_length=4, max_resources_event=4, **k)\n"
         f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
@@ -115,7 +117,8 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
                    ("ising_1024", "f64"), ("ising_1024", "f32"), ("coloring_1m_deg6", "f64"),
                    ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32"),
                    ("peav_50k", "f64"), ("peav_50k", "f32"), ("coloring_100k_d8", "f64"), ("coloring_100k_d8", "f32"),
-                   ("meeting_50k_float", "f64"), ("meeting_50k_float", "f32")}
+                   ("meeting_50k_float", "f64"), ("meeting_50k_float", "f32"),
+                   ("meeting_50k_hetero", "f64"), ("meeting_50k_hetero", "f32")}
     for c in out["configs"]:
         assert c["parity_checked"] is True and c["parity_test"].startswith("tests/test_gpu_parity.py::")
         rf = c["roofline"]

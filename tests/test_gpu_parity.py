@@ -96,6 +96,8 @@ _FULL = {
     "coloring_100k_d8": (lambda: G.random_coloring(100_000, avg_degree=4, n_colors=8, seed=0, names=False), "min", [1, 5, 34]),
     # configs[4] with real-valued utilities: the workgroup-per-factor kernel on FULL-WIDTH 24^3 tables
     "meeting_50k_float": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False, float_tables=True), "max", [1, 3, 10]),
+    # configs[4] over 18..24 slots per variable: every table on a lane grid that overhangs it (box records, round 5)
+    "meeting_50k_hetero": (lambda: G.meeting_hetero(50_000, doms=(24, 23, 22, 21, 20, 19, 18), arity=3, seed=0, names=False), "max", [1, 3, 26]),
 }
 _full_cache = {}
 
