@@ -16,7 +16,9 @@ from pydcop_amd.graph import Params  # noqa: E402
 def instance(seed):
     rng = np.random.default_rng(1000 + seed)
     nv, nf = int(rng.integers(3, 60)), int(rng.integers(1, 120))
-    doms = tuple(int(x) for x in rng.choice([1, 2, 3, 4, 5, 7, 9, 17], size=int(rng.integers(1, 4))))
+    # ($FUZZ_DOMS=big: ad-hoc sweeps over the domains of the round-5 kernels too -- lane grids of 16 / 64 lanes, box overhang)
+    choices = [1, 2, 3, 4, 5, 7, 9, 17] if os.environ.get("FUZZ_DOMS") != "big" else [1, 2, 3, 4, 5, 6, 8, 9, 12, 17, 21, 24, 33]
+    doms = tuple(int(x) for x in rng.choice(choices, size=int(rng.integers(1, 4))))
     g = G.random_mixed(nv, nf, seed=seed, max_arity=int(rng.integers(1, 5)), dom_choices=doms,
                        float_tables=bool(rng.integers(0, 2)))
     kw = dict(mode="max" if rng.integers(0, 2) else "min", dtype="f32" if rng.integers(0, 3) == 0 else "f64",
@@ -24,6 +26,8 @@ def instance(seed):
               damping_nodes=["vars", "factors", "both", "none"][int(rng.integers(0, 4))],
               damping=float(rng.choice([0.0, 0.3, 0.5])), stability=float(rng.choice([0.02, 0.1, 0.5])))
     flags = int(rng.choice([0, 0, 2048, 8192, 256, 16, 8, 2048 | 8192]))
+    if os.environ.get("FUZZ_DOMS") == "big":  # (+ the round-5 switches: generic instead of lane grids, no pack8, pack8 in its own launch)
+        flags |= int(rng.choice([0, 0, 0, 524288, 1048576, 2097152]))
     return g, kw, flags, rng
 
 
