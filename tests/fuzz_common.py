@@ -19,7 +19,10 @@ def instance(seed):
     # ($FUZZ_DOMS=big: ad-hoc sweeps over the domains of the round-5 kernels too -- lane grids of 16 / 64 lanes, box overhang)
     choices = [1, 2, 3, 4, 5, 7, 9, 17] if os.environ.get("FUZZ_DOMS") != "big" else [1, 2, 3, 4, 5, 6, 8, 9, 12, 17, 21, 24, 33]
     doms = tuple(int(x) for x in rng.choice(choices, size=int(rng.integers(1, 4))))
-    g = G.random_mixed(nv, nf, seed=seed, max_arity=int(rng.integers(1, 5)), dom_choices=doms,
+    max_arity = int(rng.integers(1, 5))
+    if os.environ.get("FUZZ_DOMS") == "big" and max(doms) > 17:
+        max_arity = min(max_arity, 3 if max(doms) <= 24 else 2)  # (keeps the emulated sweep's tables small)
+    g = G.random_mixed(nv, nf, seed=seed, max_arity=max_arity, dom_choices=doms,
                        float_tables=bool(rng.integers(0, 2)))
     kw = dict(mode="max" if rng.integers(0, 2) else "min", dtype="f32" if rng.integers(0, 3) == 0 else "f64",
               start_messages=["leafs", "leafs_vars", "all"][int(rng.integers(0, 3))],
@@ -90,4 +93,6 @@ if __name__ == "__main__":
             except Exception as ex:  # report and go on
                 bad += 1
                 print("FAIL", f.__name__, "seed", s, repr(ex)[:300], flush=True)
+        if s % 25 == 24:
+            print("... seed", s, "failures so far:", bad, flush=True)
     print("failures:", bad)

@@ -16,3 +16,11 @@ def test_fuzz_maxsum(seed, oracle_built):
 @pytest.mark.parametrize("seed", range(0, 60))
 def test_fuzz_amaxsum_dsa_mgm(seed, oracle_built):
     fuzz_others(seed, None)
+
+
+@pytest.mark.parametrize("seed", range(0, 40))
+def test_fuzz_maxsum_wide_domains(seed, oracle_built, monkeypatch):
+    """Domains up to 33 values (round 5: lane-grid factor kernels, the lane-per-edge variable class of 5..8 values, box records
+    overhanging their tables), their layout switches among the random flags."""
+    monkeypatch.setenv("FUZZ_DOMS", "big")
+    fuzz_maxsum(seed, None)
