@@ -226,7 +226,10 @@ int mxs_cycle_bytes(const mxs_engine *e, int64_t *algorithmic_bytes,
  * is exactly representable in a narrower type is stored in it and widened on load: lossless --
  * the arithmetic and every result are bit for bit those of full-width tables -- and up to 4.5x
  * fewer table bytes per cycle.  An update that does not fit (mxs_update_factor_table,
- * mxs_set_parent_table) moves the class back to full width. */
+ * mxs_set_parent_table) moves the class back to full width.  Likewise per factor for the
+ * workgroup- / wave-per-factor kernels (lane-packed slots, box records) and for the lane-grid
+ * kernel of binary / unary tables, whose image -- the row-major table cut into lane pieces -- is
+ * counted at every width. */
 int mxs_table_storage(const mxs_engine *e, int64_t factors[4], int64_t *table_bytes_per_cycle);
 
 /* Order of the binary factors inside their classes: *tiled = 1 when they are grouped by (window of the

@@ -2156,7 +2156,7 @@ int mxs_destroy(mxs_engine* e) {
 
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
-int32_t mxs_version(void) { return 200; }
+int32_t mxs_version(void) { return 210; }  // 2.1: + mxs_run_reps, mxs_factor_kernels, mxs_variable_kernels (round 5)
 #ifndef MXS_BUILD_KIND   // 1: the hipcc build for gfx950; 0: anything else (the host emulation of tests/emu), refused by the
 #if defined(__HIPCC__)   // binding outside tests (pydcop_amd/engine.py, load_library).  Derived from the compiler: a build that
 #define MXS_BUILD_KIND 1 // forgets the flag cannot claim to be the device build.
