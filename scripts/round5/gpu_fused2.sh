@@ -1,5 +1,7 @@
 #!/bin/bash
 # Round 5: the fused sharded launch on shard 0 of the 8-way cut of configs[3] with the cap on waiting cut blocks raised (1 339 cut blocks).
+# (Provenance only: the measurement build honoured $MAXSUM_FUSED_MAX_CUT_BLOCKS; the parked workgroups starved the exchange -- the
+# 5-s in-kernel timeout fired -- and the override was removed again)
 TAG=${1:-r5_fused2}
 R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
 for f in 1 0; do
