@@ -1666,7 +1666,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, co
 }
 
 // ---------------------------------------------------------------------------
-// Variable side, wide class: domains too large for the packed class (5 <= D <= 256) or degrees
+// Variable side, wide class: domains too large for the packed classes (9 <= D <= 256; 5..8: k_variable_pack8) or degrees
 // above 64, as long as deg * D <= 1024, deg <= 256.  ONE WORKGROUP PER RUN OF VARIABLES of one
 // domain size (layout.h WideBlock; e.g. 32 variables of D = 24 and degree 3), every phase with
 // all lanes busy:

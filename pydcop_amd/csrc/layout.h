@@ -53,7 +53,7 @@ enum Kind : int32_t {
                     // variables of a wave have the same degree and are packed side
                     // by side (64/deg per wave), cross-lane sums
     K_V_GEN = 6,    // anything: thread per variable, scalar loops
-    K_V_WIDE = 7,   // 5 <= D <= 256 or deg > 64, deg * D <= 1024: a workgroup per run of variables
+    K_V_WIDE = 7,   // 9 <= D <= 256 (5..8: K_V_PACK8) or deg > 64, deg * D <= 1024: a workgroup per run of variables
                     // of one domain size (WideBlock), messages staged in LDS (own launch)
     K_V_PACK8 = 8,  // 5 <= D <= 8, 1 <= deg <= 64: the lane-per-edge scheme of K_V_PACK on records of 8 elements,
                     // the variable's own D at run time (own launch, k_variable_pack8)

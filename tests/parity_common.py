@@ -97,7 +97,7 @@ def check_golden(graph, params_kw, meta, ref_idx, ref_cost, lib_path=None, **ext
 
 
 # (name, graph factory, Params kwargs) -- small seeded instances covering every
-# kernel class: register binary/unary D in {2,3,4}, generic factors (mixed
+# kernel class: register binary/unary D in {2,3,4}, lane-grid / workgroup / generic factors (mixed
 # domains, arity 1..3, D=5..8), register variables deg<=4 / <=8, generic
 # variables (deg>8, D>4), isolated variables, initial values.
 def parity_cases():
