@@ -39,7 +39,18 @@ every shard is exchange-bound.)  Labelled extras, never part of `value`: that we
 partitioned N ways (strong: it is too small to gain).  --workload NAME: strong scaling of that workload.  After every timed region rank 0 re-runs the instance
 on a single engine: the sharded selection and beliefs must be bit-identical, otherwise the run
 exits with a non-zero status.
-Rank 0 prints ONE JSON line.
+
+OUTPUT (round 6 -- the driver keeps only the tail of stdout, and round 5's single 28-KB line did not fit it):
+the LAST line of stdout is ONE COMPACT JSON object (< 4 KB: the contract's keys, `config`, `timing`,
+`roofline`, `cpu_baseline`, and `rows` = {"workload/dtype": [us per cycle, fraction of the HBM peak]} as
+a one-glance summary).  Everything else -- one record per other BASELINE configuration / widened workload
+("row": "config"), per widened algorithm ("row": "algorithm"), the reference's thread-agent runs
+("row": "cpu_baseline_detail"), the N > 1 extras ("row": "extra") -- is printed BEFORE it, one short JSON
+line each (every such line starts with {"row":), and the whole set is also written to `bench_rows.json`
+next to this script (--rows-file).
+
+`python bench.py --gpus N` with N > 1 from a plain shell (no WORLD_SIZE in the environment) re-launches
+itself under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1`.
 """
 import argparse
 import json
@@ -59,10 +70,39 @@ KERNEL_OF = {"meeting_50k": "k_factor_box3 + k_variable_wide (one cycle)",
              "peav_50k": "k_factor_bin (lane grids 4x4 of 5x5 / 6x6 boxes, full-width + f32 images) + k_variable_wide (one cycle)",
              "coloring_100k_d8": "k_factor_bin (lane grid 2x2 of 4x4 boxes, int8 image) with the k_variable_pack8 workgroups "
                                  "first in its grid: ONE launch per cycle"}
+# tables stored narrower than the arithmetic type (lossless): once the stored bytes of a cycle fall below this share of
+# the algorithmic bytes, the row LEADS with the stored-byte fraction (coloring_100k_d8 advertised 0.85 on
+# int8 tables it never moved at the arithmetic width); the other basis always rides beside it
+NARROW_LEADS = 0.8
 INFINITY_CACHE_BYTES = 256 << 20  # MI355X_MICROARCH.md: 256 MB of Infinity Cache in front of the HBM
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "traffic.json")
 REFERENCE_BASELINE_FILE = os.path.join(ROOT, "profiles", "reference_thread_agents.json")
 METRIC = "MaxSum iterations/sec on 100k-var random graph-coloring DCOP"
+ROWS_FILE = os.path.join(ROOT, "bench_rows.json")
+FINAL_LINE_LIMIT = 4096   # bytes; tests/test_bench_cli.py holds the final line to it
+ROWS = []
+
+
+def emit_row(kind, rec):
+    """One detail record: its own short JSON line on stdout (BEFORE the final line) + bench_rows.json."""
+    rec = {"row": kind, **rec}
+    ROWS.append(rec)
+    print(json.dumps(rec), flush=True)
+    return rec
+
+
+def write_rows(path, final):
+    try:
+        with open(path, "w") as f:
+            json.dump({"final_line": final, "rows": ROWS}, f, indent=1)
+    except OSError as e:   # a read-only checkout must not cost the run its line
+        print(f"[bench] cannot write {path}: {e}", file=sys.stderr)
+
+
+def row_summary(rows):
+    """{"workload/dtype": [us per cycle, roofline.frac]} -- the one-glance view the final line carries."""
+    return {f"{c['workload']}/{c['dtype']}": [round(c["roofline"]["avg_launch_us"], 2), round(c["roofline"]["frac"], 3)]
+            for c in rows}
 
 # BASELINE.json configs beside the metric's own: (workload, dtypes, -m gpu test that checks the
 # HIP path against the oracle bit for bit AT THIS SIZE)
@@ -96,7 +136,7 @@ def measured_traffic(workload, dtype):
         rec = t.get(f"{workload}/{dtype}")
         if not rec:
             return None, None
-        return rec.get("bytes_per_launch"), f"profiles/traffic.json (static, {rec.get('source')}: {rec.get('file')})"
+        return rec.get("bytes_per_launch"), f"static: {rec.get('file')}"
     except (OSError, ValueError):
         return None, None
 
@@ -171,18 +211,19 @@ def reference_thread_agents(graph, budget_s=25.0, n_vars=1000):
     per_iter = 2 * graph.n_edges
     keep = ("n_vars", "n_edges", "agents", "timeout_s", "time_s", "cycle_median", "cycle_min", "cycle_max",
             "iterations_per_s", "edge_messages_per_s", "run_wall_s")
+    # the runs themselves: a detail row (bench_rows.json), not part of the final line
+    emit_row("cpu_baseline_detail", {"what": "pydcop run_local_thread_dcop, thread agents + orchestrator, maxsum defaults, "
+                                             f"{n_vars}-variable instance of the metric's family, {budget_s:.0f} s per agent count",
+                                     "host": best.get("host", ""), "thread_agents": [{k: r.get(k) for k in keep} for r in runs]})
     return {"value": best["edge_messages_per_s"] / per_iter, "unit": "iterations/s", "cores": int(best["agents"]),
             "kind": "reference",
-            "sample": f"pydcop run_local_thread_dcop (thread agents + orchestrator, maxsum defaults) on a {n_vars}-variable "
-                      f"instance of the same family for {budget_s:.0f} s per agent count k in {ks}: best k = {best['agents']}, "
-                      f"{best['iterations_per_s']} iterations/s of THAT instance = {best['edge_messages_per_s']:.0f} "
-                      f"edge-messages/s, / {per_iter} edge-messages per iteration of this instance; CPython, GIL-bound "
-                      f"(about one core busy whatever k); {best.get('host', '')}",
+            "sample": f"reference thread agents (run_local_thread_dcop, maxsum defaults) on a {n_vars}-variable instance of the "
+                      f"same family, {budget_s:.0f} s per k in {ks}: best k={best['agents']}, {best['iterations_per_s']:.3g} it/s "
+                      f"there = {best['edge_messages_per_s']:.0f} edge-messages/s, / {per_iter} per iteration here; GIL-bound",
             # `value` is an EXTRAPOLATION of the sample to the benchmarked instance (the reference cannot run it);
             # what was timed directly on the benchmarked instance is `port` (the C restatement)
             "extrapolated": True, "sample_measured_here": True, "sample_n_vars": n_vars,
-            "edge_messages_per_s": best["edge_messages_per_s"],
-            "thread_agents": [{k: r.get(k) for k in keep} for r in runs]}
+            "edge_messages_per_s": best["edge_messages_per_s"]}
 
 
 def cpu_baseline(graph, mode, dtype, budget_s=12.0, reference_budget_s=25.0):
@@ -220,15 +261,15 @@ def cpu_baseline(graph, mode, dtype, budget_s=12.0, reference_budget_s=25.0):
     ora.close()
     port = {"value": n / dt, "unit": "iterations/s", "cores": cores, "kind": "port",
             "sample": f"{n} cycles of the same instance, oracle/maxsum_oracle.c (OpenMP, best of "
-                      f"1..{avail} threads = {cores}; host has {os.cpu_count()} logical cpus)"}
+                      f"1..{avail} threads = {cores}; {os.cpu_count()} logical cpus)"}
     ref = reference_thread_agents(graph, reference_budget_s) if reference_budget_s > 0 else None
     if ref is None:
         return port
     ref["port"] = port
-    # recorded runs at 10k variables (minutes of wall time each; not repeated in every bench run)
+    # recorded runs at 10k variables (minutes of wall time each; not repeated in every bench run): a detail row
     try:
         with open(REFERENCE_BASELINE_FILE) as f:
-            ref["recorded"] = json.load(f)
+            emit_row("cpu_baseline_recorded", {"file": "profiles/reference_thread_agents.json", "recorded": json.load(f)})
     except (OSError, ValueError):
         pass
     return ref
@@ -240,12 +281,12 @@ def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None, graph=Non
     every entry is exactly representable in a narrower type in that type (lossless, results
     bit-identical; include/maxsum_gpu.h mxs_table_storage): `stored_bytes_per_launch` is the
     same count with the tables at their stored width and `frac_of_stored_bytes` the fraction of
-    the HBM peak those bytes correspond to.  Where the tables dominate and are stored narrow --
-    the stored count is less than half of the algorithmic one (meeting_50k: 24^3 int8 entries per
-    factor) -- the algorithmic figure would exceed what the memory system can move (a "fraction"
-    above 1), so there `achieved` / `frac` are computed from the STORED bytes (`bytes_basis`:
-    "stored") and the algorithmic figure is kept as the labelled extra `achieved_algorithmic` /
-    `frac_algorithmic`."""
+    the HBM peak those bytes correspond to.  Where the stored count is below NARROW_LEADS of the
+    algorithmic one (meeting_50k: 24^3 int8 entries per factor; coloring_100k_d8: 8 x 8 int8) the
+    algorithmic figure overstates what the memory system has to move, so there `achieved` / `frac`
+    are computed from the STORED bytes (`bytes_basis`: "stored") and the algorithmic figure is kept as
+    the labelled extra `achieved_algorithmic` / `frac_algorithmic`.  `resident` says whether a cycle's
+    working set fits the 256-MB Infinity Cache: a cache-resident fraction "of the HBM peak" is nominal."""
     kernel_s = max(kernel_s, 1e-12)  # (the emulated engine of the CPU tests has no event clock)
     achieved = bytes_cycle / kernel_s / 1e9
     traffic, source = measured_traffic(workload, dtype)
@@ -269,17 +310,15 @@ def roofline_of(workload, dtype, bytes_cycle, kernel_s, launches=None, graph=Non
         r["table_storage"] = {k: v for k, v in storage.items() if k != "bytes_per_cycle" and v}
         r["stored_bytes_per_launch"] = stored
         r["frac_of_stored_bytes"] = stored / kernel_s / 1e9 / HBM_PEAK_GBPS
-        if 2 * stored < bytes_cycle:
+        if stored < NARROW_LEADS * bytes_cycle:
             r["achieved_algorithmic"], r["frac_algorithmic"] = r["achieved"], r["frac"]
             r["achieved"] = stored / kernel_s / 1e9
             r["frac"] = r["frac_of_stored_bytes"]
             r["bytes_basis"] = "stored"
-            r["bound_note"] = ("table-dominated, tables stored narrow: the launch is bound by instructions "
-                               "(VALU), not by bytes -- DESIGN.md section 5")
     return r
 
 
-def timed_repetitions(runner, steps, warmup, warm_s=0.1, region_s=0.05):
+def timed_repetitions(runner, steps, warmup, warm_s=0.1, region_s=0.05, min_reps=9):
     """The N = 1 timed region (module docstring): `warmup` steps, warm-up by time, then R back-to-back
     repetitions of EXACTLY `steps` cycles, synchronize on both sides.  -> (ms per step = median
     repetition / steps, the `timing` object of the line)."""
@@ -297,7 +336,7 @@ def timed_repetitions(runner, steps, warmup, warm_s=0.1, region_s=0.05):
     runner.run(steps)
     runner.sync()
     one = max(time.perf_counter() - t0, 1e-7)
-    reps = int(min(5000, max(3, math.ceil(region_s / one))))
+    reps = int(min(5000, max(min_reps, math.ceil(region_s / one))))   # (a median of 3 is thin)
     runner.sync()
     t0 = time.perf_counter()
     ms = runner.run_reps(steps, reps)   # enqueued back to back; returns after the last one (one host wait)
@@ -310,7 +349,8 @@ def timed_repetitions(runner, steps, warmup, warm_s=0.1, region_s=0.05):
         "repeats": reps, "steps_per_repetition": steps, "warmup_steps": warmup, "warmup_by_time_steps": n_warm,
         "ms_per_step_median": float(np.median(per)), "ms_per_step_min": float(per.min()), "ms_per_step_max": float(per.max()),
         "ms_per_step_mean": float(per.mean()), "clock": "HIP events on the engine's stream, one per repetition boundary",
-        "wall_ms_per_step_over_the_region": wall_ms_step, "region_ms": 1e3 * wall}
+        # the cross-round comparable (rounds 1-4 led with it): host clock over ALL repetitions, launch gaps included
+        "wall_ms_per_step_over_the_region": wall_ms_step, "wall_iterations_per_s": 1e3 / wall_ms_step, "region_ms": 1e3 * wall}
 
 
 def time_config(workload, dtype, graph, mode, budget_s=1.5):
@@ -354,7 +394,7 @@ def extra_configs(skip=()):
             rec = time_config(workload, dtype, graph, mode)
             rec["parity_checked"] = True
             rec["parity_test"] = test.format(dtype=dtype)
-            out.append(rec)
+            out.append(emit_row("config", rec))
         del graph
     return out
 
@@ -474,7 +514,7 @@ def other_algorithms(n_vars, device=0):
                                                 + ("; + the concerned variables' costs and gains (MGM)" if mgm else ""),
                                      "launches_per_cycle": 2 if mgm else 1},
                         "parity_test": test})
-    return out
+    return [emit_row("algorithm", a) for a in out]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -519,6 +559,9 @@ def sharded_run(graph, params, rank, world, dev, backend, warmup, steps, torch, 
     t = torch.tensor([elapsed], device=tdev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed = float(t.item())
+    seen = torch.ones(1, device=tdev)          # how many ranks the communicator (RCCL under nccl) really spans
+    dist.all_reduce(seen, op=dist.ReduceOp.SUM)
+    ranks_seen = int(seen.item())
 
     # outside the timed region: the sharded run must select what ONE engine sweeping the whole
     # instance selects after the same number of cycles (bit-identical beliefs too)
@@ -543,11 +586,42 @@ def sharded_run(graph, params, rank, world, dev, backend, warmup, steps, torch, 
         diff = int((idx_sh != idx_1).sum()) + int((bel_sh != bel_1).sum())
         if diff:
             print(f"[bench] sharded run differs from the single engine in {diff} places", file=sys.stderr)
-        out = {"elapsed": elapsed, "collective": collective, "one_gpu_iterations_per_s": one_gpu,
+        out = {"elapsed": elapsed, "collective": collective, "one_gpu_iterations_per_s": one_gpu, "ranks_seen": ranks_seen,
                "check": {"cycles": int(n_cycles), "identical_to_single_engine": diff == 0, "differences": diff}}
         out["shard_rank0"] = shard_info
     dist.barrier()
     return out
+
+
+def self_launch(n):
+    """Re-run this command line under torch.distributed.run with `n` ranks on this node."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    # MAXSUM_BENCH_ENTRY: what the ranks execute (tests/test_bench_cli.py wraps this script in the emulated engine's
+    # runner, the way it does for its explicit torch.distributed.run test); default: this file
+    entry = os.environ.get("MAXSUM_BENCH_ENTRY", "").split() or [os.path.abspath(__file__)]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")   # (what torch.distributed.run would set itself, with a warning)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n),
+           "--master-addr", "127.0.0.1", "--master-port", str(port)] + entry + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
+
+
+def final_print(out, rows_file):
+    """The LAST stdout line: compact (FINAL_LINE_LIMIT), after every detail row; the rows go to `rows_file` too."""
+    out["rows_file"] = os.path.relpath(rows_file, ROOT) if rows_file.startswith(ROOT) else rows_file
+    line = json.dumps(out)
+    if len(line) >= FINAL_LINE_LIMIT:   # never silently: drop the summary first, then say so
+        out.pop("rows", None)
+        out["truncated"] = True
+        line = json.dumps(out)
+    write_rows(rows_file, out)
+    print(line, flush=True)
 
 
 def main():
@@ -570,16 +644,22 @@ def main():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="N > 1: torch.distributed backend; gloo only for the CPU test of this script "
                          "(tests/test_bench_cli.py, emulated engine)")
+    ap.add_argument("--rows-file", default=ROWS_FILE, help="where the detail rows go (default: bench_rows.json beside this script)")
     ap.add_argument("--vars-per-gpu", type=int, default=100_000,
                     help="testing only: scales the colouring workloads (the metric is defined at 100000)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a plain `python3 bench.py --gpus N` (the way the driver runs --gpus 1): become the launcher -- one rank per
+        # GPU under torch.distributed.run, loopback rendezvous; the ranks' stdout is ours, rank 0 prints the lines
+        return self_launch(args.gpus)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 with "
-                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+                         "python -m torch.distributed.run --nproc-per-node N bench.py --gpus N "
+                         "(or unset WORLD_SIZE: bench.py then launches its own ranks)")
     # N > 1 without --workload: STRONG scaling of BASELINE configs[3] (what north_star's ">= 6x at 8 GPUs" refers to)
     workload = args.workload or ("coloring_100k" if args.gpus == 1 else "coloring_1m_deg6")
 
@@ -615,31 +695,39 @@ def main():
         for wl, _, test in EXTRA_CONFIGS:
             if wl == workload and workload != "coloring_100k":
                 parity = test.format(dtype=args.dtype)
+        rf = roofline_of(workload, args.dtype, bytes_cycle, ms_step * 1e-3, launches, graph, storage)
+        emit_row("headline_detail", {"workload": workload, "dtype": args.dtype, "timing": timing, "factor_order": order,
+                                     "factor_kernels": {k: v for k, v in kernels.items() if v}, "roofline": dict(rf)})
+        rf.pop("table_storage", None)
+        tkeep = ("repeats", "steps_per_repetition", "ms_per_step_median", "ms_per_step_min", "ms_per_step_max",
+                 "wall_ms_per_step_over_the_region", "wall_iterations_per_s", "clock")
         out.update({
-            "value": 1e3 / ms_step, "ms_per_step": ms_step, "scaling": "weak", "timing": timing,
+            "value": 1e3 / ms_step, "ms_per_step": ms_step, "scaling": "weak",
+            "timing": {k: timing[k] for k in tkeep},
             "config": {"workload": workload, "n_vars": graph.n_vars, "n_factors": graph.n_factors,
                        "n_edges": graph.n_edges, "domain": int(graph.dom_size.max()),
                        "edge_messages_per_s": 1e3 / ms_step * 2 * graph.n_edges,
                        "params": "damping 0.5/both, stability 0.1, start leafs",
                        "parallelism": f"one GPU, {launches} launch(es) per cycle",
-                       "factor_kernels": {k: v for k, v in kernels.items() if v},
-                       "factor_order": order, "parity_checked": True, "parity_test": parity},
-            "roofline": roofline_of(workload, args.dtype, bytes_cycle, ms_step * 1e-3, launches, graph, storage),
+                       "parity_checked": True, "parity_test": parity},
+            "roofline": rf,
         })
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(graph, mode, args.dtype, reference_budget_s=args.reference_budget)
         if args.configs == "all" and args.workload is None:
             del graph
-            out["configs"] = extra_configs(skip={(workload, args.dtype)})
+            rows = extra_configs(skip={(workload, args.dtype)})
             # the headline instance fits the Infinity Cache: the HBM-resident figure of the same kernel rides
             # beside it (BASELINE configs[3] on one GPU, same dtype)
-            for c in out["configs"]:
+            for c in rows:
                 if c["workload"] == "coloring_1m_deg6" and c["dtype"] == args.dtype:
                     out["roofline"]["hbm_resident_reference"] = {
                         "workload": c["workload"], "frac": c["roofline"]["frac"], "achieved": c["roofline"]["achieved"],
                         "avg_launch_us": c["roofline"]["avg_launch_us"], "resident": c["roofline"]["resident"]}
-            out["algorithms"] = other_algorithms(args.vars_per_gpu, device=local_rank)
-        print(json.dumps(out), flush=True)
+            out["rows"] = row_summary(rows)
+            for a in other_algorithms(args.vars_per_gpu, device=local_rank):
+                out["rows"][a["algo"].split()[0]] = [round(a.get("us_per_cycle", 0.0), 2) or None, round(a["roofline"]["frac"], 3)]
+        final_print(out, args.rows_file)
         return
 
     import torch.distributed as dist
@@ -665,7 +753,7 @@ def main():
             "unit": f"iterations/s of ONE {graph.n_vars}-variable instance (not the N = 1 line's 100k-variable instance: "
                     "scaling = value / one_gpu_iterations_per_s)",
             "iterations_per_s_of_the_instance": its,
-            "one_gpu_iterations_per_s": res["one_gpu_iterations_per_s"],
+            "one_gpu_iterations_per_s": res["one_gpu_iterations_per_s"], "ranks_seen": res["ranks_seen"],
             "north_star_speedup": {"workload": label, "n_gpus": args.gpus, "scaling": "strong",
                                    "speedup_vs_one_gpu": its / res["one_gpu_iterations_per_s"], "iterations_per_s": its,
                                    "one_gpu_iterations_per_s": res["one_gpu_iterations_per_s"]},
@@ -712,12 +800,15 @@ def main():
                     rec["aggregate_iterations_per_s_per_100k_variables"] = its2 * scale
                     rec["note"] = (f"ONE instance of {scale} x {args.vars_per_gpu} variables, {args.vars_per_gpu} per GPU; the "
                                    "aggregate = N x iterations/s of that instance")
-                extras.append(rec)
+                extras.append(emit_row("extra", rec))
             del g2
-        if rank == 0:
-            out["extras"] = extras
+        if rank == 0:   # the final line keeps the two numbers each extra is read for
+            out["extras"] = [{k: e.get(k) for k in ("workload", "scaling", "n_vars", "iterations_per_s_of_this_instance",
+                                                    "speedup_vs_one_gpu", "aggregate_iterations_per_s_per_100k_variables",
+                                                    "exchange")} | {"identical_to_single_engine": e["check"]["identical_to_single_engine"]}
+                             for e in extras]
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        final_print(out, args.rows_file)
     flag = torch.tensor([1 if failed else 0], device="cuda" if args.backend == "nccl" else "cpu")
     dist.broadcast(flag, src=0)
     dist.destroy_process_group()

@@ -14,6 +14,23 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _final_and_rows(stdout, rows_file):
+    """The contract of the output (the driver keeps a tail of stdout, round 5's single 28-KB line did not
+    fit it): the LAST JSON line is the compact one (< 4 KB); every line before it is a detail row {"row": kind, ...};
+    the rows file holds both."""
+    lines = [ln for ln in stdout.splitlines() if ln.startswith("{")]
+    assert lines and stdout.rstrip().splitlines()[-1] == lines[-1]
+    assert len(lines[-1]) < 4096, len(lines[-1])
+    final = json.loads(lines[-1])
+    assert "row" not in final and "metric" in final and "value" in final
+    rows = [json.loads(ln) for ln in lines[:-1]]
+    assert all("row" in x and "metric" not in x for x in rows)
+    with open(rows_file) as f:
+        saved = json.load(f)
+    assert saved["rows"] == rows and saved["final_line"] == final
+    return final, rows
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -31,12 +48,11 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
            os.path.join(ROOT, "tests", "emu", "run_emulated.py"), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
-           "--backend", "gloo", "--vars-per-gpu", "300"]
+           "--backend", "gloo", "--vars-per-gpu", "300", "--rows-file", str(tmp_path / "rows.json")]
     r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout  # rank 0 only, one line
-    out = json.loads(lines[0])
+    out, rows = _final_and_rows(r.stdout, tmp_path / "rows.json")
+    assert [x["row"] for x in rows] == ["extra", "extra"]   # rank 0 only
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
                 "scaling", "vs_baseline", "dtype", "data", "config", "roofline", "extras"):
         assert key in out, key
@@ -59,7 +75,9 @@ def test_bench_two_ranks_gloo(collective, tmp_path):
     assert cfg["check"] == {"cycles": 8, "identical_to_single_engine": True, "differences": 0}
     # labelled extras: the weak-scaling aggregate of the metric's family (ONE 2 x 300-variable instance) and the metric's
     # own instance split two ways
-    weak, small = out["extras"]
+    assert [e["workload"] for e in out["extras"]] == ["coloring_100k x2", "coloring_100k"]   # the final line: a summary
+    assert all(e["identical_to_single_engine"] for e in out["extras"])
+    weak, small = rows
     assert weak["scaling"] == "weak" and weak["n_vars"] == 600 and weak["workload"] == "coloring_100k x2"
     assert abs(weak["aggregate_iterations_per_s_per_100k_variables"] - 2 * weak["iterations_per_s_of_this_instance"]) < 1e-9 * weak["iterations_per_s_of_this_instance"]
     assert small["scaling"] == "strong" and small["n_vars"] == 300 and small["workload"] == "coloring_100k"
@@ -74,7 +92,7 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     with roofline + traffic source + the parity test id."""
     from emu.build_emu import build
     code = (
-        "import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400', '--reference-budget', '4']\n"
+        f"import sys, runpy; sys.argv = ['bench.py', '--steps', '4', '--warmup', '1', '--vars-per-gpu', '400', '--reference-budget', '4', '--rows-file', {str(tmp_path / 'rows.json')!r}]\n"
         f"from pydcop_amd import engine; engine.register_test_engine({build()!r}, make_default=True)\n"
         "import pydcop_amd.generators as G\n"
         "_ising, _meet, _col = G.ising_grid, G.meeting_like, G.random_coloring\n"
@@ -89,13 +107,22 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
     env = dict(os.environ, OMP_NUM_THREADS="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    out = json.loads(lines[0])
+    out, rows = _final_and_rows(r.stdout, tmp_path / "rows.json")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "timing", "rows", "rows_file"):
+        assert key in out, key
     assert out["n_gpus"] == 1 and out["config"]["workload"] == "coloring_100k" and out["dtype"] == "f64"
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "bytes_basis", "algorithmic_bytes_per_launch",
+                "stored_bytes_per_launch", "avg_launch_us", "resident", "kernel", "hbm_resident_reference"):
+        assert key in out["roofline"], key
+    configs = [x for x in rows if x["row"] == "config"]
+    algos = [x for x in rows if x["row"] == "algorithm"]
+    head = [x for x in rows if x["row"] == "headline_detail"]
+    assert len(head) == 1 and head[0]["timing"]["warmup_by_time_steps"] > 0 and head[0]["factor_kernels"]
     # the timed region: repetitions of exactly `steps` cycles, the median one is the line's ms_per_step
     tm = out["timing"]
-    assert tm["steps_per_repetition"] == out["steps"] == 4 and tm["repeats"] >= 3 and tm["warmup_by_time_steps"] > 0
+    assert tm["steps_per_repetition"] == out["steps"] == 4 and tm["repeats"] >= 9
+    assert tm["wall_iterations_per_s"] > 0   # the host-clock rate over the whole region, beside the event-clock median
     assert tm["ms_per_step_min"] <= out["ms_per_step"] == tm["ms_per_step_median"] <= tm["ms_per_step_max"]
     assert abs(out["value"] - 1e3 / out["ms_per_step"]) < 1e-9 * out["value"]
     from oracle.stage_reference import locate
@@ -105,40 +132,64 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
         # the reference's rate on the benchmarked instance is an extrapolation of a measured sample, labelled so
         assert cb["extrapolated"] is True and cb["sample_measured_here"] is True and cb["sample_n_vars"] == 1000
         assert cb["port"]["kind"] == "port" and cb["port"]["value"] > 0
-        assert all(r["n_vars"] == 1000 for r in cb["thread_agents"])
+        detail = [x for x in rows if x["row"] == "cpu_baseline_detail"]
+        assert len(detail) == 1 and all(t["n_vars"] == 1000 for t in detail[0]["thread_agents"])
     else:
         assert cb["kind"] == "port" and cb["value"] > 0
     assert out["roofline"]["traffic_source"] is None or "static" in out["roofline"]["traffic_source"]
     # a cache-resident headline never travels alone: the HBM-resident figure of the same kernel beside it
     assert out["roofline"]["resident"] in ("infinity_cache", "hbm")
     assert out["roofline"]["hbm_resident_reference"]["workload"] == "coloring_1m_deg6"
-    got = {(c["workload"], c["dtype"]) for c in out["configs"]}
+    got = {(c["workload"], c["dtype"]) for c in configs}
+    assert {f"{w}/{d}" for w, d in got} | {"amaxsum", "dsa", "mgm"} == set(out["rows"])   # the one-glance summary
+    for c in configs:
+        us, frac = out["rows"][f"{c['workload']}/{c['dtype']}"]
+        assert abs(us - c["roofline"]["avg_launch_us"]) <= 0.01 and abs(frac - c["roofline"]["frac"]) <= 0.001
     assert got == {("coloring_100k", "f32"), ("coloring_10k", "f64"), ("coloring_10k", "f32"),
                    ("ising_1024", "f64"), ("ising_1024", "f32"), ("coloring_1m_deg6", "f64"),
                    ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32"),
                    ("peav_50k", "f64"), ("peav_50k", "f32"), ("coloring_100k_d8", "f64"), ("coloring_100k_d8", "f32"),
                    ("meeting_50k_float", "f64"), ("meeting_50k_float", "f32"),
                    ("meeting_50k_hetero", "f64"), ("meeting_50k_hetero", "f32")}
-    for c in out["configs"]:
+    for c in configs:
         assert c["parity_checked"] is True and c["parity_test"].startswith("tests/test_gpu_parity.py::")
         rf = c["roofline"]
         for key in ("achieved", "frac", "algorithmic_bytes_per_launch", "avg_launch_us", "traffic", "traffic_source"):
             assert key in rf
         assert c["ms_per_step"] > 0 and c["iterations_per_s"] > 0
     # the widened rows: amaxsum, DSA, MGM on the metric's instance, each naming its parity test
-    algos = out["algorithms"]
     assert [a["algo"].split()[0] for a in algos] == ["amaxsum", "dsa", "mgm"]
     assert algos[0]["messages"] > 0 and algos[0]["messages_per_s"] > 0
     for a in algos[1:]:
         assert a["cycles_per_s"] > 0 and a["cost_now"] <= a["cost_at_start"]
     for a in algos:   # every widened row with bytes by a stated formula and a fraction of the peak
         assert a["roofline"]["achieved"] > 0 and 0 < a["roofline"]["frac"] and "formula" in a["roofline"]
-    for c in out["configs"]:  # no fraction of the peak above 1 at the top level of a roofline object
+    for c in configs:  # tables stored narrow enough: the row leads with the stored-byte fraction
         if c["roofline"]["bytes_basis"] == "stored":
+            assert c["roofline"]["stored_bytes_per_launch"] < 0.8 * c["roofline"]["algorithmic_bytes_per_launch"]
             assert c["roofline"]["frac"] == c["roofline"]["frac_of_stored_bytes"] and "frac_algorithmic" in c["roofline"]
     for a in algos:
         assert a["parity_test"].startswith("tests/test_gpu_") and os.path.exists(
             os.path.join(ROOT, a["parity_test"].split("::")[0]))
+
+
+def test_bench_launches_its_own_ranks(tmp_path):
+    """`python3 bench.py --gpus 2 ...` from a plain shell (no launcher, no WORLD_SIZE) -- the way the driver runs
+    --gpus 1 -- starts its own ranks under torch.distributed.run and prints the same lines (task 2)."""
+    from emu.build_emu import build, build_fake_rccl
+    build()
+    env = dict(os.environ, MAXSUM_COLLECTIVE="rccl", MAXSUM_RCCL_LIB=build_fake_rccl(), FAKE_RCCL_DIR=str(tmp_path),
+               MAXSUM_BENCH_ENTRY=os.path.join(ROOT, "tests", "emu", "run_emulated.py") + " " + os.path.join(ROOT, "bench.py"))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "2", "--backend", "gloo",
+           "--vars-per-gpu", "300", "--configs", "main", "--rows-file", str(tmp_path / "rows.json")]
+    r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    out, rows = _final_and_rows(r.stdout, tmp_path / "rows.json")
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["scaling"] == "strong" and rows == []
+    assert out["config"]["check"]["identical_to_single_engine"] and out["north_star_speedup"]["n_gpus"] == 2
+    assert out["ranks_seen"] == 2
 
 
 def test_bench_rejects_mismatched_world():
