@@ -147,6 +147,10 @@ def make_workload(name, scale=1, per_gpu=100_000):
         return G.random_coloring(per_gpu * scale, avg_degree=4, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_10k":      # BASELINE.json configs[1]
         return G.random_coloring(10_000, avg_degree=4, n_colors=3, seed=0, names=False), "min"
+    if name == "coloring_100k_scalefree":   # graphcoloring.py --graph scalefree --m_edge 2 (:322-340): hub variables of degree
+        return G.scalefree_coloring(per_gpu, m=2, n_colors=3, seed=0, names=False), "min"          # up to ~ 700 at 100k
+    if name == "coloring_1m_scalefree":     # ... 82 variables above degree 256 (up to 2 207), HBM-resident
+        return G.scalefree_coloring(per_gpu * 10, m=2, n_colors=3, seed=0, names=False), "min"
     if name == "coloring_100k_hard":
         return G.random_coloring(100_000, seed=0, variant="hard", names=False), "min"
     if name == "ising_1024":        # configs[2]

@@ -7,6 +7,8 @@ build_computation_graph O(V*F)); these follow their *instance conventions* only:
   random_coloring  soft: extensional tables of `randint(0, 9)` costs
                    (graphcoloring.py:355-375); hard: cost 1000 on equal colours
                    (graphcoloring.py:378-413)
+  scalefree_coloring  the same tables on a Barabasi-Albert graph (`--graph scalefree`,
+                   graphcoloring.py:322-340): hub variables of degree ~ sqrt(n)
   ising_grid       periodic grid, binary [[k,-k],[-k,k]] with k~U(-r, r) and
                    unary [u,-u] with u~U(-ur, ur) kept as real unary factors
                    (ising.py:285, 362-383, 412-420)
@@ -64,12 +66,59 @@ def _random_simple_edges(n_vars, n_edges, rng):
     return pairs[:n_edges]
 
 
-def random_coloring(n_vars, avg_degree=4, n_colors=3, seed=0, variant="soft",
-                    unary_noise=0.01, names=True) -> FlatGraph:
-    """Random graph colouring: n_vars*avg_degree/2 binary factors on G(n, m)."""
+def _barabasi_albert_edges(n_vars, m, rng):
+    """Barabasi-Albert preferential attachment, the construction of nx.barabasi_albert_graph the reference's
+    `--graph scalefree` calls (graphcoloring.py:322-340): a star on m + 1 nodes, then every new node attaches to m
+    DISTINCT existing nodes drawn with probability proportional to their degree (uniform draws from the list of
+    edge endpoints); the node names are shuffled afterwards, as the reference does (:332-339).  O(E)."""
+    if not 1 <= m < n_vars:
+        raise ValueError("scale-free graph: 1 <= m < n_vars")
+    n_edges = m + (n_vars - m - 1) * m
+    ends = np.empty(2 * n_edges, dtype=np.int64)       # every edge's two endpoints = the attachment urn
+    src = np.empty(n_edges, dtype=np.int64)
+    dst = np.empty(n_edges, dtype=np.int64)
+    for i in range(m):                                  # the star: node m is the centre
+        src[i], dst[i] = i, m
+        ends[2 * i], ends[2 * i + 1] = i, m
+    ne = m
+    u = rng.random(size=(n_vars, 2 * m + 8))            # pre-drawn uniforms; a row per new node
+    for node in range(m + 1, n_vars):
+        L = 2 * ne
+        targets = []
+        j = 0
+        row = u[node]
+        while len(targets) < m:
+            if j >= row.shape[0]:
+                row, j = rng.random(size=row.shape[0]), 0
+            t = int(ends[int(row[j] * L)])
+            j += 1
+            if t not in targets:
+                targets.append(t)
+        for t in targets:
+            src[ne], dst[ne] = node, t
+            ends[2 * ne], ends[2 * ne + 1] = node, t
+            ne += 1
+    relabel = rng.permutation(n_vars)
+    return np.stack([relabel[src], relabel[dst]], axis=1)
+
+
+def scalefree_coloring(n_vars, m=2, n_colors=3, seed=0, variant="soft", unary_noise=0.01, names=True) -> FlatGraph:
+    """Graph colouring on a Barabasi-Albert graph -- what `pydcop generate graph_coloring --graph scalefree
+    --m_edge m` emits (graphcoloring.py:322-340): about m * n_vars binary factors, average degree 2 m, and a few
+    HUB variables whose degree grows like sqrt(n_vars) (100k variables, m = 2: maximum degree ~ 1 000)."""
     rng = np.random.default_rng(seed)
-    n_factors = int(n_vars * avg_degree // 2)
-    pairs = _random_simple_edges(n_vars, n_factors, rng)
+    return random_coloring(n_vars, n_colors=n_colors, variant=variant, unary_noise=unary_noise, names=names,
+                           pairs=_barabasi_albert_edges(n_vars, m, rng), rng=rng)
+
+
+def random_coloring(n_vars, avg_degree=4, n_colors=3, seed=0, variant="soft",
+                    unary_noise=0.01, names=True, pairs=None, rng=None) -> FlatGraph:
+    """Random graph colouring: n_vars*avg_degree/2 binary factors on G(n, m) (or on the given `pairs`)."""
+    rng = rng if rng is not None else np.random.default_rng(seed)
+    if pairs is None:
+        n_factors = int(n_vars * avg_degree // 2)
+        pairs = _random_simple_edges(n_vars, n_factors, rng)
+    n_factors = pairs.shape[0]
     # random orientation of each constraint's scope
     flip = rng.random(n_factors) < 0.5
     pairs = np.where(flip[:, None], pairs[:, ::-1], pairs)
