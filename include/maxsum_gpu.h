@@ -139,7 +139,9 @@ typedef struct mxs_params {
                                 bit20 (1048576) no lane-per-edge kernel for variables of 5..8 values
                                           (the workgroup-per-run kernel of the wide class instead)
                                 bit21 (2097152) that kernel as a launch of its own (default: its workgroups
-                                          are the first ones of the largest lane-grid factor launch)   */
+                                          are the first ones of the largest lane-grid factor launch)
+                                bit22 (4194304) no hub class: variables beyond the packed / wide classes
+                                          take one thread each (the round-5 behaviour; A/B runs)   */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;
@@ -250,8 +252,10 @@ int mxs_factor_kernels(const mxs_engine *e, int64_t counts[6]);
 /* Which kernel runs on_new_cycle of how many variables (maxsum.py:525-565): counts[0] packed class (lane per
  * edge, D <= 4, degree <= 64: part of the sweep launch); [1] the same scheme on 8-element records (5 <= D <= 8;
  * own launch); [2] wide class (a workgroup per run of variables of one domain size, messages staged in LDS);
- * [3] generic (thread per variable); [4] not swept (isolated variables after cycle 0, a shard's ghosts). */
-int mxs_variable_kernels(const mxs_engine *e, int64_t counts[5]);
+ * [3] generic (thread per variable); [4] not swept (isolated variables after cycle 0, a shard's ghosts);
+ * [5] hub class (round 6: degree above 64 on a domain of at most 8 values, above 256 on any, deg * D > 1024 -- a
+ * wave per 64 outgoing edges, a lane per edge; part of the sweep launch). */
+int mxs_variable_kernels(const mxs_engine *e, int64_t counts[6]);
 
 /* Replace the cost table of factor `factor` (caller's factor index) by one of the
  * same shape, row-major over its scope; messages, counters and the selection

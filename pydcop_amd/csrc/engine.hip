@@ -213,6 +213,8 @@ struct Engine : EngineBase {
     uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
     DevBuf<NaryDesc> ndesc;
     DevBuf<WideBlock> wide_blocks;
+    DevBuf<HubWave> hub_waves;
+    bool has_hub = false;        // a K_V_HUB class rides in the sweep launch: the k_sweep_hub instantiations
 #ifdef MXS_WIDE_PROFILE
     DevBuf<int64_t> wide_prof;
 #endif
@@ -284,6 +286,7 @@ struct Engine : EngineBase {
         a.vslot_v2f = vslot_v2f.p;
         a.vell = vell.p;
         a.vwave = vwave.p;
+        a.hub_waves = hub_waves.p;
         a.vdom = vdom.p;
         a.vcost_off = vcost_off.p;
         a.init_idx = init_idx.p;
@@ -364,6 +367,20 @@ struct Engine : EngineBase {
                 case 4: hipLaunchKernelGGL((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
                 default: hipLaunchKernelGGL((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
             }
+        } else if (has_hub) {  // the instantiations that carry the hub class (kernels.h variable_hub): D = 3 or any
+#define MXS_SWEEP_HUB(DS)                                                                                         \
+    do {                                                                                                           \
+        if (streaming) {                                                                                           \
+            if (a.sched) hipLaunchKernelGGL((k_sweep_hub<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);  \
+            else hipLaunchKernelGGL((k_sweep_hub<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);         \
+        } else {                                                                                                   \
+            if (a.sched) hipLaunchKernelGGL((k_sweep_hub<T, DS, MXS_NT, true>), grid, block, 0, stream, a);        \
+            else hipLaunchKernelGGL((k_sweep_hub<T, DS, MXS_NT, false>), grid, block, 0, stream, a);               \
+        }                                                                                                          \
+    } while (0)
+            if (L.dsel == 3) MXS_SWEEP_HUB(3);
+            else MXS_SWEEP_HUB(0);
+#undef MXS_SWEEP_HUB
         } else {
             // <.., policy, schedule>: NT_STREAMING when the cycle does not fit the Infinity Cache (kernels.h);
             // the lean instantiation when the launch has a block schedule
@@ -745,6 +762,8 @@ struct Engine : EngineBase {
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         HIP_TRY(wide_blocks.upload(L.wide_blocks, stream));
+        HIP_TRY(hub_waves.upload(L.hub_waves, stream));
+        has_hub = !L.hub_waves.empty();
 #ifdef MXS_WIDE_PROFILE
         if (!L.wide_blocks.empty()) {
             HIP_TRY(wide_prof.alloc(8 * L.wide_blocks.size()));
@@ -2055,11 +2074,11 @@ int mxs_factor_kernels(const mxs_engine* e, int64_t counts[6]) {
     return MXS_OK;
 }
 
-int mxs_variable_kernels(const mxs_engine* e, int64_t counts[5]) {
+int mxs_variable_kernels(const mxs_engine* e, int64_t counts[6]) {
     CHECK_HANDLE(e);
     if (!counts) return MXS_OK;
     const mxs::Layout& L = e->impl->L;
-    for (int i = 0; i < 5; ++i) counts[i] = 0;
+    for (int i = 0; i < 6; ++i) counts[i] = 0;
     int64_t swept = 0;
     for (const mxs::ClassInfo& ci : L.classes) {
         int64_t n = 0;
@@ -2070,6 +2089,9 @@ int mxs_variable_kernels(const mxs_engine* e, int64_t counts[5]) {
             counts[2] += (n = ci.count);
         } else if (ci.kind == mxs::K_V_GEN && !ci.start_only) {
             counts[3] += (n = ci.count);
+        } else if (ci.kind == mxs::K_V_HUB) {  // (count = waves: a variable's first wave starts at its edge 0)
+            for (int32_t w = ci.first; w < ci.first + ci.count; ++w) n += L.hub_waves[w].ko0 == 0;
+            counts[5] += n;
         }
         swept += n;
     }
@@ -2156,7 +2178,8 @@ int mxs_destroy(mxs_engine* e) {
 
 const char* mxs_last_error(void) { return g_err.c_str(); }
 
-int32_t mxs_version(void) { return 210; }  // 2.1: + mxs_run_reps, mxs_factor_kernels, mxs_variable_kernels (round 5)
+int32_t mxs_version(void) { return 220; }  // 2.1: + mxs_run_reps, mxs_factor_kernels, mxs_variable_kernels (round 5)
+                                           // 2.2: mxs_variable_kernels reports six classes (+ the hub class, round 6)
 #ifndef MXS_BUILD_KIND   // 1: the hipcc build for gfx950; 0: anything else (the host emulation of tests/emu), refused by the
 #if defined(__HIPCC__)   // binding outside tests (pydcop_amd/engine.py, load_library).  Derived from the compiler: a build that
 #define MXS_BUILD_KIND 1 // forgets the flag cannot claim to be the device build.

@@ -159,6 +159,7 @@ struct SweepArgs {
     const int32_t* vslot_v2f;  // [n_edges] CSR slot -> V2F offset
     const int32_t* vell;       // per lane of the packed variable classes: F2V offset / -1
     const WaveMeta* vwave;     // per wave of the packed variable classes
+    const HubWave* hub_waves;  // per wave of the K_V_HUB class
     const int32_t* vdom;
     const int64_t* vcost_off;
     const int32_t* init_idx;
@@ -858,6 +859,150 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 }
 
 // ---------------------------------------------------------------------------
+// Variable side, hub class (round 6): the variables no other class takes -- degree above 64 on a small domain, above
+// 256 on any, deg * D > 1024 -- i.e. the hubs of a scale-free graph (graphcoloring.py:322-340, `--graph scalefree`:
+// 100k variables, m = 2 -> degrees up to ~1 000).  The reference's costs_for_factor (maxsum.py:651-665) is, per
+// OUTGOING edge, ONE serial accumulator `sum_cost` through all (d, f != target) in d-major order plus D serial sums
+// msg_costs[d] over the same terms: O(deg * D) dependent additions per edge, O(deg^2 * D) per variable, none of which
+// may be reassociated.  variable_generic walked all of a variable's edges in ONE thread (a 1 000-edge hub: 6e6
+// dependent loads + additions, holding the whole cycle).  Here a WAVE takes 64 outgoing edges of one variable
+// (layout.h HubWave), a lane per edge: the deg chains are independent, so the depth drops from O(deg^2 * D) to
+// O(deg * D), the reference's order inside each chain untouched.
+//   * steps of (a few values of d) x (up to HUB_TILE edges): the wave stages the F->V elements in_k[d] in LDS (every
+//     lane reads the SAME element next: broadcast reads, no conflicts), the next step's elements in flight meanwhile;
+//   * per element two additions in the lane: sum_cost += x, msg[d] += x.  The lane's own edge (k == ko) and the
+//     padding of the last tile contribute -0.0, the exact additive identity of IEEE addition (y + -0.0 == y bit
+//     for bit, for y = +-0, inf and NaN as well): no branch on the chains;
+//   * msg[d] is parked in the lane's own record of v2f_new (nobody reads the new buffer in this cycle) until
+//     sum_cost is complete, then normalised, damped and filtered like every other message (maxsum.py:540-564);
+//   * the lane one past the last edge leaves nothing out: its sums are the beliefs of select_value
+//     (maxsum.py:607-610), the selection falls out of the same loop.
+// Rides in the sweep launch (k_sweep_hub), its workgroups first in the grid.
+// ---------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassInfo& ci, int item0) {
+    constexpr int R = HUB_LDS / 64;
+    __shared__ __attribute__((aligned(16))) T s_hub[HUB_WAVES * HUB_LDS];
+    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
+    const int item = item0 + wave;
+    if (item >= ci.count) return;  // (wave-uniform)
+    const HubWave hw = a.hub_waves[ci.first + item];
+    const int v = __builtin_amdgcn_readfirstlane(hw.var), ko0 = __builtin_amdgcn_readfirstlane(hw.ko0);
+    const int D = a.vdom[v], k0 = a.vrowptr[v], deg = a.vrowptr[v + 1] - k0;
+    const int ko = ko0 + lane;
+    const bool real = ko < deg, bel = ko == deg;
+    const T* c = a.var_cost + a.vcost_off[v];
+    T* tile = s_hub + wave * HUB_LDS;
+    const int vo = a.vslot_v2f[k0 + (real ? ko : 0)];
+    const T nzero = (T)-0.0;
+    // A step = ND values of d x NK edges: rows of ROW = 8 + NK elements -- the own cost c[d] (msg_costs[d] starts from it) and
+    // seven fillers, then in_kt[d] .. in_{kt+NK-1}[d] (NK a multiple of 8; past the degree: -0.0).  A degree above HUB_TILE takes
+    // several steps per d (ND = 1); a small one several d per step, so that a wide domain does not cost a round trip each.
+    const int NK = deg < HUB_TILE ? ((deg + 7) & ~7) : HUB_TILE, ROW = NK + 8;
+    const int ND = HUB_LDS / ROW;
+    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint32_t)ROW - 1) / (uint32_t)ROW);  // e / ROW for e < 2^16
+    T pre[R];
+    auto request = [&](int d0, int kt) __attribute__((always_inline)) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = lane + 64 * r;
+            const int dd = (int)(((uint64_t)(uint32_t)e * magic) >> 32), p = e - dd * ROW;
+            const int dc = d0 + dd, k = kt + p - 8;
+            const bool row_ok = dd < ND && dc < D;
+            const bool is_x = row_ok && p >= 8 && k < deg;
+            const int off = a.vslot_f2v[k0 + (is_x ? k : 0)];
+            const T x = a.f2v_old[off + (is_x ? dc : 0)];
+            const T cc = c[row_ok ? dc : 0];
+            pre[r] = is_x ? x : ((row_ok && p == 0) ? cc : nzero);
+        }
+    };
+    T s = (T)0, m = (T)0, best_c = (T)0;
+    int best = 0;
+    int d0 = 0, kt = 0;
+    request(0, 0);
+    while (d0 < D) {
+        __builtin_amdgcn_wave_barrier();  // the previous step's reads are over
+#pragma unroll
+        for (int r = 0; r < R; ++r) tile[lane + 64 * r] = pre[r];
+        __builtin_amdgcn_wave_barrier();
+        // the step after this one: the next edges of this d, or the next values of d
+        const bool last_k = kt + NK >= deg;
+        const int d0n = last_k ? d0 + ND : d0, ktn = last_k ? 0 : kt + NK;
+        if (d0n < D) request(d0n, ktn);
+        const int n = deg - kt < NK ? deg - kt : NK;
+        for (int dd = 0; dd < ND && d0 + dd < D; ++dd) {
+            const T* row = tile + dd * ROW;
+            if (kt == 0) m = row[0];  // msg_costs[d] = cost_for_val(d), maxsum.py:648
+            for (int kk = 0; kk < n; kk += 8) {
+                T x[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[u] = row[8 + kk + u];
+                const int kabs = kt + kk;
+                if (kabs + 8 > ko0 && kabs < ko0 + 64) {  // (wave-uniform) the block holds the own edge of some lane
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) x[u] = (kabs + u == ko) ? nzero : x[u];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    s += x[u];
+                    m += x[u];
+                }
+            }
+            if (last_k) {  // msg_costs[d] is complete
+                const int d = d0 + dd;
+                if (real) a.v2f_new[vo + d] = m;  // parked until sum_cost is complete
+                if (d == 0 || m < best_c) {       // (the belief lane's: first index attaining the minimum)
+                    best = d;
+                    best_c = m;
+                }
+            }
+        }
+        d0 = d0n;
+        kt = ktn;
+    }
+    if (bel) {
+        if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
+            best = a.init_idx[v];
+            best_c = (T)0;
+        }
+        a.sel[v] = best;
+        a.belief[v] = best_c;
+    }
+    if (!real) return;
+    // ---- normalise, damp, filter (the lane's own edge) ---------------------------------------
+    const T avg = s / (T)D;
+    const T* prev = a.v2f_old + vo;
+    T* w = a.v2f_new + vo;
+    const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) || a.start_mode != MXS_START_LEAFS;
+    const uint8_t cnt = a.start ? 0 : a.cV[k0 + ko];
+    const bool damp = cnt > 0 && a.damp_v;
+    bool match = cnt > 0;
+    for (int dd = 0; dd < D; ++dd) {
+        T mm = w[dd] - avg;
+        if (a.start) {
+            w[dd] = start_sends ? mm : (T)0;
+            continue;
+        }
+        const T p = prev[dd];
+        if (damp) mm = a.damping * p + ((T)1 - a.damping) * mm;
+        if (match) match = comp_match(mm, p, a.stability);
+        w[dd] = mm;
+    }
+    uint8_t out = 1;
+    if (a.start) {
+        out = 0;
+    } else if (match) {
+        if (cnt < SAME_COUNT) {
+            out = (uint8_t)(cnt + 1);
+        } else {  // not sent: the receiver keeps the old message
+            out = cnt;
+            for (int dd = 0; dd < D; ++dd) w[dd] = prev[dd];
+        }
+    }
+    a.cV[k0 + ko] = out;
+}
+
+// ---------------------------------------------------------------------------
 // The sweep: one block = up to blockDim.x items of one class.  The class and the
 // first item of a block follow from blockIdx and the class table in the kernel
 // arguments.  DSEL != 0 instantiates the register / wave paths for that domain
@@ -927,7 +1072,8 @@ __device__ __forceinline__ void wait_for_halo(uint32_t* flags, uint32_t need, in
 // then carries neither the compare chain on block_base[] nor the halo wait of the cut classes (which run
 // in launches without schedule), and its prologue is two dependent scalar loads (schedule word, class
 // record) instead of a chain of argument pieces.
-template <typename T, int DSEL, bool P2P = false, int NT = MXS_NT, bool SCHED = false>
+// HUB: the launch may hold the K_V_HUB class (its LDS tile and its registers are in that instantiation only).
+template <typename T, int DSEL, bool P2P = false, int NT = MXS_NT, bool SCHED = false, bool HUB = false>
 __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     int c = 0, blk = -1;
     if (SCHED || a.sched != nullptr) {
@@ -943,6 +1089,10 @@ __device__ __forceinline__ int sweep_block(const SweepArgs<T>& a) {
     // before the first vector load -- measured no gain: profiles/r03_class_preload_ab_v1.txt.)
     const int item = (blk >= 0 ? blk : (int)blockIdx.x - ci.block_base) * ci.per_block;
     if (!SCHED && ci.wait_halo && a.halo_flags != nullptr) wait_for_halo(a.halo_flags, a.need_epoch, a.n_peers, a.me);
+    if (HUB && ci.kind == K_V_HUB) {
+        variable_hub<T>(a, ci, item);
+        return ci.kind;
+    }
     if (ci.kind == K_F_GEN || ci.kind == K_V_GEN) {
         const int j = item + (int)threadIdx.x;
         if (j >= ci.count) return ci.kind;
@@ -992,12 +1142,19 @@ k_sweep_d2(SweepArgs<T> a) {
     sweep_block<T, 2, false, NT, SCHED>(a);
 }
 
+// The sweep of a graph with hub variables (K_V_HUB): a kernel of its own, so that the hub path's LDS tile and registers cost
+// the plain sweep nothing.  DSEL 3 (colourings) or 0.
+template <typename T, int DSEL, int NT = MXS_NT, bool SCHED = false>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_hub(SweepArgs<T> a) {
+    sweep_block<T, DSEL, false, NT, SCHED, true>(a);
+}
+
 // The sweep of a shard in peer-store mode (engine.hip, p2p): same blocks, plus the stores of
 // cut-edge records into the peers' ghost regions and the ghost addressing of the cut factors.
 // A kernel of its own so that these cost the plain sweep no register.
 template <typename T, int DSEL>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_p2p(SweepArgs<T> a) {
-    sweep_block<T, DSEL, true>(a);
+    sweep_block<T, DSEL, true, MXS_NT, false, true>(a);
 }
 
 // Profiling twin (mxs_debug_timeline): when did each block start, when were its stores done.
@@ -1005,7 +1162,7 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_p2p(SweepArgs<
 template <typename T, int DSEL>
 __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_timeline(SweepArgs<T> a) {
     const int64_t t0 = (int64_t)wall_clock64();
-    const int kind = sweep_block<T, DSEL>(a);
+    const int kind = sweep_block<T, DSEL, false, MXS_NT, false, true>(a);
     __builtin_amdgcn_s_waitcnt(0);  // loads back, stores acknowledged
     const int64_t t1 = (int64_t)wall_clock64();
     if (threadIdx.x == 0) {

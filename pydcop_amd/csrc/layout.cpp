@@ -37,6 +37,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.pack8_fused = !(f & 2097152);           // bit21: the lane-per-edge class of 5..8 values in a launch of its own
     o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
+    o.hub = !(f & 4194304);                   // bit22: no wave-per-64-edges class for hub variables (thread per variable instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
     if (f & 131072) o.tile_bytes = MXS_TILE_BYTES;       // bit17: always tiled
     if (f & 262144) o.tile_bytes = 0;                    // bit18: never tiled
@@ -197,8 +198,12 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         } else if (!L.opt.no_specialise && L.opt.pack8 && D > MAX_REG_D && D <= MAX_PACK8_D && deg <= MAX_PACK_DEG) {
             kind = K_V_PACK8;  // lane per edge on 8-element records, D at run time
             sub = 0;
-        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256) {
+        } else if (!L.opt.no_specialise && D <= 256 && (int64_t)deg * D <= 1024 && deg <= 256 &&
+                   !(L.opt.hub && D <= MAX_PACK8_D && deg > MAX_PACK_DEG)) {  // (deg > 64 on a packed-class domain: a hub, below)
             kind = K_V_WIDE;  // workgroup per run of variables of one D, messages staged in LDS
+            sub = 0;
+        } else if (!L.opt.no_specialise && L.opt.hub) {
+            kind = K_V_HUB;   // a wave per 64 outgoing edges, a lane per edge (round 6; before: a thread per variable)
             sub = 0;
         } else { kind = K_V_GEN; sub = 0; }
         // sort key: class, then degree (the packed class needs equal degrees side
@@ -623,6 +628,21 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 if (L.vdom[w] != ci.uni_D) ci.uni_D = 0;
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
+        } else if (kind == K_V_HUB) {
+            // its waves: 64 outgoing edges of one variable each, the belief lane behind the last edge; the longest
+            // chains (highest degree x domain) first -- they are the first workgroups of the sweep's grid
+            ci.kind = K_V_HUB;
+            std::vector<int> order(vj - vi);
+            std::iota(order.begin(), order.end(), vi);
+            std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
+                return (int64_t)(L.vrowptr[x + 1] - L.vrowptr[x]) * L.vdom[x] > (int64_t)(L.vrowptr[y + 1] - L.vrowptr[y]) * L.vdom[y];
+            });
+            ci.first = (int32_t)L.hub_waves.size();
+            for (int w : order) {
+                const int deg = L.vrowptr[w + 1] - L.vrowptr[w];
+                for (int ko0 = 0; ko0 <= deg; ko0 += 64) L.hub_waves.push_back(HubWave{w, ko0});
+            }
+            ci.count = (int32_t)L.hub_waves.size() - ci.first;
         } else if (kind == K_V_WIDE) {
             ci.kind = K_V_WIDE;
             // its workgroups: runs of one D that fit the kernel's LDS arrays
@@ -701,7 +721,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.classes[cls].per_block = BLOCK;  // (its own launch: count / BLOCK workgroups)
                 L.pack8_classes.push_back(cls);
             } else {
-                sweep_class(cls, BLOCK);
+                sweep_class(cls, ci.kind == K_V_HUB ? HUB_WAVES : BLOCK);
             }
         }
         vi = vj;
@@ -717,6 +737,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
     {
         auto prio = [&](int c) {
             switch (L.classes[c].kind) {
+                case K_V_HUB: return -1;  // serial chains of thousands of additions: the first workgroups of the grid
                 case K_V_GEN: return 0;
                 case K_F_GEN: return 1;
                 case K_V_PACK: return 2;
@@ -729,7 +750,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             std::vector<int32_t> keep;     // bit5 = factor side only, bit6 = variable side only
             for (int c : L.sweep_order) {
                 const int k = L.classes[c].kind;
-                const bool is_var = k == K_V_GEN || k == K_V_PACK;
+                const bool is_var = k == K_V_GEN || k == K_V_PACK || k == K_V_HUB;
                 if (((p.layout_flags & 32) && !is_var) || ((p.layout_flags & 64) && is_var)) keep.push_back(c);
             }
             L.sweep_order = keep;
@@ -764,6 +785,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         if (L.opt.schedule && L.n_blocks_sweep >= 2 && !(p.layout_flags & (32 | 64))) {
             struct Blk { double key; int prio; uint32_t code; };
             std::vector<Blk> blks;
+            std::vector<uint32_t> hub_blks;
             blks.reserve(L.n_blocks_sweep);
             auto first_var_of_factor = [&](int fi) { return (double)L.edge_var_int[L.frowptr[fi]]; };
             for (size_t slot = 0; slot < L.sweep_order.size(); ++slot) {
@@ -775,6 +797,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     const int64_t i1 = std::min<int64_t>(ci.count, i0 + ci.per_block) - 1;
                     double k0 = 0, k1 = 0;
                     int prio = 1;
+                    if (ci.kind == K_V_HUB) {  // not part of the locality order: the first workgroups of the grid (below)
+                        hub_blks.push_back((uint32_t)(slot << 24) | (uint32_t)j);
+                        continue;
+                    }
                     switch (ci.kind) {
                         case K_V_PACK: {  // lanes -> the wave's first variable
                             const WaveMeta& w0 = L.vwave[(ci.ell_base + i0) >> 6];
@@ -802,16 +828,20 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     blks.push_back(Blk{0.5 * (k0 + k1), prio, (uint32_t)(slot << 24) | (uint32_t)j});
                 }
             }
-            if ((int)blks.size() == L.n_blocks_sweep) {
+            if ((int)(blks.size() + hub_blks.size()) == L.n_blocks_sweep) {
                 std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) {
                     return a.key != b.key ? a.key < b.key : a.prio < b.prio;
                 });
-                // XCD x runs the workgroups b = x, x + 8, x + 16, ...: hand it the x-th
-                // contiguous piece of the order
+                // the hub workgroups (K_V_HUB: the longest blocks by far) are the first of the grid, dealt round the XCDs;
+                // behind them XCD x runs the workgroups b = x, x + 8, x + 16, ...: hand it the x-th contiguous piece of
+                // the order
                 L.sched.assign(L.n_blocks_sweep, 0);
+                const int64_t nh = (int64_t)hub_blks.size();
+                for (int64_t b = 0; b < nh; ++b) L.sched[b] = hub_blks[b];
                 int64_t m = 0;
                 for (int x = 0; x < NUM_XCD; ++x)
-                    for (int64_t b = x; b < L.n_blocks_sweep; b += NUM_XCD) L.sched[b] = blks[m++].code;
+                    for (int64_t b = nh + ((x - nh) % NUM_XCD + NUM_XCD) % NUM_XCD; b < L.n_blocks_sweep; b += NUM_XCD)
+                        L.sched[b] = blks[m++].code;
             }
         }
         // one compile-time D for every register / wave class -> leaner kernel

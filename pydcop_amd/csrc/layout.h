@@ -57,6 +57,10 @@ enum Kind : int32_t {
                     // of one domain size (WideBlock), messages staged in LDS (own launch)
     K_V_PACK8 = 8,  // 5 <= D <= 8, 1 <= deg <= 64: the lane-per-edge scheme of K_V_PACK on records of 8 elements,
                     // the variable's own D at run time (own launch, k_variable_pack8)
+    K_V_HUB = 9,    // everything the classes above leave (round 6): deg > 64 with D <= 8, deg > 256, deg * D > 1024, D > 256 --
+                    // the hub variables of a scale-free graph.  One WAVE per 64 outgoing edges of ONE variable (HubWave), a lane
+                    // per edge walking the reference's serial chains over the other edges; rides in the sweep launch, first in
+                    // its grid (kernels.h variable_hub)
 };
 
 #ifndef MXS_BLOCK
@@ -330,6 +334,17 @@ struct WideBlock {
     int64_t cost_off;    // element offset of the first variable's own costs (vcost_off[first_var])
 };
 
+// One wave of the K_V_HUB class: 64 consecutive outgoing edges (CSR slots ko0 .. ko0 + 63) of variable `var`.  The lane with
+// ko == deg (one past the last edge) is the variable's BELIEF lane: the same chain with nothing left out is
+// select_value's sum (maxsum.py:607-610).  A variable of degree deg takes ceil((deg + 1) / 64) waves.
+struct HubWave {
+    int32_t var;   // internal variable id
+    int32_t ko0;   // first outgoing edge (position in the variable's slot range) of lane 0
+};
+constexpr int HUB_TILE = 512;            // edges of one value of d a wave stages in LDS per step, at most
+constexpr int HUB_LDS = 640;             // elements of a wave's LDS area: rows of 8 + NK elements (kernels.h variable_hub)
+constexpr int HUB_WAVES = BLOCK / 64;    // waves (items) per workgroup of the class
+
 struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY factors
     int32_t arity, nj;   // nj = ceil(R / BLOCK), R = product of the dimensions after the first
     int32_t threads;     // block size: ceil(R / nj) rounded up to whole waves -- when R allows
@@ -389,6 +404,7 @@ struct LayoutOptions {
     bool pack8_fused = true;     // ... as the first workgroups of the largest lane-grid factor launch instead of a launch of their own
     bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
+    bool hub = true;             // variables beyond the packed / wide classes use the wave-per-64-edges class (K_V_HUB) instead of a thread each
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable
     int64_t tile_bytes = -1;     // binary factors in tiled order: > 0 windows of about this many bytes, 0 never, < 0 per instance (layout.cpp)
 };
@@ -434,6 +450,7 @@ struct Layout {
     std::vector<int32_t> pack8_classes;   // K_V_PACK8 classes (at most one): their own launch
     std::vector<int32_t> wide_classes;    // K_V_WIDE classes (at most one: every wide variable, sorted by D)
     std::vector<WideBlock> wide_blocks;   // the workgroups of the K_V_WIDE launch
+    std::vector<HubWave> hub_waves;       // the waves of the K_V_HUB class (longest chains first)
 
     // per internal edge (factor-major)
     std::vector<int32_t> f2v_off;    // element offset of the edge's F->V message

@@ -391,9 +391,9 @@ class MaxSumEngine:
 
     def variable_kernels(self) -> dict:
         """Variables per kernel of the variable side (mxs_variable_kernels)."""
-        n = (C.c_int64 * 5)()
+        n = (C.c_int64 * 6)()
         self._check(self._lib.mxs_variable_kernels(self._h, n))
-        return dict(zip(("packed", "packed8", "wide", "generic", "not_swept"), (int(x) for x in n)))
+        return dict(zip(("packed", "packed8", "wide", "generic", "not_swept", "hub"), (int(x) for x in n)))
 
     def table_storage(self) -> dict:
         """{"full", "f32", "i16", "i8"}: factors per table storage type, and "bytes_per_cycle": the

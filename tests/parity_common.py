@@ -125,16 +125,16 @@ def parity_cases():
         setattr(g, what, a)
         return g
 
-    def hub(seed, nf=40, n=60):
-        # one variable in nf more factors (packed class up to degree 64, wide class above),
-        # some isolated variables
-        g = G.random_coloring(n, avg_degree=3, seed=seed)
+    def hub(seed, nf=40, n=60, colors=3):
+        # one variable in nf more factors (packed class up to degree 64, hub class above -- round 5: wide class up to 256,
+        # a thread per variable beyond), some isolated variables
+        g = G.random_coloring(n, avg_degree=3, n_colors=colors, seed=seed)
         rng = np.random.default_rng(seed)
         others = rng.choice(np.arange(1, n - 10), size=nf, replace=False)
         edge_var = np.concatenate([g.edge_var, np.stack([np.zeros(nf, int), others], 1).reshape(-1)])
         rowptr = np.concatenate([g.factor_rowptr, g.factor_rowptr[-1] + 2 * np.arange(1, nf + 1)])
-        tables = np.concatenate([g.tables, rng.integers(0, 10, nf * 9).astype(float)])
-        toff = np.concatenate([g.table_off, g.table_off[-1] + 9 * np.arange(1, nf + 1)])
+        tables = np.concatenate([g.tables, rng.integers(0, 10, nf * colors * colors).astype(float)])
+        toff = np.concatenate([g.table_off, g.table_off[-1] + colors * colors * np.arange(1, nf + 1)])
         from pydcop_amd.graph import FlatGraph
         dom = np.concatenate([g.dom_size, [3, 3, 2]])  # 3 isolated variables
         cost = np.concatenate([g.var_cost, rng.uniform(0, 1, 8)])
@@ -240,6 +240,21 @@ def parity_cases():
         # arity 3 / 4 with FEWER than 64 entries per value of the first variable: one wave with idle lanes (round 5; generic before)
         ("nary_small_rows_5x5x5", lambda: G.meeting_like(30, n_factors=20, dom=5, arity=3, seed=65), {"mode": "max"}),
         ("nary_small_rows_mixed", lambda: G.random_mixed(40, 40, seed=66, max_arity=4, dom_choices=(3, 4, 5, 7)), {"start_messages": "all"}),
+        # hub class (round 6, kernels.h variable_hub): a wave per 64 outgoing edges of one variable, a lane per edge.  Degrees the
+        # scale-free generator of the reference reaches (graphcoloring.py:322-340: ~1 000 at 100k variables, ~3 400 at 1M), one
+        # tile and several per value of d (HUB_TILE = 512), domains of the packed-on-8 class, a wide domain at a degree the wide
+        # class cannot stage (deg * D > 1024), hard constraints, initial values
+        ("hub_deg300", lambda: hub(71, nf=300, n=400), {}),
+        ("hub_deg1100_max_all", lambda: hub(72, nf=1100, n=1300), {"mode": "max", "start_messages": "all"}),
+        ("hub_deg3400", lambda: hub(73, nf=3400, n=3600), {"start_messages": "leafs_vars", "damping_nodes": "vars"}),
+        ("hub_deg513_d2", lambda: hub(74, nf=510, n=640, colors=2), {"damping_nodes": "factors"}),
+        ("hub_deg200_d6", lambda: hub(75, nf=200, n=300, colors=6), {"mode": "max"}),
+        ("hub_deg90_d24", lambda: hub(76, nf=90, n=140, colors=24), {"mode": "max", "start_messages": "all"}),
+        ("hub_scalefree_2000", lambda: G.scalefree_coloring(2000, m=2, seed=77), {}),
+        ("hub_scalefree_m3_d4_init", lambda: with_init(G.scalefree_coloring(1500, m=3, n_colors=4, seed=78), 78), {"damping": 0.3}),
+        ("hard_hub_deg300_inf", lambda: hard(hub(79, nf=300, n=400), 79, 0.3, np.inf), {}),
+        ("hard_hub_deg150_varcost_neg_inf_max", lambda: hard(hub(80, nf=150, n=220), 80, 0.2, -np.inf, "var_cost"),
+         {"mode": "max", "start_messages": "all"}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
     ]

@@ -211,6 +211,29 @@ def test_emu_lane_grid_takes_the_binary_factors_beyond_the_register_classes(emu_
         assert e.variable_kernels()["packed"] == three.n_vars - int((np.diff(three.var_rowptr) == 0).sum())
 
 
+def test_emu_hub_variables_take_the_hub_class(emu_lib, oracle_built):
+    """layout.cpp: degree above 64 on a domain of at most 8 values, above 256 or deg * D > 1024 on any, D > 256 -> K_V_HUB
+    (kernels.h variable_hub: a wave per 64 outgoing edges), inside the sweep launch; flag 4194304: the round-5 classes (wide up
+    to degree 256, a thread per variable beyond).  Every message the oracle's, in class order and scheduled."""
+    from pydcop_amd import generators as G
+    g = G.scalefree_coloring(8000, m=3, seed=5, names=False)
+    deg = np.diff(g.var_rowptr)
+    assert deg.max() > 256
+    with MaxSumEngine(g, Params(), lib_path=emu_lib) as e:
+        vk = e.variable_kernels()
+        assert vk["hub"] == int((deg > 64).sum()) > 0 and vk["generic"] == 0 and vk["wide"] == 0, vk
+        assert e.cycle_bytes()[1] == 1   # one launch per cycle
+    with MaxSumEngine(g, Params(layout_flags=4194304), lib_path=emu_lib) as e:
+        vk = e.variable_kernels()
+        assert vk["hub"] == 0 and vk["generic"] == int((deg > 256).sum()) and vk["wide"] == int(((deg > 64) & (deg <= 256)).sum()), vk
+    for flags in (0, 2048, 4194304, 8):
+        compare_with_oracle(oracle_built, g, Params(layout_flags=flags), 0, lib_path=emu_lib, steps=[0, 1, 2, 6])
+    compare_with_oracle(oracle_built, g, Params(dtype="f32", mode="max", start_messages="all"), 0, lib_path=emu_lib, steps=[0, 1, 5])
+    wide_dom = G.random_mixed(6, 8, seed=23, max_arity=2, dom_choices=(300, 3))   # D = 300: beyond the wide class
+    with MaxSumEngine(wide_dom, Params(), lib_path=emu_lib) as e:
+        assert e.variable_kernels()["hub"] > 0 and e.variable_kernels()["generic"] == 0
+
+
 def test_emu_variables_of_5_to_8_values_take_the_lane_per_edge_kernel(emu_lib, oracle_built):
     """layout.cpp: 5 <= D <= 8 and degree <= 64 -> K_V_PACK8 (k_variable_pack8), in both widths (records of 8 elements);
     flag 1048576 leaves them in the wide class; larger domains stay wide.  Every message the oracle's."""

@@ -98,6 +98,10 @@ _FULL = {
     "meeting_50k_float": (lambda: G.meeting_like(50_000, dom=24, arity=3, seed=0, names=False, float_tables=True), "max", [1, 3, 10]),
     # configs[4] over 18..24 slots per variable: every table on a lane grid that overhangs it (box records, round 5)
     "meeting_50k_hetero": (lambda: G.meeting_hetero(50_000, doms=(24, 23, 22, 21, 20, 19, 18), arity=3, seed=0, names=False), "max", [1, 3, 26]),
+    # round 6: what `--graph scalefree` emits (graphcoloring.py:322-340) -- hub variables of degree up to ~700 (100k) / ~2 200 (1M):
+    # the wave-per-64-edges class (kernels.h variable_hub) riding in the sweep launch, one tile and several per value of d
+    "coloring_100k_scalefree": (lambda: G.scalefree_coloring(100_000, m=2, n_colors=3, seed=0, names=False), "min", [1, 5, 34]),
+    "coloring_1m_scalefree": (lambda: G.scalefree_coloring(1_000_000, m=2, n_colors=3, seed=0, names=False), "min", [1, 5, 34]),
 }
 _full_cache = {}
 
@@ -120,6 +124,19 @@ def test_full_size_bit_exact_vs_oracle(name, dtype, oracle_built):
                         expect_silent=dtype == "f64" and name != "meeting_50k_float")
     if dtype == "f32":
         _full_cache.clear()
+
+
+def test_scalefree_hubs_take_the_hub_class():
+    """No variable of a scale-free colouring is left to the thread-per-variable kernel (one thread walked a hub's
+    O(deg^2 * D) chain); flag 4194304 restores that for A/B runs."""
+    g = _full_graph("coloring_100k_scalefree")
+    deg = np.diff(g.var_rowptr)
+    with MaxSumEngine(g, Params()) as e:
+        vk = e.variable_kernels()
+        assert vk["generic"] == 0 and vk["wide"] == 0 and vk["hub"] == int((deg > 64).sum()) and e.cycle_bytes()[1] == 1, vk
+    with MaxSumEngine(g, Params(layout_flags=4194304)) as e:
+        vk = e.variable_kernels()
+        assert vk["hub"] == 0 and vk["generic"] == int((deg > 256).sum()), vk
 
 
 def test_graph_replay_equals_eager(oracle_built):
