@@ -204,6 +204,7 @@ struct Engine : EngineBase {
     DevBuf<FactorGen> fgen;
     DevBuf<uint32_t> sched;     // block schedule of launch 0 (Layout::sched), may be empty
     DevBuf<uint8_t> ctables;    // compact table records (Layout::ctables), may be empty
+    size_t ctables_used = 0;    // bytes of it that hold images once append_bin2_full_image has grown it (0: ctables.n)
     DevBuf<ClassInfo> classes;  // sweep classes in launch order
     DevBuf<ClassInfo> classes2; // cut factor classes (second sweep launch of a sharded cycle)
     DevBuf<ClassInfo> classes_f; // both lists as ONE grid (fused sharded launch), cut classes last
@@ -213,7 +214,7 @@ struct Engine : EngineBase {
     uint32_t unpacks = 0;        // unpack kernels enqueued since the last reset
     DevBuf<NaryDesc> ndesc;
     DevBuf<WideBlock> wide_blocks;
-    DevBuf<HubWave> hub_waves;
+    DevBuf<HubBlock> hub_blocks;
     bool has_hub = false;        // a K_V_HUB class rides in the sweep launch: the k_sweep_hub instantiations
 #ifdef MXS_WIDE_PROFILE
     DevBuf<int64_t> wide_prof;
@@ -286,7 +287,7 @@ struct Engine : EngineBase {
         a.vslot_v2f = vslot_v2f.p;
         a.vell = vell.p;
         a.vwave = vwave.p;
-        a.hub_waves = hub_waves.p;
+        a.hub_blocks = hub_blocks.p;
         a.vdom = vdom.p;
         a.vcost_off = vcost_off.p;
         a.init_idx = init_idx.p;
@@ -360,6 +361,9 @@ struct Engine : EngineBase {
                 case 4: hipLaunchKernelGGL((k_sweep_p2p<T, 4>), grid, block, 0, stream, a); break;
                 default: hipLaunchKernelGGL((k_sweep_p2p<T, 0>), grid, block, 0, stream, a); break;
             }
+        } else if (timeline_on && has_hub) {  // profiling twin, hub class on board
+            if (L.dsel == 3) hipLaunchKernelGGL((k_sweep_timeline_hub<T, 3>), grid, block, 0, stream, a);
+            else hipLaunchKernelGGL((k_sweep_timeline_hub<T, 0>), grid, block, 0, stream, a);
         } else if (timeline_on) {  // profiling twin
             switch (L.dsel) {
                 case 2: hipLaunchKernelGGL((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
@@ -444,6 +448,7 @@ struct Engine : EngineBase {
     // after the other, the fork / join events cost more than the overlap hides -- profiles/r05_d8_overlap_ab_v1.txt.)
     int pack8_host_group() const {
         if (L.pack8_classes.empty() || !L.opt.pack8_fused) return -1;
+        if (params.layout_flags & (32 | 64)) return -1;  // (one-side timing experiments: the class keeps a launch of its own)
         int best = -1;
         for (size_t i = 0; i < L.nary_launches.size(); ++i) {
             const NaryLaunch& nl = L.nary_launches[i];
@@ -536,6 +541,13 @@ struct Engine : EngineBase {
             // isolated variables only act in cycle 0
             int rc = launch_sweep(a, (start || L.sweep_regular) ? L.n_blocks_sweep : 0);
             if (rc) return rc;
+            // (timing experiments, results wrong: layout_flags bit5 = variable side only, bit6 = factor side only -- the launches
+            // outside the sweep honour them too)
+            const bool vars_only = (params.layout_flags & 32) != 0, factors_only = (params.layout_flags & 64) != 0;
+            if (vars_only || factors_only) {
+                if (!factors_only) { rc = launch_wide(a, stream); if (rc) return rc; }
+                return vars_only ? MXS_OK : launch_nary(a, 0);
+            }
             const bool fork = overlap && !capturing && n_wide_launches() > 0 && !L.nary_launches.empty();
             hipStream_t ws = stream;
             if (fork) {  // the side stream starts where the compute stream is now
@@ -762,8 +774,8 @@ struct Engine : EngineBase {
         HIP_TRY(halo_flags.alloc(64));
         HIP_TRY(ndesc.upload(L.ndesc, stream));
         HIP_TRY(wide_blocks.upload(L.wide_blocks, stream));
-        HIP_TRY(hub_waves.upload(L.hub_waves, stream));
-        has_hub = !L.hub_waves.empty();
+        HIP_TRY(hub_blocks.upload(L.hub_blocks, stream));
+        has_hub = !L.hub_blocks.empty();
 #ifdef MXS_WIDE_PROFILE
         if (!L.wide_blocks.empty()) {
             HIP_TRY(wide_prof.alloc(8 * L.wide_blocks.size()));
@@ -1241,15 +1253,22 @@ struct Engine : EngineBase {
             HIP_TRY(copy_sync(cur.data(), eval_tables.p + L.eval_tab_off[fi], sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, stream));
             values = cur.data();
         }
-        const size_t old_bytes = ctables.n, off = (old_bytes + 15) / 16 * 16, bytes = (size_t)nary_place_bytes(pl, d.dom[0]);
+        // (ctables.n = the buffer's CAPACITY from here on, ctables_used what holds images: the buffer grows geometrically, so a
+        // stream of widened factors copies O(total) bytes, not O(total) per update -- ADVICE r5.  The narrow image the factor leaves
+        // stays behind as dead space, and the host copy L.ctables is NOT kept current: the device buffer is authoritative after init.)
+        if (ctables_used == 0) ctables_used = ctables.n;
+        const size_t old_bytes = ctables_used, off = (old_bytes + 15) / 16 * 16, bytes = (size_t)nary_place_bytes(pl, d.dom[0]);
         std::vector<uint8_t> rec(bytes, 0);
         for (int64_t k = 0; k < n; ++k) encode_tab_entry(values[k], TAB_FULL, (int)sizeof(T), rec.data() + nary_place_pos(pl, k));
-        DevBuf<uint8_t> grown;
-        HIP_TRY(grown.alloc(off + bytes));
-        if (old_bytes) HIP_TRY(copy_sync(grown.p, ctables.p, old_bytes, hipMemcpyDeviceToDevice, stream));
-        HIP_TRY(copy_sync(grown.p + off, rec.data(), bytes, hipMemcpyHostToDevice, stream));
-        std::swap(ctables.p, grown.p);
-        std::swap(ctables.n, grown.n);
+        if (off + bytes > ctables.n) {
+            DevBuf<uint8_t> grown;
+            HIP_TRY(grown.alloc(std::max(off + bytes, 2 * ctables.n + ((size_t)1 << 20))));
+            if (old_bytes) HIP_TRY(copy_sync(grown.p, ctables.p, old_bytes, hipMemcpyDeviceToDevice, stream));
+            std::swap(ctables.p, grown.p);
+            std::swap(ctables.n, grown.n);
+        }
+        HIP_TRY(copy_sync(ctables.p + off, rec.data(), bytes, hipMemcpyHostToDevice, stream));
+        ctables_used = off + bytes;
         *at = (int64_t)off;
         return MXS_OK;
     }
@@ -2089,8 +2108,8 @@ int mxs_variable_kernels(const mxs_engine* e, int64_t counts[6]) {
             counts[2] += (n = ci.count);
         } else if (ci.kind == mxs::K_V_GEN && !ci.start_only) {
             counts[3] += (n = ci.count);
-        } else if (ci.kind == mxs::K_V_HUB) {  // (count = waves: a variable's first wave starts at its edge 0)
-            for (int32_t w = ci.first; w < ci.first + ci.count; ++w) n += L.hub_waves[w].ko0 == 0;
+        } else if (ci.kind == mxs::K_V_HUB) {  // (count = workgroups: a variable's first one starts at its edge 0)
+            for (int32_t w = ci.first; w < ci.first + ci.count; ++w) n += L.hub_blocks[w].ko0 == 0;
             counts[5] += n;
         }
         swept += n;

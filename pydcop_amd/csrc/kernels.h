@@ -159,7 +159,7 @@ struct SweepArgs {
     const int32_t* vslot_v2f;  // [n_edges] CSR slot -> V2F offset
     const int32_t* vell;       // per lane of the packed variable classes: F2V offset / -1
     const WaveMeta* vwave;     // per wave of the packed variable classes
-    const HubWave* hub_waves;  // per wave of the K_V_HUB class
+    const HubBlock* hub_blocks;  // per workgroup of the K_V_HUB class
     const int32_t* vdom;
     const int64_t* vcost_off;
     const int32_t* init_idx;
@@ -864,103 +864,177 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 // 100k variables, m = 2 -> degrees up to ~1 000).  The reference's costs_for_factor (maxsum.py:651-665) is, per
 // OUTGOING edge, ONE serial accumulator `sum_cost` through all (d, f != target) in d-major order plus D serial sums
 // msg_costs[d] over the same terms: O(deg * D) dependent additions per edge, O(deg^2 * D) per variable, none of which
-// may be reassociated.  variable_generic walked all of a variable's edges in ONE thread (a 1 000-edge hub: 6e6
-// dependent loads + additions, holding the whole cycle).  Here a WAVE takes 64 outgoing edges of one variable
-// (layout.h HubWave), a lane per edge: the deg chains are independent, so the depth drops from O(deg^2 * D) to
-// O(deg * D), the reference's order inside each chain untouched.
-//   * steps of (a few values of d) x (up to HUB_TILE edges): the wave stages the F->V elements in_k[d] in LDS (every
-//     lane reads the SAME element next: broadcast reads, no conflicts), the next step's elements in flight meanwhile;
+// may be reassociated.  variable_generic walked all of a variable's edges in ONE thread (a 700-edge hub: 3e6
+// dependent loads + additions, 555 ms per cycle: profiles/r06_before_coloring_100k_scalefree_f64.json).  Here a
+// WORKGROUP takes HUB_EDGES outgoing edges of one variable (layout.h HubBlock), a lane per edge: the deg chains are
+// independent, so the depth drops from O(deg^2 * D) to O(deg * D), the reference's order inside each chain untouched.
+//   * steps of (a few values of d) x (up to HUB_TILE edges): the workgroup stages the F->V elements in_k[d] in LDS
+//     ONCE for its four waves (every lane reads the SAME element next: broadcast reads, no conflicts); degree 700 on
+//     three values is one step -- a step is two dependent round trips to memory (slot offsets, elements), and what
+//     a block's life is made of is such round trips (~1.2 us each in a busy launch) beside the chains themselves
+//     (~5 ns per element): the block's record (HubBlock) holds every per-variable quantity so that nothing else is
+//     chained in front;
 //   * per element two additions in the lane: sum_cost += x, msg[d] += x.  The lane's own edge (k == ko) and the
 //     padding of the last tile contribute -0.0, the exact additive identity of IEEE addition (y + -0.0 == y bit
 //     for bit, for y = +-0, inf and NaN as well): no branch on the chains;
-//   * msg[d] is parked in the lane's own record of v2f_new (nobody reads the new buffer in this cycle) until
-//     sum_cost is complete, then normalised, damped and filtered like every other message (maxsum.py:540-564);
+//   * msg[d] waits in registers (D <= 4; wider domains: parked in the lane's own record of v2f_new, which nobody
+//     reads in this cycle) until sum_cost is complete, then it is normalised, damped and filtered like every
+//     other message (maxsum.py:540-564);
 //   * the lane one past the last edge leaves nothing out: its sums are the beliefs of select_value
 //     (maxsum.py:607-610), the selection falls out of the same loop.
 // Rides in the sweep launch (k_sweep_hub), its workgroups first in the grid.
 // ---------------------------------------------------------------------------
+// Workgroup barrier that orders the block's LDS traffic only: the global loads a wave has in flight stay
+// in flight (__syncthreads() is a fence over every address space: it drains them, vmcnt(0)).
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
 template <typename T>
-__device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassInfo& ci, int item0) {
-    constexpr int R = HUB_LDS / 64;
-    __shared__ __attribute__((aligned(16))) T s_hub[HUB_WAVES * HUB_LDS];
-    const int wave = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
-    const int item = item0 + wave;
-    if (item >= ci.count) return;  // (wave-uniform)
-    const HubWave hw = a.hub_waves[ci.first + item];
-    const int v = __builtin_amdgcn_readfirstlane(hw.var), ko0 = __builtin_amdgcn_readfirstlane(hw.ko0);
-    const int D = a.vdom[v], k0 = a.vrowptr[v], deg = a.vrowptr[v + 1] - k0;
-    const int ko = ko0 + lane;
-    const bool real = ko < deg, bel = ko == deg;
-    const T* c = a.var_cost + a.vcost_off[v];
-    T* tile = s_hub + wave * HUB_LDS;
-    const int vo = a.vslot_v2f[k0 + (real ? ko : 0)];
+__device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
+    constexpr int R = HUB_LDS / BLOCK;
+    __shared__ __attribute__((aligned(16))) T s_hub[HUB_LDS + 64];  // (+ slack: the read-ahead of the last row)
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    const HubBlock hb = a.hub_blocks[ci.first + item];  // block-uniform: scalar loads, everything the block needs
+    const int D = hb.D, k0 = hb.slot0, deg = hb.deg;
+    const int ko = hb.ko0 + tid;
+    const int ko_w = hb.ko0 + (wave << 6);       // first edge of this wave
+    const bool wave_on = wave < HUB_CW && ko_w <= deg;  // (wave-uniform) a compute wave with an edge, or the belief lane
+    const bool real = wave_on && ko < deg, bel = wave_on && ko == deg;
+    const T* c = a.var_cost + hb.cost_off;
     const T nzero = (T)-0.0;
+    if (wave_on) __builtin_amdgcn_s_setprio(3);  // chains of dependent additions: whenever they can issue, they should
     // A step = ND values of d x NK edges: rows of ROW = 8 + NK elements -- the own cost c[d] (msg_costs[d] starts from it) and
     // seven fillers, then in_kt[d] .. in_{kt+NK-1}[d] (NK a multiple of 8; past the degree: -0.0).  A degree above HUB_TILE takes
-    // several steps per d (ND = 1); a small one several d per step, so that a wide domain does not cost a round trip each.
+    // several steps per d (ND = 1); a smaller one several d per step -- degree 700 on three values: ONE step.
     const int NK = deg < HUB_TILE ? ((deg + 7) & ~7) : HUB_TILE, ROW = NK + 8;
     const int ND = HUB_LDS / ROW;
-    const uint32_t magic = (uint32_t)((((uint64_t)1 << 32) + (uint32_t)ROW - 1) / (uint32_t)ROW);  // e / ROW for e < 2^16
+    const uint32_t magic = hb.magic;  // ceil(2^32 / ROW): e / ROW for e < 2^16
+    // what the epilogue needs of the lane's own edge, requested before anything else
+    const int vo = a.vslot_v2f[k0 + (real ? ko : 0)];
+    const uint8_t cnt = a.start ? 0 : a.cV[k0 + (real ? ko : 0)];
+    // Every load is unconditional -- ONE index load and ONE value load per element, from a selected address (clamped indices,
+    // no branch: the R requests of a step leave the wave back to back; with two candidate loads per element the compiler
+    // built a branch and a full wait around each, 20 serial round trips per step).
     T pre[R];
     auto request = [&](int d0, int kt) __attribute__((always_inline)) {
+        int off[R];
 #pragma unroll
         for (int r = 0; r < R; ++r) {
-            const int e = lane + 64 * r;
+            const int e = tid + BLOCK * r;
+            const int dd = (int)(((uint64_t)(uint32_t)e * magic) >> 32), p = e - dd * ROW;
+            const int k = kt + p - 8;
+            const bool is_x = dd < ND && d0 + dd < D && p >= 8 && k < deg;
+            off[r] = a.vslot_f2v[k0 + (is_x ? k : 0)];
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const int e = tid + BLOCK * r;
             const int dd = (int)(((uint64_t)(uint32_t)e * magic) >> 32), p = e - dd * ROW;
             const int dc = d0 + dd, k = kt + p - 8;
             const bool row_ok = dd < ND && dc < D;
-            const bool is_x = row_ok && p >= 8 && k < deg;
-            const int off = a.vslot_f2v[k0 + (is_x ? k : 0)];
-            const T x = a.f2v_old[off + (is_x ? dc : 0)];
-            const T cc = c[row_ok ? dc : 0];
-            pre[r] = is_x ? x : ((row_ok && p == 0) ? cc : nzero);
+            const bool is_x = row_ok && p >= 8 && k < deg, is_c = row_ok && p == 0;
+            const T* src = is_x ? a.f2v_old + (off[r] + dc) : c + (is_c ? dc : 0);
+            pre[r] = *src;
         }
     };
+    // msg_costs[d] until sum_cost is complete: in registers for D <= 4, else parked in the lane's own record of v2f_new
+    T mreg[4] = {(T)0, (T)0, (T)0, (T)0};
+    const bool park = D > 4;
     T s = (T)0, m = (T)0, best_c = (T)0;
     int best = 0;
     int d0 = 0, kt = 0;
     request(0, 0);
     while (d0 < D) {
-        __builtin_amdgcn_wave_barrier();  // the previous step's reads are over
+        lds_barrier();  // the previous step's reads are over
 #pragma unroll
-        for (int r = 0; r < R; ++r) tile[lane + 64 * r] = pre[r];
-        __builtin_amdgcn_wave_barrier();
+        for (int r = 0; r < R; ++r) {  // own cost | message element | filler (-0.0)
+            const int e = tid + BLOCK * r;
+            const int dd = (int)(((uint64_t)(uint32_t)e * magic) >> 32), p = e - dd * ROW;
+            const bool row_ok = dd < ND && d0 + dd < D;
+            s_hub[e] = (row_ok && (p == 0 || (p >= 8 && kt + p - 8 < deg))) ? pre[r] : nzero;
+        }
+        lds_barrier();
         // the step after this one: the next edges of this d, or the next values of d
         const bool last_k = kt + NK >= deg;
         const int d0n = last_k ? d0 + ND : d0, ktn = last_k ? 0 : kt + NK;
         if (d0n < D) request(d0n, ktn);
         const int n = deg - kt < NK ? deg - kt : NK;
-        for (int dd = 0; dd < ND && d0 + dd < D; ++dd) {
-            const T* row = tile + dd * ROW;
-            if (kt == 0) m = row[0];  // msg_costs[d] = cost_for_val(d), maxsum.py:648
-            for (int kk = 0; kk < n; kk += 8) {
-                T x[8];
+        if (wave_on)
+            for (int dd = 0; dd < ND && d0 + dd < D; ++dd) {
+                const T* row = s_hub + dd * ROW;
+                if (kt == 0) m = row[0];  // msg_costs[d] = cost_for_val(d), maxsum.py:648
+                // Three runs of the row: before, inside and behind the 64 edges this wave's lanes own -- only the middle one
+                // pays the selects (k == ko contributes -0.0).  A run walks blocks of eight elements, the reads of the
+                // blocks ahead requested from LDS before the additions of the current one (three register sets by hand:
+                // the chains wait for nothing but themselves); no branch but the loop's own.
+                auto fetch = [&](T (&x)[8], int kk) __attribute__((always_inline)) {
+#if defined(MXS_HUB_EXP) && MXS_HUB_EXP == 1   // timing experiment (results wrong): no LDS read in the chain loop
 #pragma unroll
-                for (int u = 0; u < 8; ++u) x[u] = row[8 + kk + u];
-                const int kabs = kt + kk;
-                if (kabs + 8 > ko0 && kabs < ko0 + 64) {  // (wave-uniform) the block holds the own edge of some lane
+                    for (int u = 0; u < 8; ++u) x[u] = (T)(kk + u) * m;
+#else
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = (kabs + u == ko) ? nzero : x[u];
-                }
+                    for (int u = 0; u < 8; ++u) x[u] = row[8 + kk + u];
+#endif
+                };
+                auto consume = [&](T (&x)[8], int kk, auto sel) __attribute__((always_inline)) {
+                    if constexpr (decltype(sel)::value) {
+                        const int kabs = kt + kk;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
-                    s += x[u];
-                    m += x[u];
+                        for (int u = 0; u < 8; ++u) x[u] = (kabs + u == ko) ? nzero : x[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        s += x[u];
+#if !(defined(MXS_HUB_EXP) && MXS_HUB_EXP == 2)  // timing experiment (results wrong): sum_cost chain only
+                        m += x[u];
+#endif
+                    }
+                };
+                auto run = [&](int k_lo, int k_hi, auto sel) __attribute__((always_inline)) {  // [k_lo, k_hi): multiples of 8
+                    if (k_lo >= k_hi) return;
+                    T xa[8], xb[8], xc[8];
+                    fetch(xa, k_lo);
+                    fetch(xb, k_lo + 8);
+                    int kk = k_lo;
+                    for (; kk + 24 <= k_hi; kk += 24) {  // (reads past the run's end: the row's next blocks or the slack, never used)
+                        fetch(xc, kk + 16);
+                        consume(xa, kk, sel);
+                        fetch(xa, kk + 24);
+                        consume(xb, kk + 8, sel);
+                        fetch(xb, kk + 32);
+                        consume(xc, kk + 16, sel);
+                    }
+                    if (kk < k_hi) consume(xa, kk, sel);
+                    if (kk + 8 < k_hi) consume(xb, kk + 8, sel);
+                };
+                const int n8 = (n + 7) & ~7;  // (the row is padded with -0.0 to whole blocks)
+                const int w_lo = ko_w - kt < 0 ? 0 : (ko_w - kt > n8 ? n8 : ((ko_w - kt) & ~7));
+                const int w_hi = ko_w + 64 - kt < 0 ? 0 : (ko_w + 64 - kt > n8 ? n8 : ((ko_w + 64 - kt + 7) & ~7));
+                run(0, w_lo, std::false_type{});
+                run(w_lo, w_hi, std::true_type{});
+                run(w_hi, n8, std::false_type{});
+                if (last_k) {  // msg_costs[d] is complete
+                    const int d = d0 + dd;
+                    if (park) {
+                        if (real) a.v2f_new[vo + d] = m;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) mreg[q] = d == q ? m : mreg[q];
+                    }
+                    if (d == 0 || m < best_c) {  // (the belief lane's: first index attaining the minimum)
+                        best = d;
+                        best_c = m;
+                    }
                 }
             }
-            if (last_k) {  // msg_costs[d] is complete
-                const int d = d0 + dd;
-                if (real) a.v2f_new[vo + d] = m;  // parked until sum_cost is complete
-                if (d == 0 || m < best_c) {       // (the belief lane's: first index attaining the minimum)
-                    best = d;
-                    best_c = m;
-                }
-            }
-        }
         d0 = d0n;
         kt = ktn;
     }
     if (bel) {
+        const int v = hb.var;
         if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
             best = a.init_idx[v];
             best_c = (T)0;
@@ -974,11 +1048,11 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
     const T* prev = a.v2f_old + vo;
     T* w = a.v2f_new + vo;
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) || a.start_mode != MXS_START_LEAFS;
-    const uint8_t cnt = a.start ? 0 : a.cV[k0 + ko];
     const bool damp = cnt > 0 && a.damp_v;
     bool match = cnt > 0;
     for (int dd = 0; dd < D; ++dd) {
-        T mm = w[dd] - avg;
+        T mm = park ? w[dd] : (dd == 0 ? mreg[0] : dd == 1 ? mreg[1] : dd == 2 ? mreg[2] : mreg[3]);
+        mm = mm - avg;
         if (a.start) {
             w[dd] = start_sends ? mm : (T)0;
             continue;
@@ -1159,10 +1233,10 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_p2p(SweepArgs<
 
 // Profiling twin (mxs_debug_timeline): when did each block start, when were its stores done.
 // A kernel of its own so that the instrumentation costs the real one no register.
-template <typename T, int DSEL>
-__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_timeline(SweepArgs<T> a) {
+template <typename T, int DSEL, bool HUB>
+__device__ __forceinline__ void sweep_timeline(const SweepArgs<T>& a) {
     const int64_t t0 = (int64_t)wall_clock64();
-    const int kind = sweep_block<T, DSEL, false, MXS_NT, false, true>(a);
+    const int kind = sweep_block<T, DSEL, false, MXS_NT, false, HUB>(a);
     __builtin_amdgcn_s_waitcnt(0);  // loads back, stores acknowledged
     const int64_t t1 = (int64_t)wall_clock64();
     if (threadIdx.x == 0) {
@@ -1170,6 +1244,15 @@ __global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_timeline(Sweep
         a.timeline[3 * (int64_t)blockIdx.x + 1] = t1;
         a.timeline[3 * (int64_t)blockIdx.x + 2] = kind;
     }
+}
+template <typename T, int DSEL>
+__global__ void __launch_bounds__(BLOCK, SWEEP_MIN_WAVES) k_sweep_timeline(SweepArgs<T> a) {
+    sweep_timeline<T, DSEL, false>(a);
+}
+// (with the hub class: the register budget of k_sweep_hub, which carries no clock reads -- no occupancy bound here)
+template <typename T, int DSEL>
+__global__ void __launch_bounds__(BLOCK) k_sweep_timeline_hub(SweepArgs<T> a) {
+    sweep_timeline<T, DSEL, true>(a);
 }
 
 // ---------------------------------------------------------------------------
@@ -1867,14 +1950,6 @@ __device__ __forceinline__ T wide_sum_edges(T c, const T* in, int D, int deg, in
         if (rem > 2 && k + 2 != skip) acc += x2;
     }
     return acc;
-}
-
-// Workgroup barrier that orders the block's LDS traffic only: the global loads a wave has in flight stay
-// in flight (__syncthreads() is a fence over every address space: it drains them, vmcnt(0)).
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // sum over (d, k != ko) of in[k][d], d major / k minor: the serial `sum_cost` chain of costs_for_factor (ONE

@@ -402,8 +402,18 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     L.edge_dom[ei] = D;
                     L.edge_half[ei] = H;
                     int64_t at = off;
-                    if (split) at = off + (int64_t)(e - g.factor_rowptr[f]) * half_len + (int64_t)(f2 - fi) * Hc;
-                    else off += H;
+                    if (split) {
+                        at = off + (int64_t)(e - g.factor_rowptr[f]) * half_len + (int64_t)(f2 - fi) * Hc;
+                    } else {
+                        // every record on the alignment its readers assume (kernels.h Msg::ALIGN: 16 bytes when its length is a
+                        // multiple of 16, else 8, else the word) -- behind a tight 3-element record a scope such as (D = 3, D = 7)
+                        // would put the 8-element one on a 12- / 24-byte offset
+                        const int bytes = H * L.opt.word;
+                        const int al = (bytes % 16 == 0 ? 16 : bytes % 8 == 0 ? 8 : L.opt.word) / L.opt.word;
+                        off = (off + al - 1) / al * al;
+                        at = off;
+                        off += H;
+                    }
                     if (at > ((int64_t)1 << 31) - 8192) return "message buffer exceeds 2^31 elements";
                     L.f2v_off[ei] = (int32_t)at;
                 }
@@ -629,7 +639,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
         } else if (kind == K_V_GEN) {
             ci.kind = K_V_GEN;
         } else if (kind == K_V_HUB) {
-            // its waves: 64 outgoing edges of one variable each, the belief lane behind the last edge; the longest
+            // its workgroups: HUB_EDGES outgoing edges of one variable each, the belief lane behind the last edge; the longest
             // chains (highest degree x domain) first -- they are the first workgroups of the sweep's grid
             ci.kind = K_V_HUB;
             std::vector<int> order(vj - vi);
@@ -637,12 +647,15 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             std::stable_sort(order.begin(), order.end(), [&](int x, int y) {
                 return (int64_t)(L.vrowptr[x + 1] - L.vrowptr[x]) * L.vdom[x] > (int64_t)(L.vrowptr[y + 1] - L.vrowptr[y]) * L.vdom[y];
             });
-            ci.first = (int32_t)L.hub_waves.size();
+            ci.first = (int32_t)L.hub_blocks.size();
             for (int w : order) {
                 const int deg = L.vrowptr[w + 1] - L.vrowptr[w];
-                for (int ko0 = 0; ko0 <= deg; ko0 += 64) L.hub_waves.push_back(HubWave{w, ko0});
+                const uint32_t row = 8u + (uint32_t)(deg < HUB_TILE ? ((deg + 7) & ~7) : HUB_TILE);
+                for (int ko0 = 0; ko0 <= deg; ko0 += HUB_EDGES)
+                    L.hub_blocks.push_back(HubBlock{w, ko0, L.vdom[w], deg, L.vrowptr[w],
+                                                    (uint32_t)((((uint64_t)1 << 32) + row - 1) / row), L.vcost_off[w]});
             }
-            ci.count = (int32_t)L.hub_waves.size() - ci.first;
+            ci.count = (int32_t)L.hub_blocks.size() - ci.first;
         } else if (kind == K_V_WIDE) {
             ci.kind = K_V_WIDE;
             // its workgroups: runs of one D that fit the kernel's LDS arrays
@@ -721,7 +734,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 L.classes[cls].per_block = BLOCK;  // (its own launch: count / BLOCK workgroups)
                 L.pack8_classes.push_back(cls);
             } else {
-                sweep_class(cls, ci.kind == K_V_HUB ? HUB_WAVES : BLOCK);
+                sweep_class(cls, ci.kind == K_V_HUB ? 1 : BLOCK);
             }
         }
         vi = vj;
@@ -786,6 +799,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             struct Blk { double key; int prio; uint32_t code; };
             std::vector<Blk> blks;
             std::vector<uint32_t> hub_blks;
+            std::vector<Blk> long_blks;           // packed-class blocks of degree >= LONG_PACK_DEG
+            constexpr int LONG_PACK_DEG = 24;
             blks.reserve(L.n_blocks_sweep);
             auto first_var_of_factor = [&](int fi) { return (double)L.edge_var_int[L.frowptr[fi]]; };
             for (size_t slot = 0; slot < L.sweep_order.size(); ++slot) {
@@ -805,6 +820,14 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         case K_V_PACK: {  // lanes -> the wave's first variable
                             const WaveMeta& w0 = L.vwave[(ci.ell_base + i0) >> 6];
                             const WaveMeta& w1 = L.vwave[(ci.ell_base + i1) >> 6];
+                            // A wave of high-degree variables walks chains of 3 * deg dependent steps (16 us at degree 64 where a
+                            // block of degree-4 variables takes 5): such blocks -- the class is sorted by degree, they are its last --
+                            // would start last in the locality order and be the launch's tail (scale-free graphs: 45 us of a
+                            // 37-us launch's timeline).  They go to the front, behind the hub workgroups, longest first.
+                            if ((int)((uint32_t)w1.deg_nv & 255u) >= LONG_PACK_DEG) {
+                                long_blks.push_back(Blk{-(double)((uint32_t)w1.deg_nv & 255u), 0, (uint32_t)(slot << 24) | (uint32_t)j});
+                                continue;
+                            }
                             k0 = w0.first_var;
                             k1 = w1.first_var + (int)(((uint32_t)w1.deg_nv >> 8) & 255u) - 1;
                             prio = 0;
@@ -828,6 +851,8 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     blks.push_back(Blk{0.5 * (k0 + k1), prio, (uint32_t)(slot << 24) | (uint32_t)j});
                 }
             }
+            std::stable_sort(long_blks.begin(), long_blks.end(), [](const Blk& a, const Blk& b) { return a.key < b.key; });
+            for (const Blk& b : long_blks) hub_blks.push_back(b.code);
             if ((int)(blks.size() + hub_blks.size()) == L.n_blocks_sweep) {
                 std::stable_sort(blks.begin(), blks.end(), [](const Blk& a, const Blk& b) {
                     return a.key != b.key ? a.key < b.key : a.prio < b.prio;

@@ -58,7 +58,7 @@ enum Kind : int32_t {
     K_V_PACK8 = 8,  // 5 <= D <= 8, 1 <= deg <= 64: the lane-per-edge scheme of K_V_PACK on records of 8 elements,
                     // the variable's own D at run time (own launch, k_variable_pack8)
     K_V_HUB = 9,    // everything the classes above leave (round 6): deg > 64 with D <= 8, deg > 256, deg * D > 1024, D > 256 --
-                    // the hub variables of a scale-free graph.  One WAVE per 64 outgoing edges of ONE variable (HubWave), a lane
+                    // the hub variables of a scale-free graph.  One WORKGROUP per 256 outgoing edges of ONE variable (HubBlock), a lane
                     // per edge walking the reference's serial chains over the other edges; rides in the sweep launch, first in
                     // its grid (kernels.h variable_hub)
 };
@@ -334,16 +334,26 @@ struct WideBlock {
     int64_t cost_off;    // element offset of the first variable's own costs (vcost_off[first_var])
 };
 
-// One wave of the K_V_HUB class: 64 consecutive outgoing edges (CSR slots ko0 .. ko0 + 63) of variable `var`.  The lane with
-// ko == deg (one past the last edge) is the variable's BELIEF lane: the same chain with nothing left out is
-// select_value's sum (maxsum.py:607-610).  A variable of degree deg takes ceil((deg + 1) / 64) waves.
-struct HubWave {
-    int32_t var;   // internal variable id
-    int32_t ko0;   // first outgoing edge (position in the variable's slot range) of lane 0
+// One workgroup of the K_V_HUB class: HUB_EDGES consecutive outgoing edges (positions ko0 .. of the variable's slot range)
+// of ONE variable, a lane per edge.  The lane with ko == deg (one past the last edge) is the variable's BELIEF lane: the same
+// chain with nothing left out is select_value's sum (maxsum.py:607-610).  A variable of degree deg takes ceil((deg + 1) / HUB_EDGES)
+// workgroups.  Everything a block needs in one record (read with ONE scalar load: no chain of dependent loads).
+struct HubBlock {
+    int32_t var;       // internal variable id
+    int32_t ko0;       // first outgoing edge of the block
+    int32_t D, deg;
+    int32_t slot0;     // vrowptr[var]
+    uint32_t magic;    // ceil(2^32 / ROW), ROW = 8 + min(roundup(deg, 8), HUB_TILE): e / ROW for e < 2^16 (kernels.h variable_hub)
+    int64_t cost_off;  // vcost_off[var]
 };
-constexpr int HUB_TILE = 512;            // edges of one value of d a wave stages in LDS per step, at most
-constexpr int HUB_LDS = 640;             // elements of a wave's LDS area: rows of 8 + NK elements (kernels.h variable_hub)
-constexpr int HUB_WAVES = BLOCK / 64;    // waves (items) per workgroup of the class
+#ifndef MXS_HUB_CW
+#define MXS_HUB_CW 2   // compute waves per workgroup: the whole workgroup stages, HUB_CW waves walk chains -- every lane of a
+#endif                 // wave reads the SAME LDS element (512 bytes returned per element and wave): four such waves on one CU are
+                       // bound by the LDS return path (128 B / clk), two are not (profiles/r06_hub_steps_v1.txt)
+constexpr int HUB_CW = MXS_HUB_CW;
+constexpr int HUB_EDGES = 64 * HUB_CW;   // outgoing edges per workgroup
+constexpr int HUB_TILE = 2048;           // edges of one value of d staged in LDS per step, at most
+constexpr int HUB_LDS = 2560;            // elements of a workgroup's LDS area: rows of 8 + NK elements (kernels.h variable_hub)
 
 struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY factors
     int32_t arity, nj;   // nj = ceil(R / BLOCK), R = product of the dimensions after the first
@@ -450,7 +460,7 @@ struct Layout {
     std::vector<int32_t> pack8_classes;   // K_V_PACK8 classes (at most one): their own launch
     std::vector<int32_t> wide_classes;    // K_V_WIDE classes (at most one: every wide variable, sorted by D)
     std::vector<WideBlock> wide_blocks;   // the workgroups of the K_V_WIDE launch
-    std::vector<HubWave> hub_waves;       // the waves of the K_V_HUB class (longest chains first)
+    std::vector<HubBlock> hub_blocks;     // the workgroups of the K_V_HUB class (longest chains first)
 
     // per internal edge (factor-major)
     std::vector<int32_t> f2v_off;    // element offset of the edge's F->V message

@@ -51,8 +51,15 @@ __device__ __forceinline__ T box_entry(const uint32_t* w, int e) {
     else return (T)(int)(int16_t)(uint16_t)(w[e >> 1] >> (16 * (e & 1)));
 }
 
+#ifndef MXS_BOX_EU
+#define MXS_BOX_EU 0  // > 0: register budget for that many waves per SIMD (experiments: profiles/r06_box3_isa.txt)
+#endif
 template <typename T, typename TT, bool NEG, int B0, int B1, int B2>
-__global__ void __launch_bounds__(BOX_WAVES * 64) k_factor_box3(SweepArgs<T> a, const NaryDesc* descs, int n_factors) {
+__global__ void __launch_bounds__(BOX_WAVES * 64)
+#if MXS_BOX_EU > 0
+__attribute__((amdgpu_waves_per_eu(MXS_BOX_EU, MXS_BOX_EU)))
+#endif
+k_factor_box3(SweepArgs<T> a, const NaryDesc* descs, int n_factors) {
     constexpr int E = B0 * B1 * B2, NV = B0 + B1 + B2;
     constexpr int NW = box_rec_words(E, (int)sizeof(TT)), FULL = NW / 4, REST = NW % 4;
     // A record of more than BOX_MAX_WORDS dwords (int16 entries on 6 x 6 x 6 boxes: 108) is worked through in TWO passes over
