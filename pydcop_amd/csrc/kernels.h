@@ -874,7 +874,8 @@ __device__ __forceinline__ void variable_generic(const SweepArgs<T>& a, const Cl
 //     a block's life is made of is such round trips (~1.2 us each in a busy launch) beside the chains themselves
 //     (~5 ns per element): the block's record (HubBlock) holds every per-variable quantity so that nothing else is
 //     chained in front;
-//   * per element two additions in the lane: sum_cost += x, msg[d] += x.  The lane's own edge (k == ko) and the
+//   * per element ONE addition in the lane: two waves share 64 edges, one walks `sum_cost`, the other `msg_costs[d]`
+//     (sum_cost crosses to its message's lane through LDS at the end).  The lane's own edge (k == ko) and the
 //     padding of the last tile contribute -0.0, the exact additive identity of IEEE addition (y + -0.0 == y bit
 //     for bit, for y = +-0, inf and NaN as well): no branch on the chains;
 //   * msg[d] waits in registers (D <= 4; wider domains: parked in the lane's own record of v2f_new, which nobody
@@ -895,14 +896,22 @@ __device__ __forceinline__ void lds_barrier() {
 template <typename T>
 __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassInfo& ci, int item) {
     constexpr int R = HUB_LDS / BLOCK;
+    static_assert(BLOCK == 128 * HUB_CW && (HUB_CW & (HUB_CW - 1)) == 0, "two waves (sum_cost, msg_costs) per 64 edges");
     __shared__ __attribute__((aligned(16))) T s_hub[HUB_LDS + 64];  // (+ slack: the read-ahead of the last row)
-    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    __shared__ T s_sum[HUB_EDGES];                                  // sum_cost of every edge of the block
+    const int tid = (int)threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const HubBlock hb = a.hub_blocks[ci.first + item];  // block-uniform: scalar loads, everything the block needs
     const int D = hb.D, k0 = hb.slot0, deg = hb.deg;
-    const int ko = hb.ko0 + tid;
-    const int ko_w = hb.ko0 + (wave << 6);       // first edge of this wave
-    const bool wave_on = wave < HUB_CW && ko_w <= deg;  // (wave-uniform) a compute wave with an edge, or the belief lane
-    const bool real = wave_on && ko < deg, bel = wave_on && ko == deg;
+    // Two waves per 64 edges: wave g walks the `sum_cost` chains of edges ko0 + 64 g .., wave HUB_CW + g the `msg_costs[d]`
+    // chains of the same edges -- ONE dependent addition per element and wave.  (A lone wave issues an instruction every
+    // 4-8 cycles: with both chains in one lane the block was bound by its own issue rate, 9 ns per element where the
+    // dependent addition costs 4: profiles/r06_hub_steps_v1.txt.)
+    const int grp = wave & (HUB_CW - 1);
+    const bool msg_role = wave >= HUB_CW;
+    const int ko_w = hb.ko0 + (grp << 6);        // first edge of this wave
+    const int ko = ko_w + lane;
+    const bool wave_on = ko_w <= deg;            // (wave-uniform) some lane has an edge, or is the belief lane
+    const bool real = msg_role && wave_on && ko < deg, bel = msg_role && wave_on && ko == deg;
     const T* c = a.var_cost + hb.cost_off;
     const T nzero = (T)-0.0;
     if (wave_on) __builtin_amdgcn_s_setprio(3);  // chains of dependent additions: whenever they can issue, they should
@@ -943,7 +952,7 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
     // msg_costs[d] until sum_cost is complete: in registers for D <= 4, else parked in the lane's own record of v2f_new
     T mreg[4] = {(T)0, (T)0, (T)0, (T)0};
     const bool park = D > 4;
-    T s = (T)0, m = (T)0, best_c = (T)0;
+    T acc = (T)0, best_c = (T)0;  // the wave's chain: sum_cost (one accumulator through every d) or msg_costs[d]
     int best = 0;
     int d0 = 0, kt = 0;
     request(0, 0);
@@ -962,22 +971,18 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
         const int d0n = last_k ? d0 + ND : d0, ktn = last_k ? 0 : kt + NK;
         if (d0n < D) request(d0n, ktn);
         const int n = deg - kt < NK ? deg - kt : NK;
-        if (wave_on)
+        auto walk = [&](auto msg_c) __attribute__((always_inline)) {
+            constexpr bool MSG = decltype(msg_c)::value;
             for (int dd = 0; dd < ND && d0 + dd < D; ++dd) {
                 const T* row = s_hub + dd * ROW;
-                if (kt == 0) m = row[0];  // msg_costs[d] = cost_for_val(d), maxsum.py:648
+                if (MSG && kt == 0) acc = row[0];  // msg_costs[d] = cost_for_val(d), maxsum.py:648
                 // Three runs of the row: before, inside and behind the 64 edges this wave's lanes own -- only the middle one
                 // pays the selects (k == ko contributes -0.0).  A run walks blocks of eight elements, the reads of the
                 // blocks ahead requested from LDS before the additions of the current one (three register sets by hand:
-                // the chains wait for nothing but themselves); no branch but the loop's own.
+                // the chain waits for nothing but itself); no branch but the loop's own.
                 auto fetch = [&](T (&x)[8], int kk) __attribute__((always_inline)) {
-#if defined(MXS_HUB_EXP) && MXS_HUB_EXP == 1   // timing experiment (results wrong): no LDS read in the chain loop
-#pragma unroll
-                    for (int u = 0; u < 8; ++u) x[u] = (T)(kk + u) * m;
-#else
 #pragma unroll
                     for (int u = 0; u < 8; ++u) x[u] = row[8 + kk + u];
-#endif
                 };
                 auto consume = [&](T (&x)[8], int kk, auto sel) __attribute__((always_inline)) {
                     if constexpr (decltype(sel)::value) {
@@ -986,12 +991,7 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
                         for (int u = 0; u < 8; ++u) x[u] = (kabs + u == ko) ? nzero : x[u];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
-                        s += x[u];
-#if !(defined(MXS_HUB_EXP) && MXS_HUB_EXP == 2)  // timing experiment (results wrong): sum_cost chain only
-                        m += x[u];
-#endif
-                    }
+                    for (int u = 0; u < 8; ++u) acc += x[u];
                 };
                 auto run = [&](int k_lo, int k_hi, auto sel) __attribute__((always_inline)) {  // [k_lo, k_hi): multiples of 8
                     if (k_lo >= k_hi) return;
@@ -1016,23 +1016,30 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
                 run(0, w_lo, std::false_type{});
                 run(w_lo, w_hi, std::true_type{});
                 run(w_hi, n8, std::false_type{});
-                if (last_k) {  // msg_costs[d] is complete
+                if (MSG && last_k) {  // msg_costs[d] is complete
                     const int d = d0 + dd;
                     if (park) {
-                        if (real) a.v2f_new[vo + d] = m;
+                        if (real) a.v2f_new[vo + d] = acc;
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) mreg[q] = d == q ? m : mreg[q];
+                        for (int q = 0; q < 4; ++q) mreg[q] = d == q ? acc : mreg[q];
                     }
-                    if (d == 0 || m < best_c) {  // (the belief lane's: first index attaining the minimum)
+                    if (d == 0 || acc < best_c) {  // (the belief lane's: first index attaining the minimum)
                         best = d;
-                        best_c = m;
+                        best_c = acc;
                     }
                 }
             }
+        };
+        if (wave_on) {
+            if (msg_role) walk(std::true_type{});
+            else walk(std::false_type{});
+        }
         d0 = d0n;
         kt = ktn;
     }
+    if (!msg_role && wave_on) s_sum[(grp << 6) + lane] = acc;  // sum_cost of edge ko: to the lane that holds its msg_costs
+    lds_barrier();
     if (bel) {
         const int v = hb.var;
         if (a.start && a.init_idx[v] >= 0) {  // value_selection(initial_value), maxsum.py:497-498
@@ -1044,7 +1051,7 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
     }
     if (!real) return;
     // ---- normalise, damp, filter (the lane's own edge) ---------------------------------------
-    const T avg = s / (T)D;
+    const T avg = s_sum[(grp << 6) + lane] / (T)D;
     const T* prev = a.v2f_old + vo;
     T* w = a.v2f_new + vo;
     const bool start_sends = (deg == 1 && a.start_mode == MXS_START_LEAFS) || a.start_mode != MXS_START_LEAFS;

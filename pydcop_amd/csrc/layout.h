@@ -346,11 +346,8 @@ struct HubBlock {
     uint32_t magic;    // ceil(2^32 / ROW), ROW = 8 + min(roundup(deg, 8), HUB_TILE): e / ROW for e < 2^16 (kernels.h variable_hub)
     int64_t cost_off;  // vcost_off[var]
 };
-#ifndef MXS_HUB_CW
-#define MXS_HUB_CW 2   // compute waves per workgroup: the whole workgroup stages, HUB_CW waves walk chains -- every lane of a
-#endif                 // wave reads the SAME LDS element (512 bytes returned per element and wave): four such waves on one CU are
-                       // bound by the LDS return path (128 B / clk), two are not (profiles/r06_hub_steps_v1.txt)
-constexpr int HUB_CW = MXS_HUB_CW;
+constexpr int HUB_CW = MXS_BLOCK / 128;  // pairs of waves per workgroup: one wave walks the sum_cost chains of 64 edges, its twin the
+                                         // msg_costs chains of the same edges (kernels.h variable_hub)
 constexpr int HUB_EDGES = 64 * HUB_CW;   // outgoing edges per workgroup
 constexpr int HUB_TILE = 2048;           // edges of one value of d staged in LDS per step, at most
 constexpr int HUB_LDS = 2560;            // elements of a workgroup's LDS area: rows of 8 + NK elements (kernels.h variable_hub)
