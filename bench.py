@@ -151,6 +151,10 @@ def make_workload(name, scale=1, per_gpu=100_000):
         return G.scalefree_coloring(per_gpu, m=2, n_colors=3, seed=0, names=False), "min"          # up to ~ 700 at 100k
     if name == "coloring_1m_scalefree":     # ... 82 variables above degree 256 (up to 2 207), HBM-resident
         return G.scalefree_coloring(per_gpu * 10, m=2, n_colors=3, seed=0, names=False), "min"
+    if name == "secp_100k":          # the reference's `generate secp` (secp.py): D = 5, light costs (unary, real), model constraints
+        return G.secp_like(60_000, 40_000, 50_000, max_model_size=3, seed=0, names=False), "min"   # (arity 3-4, {0, 10000}), rules (arity 1-3)
+    if name == "secp_100k_m4":       # --max_model_size 4: model constraints of arity 5 (3 125 entries)
+        return G.secp_like(60_000, 40_000, 50_000, max_model_size=4, seed=0, names=False), "min"
     if name == "coloring_100k_hard":
         return G.random_coloring(100_000, seed=0, variant="hard", names=False), "min"
     if name == "ising_1024":        # configs[2]

@@ -243,7 +243,7 @@ int mxs_factor_order(const mxs_engine *e, int32_t *tiled);
 /* Which kernel computes factor_costs_for_var (maxsum.py:382-447) for how many factors:
  * counts[0] register class, unary (thread per factor, D <= 4); [1] register class, binary (D x D, D <= 4);
  * [2] generic (thread per edge, scalar loops: whatever nothing else takes); [3] workgroup per factor
- * (arity 2..4, 64..1024 entries per value of the first variable; full-width or lane-packed tables);
+ * (arity 2..5, 64..1024 entries per value of the first variable; full-width or lane-packed tables);
  * [4] one wave per factor (arity 3, integer tables in box records); [5] lane grid per factor (binary /
  * unary tables beyond the register classes, up to 64 x 64: 4 / 16 / 64 lanes per factor).
  * A layout decision only: every kernel computes the same messages bit for bit. */

@@ -435,6 +435,27 @@ struct Engine : EngineBase {
         return nary_ls_cache[idx] == 1;
     }
 
+    // The largest scope (sum of domain sizes) of a launch group, rounded up to an even number of elements: what its blocks'
+    // LDS arrays are sized for (looked at once per group).
+    std::vector<int32_t> nary_cap_cache;
+    int nary_group_cap(const NaryLaunch& nl) {
+        const size_t idx = (size_t)(&nl - L.nary_launches.data());
+        if (nary_cap_cache.size() != L.nary_launches.size()) nary_cap_cache.assign(L.nary_launches.size(), -1);
+        if (nary_cap_cache[idx] < 0) {
+            int cap = 2;
+            for (int j = 0; j < nl.count; ++j) {
+                const NaryDesc& d = L.ndesc[nl.first + j];
+                int sumd = 0;
+                for (int i = 0; i < (d.arity & 255); ++i) sumd += d.dom[i];
+                cap = std::max(cap, sumd);
+            }
+            // ($MAXSUM_NARY_CAP_MIN: A/B runs of the occupancy a group's LDS footprint leaves -- elements, at most 1024)
+            if (const char* e = std::getenv("MAXSUM_NARY_CAP_MIN")) cap = std::max(cap, std::min(1024, std::atoi(e)));
+            nary_cap_cache[idx] = (cap + 1) & ~1;
+        }
+        return nary_cap_cache[idx];
+    }
+
     // the launch group of a workgroup-per-factor factor
     const NaryLaunch* launch_of(int fi) const {
         for (const NaryLaunch& x : L.nary_launches)
@@ -478,25 +499,29 @@ struct Engine : EngineBase {
             }
             const dim3 grid((unsigned)nl.count), block((unsigned)nl.threads);
             const bool ls = nary_last_same(nl);
+            // LDS of a block: three arrays as long as the group's largest scope (sum of its domain sizes), in 8-byte words
+            const int cap = nary_group_cap(nl);
+            const size_t lds = (size_t)3 * cap * 8;
 #define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
     do {                                                                                                    \
         if (AR == 3 && ls) {  /* kernels.h, nary_batch: LS */                                               \
-            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, 0, stream, a, d);  \
-            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, 0, stream, a, d);           \
-        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, 0, stream, a, d);  \
-        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, 0, stream, a, d);           \
+            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, lds, stream, a, d, cap);  \
+            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, lds, stream, a, d, cap);           \
+        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, lds, stream, a, d, cap);  \
+        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, lds, stream, a, d, cap);           \
     } while (0)
 #define MXS_NARY_CASE(AR, NJ)                                                                              \
     case (AR) * 16 + (NJ):                                                                                  \
         if (nl.tab_type == TAB_I8) MXS_NARY_PACKED(AR, NJ, int8_t);                                         \
         else if (nl.tab_type == TAB_I16) MXS_NARY_PACKED(AR, NJ, int16_t);                                  \
         else if (nl.tab_type == TAB_F32) MXS_NARY_PACKED(AR, NJ, float);                                    \
-        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, 0, stream, a, d);                  \
+        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, lds, stream, a, d, cap);           \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
                 MXS_NARY_CASE(3, 1) MXS_NARY_CASE(3, 2) MXS_NARY_CASE(3, 3) MXS_NARY_CASE(3, 4)
                 MXS_NARY_CASE(4, 1) MXS_NARY_CASE(4, 2) MXS_NARY_CASE(4, 3) MXS_NARY_CASE(4, 4)
+                MXS_NARY_CASE(5, 1) MXS_NARY_CASE(5, 2) MXS_NARY_CASE(5, 3) MXS_NARY_CASE(5, 4)
                 default: return fail(MXS_E_STATE, "no n-ary kernel for this (arity, size) group");
             }
 #undef MXS_NARY_CASE
@@ -651,6 +676,7 @@ struct Engine : EngineBase {
         L.ndesc.clear();
         L.nary_launches.clear();
         nary_ls_cache.clear();
+        nary_cap_cache.clear();
         for (size_t i = 0; i < items.size(); ++i) {
             const Item& it = items[i];
             if (i == 0 || it.cut != items[i - 1].cut || it.code != items[i - 1].code || it.type != items[i - 1].type)

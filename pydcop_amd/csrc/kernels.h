@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_timeline_hub(SweepArgs<T> a) {
 }
 
 // ---------------------------------------------------------------------------
-// Factor side, workgroup-per-factor class (arity 2..4, 64 <= R <= 1024 where R is
+// Factor side, workgroup-per-factor class (arity 2..5, 64 <= R <= 1024 where R is
 // the product of the dimensions after the first): factor_costs_for_var
 // (maxsum.py:382-447) for tables too large for one thread.
 //
@@ -1283,7 +1283,7 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_timeline_hub(SweepArgs<T> a) {
 constexpr int NARY_MAX_SUMD = 1024;  // sum of the scope's domain sizes
 constexpr int NARY_MAX_R = 1024;     // BLOCK * NARY_NJ
 constexpr int NARY_MAX_NJ = NARY_MAX_R / BLOCK;
-constexpr int NARY_MAX_ARITY = 4;
+constexpr int NARY_MAX_ARITY = 5;
 
 template <typename T>
 struct OrdKey;
@@ -1541,12 +1541,15 @@ __device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A],
 // blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
 // layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
 template <typename T, int A, int NJ>
-__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs) {
+__global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs, int cap) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
-    __shared__ T s_msg[NARY_MAX_SUMD];   // incoming V->F messages; in the epilogue the new ones
-    __shared__ U s_key[NARY_MAX_SUMD];   // running minima of the outgoing messages (ordered keys)
-    __shared__ T s_prev[NARY_MAX_SUMD];  // epilogue: the messages sent last
+    // Dynamic LDS, sized by the launch for its group's largest scope (3 arrays of `cap` elements: a block of 5 x 5 x 5 factors
+    // holds 0.4 KB where the fixed arrays of 1 024 elements held 24 KB -- and six blocks a CU: profiles/r06_secp_*):
+    HIP_DYNAMIC_SHARED(unsigned long long, s_dyn)
+    T* s_msg = (T*)s_dyn;                // incoming V->F messages; in the epilogue the new ones
+    U* s_key = (U*)(s_msg + cap);        // running minima of the outgoing messages (ordered keys)
+    T* s_prev = (T*)(s_key + cap);       // epilogue: the messages sent last
     __shared__ int s_nomatch[NARY_MAX_ARITY];
     __shared__ int s_cnt[NARY_MAX_ARITY];
     const NaryDesc fd = descs[blockIdx.x];  // block-uniform: one scalar load
@@ -1742,14 +1745,15 @@ __device__ __forceinline__ T nary_slot_entry(const uint32_t* w, int j) {
 // NEG (max mode: narrow images hold un-negated values) is a template parameter: the negation then
 // folds into the first use of the entry as an operand modifier instead of a 64-bit select per entry.
 template <typename T, int A, int NJ, typename TT, bool NEG, bool LS = false>
-__global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs) {
+__global__ void __launch_bounds__(BLOCK) k_factor_nary_packed(SweepArgs<T> a, const NaryDesc* descs, int cap) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
     constexpr int PF = MXS_NARY_PF;                         // batches requested ahead
     constexpr int SW = nary_slot_bytes(NJ, (int)sizeof(TT)) / 4;
-    __shared__ T s_msg[NARY_MAX_SUMD];
-    __shared__ U s_key[NARY_MAX_SUMD];
-    __shared__ T s_prev[NARY_MAX_SUMD];
+    HIP_DYNAMIC_SHARED(unsigned long long, s_dyn)  // (as k_factor_nary: 3 arrays of `cap` elements)
+    T* s_msg = (T*)s_dyn;
+    U* s_key = (U*)(s_msg + cap);
+    T* s_prev = (T*)(s_key + cap);
     __shared__ int s_nomatch[NARY_MAX_ARITY];
     __shared__ int s_cnt[NARY_MAX_ARITY];
     const NaryDesc fd = descs[blockIdx.x];

@@ -232,7 +232,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (ar == 1 && D0 >= 2 && D0 <= MAX_REG_D) k = FKey{K_F_UNARY, D0};
             else if (ar == 2 && D0 >= 2 && D0 <= MAX_REG_D && g.dom_size[g.edge_var[e0 + 1]] == D0)
                 k = FKey{K_F_BIN, D0};
-            else if (L.opt.nary && ar >= 2 && ar <= 4) {
+            else if (L.opt.nary && ar >= 2 && ar <= 5) {
                 // workgroup-per-factor kernel: 64 <= R <= 1024 (R = product of the
                 // dimensions after the first), staged messages fit its LDS arrays
                 int64_t R = 1, sumd = 0;
@@ -573,7 +573,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     d.tab_off = L.eval_tab_off[f2];
                     d.edge_base = L.frowptr[f2];
                     d.arity = L.frowptr[f2 + 1] - L.frowptr[f2];
-                    for (int i = 0; i < 4; ++i) {
+                    for (int i = 0; i < NARY_DESC_ARITY; ++i) {
                         const bool in = i < d.arity;
                         d.dom[i] = in ? L.edge_dom[d.edge_base + i] : 1;
                         d.f2v_off[i] = in ? L.f2v_off[d.edge_base + i] : 0;

@@ -47,7 +47,7 @@ enum Kind : int32_t {
     K_F_UNARY = 1,  // arity 1, D in {2,3,4}: thread per factor, registers
     K_F_BIN = 2,    // arity 2, D x D, D in {2,3,4}: thread per factor, registers
     K_F_GEN = 3,    // anything: thread per edge, scalar loops
-    K_F_NARY = 4,   // arity 2..4 with 64..1024 entries per value of the first variable (arity 3..4: any number up to
+    K_F_NARY = 4,   // arity 2..5 with 64..1024 entries per value of the first variable (arity 3..5: any number up to
                     // 1024 once the table has 64 entries): workgroup per factor, wavefront min-reductions (own launch)
     K_V_PACK = 5,   // D in {2,3,4}, 1 <= deg <= 64: one lane per incoming edge, the
                     // variables of a wave have the same degree and are packed side
@@ -296,17 +296,19 @@ struct ClassInfo {       // one per class, read with one scalar load
                          // reads vdom / vcost_off per variable: one more dependent load)
 };
 
+constexpr int NARY_DESC_ARITY = 6;  // slots of a descriptor; the workgroup-per-factor kernels exist up to arity 5 (round 6: the
+                                    // reference's `generate secp --max_model_size 4` writes model constraints of arity 5)
 struct NaryDesc {  // one per workgroup-per-factor (K_F_NARY) factor: everything its block
                    // needs, read with ONE scalar load (no chain of dependent loads)
     int64_t tab_off;     // element offset of its row-major table in the full-width image -- or, in a
                          // launch group with a narrow NaryLaunch::tab_type, BYTE offset in ctables
     int32_t edge_base;   // internal id of its first edge
     int32_t arity;
-    int32_t dom[4];      // domain sizes in dimensions order (1 beyond the arity)
-    int32_t v2f_off[4];  // V2F offsets of the incoming messages
-    int32_t f2v_off[4];  // F2V offsets of the outgoing messages
-    uint32_t magic[4];   // ceil(2^32 / dom[i]) (0 for dom[i] = 1): x / dom[i] == (x * magic[i]) >> 32 for the
-                         // x < 2^16 the kernel divides (a lane's index into the table rows)
+    int32_t dom[NARY_DESC_ARITY];      // domain sizes in dimensions order (1 beyond the arity)
+    int32_t v2f_off[NARY_DESC_ARITY];  // V2F offsets of the incoming messages
+    int32_t f2v_off[NARY_DESC_ARITY];  // F2V offsets of the outgoing messages
+    uint32_t magic[NARY_DESC_ARITY];   // ceil(2^32 / dom[i]) (0 for dom[i] = 1): x / dom[i] == (x * magic[i]) >> 32 for the
+                                       // x < 2^16 the kernel divides (a lane's index into the table rows)
 };
 
 // One workgroup of the K_V_WIDE launch: a run of consecutive variables of the class with the SAME

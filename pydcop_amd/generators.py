@@ -352,3 +352,97 @@ def peav_like(n_events=16_700, n_resources=12_500, slots=23, max_length=7, max_r
     var_cost = rng.uniform(0.0, unary_noise, size=int(dom_size.sum())) if unary_noise else np.zeros(int(dom_size.sum()))
     return _finish(dom_size, var_cost, np.array(rowptr, dtype=np.int32), np.array(edge_var, dtype=np.int32),
                    np.concatenate(tables) if tables else np.zeros(0), np.array(table_off, dtype=np.int64), names)
+
+
+def secp_like(n_lights=60_000, n_models=40_000, n_rules=50_000, max_model_size=3, max_rule_size=3, seed=0,
+              unary_noise=0.0, names=True, return_spec=False) -> FlatGraph:
+    """The reference's smart-environment configuration problem (`pydcop generate secp`,
+    pydcop/commands/generators/secp.py:127-176), built in O(E) on arrays: every variable has the five
+    values `range(0, 5)` (:138).
+      lights  `n_lights` variables l_i, each with a unary cost constraint `l_i * efficiency`,
+              efficiency = randint(0, 90) / 100 (build_lights :302-318) -- real-valued tables of 5;
+      models  `n_models` variables m_j, each with ONE constraint over 2..max_model_size lights and
+              m_j: `0 if 10 * abs(m_j - (l_a * i_a + l_b * i_b ..)) < 5 else 10000`, impacts
+              randint(1, 7) / 10 (build_models :201-236) -- arity 3..max_model_size + 1, integer tables of
+              5^arity entries in {0, 10000} (scope order: the lights, then the model variable);
+      rules   `n_rules` constraints `10 * (abs(v - target) + ..)` over 1..max_rule_size lights / models,
+              targets randint(0, 4) (build_rules :239-299) -- arity 1..3, integer tables in 0..120.
+    Objective min (:162).  The defaults give 100 000 variables and 150 000 factors.
+    `return_spec`: also the drawn parameters (efficiencies, impacts, targets, scopes) -- what
+    tests/test_secp_generator_vs_reference.py writes the reference's expression strings from."""
+    rng = np.random.default_rng(seed)
+    D = 5
+    n_vars = n_lights + n_models
+    dom_size = np.full(n_vars, D, dtype=np.int32)
+    var_cost = rng.uniform(0.0, unary_noise, size=n_vars * D) if unary_noise else np.zeros(n_vars * D)
+    vals = np.arange(D, dtype=np.float64)
+    scopes, tabs = [], []            # per group of equal arity: (n, arity) scopes, (n, 5^arity) tables
+    spec = {"efficiency": None, "models": [], "rules": []}
+
+    # lights' efficiency costs: unary
+    eff = rng.integers(0, 91, size=n_lights) / 100
+    scopes.append(np.arange(n_lights, dtype=np.int64)[:, None])
+    tabs.append(vals[None, :] * eff[:, None])
+    spec["efficiency"] = eff
+
+    def distinct(n, k, hi):         # n rows of k distinct integers below hi
+        s = rng.integers(0, hi, size=(n, k))
+        for _ in range(16):
+            bad = (np.diff(np.sort(s, axis=1), axis=1) == 0).any(axis=1) if k > 1 else np.zeros(n, bool)
+            if not bad.any():
+                break
+            s[bad] = rng.integers(0, hi, size=(int(bad.sum()), k))
+        return s
+
+    # models: by size
+    size = rng.integers(2, max_model_size + 1, size=n_models)
+    for k in range(2, max_model_size + 1):
+        idx = np.flatnonzero(size == k)
+        if idx.size == 0:
+            continue
+        lights = distinct(idx.size, k, n_lights)
+        impact = rng.integers(1, 8, size=(idx.size, k)) / 10
+        grids = np.meshgrid(*([vals] * (k + 1)), indexing="ij")          # l_1 .. l_k, m
+        expr = np.zeros((idx.size,) + (D,) * (k + 1))
+        for i in range(k):                                               # " l_a * i_a + l_b * i_b ..": left to right
+            term = grids[i][None] * impact[:, i].reshape((-1,) + (1,) * (k + 1))
+            expr = term if i == 0 else expr + term
+        tab = np.where(10 * np.abs(grids[k][None] - expr) < 5, 0.0, 10000.0)
+        scopes.append(np.concatenate([lights, (n_lights + idx)[:, None]], axis=1))
+        tabs.append(tab.reshape(idx.size, -1))
+        spec["models"].append((scopes[-1], impact))
+
+    # rules: by (number of lights, number of models)
+    rsize = rng.integers(1, min(max_rule_size, n_vars) + 1, size=n_rules)
+    n_l = (rng.random(n_rules) * (rsize + 1)).astype(np.int64)           # randint(0, rule_size)
+    n_l = np.minimum(n_l, rsize)
+    if n_models == 0:
+        n_l = rsize
+    for k in range(1, max_rule_size + 1):
+        for a in range(0, k + 1):
+            idx = np.flatnonzero((rsize == k) & (n_l == a))
+            if idx.size == 0:
+                continue
+            parts = []
+            if a:
+                parts.append(distinct(idx.size, a, n_lights))
+            if k - a:
+                parts.append(n_lights + distinct(idx.size, k - a, n_models))
+            scope = np.concatenate(parts, axis=1)
+            target = rng.integers(0, 5, size=(idx.size, k)).astype(np.float64)
+            grids = np.meshgrid(*([vals] * k), indexing="ij")
+            tot = np.zeros((idx.size,) + (D,) * k)
+            for i in range(k):
+                tot = tot + np.abs(grids[i][None] - target[:, i].reshape((-1,) + (1,) * k))
+            scopes.append(scope)
+            tabs.append((10 * tot).reshape(idx.size, -1))
+            spec["rules"].append((scope, target))
+
+    arity = np.concatenate([np.full(s.shape[0], s.shape[1], dtype=np.int64) for s in scopes])
+    factor_rowptr = np.concatenate([[0], np.cumsum(arity)]).astype(np.int32)
+    edge_var = np.concatenate([s.reshape(-1) for s in scopes]).astype(np.int32)
+    sizes = np.concatenate([np.full(t.shape[0], t.shape[1], dtype=np.int64) for t in tabs])
+    table_off = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
+    tables = np.concatenate([t.reshape(-1) for t in tabs]).astype(np.float64)
+    g = _finish(dom_size, var_cost, factor_rowptr, edge_var, tables, table_off, names)
+    return (g, spec) if return_spec else g

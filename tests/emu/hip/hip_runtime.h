@@ -338,6 +338,11 @@ inline void hipemu_launch(K kernel, dim3 grid, dim3 block, A... args) {
 }
 #define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
     hipemu_launch(kernel, grid, block, __VA_ARGS__)
+// dynamic LDS (HIP: `extern __shared__ type var[];`): one static area, one emulated kernel at a time
+namespace hipemu {
+alignas(16) inline unsigned char g_dynamic_lds[160 * 1024];
+}
+#define HIP_DYNAMIC_SHARED(type, var) type* var = (type*)hipemu::g_dynamic_lds;
 
 inline void __builtin_amdgcn_s_waitcnt(int) {}
 inline void __builtin_amdgcn_wave_barrier() { hipemu::yield_barrier(); }  // let the other lanes catch up

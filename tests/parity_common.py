@@ -255,6 +255,14 @@ def parity_cases():
         ("hard_hub_deg300_inf", lambda: hard(hub(79, nf=300, n=400), 79, 0.3, np.inf), {}),
         ("hard_hub_deg150_varcost_neg_inf_max", lambda: hard(hub(80, nf=150, n=220), 80, 0.2, -np.inf, "var_cost"),
          {"mode": "max", "start_messages": "all"}),
+        # round 6: the reference's `generate secp` (generators.secp_like == secp.py's expressions): D = 5, unary real tables, model
+        # constraints of arity 3..4 in {0, 10000}, rules of arity 1..3; with --max_model_size 4 ARITY 5 -- the workgroup-per-
+        # factor kernels at A = 5 (before: thread per edge)
+        ("secp_small", lambda: G.secp_like(60, 40, 50, seed=81), {}),
+        ("secp_small_m4_all", lambda: G.secp_like(50, 40, 40, max_model_size=4, seed=82, unary_noise=0.01), {"start_messages": "all"}),
+        ("nary_arity5_d5_max", lambda: G.meeting_like(30, n_factors=12, dom=5, arity=5, seed=83), {"mode": "max"}),
+        ("nary_arity5_mixed_float", lambda: G.random_mixed(30, 14, seed=84, max_arity=5, dom_choices=(3, 4, 5, 6)), {"damping_nodes": "factors"}),
+        ("hard_secp_small_m4_inf", lambda: hard(G.secp_like(50, 40, 40, max_model_size=4, seed=85), 85, 0.2, np.inf), {}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
     ]

@@ -32,6 +32,8 @@ def test_bit_exact_vs_oracle(case, dtype, oracle_built):
 @pytest.mark.parametrize("flags", [4, 8, 16, 4 + 8 + 16, 128, 256, 128 + 8, 2048, 2048 + 256, 4096 + 8, 8192, 8192 + 2048])
 def test_layout_variants(flags, oracle_built):
     for name, make, kw in parity_cases():
+        if (flags & 4) and name in ("hub_deg1100_max_all", "hub_deg3400"):
+            continue   # (generic kernels only: ONE thread walks such a hub's O(deg^2 * D) chain -- minutes; degree 513 stays in)
         compare_with_oracle(oracle_built, make(), Params(layout_flags=flags, **kw), 0, steps=[1, 9])
 
 
