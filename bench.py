@@ -69,7 +69,12 @@ KERNEL_OF = {"meeting_50k": "k_factor_box3 + k_variable_wide (one cycle)",
              "meeting_50k_hetero": "k_factor_box3 (4 x 4 x 4 lanes of 6^3 boxes overhanging tables of 18..24 values) + k_variable_wide (one cycle)",
              "peav_50k": "k_factor_bin (lane grids 4x4 of 5x5 / 6x6 boxes, full-width + f32 images) + k_variable_wide (one cycle)",
              "coloring_100k_d8": "k_factor_bin (lane grid 2x2 of 4x4 boxes, int8 image) with the k_variable_pack8 workgroups "
-                                 "first in its grid: ONE launch per cycle"}
+                                 "first in its grid: ONE launch per cycle",
+             "coloring_100k_scalefree": "k_sweep_hub (the sweep with the hub class on board: a workgroup per 128 edges of a hub variable)",
+             "coloring_1m_scalefree": "k_sweep_hub (the sweep with the hub class on board: a workgroup per 128 edges of a hub variable)",
+             "secp_100k": "k_factor_nary (arity 3) + k_factor_nary_packed (arity 4, int16) + k_factor_bin x4 (unary / binary, "
+                          "k_variable_pack8 in the largest) (one cycle)",
+             "secp_100k_m4": "k_factor_nary_packed (arity 5 and 4, int16) + k_factor_nary (arity 3) + k_factor_bin x4 (one cycle)"}
 # tables stored narrower than the arithmetic type (lossless): once the stored bytes of a cycle fall below this share of
 # the algorithmic bytes, the row LEADS with the stored-byte fraction (coloring_100k_d8 advertised 0.85 on
 # int8 tables it never moved at the arithmetic width); the other basis always rides beside it
@@ -121,6 +126,12 @@ EXTRA_CONFIGS = [
     ("meeting_50k_float", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[meeting_50k_float-{dtype}]"),
     # configs[4] with the PEAV model's heterogeneous slot counts (18..24): the box kernel's lane grid overhangs the tables
     ("meeting_50k_hetero", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[meeting_50k_hetero-{dtype}]"),
+    # round 6: the shapes of the reference's two other big generators -- `graph_coloring --graph scalefree`
+    # (hub variables: the wave-per-64-edges class riding in the sweep launch) and `secp` (D = 5, arity 1..4; with
+    # --max_model_size 4 arity 5: the workgroup-per-factor kernels at A = 5)
+    ("coloring_100k_scalefree", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[coloring_100k_scalefree-{dtype}]"),
+    ("secp_100k", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[secp_100k-{dtype}]"),
+    ("secp_100k_m4", ("f64", "f32"), "tests/test_gpu_parity.py::test_full_size_bit_exact_vs_oracle[secp_100k_m4-{dtype}]"),
 ]
 MAIN_PARITY_TEST = "tests/test_gpu_parity.py::test_north_star_100k_coloring"
 

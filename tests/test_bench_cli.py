@@ -101,6 +101,9 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
         "G.random_coloring = lambda n, **k: _col(min(n, 600), **k)\n"
         "_het = G.meeting_hetero\n"
         "G.meeting_hetero = lambda n, **k: _het(40, **{**k, 'doms': (6, 5)})\n"
+        "_sf, _secp = G.scalefree_coloring, G.secp_like\n"
+        "G.scalefree_coloring = lambda n, **k: _sf(min(n, 500), **k)\n"
+        "G.secp_like = lambda a, b, c, **k: _secp(60, 40, 50, **k)\n"
         "_peav = G.peav_like\n"
         "G.peav_like = lambda *a, **k: _peav(40, 25, slots=10, max_length=4, max_resources_event=4, **k)\n"
         f"runpy.run_path({os.path.join(ROOT, 'bench.py')!r}, run_name='__main__')\n")
@@ -150,7 +153,9 @@ def test_bench_single_gpu_line_carries_every_config(tmp_path):
                    ("coloring_1m_deg6", "f32"), ("meeting_50k", "f64"), ("meeting_50k", "f32"),
                    ("peav_50k", "f64"), ("peav_50k", "f32"), ("coloring_100k_d8", "f64"), ("coloring_100k_d8", "f32"),
                    ("meeting_50k_float", "f64"), ("meeting_50k_float", "f32"),
-                   ("meeting_50k_hetero", "f64"), ("meeting_50k_hetero", "f32")}
+                   ("meeting_50k_hetero", "f64"), ("meeting_50k_hetero", "f32"),
+                   ("coloring_100k_scalefree", "f64"), ("coloring_100k_scalefree", "f32"),
+                   ("secp_100k", "f64"), ("secp_100k", "f32"), ("secp_100k_m4", "f64"), ("secp_100k_m4", "f32")}
     for c in configs:
         assert c["parity_checked"] is True and c["parity_test"].startswith("tests/test_gpu_parity.py::")
         rf = c["roofline"]

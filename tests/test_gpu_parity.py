@@ -104,6 +104,10 @@ _FULL = {
     # the wave-per-64-edges class (kernels.h variable_hub) riding in the sweep launch, one tile and several per value of d
     "coloring_100k_scalefree": (lambda: G.scalefree_coloring(100_000, m=2, n_colors=3, seed=0, names=False), "min", [1, 5, 34]),
     "coloring_1m_scalefree": (lambda: G.scalefree_coloring(1_000_000, m=2, n_colors=3, seed=0, names=False), "min", [1, 5, 34]),
+    # round 6: the reference's `generate secp` at 100k variables (generators.secp_like: secp.py's expressions table for table);
+    # _m4 = --max_model_size 4: model constraints of arity 5 on the workgroup-per-factor kernels
+    "secp_100k": (lambda: G.secp_like(60_000, 40_000, 50_000, max_model_size=3, seed=0, names=False), "min", [1, 5, 34]),
+    "secp_100k_m4": (lambda: G.secp_like(60_000, 40_000, 50_000, max_model_size=4, seed=0, names=False), "min", [1, 5, 20]),
 }
 _full_cache = {}
 
