@@ -140,6 +140,8 @@ typedef struct mxs_params {
                                           (the workgroup-per-run kernel of the wide class instead)
                                 bit21 (2097152) that kernel as a launch of its own (default: its workgroups
                                           are the first ones of the largest lane-grid factor launch)
+                                bit23 (8388608) no small-domain lane-group kernel for factors of arity 3..5
+                                          (the workgroup-per-factor kernels instead; A/B runs)
                                 bit22 (4194304) no hub class: variables beyond the packed / wide classes
                                           take one thread each (the round-5 behaviour; A/B runs)   */
 } mxs_params;
@@ -245,9 +247,10 @@ int mxs_factor_order(const mxs_engine *e, int32_t *tiled);
  * [2] generic (thread per edge, scalar loops: whatever nothing else takes); [3] workgroup per factor
  * (arity 2..5, 64..1024 entries per value of the first variable; full-width or lane-packed tables);
  * [4] one wave per factor (arity 3, integer tables in box records); [5] lane grid per factor (binary /
- * unary tables beyond the register classes, up to 64 x 64: 4 / 16 / 64 lanes per factor).
+ * unary tables beyond the register classes, up to 64 x 64: 4 / 16 / 64 lanes per factor); [6] lane group per factor
+ * (round 6: arity 3..5, every domain at most 5 values, a narrow table: 8 / 32 lanes per factor, small_box.h).
  * A layout decision only: every kernel computes the same messages bit for bit. */
-int mxs_factor_kernels(const mxs_engine *e, int64_t counts[6]);
+int mxs_factor_kernels(const mxs_engine *e, int64_t counts[7]);
 
 /* Which kernel runs on_new_cycle of how many variables (maxsum.py:525-565): counts[0] packed class (lane per
  * edge, D <= 4, degree <= 64: part of the sweep launch); [1] the same scheme on 8-element records (5 <= D <= 8;

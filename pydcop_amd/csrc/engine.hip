@@ -27,6 +27,7 @@
 #include "kernels.h"
 #include "nary_box.h"
 #include "bin_box.h"
+#include "small_box.h"
 #include "layout.h"
 
 namespace mxs {
@@ -241,7 +242,13 @@ struct Engine : EngineBase {
     T* recv_buf = nullptr;  // halo_recv) or caller-owned memory (mxs_halo_bind)
     bool halo_ready = false;
     static constexpr int EVAL_BLOCKS = 1024;
-    static constexpr int FUSED_MAX_CUT_BLOCKS = 1024;  // half of the 2048 resident workgroup slots
+    static constexpr int FUSED_MAX_CUT_BLOCKS_DEFAULT = 1024;  // half of the 2048 resident workgroup slots
+    // ($MAXSUM_FUSED_MAX_CUT_BLOCKS: experiments with the fused sharded launch on shards with more cut workgroups -- together with
+    // $MAXSUM_COMM_CUS, which keeps CUs free for the exchange the parked workgroups wait for; profiles/r06_shard_fused_cus_v1.txt)
+    const int FUSED_MAX_CUT_BLOCKS = [] {
+        const char* e = getenv("MAXSUM_FUSED_MAX_CUT_BLOCKS");
+        return e ? std::max(1, atoi(e)) : FUSED_MAX_CUT_BLOCKS_DEFAULT;
+    }();
 
     ~Engine() override {
         for (int q = 0; q < MXS_MAX_PEERS; ++q) {
@@ -489,6 +496,11 @@ struct Engine : EngineBase {
                 const int nb8 = host ? (L.classes[L.pack8_classes[0]].count + BLOCK - 1) / BLOCK : 0;
                 if (!launch_factor_bin2<T>(nl, a, d, stream, host ? (const ClassInfo*)classes8.p : nullptr, nb8))
                     return fail(MXS_E_STATE, "no lane-grid kernel for this launch group");
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
+            if (is_small(nl.box)) {  // arity 3..5 over small domains: a lane group per factor (small_box.h)
+                if (!launch_factor_small<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no small-domain kernel for this launch group");
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -2099,11 +2111,11 @@ int mxs_factor_order(const mxs_engine* e, int32_t* tiled) {
     return MXS_OK;
 }
 
-int mxs_factor_kernels(const mxs_engine* e, int64_t counts[6]) {
+int mxs_factor_kernels(const mxs_engine* e, int64_t counts[7]) {
     CHECK_HANDLE(e);
     if (!counts) return MXS_OK;
     const mxs::Layout& L = e->impl->L;
-    for (int i = 0; i < 6; ++i) counts[i] = 0;
+    for (int i = 0; i < 7; ++i) counts[i] = 0;
     for (int fi = 0; fi < L.n_factors; ++fi) {
         if (L.f_class[fi] >= 0) {
             const int k = L.classes[L.f_class[fi]].kind;
@@ -2111,7 +2123,7 @@ int mxs_factor_kernels(const mxs_engine* e, int64_t counts[6]) {
         } else if (L.f_ndesc[fi] >= 0) {
             for (const mxs::NaryLaunch& x : L.nary_launches)
                 if (L.f_ndesc[fi] >= x.first && L.f_ndesc[fi] < x.first + x.count)
-                    counts[mxs::is_bin2(x.box) ? 5 : x.box ? 4 : 3] += 1;
+                    counts[mxs::is_small(x.box) ? 6 : mxs::is_bin2(x.box) ? 5 : x.box ? 4 : 3] += 1;
         } else {
             counts[2] += 1;
         }

@@ -37,6 +37,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.pack8_fused = !(f & 2097152);           // bit21: the lane-per-edge class of 5..8 values in a launch of its own
     o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
+    o.small = !(f & 8388608);                 // bit23: no small-domain lane-group kernel (workgroup per factor instead)
     o.hub = !(f & 4194304);                   // bit22: no wave-per-64-edges class for hub variables (thread per variable instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
     if (f & 131072) o.tile_bytes = MXS_TILE_BYTES;       // bit17: always tiled
@@ -224,6 +225,24 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
 
     // ---- classify factors ------------------------------------------------
     std::vector<FKey> fkey(nF);
+    // the narrow storage type factor f takes in the small-domain kernel (small_box.h), TAB_FULL = it does not qualify.  All
+    // qualifying factors of one arity share ONE type -- the widest any of them needs (their tables are a few hundred bytes: an
+    // int8 table stored as int16 costs nothing next to a launch of its own, 8 us of a 67-us cycle on secp_100k).
+    auto small_own_type = [&](int f, int e0, int ar) {
+        if (!L.opt.nary || !L.opt.small || !L.opt.compact_tables || ar < 3 || ar > 5) return (int)TAB_FULL;
+        for (int i = 0; i < ar; ++i)
+            if (g.dom_size[g.edge_var[e0 + i]] > SMALL_P) return (int)TAB_FULL;
+        return narrowest_tab_type(g.tables + g.table_off[f], g.table_off[f + 1] - g.table_off[f], L.opt.word);
+    };
+    std::vector<int8_t> small_own(nF, (int8_t)TAB_FULL);
+    int small_widest[6] = {TAB_I8, TAB_I8, TAB_I8, TAB_I8, TAB_I8, TAB_I8};  // (TAB_I8 > TAB_I16 > TAB_F32: smaller = wider)
+    if (!L.opt.no_specialise)
+        for (int f = 0; f < nF; ++f) {
+            const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
+            small_own[f] = (int8_t)small_own_type(f, e0, ar);
+            if (small_own[f] != TAB_FULL) small_widest[ar] = std::min(small_widest[ar], (int)small_own[f]);
+        }
+    auto small_type = [&](int f, int, int ar) { return small_own[f] == TAB_FULL ? (int)TAB_FULL : small_widest[ar]; };
     for (int f = 0; f < nF; ++f) {
         const int e0 = g.factor_rowptr[f], ar = g.factor_rowptr[f + 1] - e0;
         const int D0 = g.dom_size[g.edge_var[e0]];
@@ -232,7 +251,10 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             if (ar == 1 && D0 >= 2 && D0 <= MAX_REG_D) k = FKey{K_F_UNARY, D0};
             else if (ar == 2 && D0 >= 2 && D0 <= MAX_REG_D && g.dom_size[g.edge_var[e0 + 1]] == D0)
                 k = FKey{K_F_BIN, D0};
-            else if (L.opt.nary && ar >= 2 && ar <= 5) {
+            else if (small_type(f, e0, ar) != TAB_FULL) {
+                // arity 3..5, every domain <= SMALL_P, a narrow storage type: a lane group per factor (small_box.h)
+                k = FKey{K_F_NARY, nary_group_code(SMALL_BASE, ar, 0, SMALL_WAVES) * 4 + small_type(f, e0, ar)};
+            } else if (L.opt.nary && ar >= 2 && ar <= 5) {
                 // workgroup-per-factor kernel: 64 <= R <= 1024 (R = product of the
                 // dimensions after the first), staged messages fit its LDS arrays
                 int64_t R = 1, sumd = 0;
@@ -581,7 +603,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                         d.magic[i] = d.dom[i] > 1 ? (uint32_t)((((uint64_t)1 << 32) + d.dom[i] - 1) / d.dom[i]) : 0u;
                     }
                     // compact storage of THIS factor's table (row-major, like the full-width image)
-                    if (t != TAB_FULL || is_bin2(nl.box)) {  // narrow image: lane-packed slots or a box record per lane (layout.h);
+                    if (t != TAB_FULL || is_bin2(nl.box) || is_small(nl.box)) {  // narrow image: lane-packed slots or a box record per lane (layout.h);
                         // a lane-grid group reads its image at every width
                         const NaryPlace pl = nary_place(nl, d, L.opt.word);
                         const int64_t ne = L.eval_tab_off[f2 + 1] - L.eval_tab_off[f2];

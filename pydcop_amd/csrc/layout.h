@@ -189,7 +189,24 @@ constexpr int BIN2_N_SHAPES = (int)(sizeof(BIN2_SHAPES) / sizeof(BIN2_SHAPES[0])
 constexpr int BIN2_BASE = 32;      // NaryLaunch::box >= BIN2_BASE: shape BIN2_SHAPES[box - BIN2_BASE]
 constexpr int BIN2_WAVES = 4;      // waves per workgroup
 constexpr int BIN2_MAX_D = 64;
-constexpr bool is_bin2(int box) { return box >= BIN2_BASE; }
+// ---- small-domain layout of an n-ary table (kernels: small_box.h, k_factor_small) -------------------------------
+// Arity 3..5, every domain at most SMALL_P values, a narrow storage type: G = small_group(arity) lanes per factor; the
+// leading small_lead(arity) digits of an entry pick the lane (index in radix SMALL_P), the trailing ones its place in the
+// lane's RECORD of SMALL_P^trailing entries (radix SMALL_P, last digit fastest; digits past a domain: zero-filled).
+// The image is the records of the lanes in use back to back.
+constexpr int SMALL_BASE = 64;     // NaryLaunch::box == SMALL_BASE: the small-domain kernel
+constexpr int SMALL_P = 5;
+constexpr int SMALL_WAVES = 4;     // waves per workgroup
+constexpr bool is_small(int box) { return box >= SMALL_BASE; }
+constexpr int small_lead(int arity) { return arity == 3 ? 1 : 2; }
+constexpr int small_group(int arity) { return arity == 3 ? 8 : 32; }
+constexpr int small_pow(int e) {
+    int r = 1;
+    for (int i = 0; i < e; ++i) r *= SMALL_P;
+    return r;
+}
+constexpr int small_rec_bytes(int arity, int elem) { return (small_pow(arity - small_lead(arity)) * elem + 3) / 4 * 4; }
+constexpr bool is_bin2(int box) { return box >= BIN2_BASE && box < SMALL_BASE; }
 constexpr int bin2_piece_bytes(int b1, int elem) { return (b1 * elem + 3) / 4 * 4; }
 // the shape (index + BIN2_BASE) a table of d0 x d1 entries takes (d1 = 1, unary = true: a unary factor), 0 = none:
 // the fewest image bytes + message slots, then the fewest lanes
@@ -215,9 +232,24 @@ struct NaryPlace {
     int32_t nt, slot;     // lane-packed: threads of the block, bytes of a slot
     int32_t R;            // lane-packed: entries per value of the first variable
     int32_t d1, d2;       // box: domain sizes of dimensions 1 and 2
+    int32_t arity;        // small-domain layout: the scope
+    int32_t dom[6];
 };
 constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
     if (p.box == 0) return nary_packed_pos(k / p.R, k % p.R, p.nt, p.slot, p.elem);
+    if (is_small(p.box)) {
+        int x[6] = {0, 0, 0, 0, 0, 0};
+        int64_t rem = k;
+        for (int i = p.arity - 1; i >= 0; --i) {
+            x[i] = (int)(rem % p.dom[i]);
+            rem /= p.dom[i];
+        }
+        const int L = small_lead(p.arity);
+        int64_t lane = 0, e = 0;
+        for (int i = 0; i < L; ++i) lane = lane * SMALL_P + x[i];
+        for (int i = L; i < p.arity; ++i) e = e * SMALL_P + x[i];
+        return lane * small_rec_bytes(p.arity, p.elem) + e * p.elem;
+    }
     if (is_bin2(p.box)) {
         const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
         const int64_t piece = bin2_piece_bytes(sh.B1, p.elem), x1 = k % p.d1, x0 = k / p.d1;
@@ -236,6 +268,7 @@ constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
 // bytes of the narrow image of one factor (D0 = its first domain size)
 constexpr int64_t nary_place_bytes(const NaryPlace& p, int D0) {
     if (p.box == 0) return (int64_t)D0 * p.nt * p.slot;
+    if (is_small(p.box)) return ((int64_t)small_pow(small_lead(p.arity)) * small_rec_bytes(p.arity, p.elem) + 15) / 16 * 16;
     if (is_bin2(p.box)) {
         const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
         return ((int64_t)D0 * sh.L1 * bin2_piece_bytes(sh.B1, p.elem) + 15) / 16 * 16;
@@ -362,7 +395,8 @@ struct NaryLaunch {  // one launch per (arity, nj, threads) group of K_F_NARY fa
     int32_t count;
     int32_t cut;         // 1: factors reading ghost variables (second phase of a sharded cycle)
     int32_t tab_type;    // TabType the tables of the group are stored in (one kernel instantiation each)
-    int32_t box;         // 0: lane-packed / full-width kernels; else the box shape id (nary_box.h: one wave per
+    int32_t box;         // (>= SMALL_BASE: the small-domain kernel, small_box.h; threads = SMALL_WAVES * 64, nj = 0)
+                         // 0: lane-packed / full-width kernels; else the box shape id (nary_box.h: one wave per
                          // factor, BOX_WAVES factors per workgroup; nj = 0, threads = BOX_WAVES * 64);
                          // >= BIN2_BASE: the lane grid of a binary / unary table (bin_box.h; arity 1 or 2, nj = 0)
 };
@@ -379,6 +413,8 @@ inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 
     p.R = (int32_t)R;
     p.d1 = d.dom[1];
     p.d2 = d.dom[2];
+    p.arity = d.arity & 255;
+    for (int i = 0; i < 6; ++i) p.dom[i] = d.dom[i];
     return p;
 }
 // Sort code of a launch group: (box, arity, nj, waves) -- one kernel instantiation each.
@@ -412,6 +448,7 @@ struct LayoutOptions {
     bool box = true;             // narrow arity-3 tables that fit a box shape use the one-wave-per-factor kernel
     bool pack8_fused = true;     // ... as the first workgroups of the largest lane-grid factor launch instead of a launch of their own
     bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
+    bool small = true;           // arity 3..5 over domains of at most 5 values with a narrow table use the lane-group kernel (small_box.h)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool hub = true;             // variables beyond the packed / wide classes use the wave-per-64-edges class (K_V_HUB) instead of a thread each
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable

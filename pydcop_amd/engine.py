@@ -384,9 +384,9 @@ class MaxSumEngine:
     def factor_kernels(self) -> dict:
         """Factors per kernel of the factor side (mxs_factor_kernels): register classes, generic
         (thread per edge), workgroup per factor, one wave per factor (box records), lane grid."""
-        n = (C.c_int64 * 6)()
+        n = (C.c_int64 * 7)()
         self._check(self._lib.mxs_factor_kernels(self._h, n))
-        return dict(zip(("reg_unary", "reg_binary", "generic", "workgroup", "wave_box", "lane_grid"),
+        return dict(zip(("reg_unary", "reg_binary", "generic", "workgroup", "wave_box", "lane_grid", "lane_group_small"),
                         (int(x) for x in n)))
 
     def variable_kernels(self) -> dict:

@@ -10,8 +10,8 @@ OUT = os.path.join(HERE, "_build", "libmaxsum_emu.so")
 
 
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip", "bin_box.hip")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "nary_box.h", "bin_box.h", "layout.h", "local_search.h")] + [
+    srcs = [os.path.join(CSRC, f) for f in ("engine.hip", "layout.cpp", "amaxsum.hip", "mgm.hip", "dsa.hip", "bin_box.hip", "small_box.hip")]
+    deps = srcs + [os.path.join(CSRC, f) for f in ("kernels.h", "nary_box.h", "bin_box.h", "small_box.h", "layout.h", "local_search.h")] + [
         os.path.join(HERE, "hip", "hip_runtime.h"), os.path.join(HERE, "hipcub", "hipcub.hpp"),
         os.path.join(ROOT, "include", "maxsum_gpu.h")]
     if not force and os.path.exists(OUT) and all(
