@@ -395,6 +395,10 @@ int mxs_peer_connect(mxs_engine *e, const mxs_peer_info *all /* [world] */);
  *                    in receive order) -- no pack / unpack kernel; needs mxs_comm_init, every
  *                    sent edge in a packed variable class and sent to one shard only.
  *                    MAXSUM_SHARD_DIRECT=0 keeps the pack / unpack kernels.
+ *                    "Packed variable class" = the lane-per-edge class of domains of at most 4 values: a
+ *                    shard whose BOUNDARY variables have 5..8 values (the lane-per-edge class on 8-element
+ *                    records), wider domains or hub degrees reports 0 here and exchanges through the pack /
+ *                    unpack kernels -- correct, one launch more on each side of the collective.
  *   fused_launch     1: one sweep launch per cycle whose last blocks (the cut factors) wait
  *                    for the halo inside the kernel (opt-in: MAXSUM_SHARD_FUSED=1; measured
  *                    slower than the two-launch schedule). */

@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round 6 closing call: the full GPU suite, smoke, the DRIVER's exact command with its raw stdout kept (the final line has to parse
+# from the 8-KB tail), kernel traces of the metric's configuration under that command and of the new rows.
+TAG=${1:-r6_final}
+R=${GRAFT_REPO_ROOT:-$(pwd)}; OUT=$R/gpurun_out/$TAG; mkdir -p $OUT; cd $R; export TMPDIR=/tmp
+echo "== pytest -m gpu (everything)"
+( time timeout 2000 python3 -m pytest tests -x -q -m gpu --durations=8 ) 2>&1 | tail -24 | tee $OUT/pytest_gpu.txt
+echo "== smoke"
+timeout 300 python3 -c 'import __graft_entry__ as g; g.smoke()' 2>&1 | tail -6 | tee $OUT/smoke.txt
+echo "== the driver's command, verbatim"
+( time timeout 1500 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_driver_stdout.txt 2> $OUT/bench_driver_stderr.txt ) 2>&1 | tail -3
+tail -c 8192 $OUT/bench_driver_stdout.txt > $OUT/bench_driver_tail8k.txt
+cp bench_rows.json $OUT/bench_rows.json 2>/dev/null
+python3 - <<PY
+import json
+lines=open("$OUT/bench_driver_stdout.txt").read().strip().splitlines()
+print("lines", len(lines), "last line bytes", len(lines[-1]))
+d=json.loads(lines[-1]); r=d["roofline"]
+print({k: d[k] for k in ("value","ms_per_step","n_gpus","steps","warmup")}, "frac", r["frac"], "stored", r.get("frac_of_stored_bytes"), "traffic", r.get("frac_by_traffic"), "cpu", d["cpu_baseline"]["value"])
+for k, v in d["rows"].items(): print("  %-28s %9s us  frac %s" % (k, v[0], v[1]))
+PY
+echo "== rocprofv3 kernel trace of the metric's configuration under the driver's steps"
+cd /tmp
+rm -rf $OUT/p
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python3 $R/bench.py --no-cpu-baseline --configs main --steps 20 --warmup 5 --rows-file /tmp/rows.json > $OUT/prof_driver.log 2>&1
+f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_coloring100k_f64_driver_cmd.csv && cut -c1-200 $OUT/kernel_stats_coloring100k_f64_driver_cmd.csv | head -3
+rm -rf $OUT/p
+exit 0
