@@ -264,6 +264,11 @@ struct Engine : EngineBase {
         wide_profile_dump();
 #endif
         if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+        for (int q = 1; q < 3; ++q) {
+            if (ev_njoin[q]) (void)hipEventDestroy(ev_njoin[q]);
+            if (nstream[q]) (void)hipStreamDestroy(nstream[q]);
+        }
+        if (ev_nfork) (void)hipEventDestroy(ev_nfork);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (side) (void)hipStreamDestroy(side);
@@ -486,26 +491,62 @@ struct Engine : EngineBase {
         return best;
     }
 
+    // $MAXSUM_NARY_STREAMS = 2 / 3: the launch groups of a cycle (they read the same old buffers and write disjoint records)
+    // spread over that many streams, the longest first -- short launches (a SECP cycle is seven of 5..20 us) then overlap their
+    // ramps and tails.  Eager launches of an unsharded cycle only; one fork and one join event per extra stream and cycle.
+    int nary_streams = 1;
+    hipStream_t nstream[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_nfork = nullptr, ev_njoin[3] = {nullptr, nullptr, nullptr};
+
     int launch_nary(const SweepArgs<T>& a, int cut) {
         const int host8 = cut == 0 ? pack8_host_group() : -1;
-        for (const NaryLaunch& nl : L.nary_launches) {
+        int n_groups = 0;
+        for (const NaryLaunch& nl : L.nary_launches) n_groups += nl.cut == cut;
+        const bool multi = nary_streams > 1 && cut == 0 && !capturing && !halo_ready && n_groups >= 2;
+        std::vector<int> lane_of(L.nary_launches.size(), 0);
+        if (multi) {
+            // longest processing time first onto the least loaded stream; cost = factors x table entries
+            std::vector<std::pair<double, int>> cost;
+            for (size_t i = 0; i < L.nary_launches.size(); ++i) {
+                const NaryLaunch& nl = L.nary_launches[i];
+                if (nl.cut != cut) continue;
+                const NaryDesc& d0 = L.ndesc[nl.first];
+                double e = 1;
+                for (int k = 0; k < (d0.arity & 255); ++k) e *= d0.dom[k];
+                cost.push_back({(e + 64) * nl.count, (int)i});
+            }
+            std::sort(cost.begin(), cost.end(), [](const auto& x, const auto& y) { return x.first > y.first; });
+            double load[3] = {0, 0, 0};
+            for (const auto& c : cost) {
+                int best = 0;
+                for (int q = 1; q < nary_streams; ++q)
+                    if (load[q] < load[best]) best = q;
+                lane_of[c.second] = best;
+                load[best] += c.first;
+            }
+            HIP_TRY(hipEventRecord(ev_nfork, stream));
+            for (int q = 1; q < nary_streams; ++q) HIP_TRY(hipStreamWaitEvent(nstream[q], ev_nfork, 0));
+        }
+        for (size_t gi = 0; gi < L.nary_launches.size(); ++gi) {
+            const NaryLaunch& nl = L.nary_launches[gi];
             if (nl.cut != cut) continue;
+            hipStream_t st = (multi && lane_of[gi] > 0) ? nstream[lane_of[gi]] : stream;
             const NaryDesc* d = ndesc.p + nl.first;
             if (is_bin2(nl.box)) {  // binary / unary tables: a lane grid per factor (bin_box.h)
                 const bool host = host8 >= 0 && &nl == &L.nary_launches[host8];
                 const int nb8 = host ? (L.classes[L.pack8_classes[0]].count + BLOCK - 1) / BLOCK : 0;
-                if (!launch_factor_bin2<T>(nl, a, d, stream, host ? (const ClassInfo*)classes8.p : nullptr, nb8))
+                if (!launch_factor_bin2<T>(nl, a, d, st, host ? (const ClassInfo*)classes8.p : nullptr, nb8))
                     return fail(MXS_E_STATE, "no lane-grid kernel for this launch group");
                 HIP_TRY(hipGetLastError());
                 continue;
             }
             if (is_small(nl.box)) {  // arity 3..5 over small domains: a lane group per factor (small_box.h)
-                if (!launch_factor_small<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no small-domain kernel for this launch group");
+                if (!launch_factor_small<T>(nl, a, d, st)) return fail(MXS_E_STATE, "no small-domain kernel for this launch group");
                 HIP_TRY(hipGetLastError());
                 continue;
             }
             if (nl.box) {  // one wave per factor, minima in registers (nary_box.h)
-                if (!launch_factor_box3<T>(nl, a, d, stream)) return fail(MXS_E_STATE, "no box kernel for this launch group");
+                if (!launch_factor_box3<T>(nl, a, d, st)) return fail(MXS_E_STATE, "no box kernel for this launch group");
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -517,17 +558,17 @@ struct Engine : EngineBase {
 #define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
     do {                                                                                                    \
         if (AR == 3 && ls) {  /* kernels.h, nary_batch: LS */                                               \
-            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, lds, stream, a, d, cap);  \
-            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, lds, stream, a, d, cap);           \
-        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, lds, stream, a, d, cap);  \
-        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, lds, stream, a, d, cap);           \
+            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, lds, st, a, d, cap);  \
+            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, lds, st, a, d, cap);           \
+        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, lds, st, a, d, cap);  \
+        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, lds, st, a, d, cap);           \
     } while (0)
 #define MXS_NARY_CASE(AR, NJ)                                                                              \
     case (AR) * 16 + (NJ):                                                                                  \
         if (nl.tab_type == TAB_I8) MXS_NARY_PACKED(AR, NJ, int8_t);                                         \
         else if (nl.tab_type == TAB_I16) MXS_NARY_PACKED(AR, NJ, int16_t);                                  \
         else if (nl.tab_type == TAB_F32) MXS_NARY_PACKED(AR, NJ, float);                                    \
-        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, lds, stream, a, d, cap);           \
+        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, lds, st, a, d, cap);           \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
@@ -540,6 +581,11 @@ struct Engine : EngineBase {
 #undef MXS_NARY_PACKED
             HIP_TRY(hipGetLastError());
         }
+        if (multi)
+            for (int q = 1; q < nary_streams; ++q) {
+                HIP_TRY(hipEventRecord(ev_njoin[q], nstream[q]));
+                HIP_TRY(hipStreamWaitEvent(stream, ev_njoin[q], 0));
+            }
         return MXS_OK;
     }
 
@@ -757,6 +803,12 @@ struct Engine : EngineBase {
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
         HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        if (const char* e = getenv("MAXSUM_NARY_STREAMS")) nary_streams = std::max(1, std::min(3, atoi(e)));
+        for (int q = 1; q < nary_streams; ++q) {
+            HIP_TRY(hipStreamCreateWithFlags(&nstream[q], hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_njoin[q], hipEventDisableTiming));
+        }
+        if (nary_streams > 1) HIP_TRY(hipEventCreateWithFlags(&ev_nfork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
         {   // Two streams pay when a cycle is long: measured (profiles/r05_variable_wave_ab_v1.txt, flags=1048576 rows =

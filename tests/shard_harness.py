@@ -34,6 +34,10 @@ def make_case(name):
         return G.random_coloring(300, avg_degree=9, seed=8, names=False), {"damping_nodes": "vars"}
     if name == "coloring_2k":
         return G.random_coloring(2000, avg_degree=4, seed=11, names=False), {}
+    if name == "scalefree":      # hub variables (the wave-per-edges class, round 6) on the boundary and inside
+        return G.scalefree_coloring(1500, m=3, seed=21, names=False), {}
+    if name == "secp":           # small-domain lane-group kernel + arity-5 factors cut across shards
+        return G.secp_like(120, 80, 100, max_model_size=4, seed=22, names=False), {"start_messages": "all"}
     if name == "coloring_50k":
         return G.random_coloring(50_000, avg_degree=4, seed=1, names=False), {}
     raise ValueError(name)

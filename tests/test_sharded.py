@@ -127,7 +127,7 @@ def _check_against_single(g, kw, k, lib_path, device="cpu", steps=(0, 1, 2, 7, 2
     many.close()
 
 
-@pytest.mark.parametrize("case", ["coloring", "mixed_max", "ising", "coloring_deg9"])
+@pytest.mark.parametrize("case", ["coloring", "mixed_max", "ising", "coloring_deg9", "scalefree", "secp"])
 @pytest.mark.parametrize("k", [2, 5])
 def test_local_shards_equal_single_engine_emu(case, k, emu_lib):
     g, kw = make_case(case)
@@ -492,7 +492,8 @@ def test_nccl_world1_code_path(collective, tmp_path):
     np.testing.assert_array_equal(z["bel_25"], one.assignment()[1])
 
 
-@pytest.mark.parametrize("case,k", [("coloring", 2), ("ising", 3), ("mixed_max", 2), ("coloring_2k", 4), ("coloring_2k", 8)])
+@pytest.mark.parametrize("case,k", [("coloring", 2), ("ising", 3), ("mixed_max", 2), ("coloring_2k", 4), ("coloring_2k", 8),
+                                    ("scalefree", 3), ("secp", 2)])
 def test_local_sharded_one_process_equals_single_engine(case, k, emu_lib, fake_rccl, tmp_path, monkeypatch):
     """pydcop_amd.sharded.LocalShardedMaxSum (what the plugin's `devices` parameter runs): k
     shards on k (emulated) devices driven by k threads of ONE process through the library's own
