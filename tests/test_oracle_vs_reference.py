@@ -22,6 +22,28 @@ def _hard(g, seed, frac, value):
     g.tables = t
     return g
 
+def _hub(seed, nf, n):
+    """One variable in nf more binary factors: a degree the reference's scale-free generator produces
+    (graphcoloring.py:322-340) -- the serial chains of costs_for_factor (maxsum.py:651-665) at length 3 * nf."""
+    from pydcop_amd.graph import FlatGraph
+    g = G.random_coloring(n, avg_degree=3, seed=seed)
+    rng = np.random.default_rng(seed)
+    others = rng.choice(np.arange(1, n), size=nf, replace=False)
+    edge_var = np.concatenate([g.edge_var, np.stack([np.zeros(nf, int), others], 1).reshape(-1)])
+    rowptr = np.concatenate([g.factor_rowptr, g.factor_rowptr[-1] + 2 * np.arange(1, nf + 1)])
+    tables = np.concatenate([g.tables, rng.integers(0, 10, nf * 9).astype(float)])
+    toff = np.concatenate([g.table_off, g.table_off[-1] + 9 * np.arange(1, nf + 1)])
+    vr, ve = FlatGraph.var_side_from_edges(edge_var, n)
+    out = FlatGraph(dom_size=g.dom_size, var_cost=g.var_cost, factor_rowptr=rowptr, edge_var=edge_var,
+                    table_off=toff, tables=tables, var_rowptr=vr, var_edges=ve).validate()
+    width = len(str(n - 1))
+    out.var_names = [f"v{i:0{width}d}" for i in range(n)]
+    out.factor_names = [f"c{i:04d}" for i in range(out.n_factors)]
+    out.domains = [list(range(int(d))) for d in out.dom_size]
+    return out
+
+
+MAX_T = {"secp_arity5": 7}   # (the reference walks 5 x 5 x 625 assignments per arity-5 factor and cycle in Python)
 CASES = [
     ("soft", lambda: G.random_coloring(40, seed=11), "min", {}),
     ("hard", lambda: G.random_coloring(40, seed=12, variant="hard"), "min",
@@ -33,12 +55,18 @@ CASES = [
     ("hard_inf_nary", lambda: _hard(G.meeting_like(8, n_factors=5, dom=8, seed=15), 15, 0.9, -np.inf), "max", {}),
     ("hard_inf_binary", lambda: _hard(G.random_coloring(30, avg_degree=5, seed=16), 16, 0.3, np.inf), "min",
      {"start_messages": "all"}),
+    # round 6: the shapes of the reference's other generators -- a hub of degree 75 (scale-free colourings) and the SECP
+    # model (generators.secp_like: D = 5, arity 1..5 with --max_model_size 4)
+    ("hub_deg75", lambda: _hub(17, 72, 90), "min", {}),
+    ("secp_arity5", lambda: G.secp_like(8, 3, 6, max_model_size=4, seed=26), "min", {"start_messages": "leafs_vars"}),
 ]
 
 
 @pytest.mark.parametrize("name,make,mode,params", CASES, ids=[c[0] for c in CASES])
 @pytest.mark.parametrize("T", [0, 1, 2, 7, 25])
 def test_oracle_equals_reference(name, make, mode, params, T, oracle_built):
+    if T > MAX_T.get(name, 10 ** 9):
+        pytest.skip("bounded for this case")
     g = make()
     dcop, cg = ref_harness.flat_to_dcop(g, mode)
     vals, costs = ref_harness.run_reference_maxsum(dcop, T, params, cg=cg)
@@ -59,6 +87,8 @@ def test_oracle_equals_reference(name, make, mode, params, T, oracle_built):
 def test_oracle_messages_and_counters_equal_reference(name, make, mode, params, T, oracle_built):
     """Message-level pin of the synchronous oracle: every receiver's `_costs` and every
     sender's `_prev_messages` (message AND count) of the reference's own computations."""
+    if T > MAX_T.get(name, 10 ** 9):
+        pytest.skip("bounded for this case")
     g = make()
     dcop, cg = ref_harness.flat_to_dcop(g, mode)
     _, _, comps = ref_harness.run_reference_maxsum(dcop, T, params, cg=cg, return_comps=True)
