@@ -981,6 +981,9 @@ __device__ __forceinline__ void variable_hub(const SweepArgs<T>& a, const ClassI
                 // blocks ahead requested from LDS before the additions of the current one (three register sets by hand:
                 // the chain waits for nothing but itself); no branch but the loop's own.
                 auto fetch = [&](T (&x)[8], int kk) __attribute__((always_inline)) {
+#if defined(MXS_HUB_EXP) && MXS_HUB_EXP == 3   // timing experiment (results wrong): the chain without its LDS reads
+                    if (kk > 16) return;
+#endif
 #pragma unroll
                     for (int u = 0; u < 8; ++u) x[u] = row[8 + kk + u];
                 };
