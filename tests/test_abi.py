@@ -126,10 +126,11 @@ def test_no_kernel_uses_scratch():
     assert len(sweep) >= 2 and max(sweep.values()) <= 72, sweep
 
 
-@pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6), ("bin_box.hip", 300)])
+@pytest.mark.parametrize("source,at_least", [("dsa.hip", 10), ("mgm.hip", 14), ("amaxsum.hip", 6), ("bin_box.hip", 300),
+                                             ("small_box.hip", 30)])
 def test_no_kernel_of_the_other_engines_uses_scratch(source, at_least):
     """The same for the DSA / MGM / A-Max-Sum sources (the register arrays of the slot kernels:
-    lsearch::pick) and for the lane-grid kernels of the binary / unary factors (bin_box.hip: a lane's B0 row pieces).  rocPRIM's own sort kernels (amaxsum.hip) are not ours to judge."""
+    lsearch::pick) and for the lane-grid kernels of the binary / unary factors (bin_box.hip: a lane's B0 row pieces) and the lane-group kernels of small-domain n-ary factors (small_box.hip: a lane's record of 25 / 125 entries, its unrolled minima).  rocPRIM's own sort kernels (amaxsum.hip) are not ours to judge."""
     ks = [(n, s) for n, s in _kernel_scratch(source) if "rocprim" not in n]
     assert len(ks) >= at_least, ks
     bad = [(n, s) for n, s in ks if s != 0]
