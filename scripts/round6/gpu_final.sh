@@ -25,4 +25,23 @@ rm -rf $OUT/p
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python3 $R/bench.py --no-cpu-baseline --configs main --steps 20 --warmup 5 --rows-file /tmp/rows.json > $OUT/prof_driver.log 2>&1
 f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_coloring100k_f64_driver_cmd.csv && cut -c1-200 $OUT/kernel_stats_coloring100k_f64_driver_cmd.csv | head -3
 rm -rf $OUT/p
+if [ "$2" = "full" ]; then
+echo "== kernel traces of the round's new rows (serial launches)"
+for spec in coloring_100k_scalefree:f64 coloring_100k_scalefree:f32 coloring_1m_scalefree:f64 secp_100k:f64 secp_100k:f32 secp_100k_m4:f64 secp_100k_m4:f32; do
+  IFS=: read wl dt <<< "$spec"
+  rm -rf $OUT/p
+  MAXSUM_NARY_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python3 $R/bench.py --workload $wl --dtype $dt --steps 100 --warmup 10 --no-cpu-baseline --rows-file /tmp/rows.json > $OUT/prof_${wl}_$dt.log 2>&1
+  f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $OUT/kernel_stats_${wl}_${dt}.csv && cut -c1-160 $OUT/kernel_stats_${wl}_${dt}.csv | sed -n 2,3p
+  rm -rf $OUT/p
+done
+echo "== PMC traffic of the SECP rows on the closing code"
+cd $R
+bash scripts/gpu_pmc.sh $TAG/pmc "FETCH_SIZE WRITE_SIZE" "secp_100k:f64:0 secp_100k:f32:0 secp_100k_m4:f64:0 secp_100k_m4:f32:0" > $OUT/pmc.log 2>&1
+echo "== the stated multi-GPU prediction, re-measured on this code"
+timeout 900 python3 tools/scale_prediction.py --out $OUT/scale_prediction.json > $OUT/scale_prediction.log 2>&1
+grep '^{"n"' $OUT/scale_prediction.log | python3 -c "
+import sys, json
+for line in sys.stdin:
+    d = json.loads(line); print('N', d['n'], 'compute', round(d['shard_compute_us'],1), 'loopback', round(d.get('shard_cycle_us_rccl_loopback',-1),1), d.get('predicted_speedup_vs_one_gpu'))"
+fi
 exit 0
