@@ -232,10 +232,10 @@ inline void launch_bin2_shape(const SweepArgs<T>& a, const NaryDesc* d, int coun
     constexpr int FPB = BIN2_WAVES * (64 / (sh.L0 * sh.L1));
     const dim3 grid((unsigned)(nb8 + (count + FPB - 1) / FPB)), block((unsigned)(BIN2_WAVES * 64));
     if (nb8 > 0) {
-        if (a.tab_neg) hipLaunchKernelGGL((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
-        else hipLaunchKernelGGL((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
-    } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
-    else hipLaunchKernelGGL((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
+        if (a.tab_neg) MXS_LAUNCH((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
+        else MXS_LAUNCH((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, true>), grid, block, 0, stream, a, d, count, cls8, nb8);
+    } else if (a.tab_neg) MXS_LAUNCH((k_factor_bin<T, TT, true, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
+    else MXS_LAUNCH((k_factor_bin<T, TT, false, sh.L0, sh.L1, sh.B0, sh.B1, false>), grid, block, 0, stream, a, d, count, cls8, 0);
 }
 
 template <typename T, typename TT, int... S>

@@ -31,6 +31,7 @@
 #include "layout.h"
 
 namespace mxs {
+thread_local LaunchChain g_launch;
 
 static thread_local std::string g_err;
 
@@ -230,6 +231,10 @@ struct Engine : EngineBase {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool overlap = false, capturing = false;
+    // The launches of a cycle after its first without the AQL barrier bit (kernels.h, LaunchChain): 0 off, 1 on (and no side
+    // stream: the wide variable launches ride in the chain), 2 on beside the side stream, 3 = 1 + the cut classes of a
+    // sharded cycle chained behind the halo wait.  $MAXSUM_ANYORDER; eager launches only.
+    int any_order = 0;
     bool streaming = false;  // non-temporal stores / index loads in the sweep (cycle larger than the Infinity Cache)
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
@@ -368,30 +373,30 @@ struct Engine : EngineBase {
         const dim3 grid(nb), block(BLOCK);
         if (p2p) {  // peer-store twin
             switch (L.dsel) {
-                case 2: hipLaunchKernelGGL((k_sweep_p2p<T, 2>), grid, block, 0, stream, a); break;
-                case 3: hipLaunchKernelGGL((k_sweep_p2p<T, 3>), grid, block, 0, stream, a); break;
-                case 4: hipLaunchKernelGGL((k_sweep_p2p<T, 4>), grid, block, 0, stream, a); break;
-                default: hipLaunchKernelGGL((k_sweep_p2p<T, 0>), grid, block, 0, stream, a); break;
+                case 2: MXS_LAUNCH((k_sweep_p2p<T, 2>), grid, block, 0, stream, a); break;
+                case 3: MXS_LAUNCH((k_sweep_p2p<T, 3>), grid, block, 0, stream, a); break;
+                case 4: MXS_LAUNCH((k_sweep_p2p<T, 4>), grid, block, 0, stream, a); break;
+                default: MXS_LAUNCH((k_sweep_p2p<T, 0>), grid, block, 0, stream, a); break;
             }
         } else if (timeline_on && has_hub) {  // profiling twin, hub class on board
-            if (L.dsel == 3) hipLaunchKernelGGL((k_sweep_timeline_hub<T, 3>), grid, block, 0, stream, a);
-            else hipLaunchKernelGGL((k_sweep_timeline_hub<T, 0>), grid, block, 0, stream, a);
+            if (L.dsel == 3) MXS_LAUNCH((k_sweep_timeline_hub<T, 3>), grid, block, 0, stream, a);
+            else MXS_LAUNCH((k_sweep_timeline_hub<T, 0>), grid, block, 0, stream, a);
         } else if (timeline_on) {  // profiling twin
             switch (L.dsel) {
-                case 2: hipLaunchKernelGGL((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
-                case 3: hipLaunchKernelGGL((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
-                case 4: hipLaunchKernelGGL((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
-                default: hipLaunchKernelGGL((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
+                case 2: MXS_LAUNCH((k_sweep_timeline<T, 2>), grid, block, 0, stream, a); break;
+                case 3: MXS_LAUNCH((k_sweep_timeline<T, 3>), grid, block, 0, stream, a); break;
+                case 4: MXS_LAUNCH((k_sweep_timeline<T, 4>), grid, block, 0, stream, a); break;
+                default: MXS_LAUNCH((k_sweep_timeline<T, 0>), grid, block, 0, stream, a); break;
             }
         } else if (has_hub) {  // the instantiations that carry the hub class (kernels.h variable_hub): D = 3 or any
 #define MXS_SWEEP_HUB(DS)                                                                                         \
     do {                                                                                                           \
         if (streaming) {                                                                                           \
-            if (a.sched) hipLaunchKernelGGL((k_sweep_hub<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);  \
-            else hipLaunchKernelGGL((k_sweep_hub<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);         \
+            if (a.sched) MXS_LAUNCH((k_sweep_hub<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);  \
+            else MXS_LAUNCH((k_sweep_hub<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);         \
         } else {                                                                                                   \
-            if (a.sched) hipLaunchKernelGGL((k_sweep_hub<T, DS, MXS_NT, true>), grid, block, 0, stream, a);        \
-            else hipLaunchKernelGGL((k_sweep_hub<T, DS, MXS_NT, false>), grid, block, 0, stream, a);               \
+            if (a.sched) MXS_LAUNCH((k_sweep_hub<T, DS, MXS_NT, true>), grid, block, 0, stream, a);        \
+            else MXS_LAUNCH((k_sweep_hub<T, DS, MXS_NT, false>), grid, block, 0, stream, a);               \
         }                                                                                                          \
     } while (0)
             if (L.dsel == 3) MXS_SWEEP_HUB(3);
@@ -403,21 +408,21 @@ struct Engine : EngineBase {
 #define MXS_SWEEP(DS)                                                                                          \
     do {                                                                                                        \
         if (streaming) {                                                                                        \
-            if (a.sched) hipLaunchKernelGGL((k_sweep<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);   \
-            else hipLaunchKernelGGL((k_sweep<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);          \
+            if (a.sched) MXS_LAUNCH((k_sweep<T, DS, NT_STREAMING, true>), grid, block, 0, stream, a);   \
+            else MXS_LAUNCH((k_sweep<T, DS, NT_STREAMING, false>), grid, block, 0, stream, a);          \
         } else {                                                                                                \
-            if (a.sched) hipLaunchKernelGGL((k_sweep<T, DS, MXS_NT, true>), grid, block, 0, stream, a);         \
-            else hipLaunchKernelGGL((k_sweep<T, DS, MXS_NT, false>), grid, block, 0, stream, a);                \
+            if (a.sched) MXS_LAUNCH((k_sweep<T, DS, MXS_NT, true>), grid, block, 0, stream, a);         \
+            else MXS_LAUNCH((k_sweep<T, DS, MXS_NT, false>), grid, block, 0, stream, a);                \
         }                                                                                                       \
     } while (0)
             switch (L.dsel) {
                 case 2:  // its own kernel (SGPR budget, kernels.h)
                     if (streaming) {
-                        if (a.sched) hipLaunchKernelGGL((k_sweep_d2<T, NT_STREAMING, true>), grid, block, 0, stream, a);
-                        else hipLaunchKernelGGL((k_sweep_d2<T, NT_STREAMING, false>), grid, block, 0, stream, a);
+                        if (a.sched) MXS_LAUNCH((k_sweep_d2<T, NT_STREAMING, true>), grid, block, 0, stream, a);
+                        else MXS_LAUNCH((k_sweep_d2<T, NT_STREAMING, false>), grid, block, 0, stream, a);
                     } else {
-                        if (a.sched) hipLaunchKernelGGL((k_sweep_d2<T, MXS_NT, true>), grid, block, 0, stream, a);
-                        else hipLaunchKernelGGL((k_sweep_d2<T, MXS_NT, false>), grid, block, 0, stream, a);
+                        if (a.sched) MXS_LAUNCH((k_sweep_d2<T, MXS_NT, true>), grid, block, 0, stream, a);
+                        else MXS_LAUNCH((k_sweep_d2<T, MXS_NT, false>), grid, block, 0, stream, a);
                     }
                     break;
                 case 3: MXS_SWEEP(3); break;
@@ -558,17 +563,17 @@ struct Engine : EngineBase {
 #define MXS_NARY_PACKED(AR, NJ, TT)                                                                        \
     do {                                                                                                    \
         if (AR == 3 && ls) {  /* kernels.h, nary_batch: LS */                                               \
-            if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, lds, st, a, d, cap);  \
-            else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, lds, st, a, d, cap);           \
-        } else if (a.tab_neg) hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, lds, st, a, d, cap);  \
-        else hipLaunchKernelGGL((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, lds, st, a, d, cap);           \
+            if (a.tab_neg) MXS_LAUNCH((k_factor_nary_packed<T, AR, NJ, TT, true, AR == 3>), grid, block, lds, st, a, d, cap);  \
+            else MXS_LAUNCH((k_factor_nary_packed<T, AR, NJ, TT, false, AR == 3>), grid, block, lds, st, a, d, cap);           \
+        } else if (a.tab_neg) MXS_LAUNCH((k_factor_nary_packed<T, AR, NJ, TT, true>), grid, block, lds, st, a, d, cap);  \
+        else MXS_LAUNCH((k_factor_nary_packed<T, AR, NJ, TT, false>), grid, block, lds, st, a, d, cap);           \
     } while (0)
 #define MXS_NARY_CASE(AR, NJ)                                                                              \
     case (AR) * 16 + (NJ):                                                                                  \
         if (nl.tab_type == TAB_I8) MXS_NARY_PACKED(AR, NJ, int8_t);                                         \
         else if (nl.tab_type == TAB_I16) MXS_NARY_PACKED(AR, NJ, int16_t);                                  \
         else if (nl.tab_type == TAB_F32) MXS_NARY_PACKED(AR, NJ, float);                                    \
-        else hipLaunchKernelGGL((k_factor_nary<T, AR, NJ>), grid, block, lds, st, a, d, cap);           \
+        else MXS_LAUNCH((k_factor_nary<T, AR, NJ>), grid, block, lds, st, a, d, cap);           \
         break;
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
@@ -594,12 +599,12 @@ struct Engine : EngineBase {
     int launch_wide(const SweepArgs<T>& a, hipStream_t ws) {
         if (!L.pack8_classes.empty() && pack8_host_group() < 0) {
             const ClassInfo& ci = L.classes[L.pack8_classes[0]];
-            hipLaunchKernelGGL((k_variable_pack8<T>), dim3((unsigned)((ci.count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ws, a,
+            MXS_LAUNCH((k_variable_pack8<T>), dim3((unsigned)((ci.count + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0, ws, a,
                                (const ClassInfo*)classes8.p);
             HIP_TRY(hipGetLastError());
         }
         if (!L.wide_blocks.empty()) {
-            hipLaunchKernelGGL((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
+            MXS_LAUNCH((k_variable_wide<T>), dim3((unsigned)L.wide_blocks.size()), dim3(WIDE_TPB), 0, ws, a,
                                (const WideBlock*)wide_blocks.p);
             HIP_TRY(hipGetLastError());
         }
@@ -613,6 +618,10 @@ struct Engine : EngineBase {
     //            the only work that depends on the halo exchange of the previous cycle)
     // A single-GPU engine has no phase-2 work.
     int launch_phase(int from, bool start, int phase) {
+        struct ChainScope {  // the set of independent launches this call enqueues
+            explicit ChainScope(bool on, bool first_free) { g_launch.chain = on; g_launch.flags = (on && first_free) ? hipExtAnyOrderLaunch : 0; }
+            ~ChainScope() { g_launch = LaunchChain{}; }
+        } chain_scope(any_order > 0 && !capturing, any_order == 3 && phase == 2);
         const SweepArgs<T> a = make_args(from, start, phase);
         if (phase == 3) {  // everything of the cycle; the cut factor blocks wait inside the sweep
             int rc = launch_sweep(a, L.n_blocks_fused);
@@ -631,7 +640,7 @@ struct Engine : EngineBase {
                 if (!factors_only) { rc = launch_wide(a, stream); if (rc) return rc; }
                 return vars_only ? MXS_OK : launch_nary(a, 0);
             }
-            const bool fork = overlap && !capturing && n_wide_launches() > 0 && !L.nary_launches.empty();
+            const bool fork = overlap && !capturing && n_wide_launches() > 0 && !L.nary_launches.empty() && any_order != 1 && any_order != 3;
             hipStream_t ws = stream;
             if (fork) {  // the side stream starts where the compute stream is now
                 HIP_TRY(hipEventRecord(ev_fork, stream));
@@ -819,6 +828,7 @@ struct Engine : EngineBase {
             const char* env = getenv("MAXSUM_NARY_OVERLAP");
             overlap = L.algorithmic_bytes >= ((int64_t)400 << 20);
             if (env && (env[0] == '0' || env[0] == '1')) overlap = env[0] == '1';
+            if (const char* e = getenv("MAXSUM_ANYORDER")) any_order = std::max(0, std::min(3, atoi(e)));
         }
         {   // the comm stream's kernels (pack, RCCL, unpack) go first whenever a slot frees up
             int lo = 0, hi = 0;

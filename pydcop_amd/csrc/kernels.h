@@ -26,6 +26,7 @@
 // -ffp-contract=off so no FMA contraction changes a rounding.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cmath>
 #include <cstdint>
@@ -36,6 +37,28 @@
 #include "layout.h"
 
 namespace mxs {
+
+// The launches of ONE cycle (or of one phase of a sharded cycle) read the buffers of cycle t-1 and write disjoint
+// records of cycle t: they do not depend on each other.  On one stream HIP still sets the AQL barrier bit of every
+// dispatch, so launch k + 1 starts only when launch k has drained -- a cycle of seven 5..20-us launches (SECP) pays
+// seven ramps and seven tails.  With `chain` set the engine's FIRST launch of a set keeps the barrier (it waits for
+// everything of the cycle before), every later one goes out with hipExtAnyOrderLaunch (no barrier bit): the command
+// processor hands out its workgroups as soon as the launch before has handed out its own, the way the workgroups of
+// one grid follow each other.  No events, no second stream.  The next set's first launch waits for all of them.
+struct LaunchChain {
+    unsigned flags = 0;   // of the next launch
+    bool chain = false;   // later launches of the set go out without the barrier bit
+};
+extern thread_local LaunchChain g_launch;
+#define MXS_LAUNCH(kernel, grid, block, lds, stream, ...)                                                        \
+    do {                                                                                                         \
+        if (mxs::g_launch.flags)                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, (std::uint32_t)(lds), stream, nullptr, nullptr,           \
+                                  mxs::g_launch.flags, __VA_ARGS__);                                             \
+        else                                                                                                     \
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                   \
+        if (mxs::g_launch.chain) mxs::g_launch.flags = hipExtAnyOrderLaunch;                                     \
+    } while (0)
 
 constexpr int SAME_COUNT = 4;  // maxsum.py:106
 #ifndef MXS_ASM_MIN

@@ -7,7 +7,9 @@
 #include <cmath>
 #include <cstring>
 #include <numeric>
+#include <map>
 #include <sstream>
+#include <tuple>
 
 namespace mxs {
 
@@ -37,6 +39,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.pack8_fused = !(f & 2097152);           // bit21: the lane-per-edge class of 5..8 values in a launch of its own
     o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
+    o.merge_types = !(f & 16777216);          // bit24: lane-grid groups of one shape stay split by storage type (A/B runs)
     o.small = !(f & 8388608);                 // bit23: no small-domain lane-group kernel (workgroup per factor instead)
     o.hub = !(f & 4194304);                   // bit22: no wave-per-64-edges class for hub variables (thread per variable instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
@@ -319,6 +322,46 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             k.own = (o0 && !o1) ? 1 : ((!o0 && o1) ? 2 : 0);
         }
         fkey[f] = k;
+    }
+    // Lane-grid groups (bin_box.h) of one SHAPE that differ only in storage type: a group whose launch would be latency-bound
+    // takes the next wider type a sibling group uses and rides in that launch -- every narrow type widens exactly.  The unary
+    // factors of a SECP instance came as three launches (double 20.8 us with the variable class riding, float 4.8, int8 4.7 of a
+    // 62-us cycle, profiles/r06_kernel_stats_secp_100k_f64_v4.csv) for tables of five entries.  The price is the wider image:
+    // merged while it costs at most BIN2_MERGE_BYTES more (2 us of streaming); the large PEAV groups stay apart.
+    if (L.opt.bin2 && L.opt.compact_tables && L.opt.merge_types) {
+        struct Stat { int64_t entries[4] = {0, 0, 0, 0}; int to[4] = {0, 1, 2, 3}; };
+        std::map<std::tuple<int, int, int>, Stat> stat;  // (group code, cut, own) -> table entries per storage type
+        auto bin2_key = [&](int f, std::tuple<int, int, int>& key, int& t) {
+            const FKey& k = fkey[f];
+            if (k.kind != K_F_NARY || !is_bin2(nary_code_box(k.D >> 2))) return false;
+            key = std::make_tuple(k.D >> 2, k.cut, k.own);
+            t = k.D & 3;
+            return true;
+        };
+        std::tuple<int, int, int> key;
+        int t = 0;
+        for (int f = 0; f < nF; ++f)
+            if (bin2_key(f, key, t)) stat[key].entries[t] += g.table_off[f + 1] - g.table_off[f];
+        auto bytes_of = [&](int tt) { return tt == TAB_FULL ? (int64_t)L.opt.word : (int64_t)tab_elem_bytes(tt); };
+        bool any = false;
+        for (auto& kv : stat) {
+            Stat& st = kv.second;
+            for (int n = TAB_I8; n > TAB_FULL; --n) {  // narrowest first: what moved up is weighed again with its new sibling
+                if (!st.entries[n]) continue;
+                int w = n - 1;
+                while (w >= TAB_FULL && !st.entries[w]) --w;
+                if (w < TAB_FULL) continue;
+                if (st.entries[n] * (bytes_of(w) - bytes_of(n)) > BIN2_MERGE_BYTES) continue;
+                st.entries[w] += st.entries[n];
+                st.entries[n] = 0;
+                for (int q = TAB_FULL; q <= TAB_I8; ++q)
+                    if (st.to[q] == n) st.to[q] = w;
+                any = true;
+            }
+        }
+        if (any)
+            for (int f = 0; f < nF; ++f)
+                if (bin2_key(f, key, t)) fkey[f].D = (fkey[f].D & ~3) | stat[key].to[t];
     }
     L.factor_i2e.resize(nF);
     std::iota(L.factor_i2e.begin(), L.factor_i2e.end(), 0);

@@ -419,6 +419,9 @@ inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 
 }
 // Sort code of a launch group: (box, arity, nj, waves) -- one kernel instantiation each.
 constexpr int nary_group_code(int box, int arity, int nj, int waves) { return ((box * 16 + arity) * 16 + nj) * 16 + waves; }
+constexpr int nary_code_box(int code) { return code >> 12; }
+// A lane-grid group moves to a sibling group's wider storage type while that costs at most this many bytes per cycle (layout.cpp)
+constexpr int64_t BIN2_MERGE_BYTES = (int64_t)8 << 20;
 // the (nj, waves) of the lane-packed / full-width kernels for R entries per value of the first variable
 constexpr int nary_classic_nj(int64_t R) { return (int)((R + BLOCK - 1) / BLOCK); }
 constexpr int nary_classic_waves(int64_t R) { return (int)(((R + nary_classic_nj(R) - 1) / nary_classic_nj(R) + 63) / 64); }
@@ -449,6 +452,7 @@ struct LayoutOptions {
     bool pack8_fused = true;     // ... as the first workgroups of the largest lane-grid factor launch instead of a launch of their own
     bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
     bool small = true;           // arity 3..5 over domains of at most 5 values with a narrow table use the lane-group kernel (small_box.h)
+    bool merge_types = true;     // small lane-grid groups of one shape share the wider sibling's storage type (and its launch)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool hub = true;             // variables beyond the packed / wide classes use the wave-per-64-edges class (K_V_HUB) instead of a thread each
     bool half_cut = true;        // a shard's cut binary factors compute only the message to their own variable

@@ -261,8 +261,8 @@ inline bool launch_factor_box3(const NaryLaunch& nl, const SweepArgs<T>& a, cons
     const dim3 grid((unsigned)((nl.count + BOX_WAVES - 1) / BOX_WAVES)), block((unsigned)(BOX_WAVES * 64));
 #define MXS_BOX_LAUNCH(TT, B0, B1, B2)                                                                              \
     do {                                                                                                             \
-        if (a.tab_neg) hipLaunchKernelGGL((k_factor_box3<T, TT, true, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);  \
-        else hipLaunchKernelGGL((k_factor_box3<T, TT, false, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);           \
+        if (a.tab_neg) MXS_LAUNCH((k_factor_box3<T, TT, true, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);  \
+        else MXS_LAUNCH((k_factor_box3<T, TT, false, B0, B1, B2>), grid, block, 0, stream, a, d, (int)nl.count);           \
         return true;                                                                                                 \
     } while (0)
     if (nl.tab_type == TAB_I8) {

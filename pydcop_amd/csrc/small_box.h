@@ -234,8 +234,8 @@ template <typename T, typename TT, int A>
 inline void launch_small_one(const SweepArgs<T>& a, const NaryDesc* d, int count, hipStream_t stream) {
     constexpr int FPB = SMALL_WAVES * (64 / small_group(A));
     const dim3 grid((unsigned)((count + FPB - 1) / FPB)), block((unsigned)(SMALL_WAVES * 64));
-    if (a.tab_neg) hipLaunchKernelGGL((k_factor_small<T, TT, true, A>), grid, block, 0, stream, a, d, count);
-    else hipLaunchKernelGGL((k_factor_small<T, TT, false, A>), grid, block, 0, stream, a, d, count);
+    if (a.tab_neg) MXS_LAUNCH((k_factor_small<T, TT, true, A>), grid, block, 0, stream, a, d, count);
+    else MXS_LAUNCH((k_factor_small<T, TT, false, A>), grid, block, 0, stream, a, d, count);
 }
 
 template <typename T, typename TT>
