@@ -143,7 +143,10 @@ typedef struct mxs_params {
                                 bit23 (8388608) no small-domain lane-group kernel for factors of arity 3..5
                                           (the workgroup-per-factor kernels instead; A/B runs)
                                 bit22 (4194304) no hub class: variables beyond the packed / wide classes
-                                          take one thread each (the round-5 behaviour; A/B runs)   */
+                                          take one thread each (the round-5 behaviour; A/B runs)
+                                bit24 (16777216) lane-grid groups of one shape stay split by storage type
+                                          (default: a small group takes the wider sibling's type and
+                                          rides in its launch; A/B runs)   */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;

@@ -12,10 +12,9 @@
 // remaining U = 2 or 3 TRAILING digits run through a fully unrolled loop: the lane's 25 (125) entries are ONE
 // record of the image, in registers before anything else, every digit of every entry is a compile-time
 // constant, and so the running minima towards the trailing variables are registers (U x 5 of them), the ones
-// towards the leading variables one scalar each.  Nothing crosses lanes before the last entry: then the trailing
-// minima meet in a DPP butterfly over the G lanes (quad swaps, row half mirror, row mirror, permlane16 swap), the
-// leading ones through LDS, and one lane per outgoing message ELEMENT runs apply_damping + the send rule
-// (maxsum.py:346-377).
+// towards the leading variables one scalar each.  Nothing crosses lanes before the last entry: then every lane's
+// partial minima go through LDS once, and one lane per outgoing message ELEMENT merges the partials of its element
+// and runs apply_damping + the send rule (maxsum.py:346-377).
 //
 // Arithmetic: the reference's expression, op for op -- for output i, sum_cost = ((0 + m_a[d_a]) + m_b[d_b]) + ..
 // over the OTHER variables in dimensions order, then `f_val + sum_cost` (maxsum.py:425-438).  The sums are
@@ -54,7 +53,9 @@ __global__ void __launch_bounds__(SMALL_WAVES * 64) k_factor_small(SweepArgs<T> 
     constexpr int RW = small_rec_bytes(A, (int)sizeof(TT)) / 4;       // dwords of a lane's record
     __shared__ T s_in[SMALL_WAVES][FPW][NP + 1];      // incoming V->F messages, +inf past a domain; [NP] = +inf (lanes not in use)
     __shared__ T s_lead[SMALL_WAVES][FPW][L][G];      // minima towards the leading variables, per lane
-    __shared__ T s_trail[SMALL_WAVES][FPW][U * P];    // minima towards the trailing variables (whole factor)
+    // minima towards the trailing variables, per lane: row = message element, column = lane; G + 1 columns, so that the element
+    // lanes -- one row each -- read different banks
+    __shared__ T s_trail[SMALL_WAVES][FPW][U * P][G + 1];
     const int wv = (int)threadIdx.x >> 6, lane = (int)threadIdx.x & 63;
     const int fw = lane / G, g = lane % G;
     const int f_wave = ((int)blockIdx.x * SMALL_WAVES + wv) * FPW;
@@ -138,27 +139,14 @@ __global__ void __launch_bounds__(SMALL_WAVES * 64) k_factor_small(SweepArgs<T> 
             else acc[i - L][xt[i - L]] = min2(acc[i - L][xt[i - L]], cand);
         });
     });
-    // the trailing minima of the factor: a butterfly over its G lanes (the lanes not in use hold +inf)
+    // The trailing minima of the factor: every lane's U * P partials go through LDS once and the element lane of a value merges
+    // the GA partials of its row.  (Until this commit: a DPP butterfly over the G lanes -- quad swaps, row half mirror, row
+    // mirror, permlane16 swap.  A 64-bit minimum takes no DPP operand: three VALU instructions per value and step, 228 of the
+    // 749 of the arity-4 kernel, which is bound by VALU issue.)  Lanes not in use store their +inf; nobody reads them.
 #pragma unroll
     for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int x = 0; x < P; ++x) {
-            T k = acc[u][x];
-            k = min2(k, dpp_mov<0xB1, 0xf>(k));   // quad_perm [1,0,3,2]
-            k = min2(k, dpp_mov<0x4E, 0xf>(k));   // quad_perm [2,3,0,1]
-            k = min2(k, dpp_mov<0x141, 0xf>(k));  // row_half_mirror: 8 lanes
-            if constexpr (G == 32) {
-                k = min2(k, dpp_mov<0x140, 0xf>(k));      // row_mirror: 16 lanes
-                k = min2(swap16_lo(k), swap16_hi(k));     // lanes l ^ 16: 32 lanes
-            }
-            acc[u][x] = k;
-        }
-    if (g == 0) {
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int x = 0; x < P; ++x) s_trail[wv][fw][u * P + x] = acc[u][x];
-    }
+        for (int x = 0; x < P; ++x) s_trail[wv][fw][u * P + x][g] = acc[u][x];
 #pragma unroll
     for (int i = 0; i < L; ++i) s_lead[wv][fw][i][g] = bl[i];
     __builtin_amdgcn_wave_barrier();
@@ -172,7 +160,11 @@ __global__ void __launch_bounds__(SMALL_WAVES * 64) k_factor_small(SweepArgs<T> 
         const int i = el_i[k], d = el_d[k];
         T m = pos_inf<T>();
         if (i >= L) {
-            m = s_trail[wv][fw][(i - L) * P + d];
+            const T* row = s_trail[wv][fw][(i - L) * P + d];
+            T m4[4] = {pos_inf<T>(), pos_inf<T>(), pos_inf<T>(), pos_inf<T>()};  // (four chains: the minimum is order-independent)
+#pragma unroll
+            for (int j = 0; j < GA; ++j) m4[j & 3] = min2(m4[j & 3], row[j]);
+            m = min2(min2(m4[0], m4[1]), min2(m4[2], m4[3]));
         } else if (i >= 0) {
             if constexpr (L == 1) {
                 m = s_lead[wv][fw][0][d];

@@ -201,10 +201,16 @@ def test_emu_lane_grid_takes_the_binary_factors_beyond_the_register_classes(emu_
     with MaxSumEngine(g, Params(layout_flags=524288), lib_path=emu_lib) as e:
         assert e.factor_kernels()["generic"] == g.n_factors
     peav = G.peav_like(40, 25, slots=10, max_length=4, max_resources_event=4, seed=55)
-    with MaxSumEngine(peav, Params(mode="max"), lib_path=emu_lib) as e:
+    with MaxSumEngine(peav, Params(mode="max", layout_flags=16777216), lib_path=emu_lib) as e:
         k, st = e.factor_kernels(), e.table_storage()
         assert k["lane_grid"] == peav.n_factors and k["generic"] == 0, k
         assert st["full"] > 0 and st["i16"] > 0, st          # real-valued utilities; 0 / -penalty equality tables
+        split_launches = e.cycle_bytes()[1]
+    # default: a small group takes the wider sibling's storage type and rides in its launch (layout.cpp, BIN2_MERGE_BYTES)
+    with MaxSumEngine(peav, Params(mode="max"), lib_path=emu_lib) as e:
+        k, st = e.factor_kernels(), e.table_storage()
+        assert k["lane_grid"] == peav.n_factors and k["generic"] == 0, k
+        assert st["full"] > 0 and st["i16"] == 0 and e.cycle_bytes()[1] < split_launches, st
     three = G.random_coloring(100, seed=1)
     with MaxSumEngine(three, Params(), lib_path=emu_lib) as e:
         assert e.factor_kernels()["reg_binary"] == three.n_factors
