@@ -750,15 +750,21 @@ __device__ __forceinline__ void variable_pack8_block(const SweepArgs<T>& a, cons
     // d outer / factors inner, as the reference sums (maxsum.py:607-610, 651-665): ONE accumulator runs through all of it
     T sum_cost = (T)0, best_c = (T)0;
     int best = 0;
+    // (a class of ONE domain size -- every variable of a SECP instance has five values -- stops at it: the elements past the
+    // domain are zeros, `sum_cost + 0` leaves sum_cost as it is -- it starts at +0 and so never is -0 --, their m[] is zeroed
+    // below and the selection skips them.  The bound is the class's, not the lane's: the cross-lane reads need whole waves.)
+    const int DU = ci.uni_D ? ci.uni_D : H;
     static_for<H>([&](auto dc) __attribute__((always_inline)) {
         constexpr int d = decltype(dc)::value;
         T bd = c[d], md = c[d];
-        for (int kk = 0; kk < deg; ++kk) {
-            const T x = __shfl(in[d], seg + kk, 64);
-            bd += x;                   // select_value: every factor
-            if (kk != k) {             // costs_for_factor: every factor but the target
-                sum_cost += x;
-                md += x;
+        if (d < DU) {
+            for (int kk = 0; kk < deg; ++kk) {
+                const T x = __shfl(in[d], seg + kk, 64);
+                bd += x;                   // select_value: every factor
+                if (kk != k) {             // costs_for_factor: every factor but the target
+                    sum_cost += x;
+                    md += x;
+                }
             }
         }
         m[d] = md;
