@@ -72,9 +72,12 @@ KERNEL_OF = {"meeting_50k": "k_factor_box3 + k_variable_wide (one cycle)",
                                  "first in its grid: ONE launch per cycle",
              "coloring_100k_scalefree": "k_sweep_hub (the sweep with the hub class on board: a workgroup per 128 edges of a hub variable)",
              "coloring_1m_scalefree": "k_sweep_hub (the sweep with the hub class on board: a workgroup per 128 edges of a hub variable)",
-             "secp_100k": "k_factor_nary (arity 3) + k_factor_nary_packed (arity 4, int16) + k_factor_bin x4 (unary / binary, "
-                          "k_variable_pack8 in the largest) (one cycle)",
-             "secp_100k_m4": "k_factor_nary_packed (arity 5 and 4, int16) + k_factor_nary (arity 3) + k_factor_bin x4 (one cycle)"}
+             "secp_100k": "k_factor_small (arity 3, arity 4: lane groups, int16 records) + k_factor_bin x2 (unary with the "
+                          "k_variable_pack8 workgroups first in its grid, binary) (one cycle)",
+             "secp_100k_m4": "k_factor_small (arity 3, 4, 5) + k_factor_bin x2 (one cycle)",
+             "secp_30k_m5": "k_factor_nary<MULTI> (arity 6, full-width tables in passes) + k_factor_small (arity 3, 4, 5) + k_factor_bin x2 (one cycle)",
+             "meeting_5k_d40": "k_factor_nary<MULTI> (40^3 full-width tables, two passes of 1 024 entries per value of the first variable) "
+                                "+ k_variable_wide (one cycle)"}
 # tables stored narrower than the arithmetic type (lossless): once the stored bytes of a cycle fall below this share of
 # the algorithmic bytes, the row LEADS with the stored-byte fraction (coloring_100k_d8 advertised 0.85 on
 # int8 tables it never moved at the arithmetic width); the other basis always rides beside it
@@ -166,6 +169,10 @@ def make_workload(name, scale=1, per_gpu=100_000):
         return G.secp_like(60_000, 40_000, 50_000, max_model_size=3, seed=0, names=False), "min"   # (arity 3-4, {0, 10000}), rules (arity 1-3)
     if name == "secp_100k_m4":       # --max_model_size 4: model constraints of arity 5 (3 125 entries)
         return G.secp_like(60_000, 40_000, 50_000, max_model_size=4, seed=0, names=False), "min"
+    if name == "secp_30k_m5":        # --max_model_size 5: model constraints of arity 6 (15 625 entries): the workgroup kernel in passes
+        return G.secp_like(18_000, 12_000, 15_000, max_model_size=5, seed=0, names=False), "min"   # (--workload only: slow to generate)
+    if name == "meeting_5k_d40":     # configs[4]'s model over 40 slots: 64 000-entry tables, 1 600 entries per value of the first
+        return G.meeting_like(5_000, dom=40, arity=3, seed=0, names=False), "max"   # variable -- two passes of the workgroup kernel
     if name == "coloring_100k_hard":
         return G.random_coloring(100_000, seed=0, variant="hard", names=False), "min"
     if name == "ising_1024":        # configs[2]

@@ -146,7 +146,10 @@ typedef struct mxs_params {
                                           take one thread each (the round-5 behaviour; A/B runs)
                                 bit24 (16777216) lane-grid groups of one shape stay split by storage type
                                           (default: a small group takes the wider sibling's type and
-                                          rides in its launch; A/B runs)   */
+                                          rides in its launch; A/B runs)
+                                bit25 (33554432) no multi-pass workgroup-per-factor kernel: tables of more than
+                                          1 024 entries per value of the first variable (arity 3 over more
+                                          than 32 values, ...) and arity 6 take a thread per edge (A/B runs)   */
 } mxs_params;
 
 typedef struct mxs_engine mxs_engine;

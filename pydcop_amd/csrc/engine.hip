@@ -575,6 +575,17 @@ struct Engine : EngineBase {
         else if (nl.tab_type == TAB_F32) MXS_NARY_PACKED(AR, NJ, float);                                    \
         else MXS_LAUNCH((k_factor_nary<T, AR, NJ>), grid, block, lds, st, a, d, cap);           \
         break;
+            if (nl.nj == NARY_NJ_MULTI) {  // full-width tables in passes of NARY_MAX_R entries per value of the first variable
+                switch (nl.arity) {
+                    case 3: MXS_LAUNCH((k_factor_nary<T, 3, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
+                    case 4: MXS_LAUNCH((k_factor_nary<T, 4, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
+                    case 5: MXS_LAUNCH((k_factor_nary<T, 5, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
+                    case 6: MXS_LAUNCH((k_factor_nary<T, 6, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
+                    default: return fail(MXS_E_STATE, "no multi-pass n-ary kernel for this arity");
+                }
+                HIP_TRY(hipGetLastError());
+                continue;
+            }
             switch (nl.arity * 16 + nl.nj) {
                 MXS_NARY_CASE(2, 1) MXS_NARY_CASE(2, 2) MXS_NARY_CASE(2, 3) MXS_NARY_CASE(2, 4)
                 MXS_NARY_CASE(3, 1) MXS_NARY_CASE(3, 2) MXS_NARY_CASE(3, 3) MXS_NARY_CASE(3, 4)

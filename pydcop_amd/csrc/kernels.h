@@ -1315,7 +1315,7 @@ __global__ void __launch_bounds__(BLOCK) k_sweep_timeline_hub(SweepArgs<T> a) {
 constexpr int NARY_MAX_SUMD = 1024;  // sum of the scope's domain sizes
 constexpr int NARY_MAX_R = 1024;     // BLOCK * NARY_NJ
 constexpr int NARY_MAX_NJ = NARY_MAX_R / BLOCK;
-constexpr int NARY_MAX_ARITY = 5;
+constexpr int NARY_MAX_ARITY = 6;
 
 template <typename T>
 struct OrdKey;
@@ -1538,7 +1538,7 @@ __device__ __forceinline__ void nary_divmod(int x, int D, uint32_t magic, int& q
     r = x - q * D;
 }
 
-// dig[j][1..A-1] = the mixed-radix digits (dimensions 1..A-1, last fastest) of q_j = tid + j * NT,
+// dig[j][1..A-1] = the mixed-radix digits (dimensions 1..A-1, last fastest) of q_j = tid + j * NT (`tid`: the lane's first q),
 // those of R - 1 where q_j is past the table.  Divisions for q_0 and for the block-uniform stride
 // NT only; q_j = q_(j-1) + NT is a digit-wise addition with carry.
 template <int A, int NJ>
@@ -1572,7 +1572,11 @@ __device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A],
 
 // blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
 // layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
-template <typename T, int A, int NJ>
+// MULTI (round 6): R beyond NJ * NT -- arity 3 over more than 32 values, arity 4 over more than 10, arity 5 over more than 5,
+// arity 6 (a SECP instance generated with --max_model_size 5: 5^6 entries) -- in PASSES of NJ * NT q's: a pass walks every d0
+// for its q's exactly as the single pass does; the minima of all passes meet in the same LDS keys (they are order-independent).
+// Up to round 5's end such factors took factor_generic: a thread per edge walking the whole table.
+template <typename T, int A, int NJ, bool MULTI = false>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs, int cap) {
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
@@ -1601,16 +1605,19 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
     const T* tab = a.tables + fd.tab_off;
+    const int n_full = D0 / UNR;  // batches without a masked d0
+    const int n_pass = MULTI ? (R + NJ * NT - 1) / (NJ * NT) : 1;
+    for (int ps = 0; ps < n_pass; ++ps) {
+    const int qb = ps * (NJ * NT);
     // own q's (clamped into the table so that every load is in range)
     int qc[NJ];
     bool live[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int q = tid + j * NT;
+        const int q = qb + tid + j * NT;
         live[j] = q < R;
         qc[j] = live[j] ? q : R - 1;
     }
-    const int n_full = D0 / UNR;  // batches without a masked d0
     T cur[UNR][NJ];
     if (n_full > 0) {  // first batch: requested before anything else, independent of the messages
 #pragma unroll
@@ -1618,6 +1625,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 #pragma unroll
             for (int j = 0; j < NJ; ++j) cur[u][j] = tab[(int64_t)u * R + qc[j]];
     }
+    if (ps == 0) {
     // stage the incoming messages, arm the minima (the table loads above are in flight)
 #pragma unroll
     for (int i = 0; i < A; ++i) {
@@ -1632,10 +1640,11 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     }
     if (tid < NARY_MAX_ARITY) s_nomatch[tid] = 0;
     __syncthreads();
+    }
     // per owned q: its digits' messages and the running minima for p >= 1
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
-    nary_digits<A, NJ>(tid, NT, Dm, mg, live, dig);
+    nary_digits<A, NJ>(qb + tid, NT, Dm, mg, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -1649,7 +1658,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
         for (int i = 1; i < A; ++i) s += ms[j][i];
         s0[j] = s;
     }
-    const bool all_live = R == NJ * NT;  // block-uniform
+    const bool all_live = MULTI ? qb + NJ * NT <= R : R == NJ * NT;  // block-uniform
     for (int b = 0; b < n_full; ++b) {
         const int d0 = b * UNR;
         T nxt[UNR][NJ];
@@ -1686,6 +1695,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 #pragma unroll
             for (int p = 1; p < A; ++p) atomicMin(&s_key[off[p] + dig[j][p]], OrdKey<T>::enc(acc[j][p]));
         }
+    }  // passes
     __syncthreads();
     // apply_damping + the send rule (maxsum.py:346-377), one thread per message ELEMENT so
     // that the previous messages arrive with one round of parallel loads.

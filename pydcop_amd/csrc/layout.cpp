@@ -40,6 +40,7 @@ LayoutOptions options_from_params(const mxs_params& p) {
     o.pack8 = !(f & 1048576);                 // bit20: variables of 5..8 values stay in the wide (workgroup-per-run) class
     o.bin2 = !(f & 524288);                   // bit19: no lane-grid kernel for binary / unary factors (generic instead)
     o.merge_types = !(f & 16777216);          // bit24: lane-grid groups of one shape stay split by storage type (A/B runs)
+    o.nary_multi = !(f & 33554432);           // bit25: no multi-pass workgroup kernel (tables beyond 1 024 entries per value of the first variable and arity 6: generic)
     o.small = !(f & 8388608);                 // bit23: no small-domain lane-group kernel (workgroup per factor instead)
     o.hub = !(f & 4194304);                   // bit22: no wave-per-64-edges class for hub variables (thread per variable instead)
     o.tile_bytes = -1;                                   // tiled factor order: decided per instance (build_layout)
@@ -257,7 +258,7 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
             else if (small_type(f, e0, ar) != TAB_FULL) {
                 // arity 3..5, every domain <= SMALL_P, a narrow storage type: a lane group per factor (small_box.h)
                 k = FKey{K_F_NARY, nary_group_code(SMALL_BASE, ar, 0, SMALL_WAVES) * 4 + small_type(f, e0, ar)};
-            } else if (L.opt.nary && ar >= 2 && ar <= 5) {
+            } else if (L.opt.nary && ar >= 2 && ar <= NARY_MULTI_MAX_ARITY) {
                 // workgroup-per-factor kernel: 64 <= R <= 1024 (R = product of the
                 // dimensions after the first), staged messages fit its LDS arrays
                 int64_t R = 1, sumd = 0;
@@ -269,7 +270,12 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                 // one launch group per (arity, R / BLOCK rounded up): compile-time loop bounds
                 // (round 5: arity >= 3 also below 64 entries per value of the first variable -- one wave with idle lanes beats
                 // the thread-per-edge scalar loops of the generic class by far -- as long as the table has 64 entries at all)
-                if ((R >= 64 || (ar >= 3 && (int64_t)D0 * R >= 64)) && R <= 1024 && sumd <= 1024) {
+                if (L.opt.nary_multi && (R > 1024 || ar > 5) && R <= NARY_MULTI_MAX_R && sumd <= 1024 && (int64_t)D0 * R >= 64) {
+                    // beyond one pass of the workgroup's lanes (arity 3 over more than 32 values, arity 4 over more than 10,
+                    // arity 5 over more than 5) or arity 6: the full-width kernel in passes of 1 024 entries per value of
+                    // the first variable (kernels.h, k_factor_nary<.., MULTI>)
+                    k = FKey{K_F_NARY, nary_group_code(0, ar, NARY_NJ_MULTI, BLOCK / 64) * 4 + TAB_FULL};
+                } else if (ar <= 5 && (R >= 64 || (ar >= 3 && (int64_t)D0 * R >= 64)) && R <= 1024 && sumd <= 1024) {
                     const int nj = nary_classic_nj(R);
                     const int waves = nary_classic_waves(R);  // 1..4
                     // storage type of this factor's table (one launch group = one kernel

@@ -420,6 +420,10 @@ inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 
 // Sort code of a launch group: (box, arity, nj, waves) -- one kernel instantiation each.
 constexpr int nary_group_code(int box, int arity, int nj, int waves) { return ((box * 16 + arity) * 16 + nj) * 16 + waves; }
 constexpr int nary_code_box(int code) { return code >> 12; }
+// NaryLaunch::nj of the multi-pass groups of the full-width workgroup kernel (4 entries per lane and pass, BLOCK lanes)
+constexpr int NARY_NJ_MULTI = 15;
+constexpr int NARY_MULTI_MAX_ARITY = 6;
+constexpr int64_t NARY_MULTI_MAX_R = 65536;   // the lanes' digit arithmetic divides by multiply-high: exact well beyond this
 // A lane-grid group moves to a sibling group's wider storage type while that costs at most this many bytes per cycle (layout.cpp)
 constexpr int64_t BIN2_MERGE_BYTES = (int64_t)8 << 20;
 // the (nj, waves) of the lane-packed / full-width kernels for R entries per value of the first variable
@@ -452,6 +456,7 @@ struct LayoutOptions {
     bool pack8_fused = true;     // ... as the first workgroups of the largest lane-grid factor launch instead of a launch of their own
     bool pack8 = true;           // variables of 5..8 values and degree <= 64 use the lane-per-edge kernel (k_variable_pack8)
     bool small = true;           // arity 3..5 over domains of at most 5 values with a narrow table use the lane-group kernel (small_box.h)
+    bool nary_multi = true;      // tables beyond one pass of the workgroup-per-factor kernel, and arity 6, run it in passes (generic otherwise)
     bool merge_types = true;     // small lane-grid groups of one shape share the wider sibling's storage type (and its launch)
     bool bin2 = true;            // binary / unary tables beyond the register classes use the lane-grid kernel (bin_box.h)
     bool hub = true;             // variables beyond the packed / wide classes use the wave-per-64-edges class (K_V_HUB) instead of a thread each

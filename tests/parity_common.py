@@ -265,6 +265,18 @@ def parity_cases():
         ("hard_secp_small_m4_inf", lambda: hard(G.secp_like(50, 40, 40, max_model_size=4, seed=85), 85, 0.2, np.inf), {}),
         ("hard_wide_coloring6_deg30_max_all", lambda: hard(G.random_coloring(60, avg_degree=30, n_colors=6, seed=47), 47, 0.6,
                                                            -np.inf), {"mode": "max", "start_messages": "all"}),
+        # round 6: the workgroup-per-factor kernel in PASSES (kernels.h k_factor_nary<.., MULTI>): more than 1 024 entries per value
+        # of the first variable -- arity 3 over 33+ values, arity 4 over 11+, arity 5 over 6+ -- and arity 6, a SECP instance
+        # generated with --max_model_size 5 among them (thread per edge before)
+        ("multi_arity3_d40_max", lambda: G.meeting_like(10, n_factors=5, dom=40, arity=3, seed=86), {"mode": "max"}),
+        ("multi_arity3_d64_float_all", lambda: G.meeting_like(8, n_factors=3, dom=64, arity=3, seed=87, float_tables=True),
+         {"mode": "max", "start_messages": "all"}),
+        ("multi_arity4_d11", lambda: G.meeting_like(12, n_factors=4, dom=11, arity=4, seed=88), {"damping_nodes": "factors"}),
+        ("multi_arity5_d6_max", lambda: G.meeting_like(14, n_factors=4, dom=6, arity=5, seed=89), {"mode": "max"}),
+        ("multi_arity6_secp_m5", lambda: G.secp_like(50, 40, 40, max_model_size=5, seed=90), {}),
+        ("multi_arity6_mixed_dims", lambda: G.random_mixed(30, 12, seed=91, max_arity=6, dom_choices=(2, 3, 4, 7)), {"start_messages": "all"}),
+        ("hard_multi_arity3_d40_neg_inf", lambda: hard(G.meeting_like(10, n_factors=5, dom=40, arity=3, seed=92), 92, 0.9, -np.inf),
+         {"mode": "max"}),
     ]
 
 

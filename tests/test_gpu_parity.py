@@ -108,6 +108,10 @@ _FULL = {
     # _m4 = --max_model_size 4: model constraints of arity 5 on the workgroup-per-factor kernels
     "secp_100k": (lambda: G.secp_like(60_000, 40_000, 50_000, max_model_size=3, seed=0, names=False), "min", [1, 5, 34]),
     "secp_100k_m4": (lambda: G.secp_like(60_000, 40_000, 50_000, max_model_size=4, seed=0, names=False), "min", [1, 5, 20]),
+    # round 6: the workgroup-per-factor kernel in passes (k_factor_nary<.., MULTI>): SECP with --max_model_size 5 (arity 6, 15 625
+    # entries) and configs[4]'s model over 40 slots (64 000-entry tables: 1 600 entries per value of the first variable)
+    "secp_30k_m5": (lambda: G.secp_like(18_000, 12_000, 15_000, max_model_size=5, seed=0, names=False), "min", [1, 5, 20]),
+    "meeting_5k_d40": (lambda: G.meeting_like(5_000, dom=40, arity=3, seed=0, names=False), "max", [1, 3, 22]),
 }
 _full_cache = {}
 
