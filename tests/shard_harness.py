@@ -38,6 +38,8 @@ def make_case(name):
         return G.scalefree_coloring(1500, m=3, seed=21, names=False), {}
     if name == "secp":           # small-domain lane-group kernel + arity-5 factors cut across shards
         return G.secp_like(120, 80, 100, max_model_size=4, seed=22, names=False), {"start_messages": "all"}
+    if name == "multi":          # arity-6 models (the workgroup kernel in passes, round 6) cut across shards
+        return G.secp_like(70, 50, 50, max_model_size=5, seed=23, names=False), {}
     if name == "coloring_50k":
         return G.random_coloring(50_000, avg_degree=4, seed=1, names=False), {}
     raise ValueError(name)

@@ -127,7 +127,7 @@ def _check_against_single(g, kw, k, lib_path, device="cpu", steps=(0, 1, 2, 7, 2
     many.close()
 
 
-@pytest.mark.parametrize("case", ["coloring", "mixed_max", "ising", "coloring_deg9", "scalefree", "secp"])
+@pytest.mark.parametrize("case", ["coloring", "mixed_max", "ising", "coloring_deg9", "scalefree", "secp", "multi"])
 @pytest.mark.parametrize("k", [2, 5])
 def test_local_shards_equal_single_engine_emu(case, k, emu_lib):
     g, kw = make_case(case)
