@@ -27,7 +27,7 @@ f=$(find $OUT/p -name "*kernel_stats*.csv" | head -1); [ -n "$f" ] && cp "$f" $O
 rm -rf $OUT/p
 if [ "$2" = "full" ]; then
 echo "== kernel traces of the round's new rows (serial launches)"
-for spec in coloring_100k_scalefree:f64 coloring_100k_scalefree:f32 coloring_1m_scalefree:f64 secp_100k:f64 secp_100k:f32 secp_100k_m4:f64 secp_100k_m4:f32; do
+for spec in coloring_100k_scalefree:f64 coloring_100k_scalefree:f32 coloring_1m_scalefree:f64 secp_100k:f64 secp_100k:f32 secp_100k_m4:f64 secp_100k_m4:f32 peav_50k:f64 secp_30k_m5:f64 meeting_5k_d40:f64; do
   IFS=: read wl dt <<< "$spec"
   rm -rf $OUT/p
   MAXSUM_NARY_OVERLAP=0 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/p -o trace -- python3 $R/bench.py --workload $wl --dtype $dt --steps 100 --warmup 10 --no-cpu-baseline --rows-file /tmp/rows.json > $OUT/prof_${wl}_$dt.log 2>&1
@@ -36,7 +36,7 @@ for spec in coloring_100k_scalefree:f64 coloring_100k_scalefree:f32 coloring_1m_
 done
 echo "== PMC traffic of the SECP rows on the closing code"
 cd $R
-bash scripts/gpu_pmc.sh $TAG/pmc "FETCH_SIZE WRITE_SIZE" "secp_100k:f64:0 secp_100k:f32:0 secp_100k_m4:f64:0 secp_100k_m4:f32:0" > $OUT/pmc.log 2>&1
+bash scripts/gpu_pmc.sh $TAG/pmc "FETCH_SIZE WRITE_SIZE" "secp_100k:f64:0 secp_100k:f32:0 secp_100k_m4:f64:0 secp_100k_m4:f32:0 meeting_5k_d40:f64:0" > $OUT/pmc.log 2>&1
 echo "== the stated multi-GPU prediction, re-measured on this code"
 timeout 900 python3 tools/scale_prediction.py --out $OUT/scale_prediction.json > $OUT/scale_prediction.log 2>&1
 grep '^{"n"' $OUT/scale_prediction.log | python3 -c "
