@@ -235,6 +235,7 @@ struct Engine : EngineBase {
     // stream: the wide variable launches ride in the chain), 2 on beside the side stream, 3 = 1 + the cut classes of a
     // sharded cycle chained behind the halo wait.  $MAXSUM_ANYORDER; eager launches only.
     int any_order = 0;
+    bool wide_last = false;
     bool streaming = false;  // non-temporal stores / index loads in the sweep (cycle larger than the Infinity Cache)
     hipEvent_t ev_p1 = nullptr;    // phase 1 of the current cycle enqueued (variables are done)
     hipEvent_t ev_halo = nullptr;  // ghost messages of the last exchange are in place
@@ -658,6 +659,15 @@ struct Engine : EngineBase {
                 HIP_TRY(hipStreamWaitEvent(side, ev_fork, 0));
                 ws = side;
             }
+            if (fork && wide_last) {  // ($MAXSUM_WIDE_LAST=1, A/B runs: the factor launches reach the machine first)
+                rc = launch_nary(a, 0);
+                if (rc) return rc;
+                rc = launch_wide(a, ws);
+                if (rc) return rc;
+                HIP_TRY(hipEventRecord(ev_join, side));
+                HIP_TRY(hipStreamWaitEvent(stream, ev_join, 0));
+                return MXS_OK;
+            }
             rc = launch_wide(a, ws);
             if (rc) return rc;
             if (fork) HIP_TRY(hipEventRecord(ev_join, side));
@@ -822,7 +832,14 @@ struct Engine : EngineBase {
         }
         HIP_TRY(hipEventCreate(&ev0));
         HIP_TRY(hipEventCreate(&ev1));
-        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        {   // $MAXSUM_SIDE_PRIO = hi / lo: the side stream's priority against the compute stream's (A/B runs; default: the same)
+            int lo = 0, hi = 0;
+            HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            const char* e = getenv("MAXSUM_SIDE_PRIO");
+            if (e && (e[0] == 'h' || e[0] == 'l')) HIP_TRY(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, e[0] == 'h' ? hi : lo));
+            else HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            if (const char* w = getenv("MAXSUM_WIDE_LAST")) wide_last = w[0] == '1';
+        }
         if (const char* e = getenv("MAXSUM_NARY_STREAMS")) nary_streams = std::max(1, std::min(3, atoi(e)));
         for (int q = 1; q < nary_streams; ++q) {
             HIP_TRY(hipStreamCreateWithFlags(&nstream[q], hipStreamNonBlocking));
