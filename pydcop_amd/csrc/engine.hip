@@ -577,13 +577,25 @@ struct Engine : EngineBase {
         else MXS_LAUNCH((k_factor_nary<T, AR, NJ>), grid, block, lds, st, a, d, cap);           \
         break;
             if (nl.nj == NARY_NJ_MULTI) {  // full-width tables in passes of NARY_MAX_R entries per value of the first variable
+#define MXS_NARY_MULTI(AR)                                                                                                     \
+    case AR:                                                                                                                   \
+        if (nl.tab_type == TAB_I8) {                                                                                           \
+            if (a.tab_neg) MXS_LAUNCH((k_factor_nary<T, AR, NARY_MAX_NJ, true, int8_t, true>), grid, block, lds, st, a, d, cap);    \
+            else MXS_LAUNCH((k_factor_nary<T, AR, NARY_MAX_NJ, true, int8_t, false>), grid, block, lds, st, a, d, cap);             \
+        } else if (nl.tab_type == TAB_I16) {                                                                                   \
+            if (a.tab_neg) MXS_LAUNCH((k_factor_nary<T, AR, NARY_MAX_NJ, true, int16_t, true>), grid, block, lds, st, a, d, cap);   \
+            else MXS_LAUNCH((k_factor_nary<T, AR, NARY_MAX_NJ, true, int16_t, false>), grid, block, lds, st, a, d, cap);            \
+        } else if (nl.tab_type == TAB_FULL) {                                                                                  \
+            MXS_LAUNCH((k_factor_nary<T, AR, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap);                             \
+        } else {                                                                                                               \
+            return fail(MXS_E_STATE, "no multi-pass n-ary kernel for this storage type");                                      \
+        }                                                                                                                      \
+        break;
                 switch (nl.arity) {
-                    case 3: MXS_LAUNCH((k_factor_nary<T, 3, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
-                    case 4: MXS_LAUNCH((k_factor_nary<T, 4, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
-                    case 5: MXS_LAUNCH((k_factor_nary<T, 5, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
-                    case 6: MXS_LAUNCH((k_factor_nary<T, 6, NARY_MAX_NJ, true>), grid, block, lds, st, a, d, cap); break;
+                    MXS_NARY_MULTI(3) MXS_NARY_MULTI(4) MXS_NARY_MULTI(5) MXS_NARY_MULTI(6)
                     default: return fail(MXS_E_STATE, "no multi-pass n-ary kernel for this arity");
                 }
+#undef MXS_NARY_MULTI
                 HIP_TRY(hipGetLastError());
                 continue;
             }
@@ -754,7 +766,8 @@ struct Engine : EngineBase {
                     it.d.tab_off = L.f_tab_base[fi];
                     int64_t R = 1;
                     for (int i = 1; i < nl.arity; ++i) R *= it.d.dom[i];
-                    it.code = nary_group_code(0, nl.arity, nary_classic_nj(R), nary_classic_waves(R));
+                    // (a multi-pass group keeps its kernel: only the storage type changes)
+                    if (!(nl.box == 0 && nl.nj == NARY_NJ_MULTI)) it.code = nary_group_code(0, nl.arity, nary_classic_nj(R), nary_classic_waves(R));
                 }
                 items.push_back(it);
             }

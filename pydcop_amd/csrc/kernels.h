@@ -1576,8 +1576,13 @@ __device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A],
 // arity 6 (a SECP instance generated with --max_model_size 5: 5^6 entries) -- in PASSES of NJ * NT q's: a pass walks every d0
 // for its q's exactly as the single pass does; the minima of all passes meet in the same LDS keys (they are order-independent).
 // Up to round 5's end such factors took factor_generic: a thread per edge walking the whole table.
-template <typename T, int A, int NJ, bool MULTI = false>
+// TT / NEG (MULTI only): the table read from a NARROW ROW-MAJOR image in ctables (int8 / int16 entries at their row-major index: a
+// wave reads 64 consecutive entries per load) instead of the full-width array -- a factor of this class has at least 1 024 entries
+// per value of its first variable, eight bytes each at full width; every entry is widened (and negated in max mode: narrow
+// images hold un-negated values) before anything is computed with it, as in k_factor_nary_packed.
+template <typename T, int A, int NJ, bool MULTI = false, typename TT = T, bool NEG = false>
 __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const NaryDesc* descs, int cap) {
+    static_assert(MULTI || (std::is_same<TT, T>::value && !NEG), "narrow row-major images: the multi-pass groups only");
     typedef typename OrdKey<T>::U U;
     constexpr int UNR = NARY_UNR;
     // Dynamic LDS, sized by the launch for its group's largest scope (3 arrays of `cap` elements: a block of 5 x 5 x 5 factors
@@ -1604,7 +1609,14 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 #pragma unroll
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
-    const T* tab = a.tables + fd.tab_off;
+    const TT* tab = std::is_same<TT, T>::value ? (const TT*)(a.tables + fd.tab_off) : (const TT*)(a.ctables + fd.tab_off);
+    auto entry = [&](int64_t k) __attribute__((always_inline)) {
+        if constexpr (std::is_same<TT, T>::value) return tab[k];
+        else {
+            const T v = (T)(int)tab[k];
+            return NEG ? -v : v;
+        }
+    };
     const int n_full = D0 / UNR;  // batches without a masked d0
     const int n_pass = MULTI ? (R + NJ * NT - 1) / (NJ * NT) : 1;
     for (int ps = 0; ps < n_pass; ++ps) {
@@ -1623,7 +1635,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 #pragma unroll
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) cur[u][j] = tab[(int64_t)u * R + qc[j]];
+            for (int j = 0; j < NJ; ++j) cur[u][j] = entry((int64_t)u * R + qc[j]);
     }
     if (ps == 0) {
     // stage the incoming messages, arm the minima (the table loads above are in flight)
@@ -1666,7 +1678,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) nxt[u][j] = tab[(int64_t)(d0 + UNR + u) * R + qc[j]];
+                for (int j = 0; j < NJ; ++j) nxt[u][j] = entry((int64_t)(d0 + UNR + u) * R + qc[j]);
         } else {
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
@@ -1686,7 +1698,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
         for (int u = 0; u < UNR; ++u)
 #pragma unroll
             for (int j = 0; j < NJ; ++j)
-                cur[u][j] = tab[(int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]];
+                cur[u][j] = entry((int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]);
         nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
     }
 #pragma unroll

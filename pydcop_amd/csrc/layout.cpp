@@ -274,7 +274,13 @@ std::string build_layout(const mxs_graph& g, const mxs_params& p, Layout& L) {
                     // beyond one pass of the workgroup's lanes (arity 3 over more than 32 values, arity 4 over more than 10,
                     // arity 5 over more than 5) or arity 6: the full-width kernel in passes of 1 024 entries per value of
                     // the first variable (kernels.h, k_factor_nary<.., MULTI>)
-                    k = FKey{K_F_NARY, nary_group_code(0, ar, NARY_NJ_MULTI, BLOCK / 64) * 4 + TAB_FULL};
+                    // integer tables an int8 / int16 holds: a narrow row-major image (an eighth / a quarter of the bytes)
+                    int t = TAB_FULL;
+                    if (L.opt.compact_tables) {
+                        const int cand = narrowest_tab_type(g.tables + g.table_off[f], g.table_off[f + 1] - g.table_off[f], L.opt.word);
+                        if (cand == TAB_I8 || cand == TAB_I16) t = cand;
+                    }
+                    k = FKey{K_F_NARY, nary_group_code(0, ar, NARY_NJ_MULTI, BLOCK / 64) * 4 + t};
                 } else if (ar <= 5 && (R >= 64 || (ar >= 3 && (int64_t)D0 * R >= 64)) && R <= 1024 && sumd <= 1024) {
                     const int nj = nary_classic_nj(R);
                     const int waves = nary_classic_waves(R);  // 1..4

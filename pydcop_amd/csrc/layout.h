@@ -225,6 +225,10 @@ constexpr int bin2_shape_for(int d0, int d1, bool unary) {
     }
     return best;
 }
+// NaryLaunch::nj of the multi-pass groups of the full-width workgroup kernel (4 entries per lane and pass, BLOCK lanes)
+constexpr int NARY_NJ_MULTI = 15;
+constexpr int NARY_MULTI_MAX_ARITY = 6;
+constexpr int64_t NARY_MULTI_MAX_R = 65536;   // the lanes' digit arithmetic divides by multiply-high: exact well beyond this
 // Where entry k (row-major) of a workgroup-per-factor table lives in its narrow image.
 struct NaryPlace {
     int32_t box;          // 0: lane-packed slots (nary_packed_pos), else the box shape id (>= BIN2_BASE: lane grid of a binary table)
@@ -234,9 +238,10 @@ struct NaryPlace {
     int32_t d1, d2;       // box: domain sizes of dimensions 1 and 2
     int32_t arity;        // small-domain layout: the scope
     int32_t dom[6];
+    int32_t multi;        // box == 0: a multi-pass group -- the narrow image is the row-major table itself
 };
 constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
-    if (p.box == 0) return nary_packed_pos(k / p.R, k % p.R, p.nt, p.slot, p.elem);
+    if (p.box == 0) return p.multi ? k * p.elem : nary_packed_pos(k / p.R, k % p.R, p.nt, p.slot, p.elem);
     if (is_small(p.box)) {
         int x[6] = {0, 0, 0, 0, 0, 0};
         int64_t rem = k;
@@ -267,7 +272,7 @@ constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
 }
 // bytes of the narrow image of one factor (D0 = its first domain size)
 constexpr int64_t nary_place_bytes(const NaryPlace& p, int D0) {
-    if (p.box == 0) return (int64_t)D0 * p.nt * p.slot;
+    if (p.box == 0) return p.multi ? ((int64_t)D0 * p.R * p.elem + 15) / 16 * 16 : (int64_t)D0 * p.nt * p.slot;
     if (is_small(p.box)) return ((int64_t)small_pow(small_lead(p.arity)) * small_rec_bytes(p.arity, p.elem) + 15) / 16 * 16;
     if (is_bin2(p.box)) {
         const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
@@ -408,6 +413,7 @@ inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 
     p.elem = nl.tab_type == TAB_FULL ? word : tab_elem_bytes(nl.tab_type);
     p.nt = nl.threads;
     p.slot = nary_slot_bytes(nl.nj > 0 ? nl.nj : 1, p.elem);
+    p.multi = nl.box == 0 && nl.nj == NARY_NJ_MULTI;
     int64_t R = 1;
     for (int i = 1; i < (d.arity & 255); ++i) R *= d.dom[i];
     p.R = (int32_t)R;
@@ -420,10 +426,6 @@ inline NaryPlace nary_place(const NaryLaunch& nl, const NaryDesc& d, int word = 
 // Sort code of a launch group: (box, arity, nj, waves) -- one kernel instantiation each.
 constexpr int nary_group_code(int box, int arity, int nj, int waves) { return ((box * 16 + arity) * 16 + nj) * 16 + waves; }
 constexpr int nary_code_box(int code) { return code >> 12; }
-// NaryLaunch::nj of the multi-pass groups of the full-width workgroup kernel (4 entries per lane and pass, BLOCK lanes)
-constexpr int NARY_NJ_MULTI = 15;
-constexpr int NARY_MULTI_MAX_ARITY = 6;
-constexpr int64_t NARY_MULTI_MAX_R = 65536;   // the lanes' digit arithmetic divides by multiply-high: exact well beyond this
 // A lane-grid group moves to a sibling group's wider storage type while that costs at most this many bytes per cycle (layout.cpp)
 constexpr int64_t BIN2_MERGE_BYTES = (int64_t)8 << 20;
 // the (nj, waves) of the lane-packed / full-width kernels for R entries per value of the first variable

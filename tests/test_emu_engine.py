@@ -88,7 +88,7 @@ def test_emu_errors(emu_lib):
 
 @pytest.mark.parametrize("case", [c for c in parity_cases() if c[0] in
                                   ("coloring3_soft", "ising", "mixed_max_all", "nary_meeting_d8", "nary_mixed_dims", "bin2_coloring8_i8",
-                                   "bin2_peav_slots10", "bin2_domains_to_64_int_max")],
+                                   "bin2_peav_slots10", "bin2_domains_to_64_int_max", "multi_arity3_d40_max", "multi_arity6_secp_m5")],
                          ids=lambda c: c[0])
 def test_emu_table_updates(case, emu_lib, oracle_built):
     name, make, kw = case
