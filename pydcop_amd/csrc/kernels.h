@@ -1570,6 +1570,13 @@ __device__ __forceinline__ void nary_digits(int tid, int NT, const int (&Dm)[A],
         for (int i = 1; i < A; ++i) dig[j][i] = live[j] ? dig[j][i] : Dm[i] - 1;
 }
 
+// entry j of a run of narrow entries held in dwords (little endian), widened exactly
+template <typename T, typename TT>
+__device__ __forceinline__ T nary_slot_entry_fwd(const uint32_t* w, int j) {
+    if constexpr (sizeof(TT) == 1) return (T)(int)(int8_t)(uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+    else return (T)(int)(int16_t)(uint16_t)(w[j >> 1] >> (16 * (j & 1)));
+}
+
 // blockDim.x = NT threads (a multiple of 64, <= BLOCK) with R <= NJ * NT: the launch groups of
 // layout.cpp pick NT so that, whenever R allows it, every lane owns exactly NJ live q's.
 // MULTI (round 6): R beyond NJ * NT -- arity 3 over more than 32 values, arity 4 over more than 10, arity 5 over more than 5,
@@ -1610,11 +1617,33 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     for (int i = 1; i < A; ++i) R *= Dm[i];
     const int D0 = Dm[0];
     const TT* tab = std::is_same<TT, T>::value ? (const TT*)(a.tables + fd.tab_off) : (const TT*)(a.ctables + fd.tab_off);
+    // RUN (narrow images): a lane owns NJ CONSECUTIVE q's of a pass -- its NJ entries of a table row are one 4- / 8-byte load (four
+    // byte loads with the strided assignment below: meeting_5k_d40 341 -> 330 us, profiles/r06_multi_pass_nary_v3.txt); full-width tables keep
+    // q = tid + j * NT, where a wave's load instruction reads 64 consecutive entries.
+    constexpr bool RUN = !std::is_same<TT, T>::value;
     auto entry = [&](int64_t k) __attribute__((always_inline)) {
-        if constexpr (std::is_same<TT, T>::value) return tab[k];
+        if constexpr (!RUN) return tab[k];
         else {
             const T v = (T)(int)tab[k];
             return NEG ? -v : v;
+        }
+    };
+    // the lane's NJ entries of the row that starts at entry `row` (run_ok: its q's are all inside the row)
+    // (no branch: a run that crosses the end of its row reads on into the next row -- behind the last row into the 16 bytes of
+    // slack every such image ends with, layout.h nary_place_bytes -- and those entries belong to q's that are not live: masked)
+    auto load_row = [&](int64_t row, const int (&qcl)[NJ], bool, T (&out)[NJ]) __attribute__((always_inline)) {
+        if constexpr (RUN) {
+            constexpr int BYTES = NJ * (int)sizeof(TT);
+            uint32_t w[(BYTES + 3) / 4];
+            __builtin_memcpy(w, (const uint8_t*)tab + (row + qcl[0]) * (int64_t)sizeof(TT), BYTES);  // (any byte offset: gfx950 reads unaligned dwords)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const T v = nary_slot_entry_fwd<T, TT>(w, j);
+                out[j] = NEG ? -v : v;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) out[j] = entry(row + qcl[j]);
         }
     };
     const int n_full = D0 / UNR;  // batches without a masked d0
@@ -1626,16 +1655,15 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     bool live[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-        const int q = qb + tid + j * NT;
+        const int q = RUN ? qb + tid * NJ + j : qb + tid + j * NT;
         live[j] = q < R;
         qc[j] = live[j] ? q : R - 1;
     }
+    const bool run_ok = RUN && live[NJ - 1];
     T cur[UNR][NJ];
     if (n_full > 0) {  // first batch: requested before anything else, independent of the messages
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) cur[u][j] = entry((int64_t)u * R + qc[j]);
+        for (int u = 0; u < UNR; ++u) load_row((int64_t)u * R, qc, run_ok, cur[u]);
     }
     if (ps == 0) {
     // stage the incoming messages, arm the minima (the table loads above are in flight)
@@ -1656,7 +1684,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     // per owned q: its digits' messages and the running minima for p >= 1
     T ms[NJ][A], acc[NJ][A], s0[NJ];
     int dig[NJ][A];
-    nary_digits<A, NJ>(qb + tid, NT, Dm, mg, live, dig);
+    nary_digits<A, NJ>(RUN ? qb + tid * NJ : qb + tid, RUN ? 1 : NT, Dm, mg, live, dig);
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
 #pragma unroll
@@ -1676,9 +1704,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
         T nxt[UNR][NJ];
         if (b + 1 < n_full) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                for (int j = 0; j < NJ; ++j) nxt[u][j] = entry((int64_t)(d0 + UNR + u) * R + qc[j]);
+            for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + UNR + u) * R, qc, run_ok, nxt[u]);
         } else {
 #pragma unroll
             for (int u = 0; u < UNR; ++u)
@@ -1695,10 +1721,7 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     if (n_full * UNR < D0) {  // tail batch
         const int d0 = n_full * UNR;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-                cur[u][j] = entry((int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R + qc[j]);
+        for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R, qc, run_ok, cur[u]);
         nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
     }
 #pragma unroll

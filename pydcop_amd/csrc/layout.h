@@ -272,7 +272,7 @@ constexpr int64_t nary_place_pos(const NaryPlace& p, int64_t k) {
 }
 // bytes of the narrow image of one factor (D0 = its first domain size)
 constexpr int64_t nary_place_bytes(const NaryPlace& p, int D0) {
-    if (p.box == 0) return p.multi ? ((int64_t)D0 * p.R * p.elem + 15) / 16 * 16 : (int64_t)D0 * p.nt * p.slot;
+    if (p.box == 0) return p.multi ? ((int64_t)D0 * p.R * p.elem + 15) / 16 * 16 + 16 : (int64_t)D0 * p.nt * p.slot;  // (+ 16: a lane's run may end behind the last row)
     if (is_small(p.box)) return ((int64_t)small_pow(small_lead(p.arity)) * small_rec_bytes(p.arity, p.elem) + 15) / 16 * 16;
     if (is_bin2(p.box)) {
         const Bin2Shape sh = BIN2_SHAPES[p.box - BIN2_BASE];
