@@ -1628,23 +1628,37 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
             return NEG ? -v : v;
         }
     };
-    // the lane's NJ entries of the row that starts at entry `row` (run_ok: its q's are all inside the row)
-    // (no branch: a run that crosses the end of its row reads on into the next row -- behind the last row into the 16 bytes of
-    // slack every such image ends with, layout.h nary_place_bytes -- and those entries belong to q's that are not live: masked)
-    auto load_row = [&](int64_t row, const int (&qcl)[NJ], bool, T (&out)[NJ]) __attribute__((always_inline)) {
+    // A table row as a lane holds it between its load and its use: NJ values -- or, RUN, the raw dwords of its NJ narrow entries,
+    // widened (and negated) only where they are used: the prefetched batch is 4 registers to carry, not 32, and the negation
+    // folds into the additions as an operand modifier (26 VALU instructions per table entry before, SQ_INSTS_VALU of
+    // profiles/r06_multi_pass_pmc_v1.txt: 2 of them the copies of the double buffer, 1 the sign).
+    constexpr int RWD = RUN ? (NJ * (int)sizeof(TT) + 3) / 4 : 1;
+    struct RowT { T v[NJ]; };
+    struct RowW { uint32_t w[RWD]; };
+    typedef typename std::conditional<RUN, RowW, RowT>::type Row;
+    // the lane's NJ entries of the row that starts at entry `row`.  (RUN, no branch: a run that crosses the end of its row reads
+    // on into the next row -- behind the last row into the 16 bytes of slack every such image ends with, layout.h
+    // nary_place_bytes -- and those entries belong to q's that are not live: masked)
+    auto load_row = [&](int64_t row, const int (&qcl)[NJ], Row& out) __attribute__((always_inline)) {
         if constexpr (RUN) {
-            constexpr int BYTES = NJ * (int)sizeof(TT);
-            uint32_t w[(BYTES + 3) / 4];
-            __builtin_memcpy(w, (const uint8_t*)tab + (row + qcl[0]) * (int64_t)sizeof(TT), BYTES);  // (any byte offset: gfx950 reads unaligned dwords)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const T v = nary_slot_entry_fwd<T, TT>(w, j);
-                out[j] = NEG ? -v : v;
-            }
+            __builtin_memcpy(out.w, (const uint8_t*)tab + (row + qcl[0]) * (int64_t)sizeof(TT), NJ * sizeof(TT));  // (any byte offset: gfx950 reads unaligned dwords)
         } else {
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) out[j] = entry(row + qcl[j]);
+            for (int j = 0; j < NJ; ++j) out.v[j] = entry(row + qcl[j]);
         }
+    };
+    auto unpack = [&](const Row (&r)[UNR], T (&tv)[UNR][NJ]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                if constexpr (RUN) {
+                    const T v = nary_slot_entry_fwd<T, TT>(r[u].w, j);
+                    tv[u][j] = NEG ? -v : v;
+                } else {
+                    tv[u][j] = r[u].v[j];
+                }
+            }
     };
     const int n_full = D0 / UNR;  // batches without a masked d0
     const int n_pass = MULTI ? (R + NJ * NT - 1) / (NJ * NT) : 1;
@@ -1659,11 +1673,12 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
         live[j] = q < R;
         qc[j] = live[j] ? q : R - 1;
     }
-    const bool run_ok = RUN && live[NJ - 1];
-    T cur[UNR][NJ];
+    // (RUN: a wave none of whose lanes has a live q in this pass sits it out -- no workgroup barrier below the first pass)
+    if (RUN && ps > 0 && qb + (tid & ~63) * NJ >= R) continue;
+    Row cur[UNR];
     if (n_full > 0) {  // first batch: requested before anything else, independent of the messages
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) load_row((int64_t)u * R, qc, run_ok, cur[u]);
+        for (int u = 0; u < UNR; ++u) load_row((int64_t)u * R, qc, cur[u]);
     }
     if (ps == 0) {
     // stage the incoming messages, arm the minima (the table loads above are in flight)
@@ -1701,28 +1716,36 @@ __global__ void __launch_bounds__(BLOCK) k_factor_nary(SweepArgs<T> a, const Nar
     const bool all_live = MULTI ? qb + NJ * NT <= R : R == NJ * NT;  // block-uniform
     for (int b = 0; b < n_full; ++b) {
         const int d0 = b * UNR;
-        T nxt[UNR][NJ];
+        Row nxt[UNR];
         if (b + 1 < n_full) {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + UNR + u) * R, qc, run_ok, nxt[u]);
+            for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + UNR + u) * R, qc, nxt[u]);
         } else {
 #pragma unroll
-            for (int u = 0; u < UNR; ++u)
+            for (int u = 0; u < UNR; ++u) {
+                if constexpr (RUN) {
 #pragma unroll
-                for (int j = 0; j < NJ; ++j) nxt[u][j] = pos_inf<T>();
+                    for (int x = 0; x < RWD; ++x) nxt[u].w[x] = 0u;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NJ; ++j) nxt[u].v[j] = pos_inf<T>();
+                }
+            }
         }
-        if (all_live) nary_batch<T, A, NJ, false>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
-        else nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+        T tv[UNR][NJ];
+        unpack(cur, tv);
+        if (all_live) nary_batch<T, A, NJ, false>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+        else nary_batch<T, A, NJ, true>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
 #pragma unroll
-        for (int u = 0; u < UNR; ++u)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) cur[u][j] = nxt[u][j];
+        for (int u = 0; u < UNR; ++u) cur[u] = nxt[u];
     }
     if (n_full * UNR < D0) {  // tail batch
         const int d0 = n_full * UNR;
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R, qc, run_ok, cur[u]);
-        nary_batch<T, A, NJ, true>(cur, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
+        for (int u = 0; u < UNR; ++u) load_row((int64_t)(d0 + u < D0 ? d0 + u : D0 - 1) * R, qc, cur[u]);
+        T tv[UNR][NJ];
+        unpack(cur, tv);
+        nary_batch<T, A, NJ, true>(tv, d0, D0, s_msg + off[0], ms, s0, live, acc, s_key + off[0]);
     }
 #pragma unroll
     for (int j = 0; j < NJ; ++j)
