@@ -27,6 +27,8 @@ def emu_lib():
 LAYOUTS = {"default": 0, "generic": 4, "keep_order": 8, "no_nary": 16,
            "unsorted_factors": 256, "sorted_keep_order": 128 + 8,
            "class_order_blocks": 2048, "full_width_tables": 8192, "r01_layout": 2048 + 8192}
+# round-6 switches, on the cases they change only (the whole list under every layout is the GPU suite's job)
+LAYOUTS_R6 = {"split_storage_types": 16777216, "no_multi_pass": 33554432}
 
 
 @pytest.mark.parametrize("case", parity_cases(), ids=lambda c: c[0])
@@ -44,6 +46,14 @@ def test_emu_layout_variants(layout, emu_lib, oracle_built):
         for dtype in (("f64", "f32") if (layout == "unsorted_factors" and name in ("coloring3_soft", "mixed", "nary_meeting_d8")) else ("f64",)):
             compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS[layout], dtype=dtype, **kw), 0,
                                 lib_path=emu_lib, steps=[1, 6])
+
+
+@pytest.mark.parametrize("layout", list(LAYOUTS_R6))
+def test_emu_layout_variants_round6(layout, emu_lib, oracle_built):
+    names = ("secp_small", "secp_small_m4_all", "bin2_peav_slots10", "multi_arity3_d40_max", "multi_arity4_d11", "multi_arity6_secp_m5")
+    for name, make, kw in parity_cases():
+        if name in names:
+            compare_with_oracle(oracle_built, make(), Params(layout_flags=LAYOUTS_R6[layout], **kw), 0, lib_path=emu_lib, steps=[1, 6])
 
 
 @pytest.mark.parametrize("path", golden_files(), ids=lambda p: os.path.basename(p)[:-4])

@@ -29,7 +29,8 @@ def test_bit_exact_vs_oracle(case, dtype, oracle_built):
                         steps=[0, 1, 1, 2, 8, 30])
 
 
-@pytest.mark.parametrize("flags", [4, 8, 16, 4 + 8 + 16, 128, 256, 128 + 8, 2048, 2048 + 256, 4096 + 8, 8192, 8192 + 2048])
+@pytest.mark.parametrize("flags", [4, 8, 16, 4 + 8 + 16, 128, 256, 128 + 8, 2048, 2048 + 256, 4096 + 8, 8192, 8192 + 2048,
+                                   16777216, 33554432])  # (round 6: storage types of a lane-grid shape kept apart; no multi-pass workgroup kernel)
 def test_layout_variants(flags, oracle_built):
     for name, make, kw in parity_cases():
         if (flags & 4) and name in ("hub_deg1100_max_all", "hub_deg3400"):
