@@ -1477,6 +1477,12 @@ __device__ __forceinline__ void nary_batch(const T (&tv)[NARY_UNR][NJ], int d0, 
     T best0[NARY_UNR];
 #pragma unroll
     for (int u = 0; u < NARY_UNR; ++u) {
+        // (a row past the table -- the tail batch of a first dimension that is no multiple of NARY_UNR: three of the eight rows a
+        // five-value first variable makes the block walk -- is skipped, block-uniformly, instead of computed and masked)
+        if (MASKED && d0 + u >= D0) {
+            best0[u] = pos_inf<T>();
+            continue;
+        }
         const T m0 = s_m0[(!MASKED || d0 + u < D0) ? d0 + u : 0];
         const T a0 = m0;  // = 0 + the message, added when it was staged
         T b0 = pos_inf<T>();
